@@ -1,0 +1,109 @@
+"""ctypes binding of libhps.so (C ABI: include/hps.h).
+
+PyTorch is only plumbing here: tensors own device memory, ``data_ptr()`` and the current HIP stream
+are handed to the library.  There is no CPU implementation behind these calls -- if the library or a
+HIP device is missing the call fails loudly.
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libhps.so")
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+
+# name -> argtypes (restype is always int unless listed in _RESTYPES)
+_PROTOTYPES = {
+    "hps_version": [],
+    "hps_last_error": [],
+    "hps_smpl_pose_prep": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
+    "hps_smpl_blend": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "hps_smpl_lbs": [_P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
+    "hps_smpl_joints": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
+    "hps_vertex_uncertainty": [_P, _P, _I, _I, _I, _P],
+    "hps_mf_sample": [_P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _c.c_float, _P, _P, _P, _c.c_uint64,
+                      _c.c_int64, _I, _P, _P, _P, _P],
+    "hps_quat_to_rotmat": [_P, _P, _I, _P],
+    "hps_rot6d_to_rotmat": [_P, _P, _I, _P],
+    "hps_batch_rodrigues": [_P, _P, _I, _P],
+    "hps_linear": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "hps_head_joint_level": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _I, _I, _P],
+    "hps_head_svd_finish": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P],
+    "hps_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "hps_conv2d_bn_act": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "hps_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P],
+    "hps_global_avgpool": [_P, _P, _I, _I, _I, _P],
+}
+_RESTYPES = {"hps_last_error": _c.c_char_p}
+
+EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
+
+_lib = None
+
+
+class HpsError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libhps.so and attach prototypes; raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HpsError(
+            "libhps.so is missing (%s). Build it with `python -m hierarchicalprobabilistic3dhuman_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the build is stale: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, _I)
+    _lib = lib
+    return lib
+
+
+def require_device(t, what="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise HpsError(
+            "%s must live on a HIP (MI355X) device; this package has no CPU path "
+            "(the CPU oracle under oracle/ is test infrastructure only)" % what)
+
+
+def ptr(t, dtype=torch.float32, what="tensor"):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    require_device(t, what)
+    if t.dtype != dtype:
+        raise HpsError("%s: expected %s, got %s" % (what, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise HpsError("%s must be contiguous" % what)
+    return _P(t.data_ptr())
+
+
+def iptr(t, what="index tensor"):
+    return ptr(t, torch.int32, what)
+
+
+def stream():
+    return _P(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.hps_last_error()
+        raise HpsError("%s failed (code %d): %s" % (name, rc, msg.decode() if msg else ""))
+
+
+def f32c(t):
+    """fp32 contiguous view/copy on the same device."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

@@ -1,0 +1,271 @@
+// ResNet-18 encoder kernels (models/resnet.py:202-217): implicit-GEMM convolution
+// on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32) with eval-mode BatchNorm, residual add
+// and ReLU fused into the epilogue; NHWC max-pool / global average pool; NCHW -> NHWC input relayout.
+//
+// GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin.  Activations are NHWC so a K-run of
+// one filter tap is contiguous channels of one input pixel; the filter is stored k-major (K, Cout).
+#include "hps_common.h"
+
+namespace hps {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CBK = 16;        // K-chunk
+constexpr int LDA = CBK + 1;   // odd pitch: the 32 pixel rows a half-wave reads hit 32 distinct banks
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(
+    const float* __restrict__ x, const float* __restrict__ wk, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ residual, float* __restrict__ y, int H, int W,
+    int Cin, int Cout, int KW, int stride, int pad, int Ho, int Wo, int Mtot, int Kreal, int Kp, int relu,
+    int tiles_m) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_LD = BM * 4 / 256;       // float4 loads per thread for the A chunk
+    constexpr int B_LD = (CBK * BN / 4 + 255) / 256;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    static_assert(BM * 4 % 256 == 0, "A tile divides over 256 threads");
+
+    __shared__ float sA[2][BM][LDA];
+    __shared__ __attribute__((aligned(16))) float sB[2][CBK][BN];
+
+    const int tile_n = blockIdx.x / tiles_m, tile_m = blockIdx.x % tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    const int kl = lane >> 5, il = lane & 31;
+
+    // ---- per-thread A-load coordinates (fixed over the K loop) ----
+    int a_pix[A_LD];          // pixel row inside the tile
+    int a_hi0[A_LD], a_wi0[A_LD];
+    long a_base[A_LD];        // element offset of image b, or -1 if the pixel is outside M
+    const int a_q = (tid & 3) * 4;   // k offset inside the chunk
+#pragma unroll
+    for (int r = 0; r < A_LD; ++r) {
+        const int f = tid + r * 256;
+        a_pix[r] = f >> 2;
+        const int m = m0 + a_pix[r];
+        if (m < Mtot) {
+            const int b = m / (Ho * Wo), rem = m % (Ho * Wo);
+            a_hi0[r] = (rem / Wo) * stride - pad;
+            a_wi0[r] = (rem % Wo) * stride - pad;
+            a_base[r] = (long)b * H * W * Cin;
+        } else {
+            a_hi0[r] = 0; a_wi0[r] = 0; a_base[r] = -1;
+        }
+    }
+    constexpr int BN4 = BN / 4;
+
+    auto load_a = [&](int k0, float4* ra) {
+        const int k = k0 + a_q;
+        const int tap = k / Cin, ci = k - tap * Cin;
+        const int kh = tap / KW, kw = tap - kh * KW;
+        const bool kvalid = k < Kreal;
+#pragma unroll
+        for (int r = 0; r < A_LD; ++r) {
+            const int hi = a_hi0[r] + kh, wi = a_wi0[r] + kw;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kvalid && a_base[r] >= 0 && hi >= 0 && hi < H && wi >= 0 && wi < W)
+                v = *reinterpret_cast<const float4*>(x + a_base[r] + ((long)hi * W + wi) * Cin + ci);
+            ra[r] = v;
+        }
+    };
+    auto load_b = [&](int k0, float4* rb) {
+#pragma unroll
+        for (int r = 0; r < B_LD; ++r) {
+            const int f = tid + r * 256;
+            const int row = f / BN4, c4 = f - row * BN4;
+            if (row < CBK) rb[r] = *reinterpret_cast<const float4*>(wk + (size_t)(k0 + row) * Cout + n0 + c4 * 4);
+        }
+    };
+    auto store_ab = [&](int buf, const float4* ra, const float4* rb) {
+#pragma unroll
+        for (int r = 0; r < A_LD; ++r) {
+            float* d = &sA[buf][a_pix[r]][a_q];
+            d[0] = ra[r].x; d[1] = ra[r].y; d[2] = ra[r].z; d[3] = ra[r].w;
+        }
+#pragma unroll
+        for (int r = 0; r < B_LD; ++r) {
+            const int f = tid + r * 256;
+            const int row = f / BN4, c4 = f - row * BN4;
+            if (row < CBK) *reinterpret_cast<float4*>(&sB[buf][row][c4 * 4]) = rb[r];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 ra[A_LD], rb[B_LD];
+    load_a(0, ra);
+    load_b(0, rb);
+    const int nchunks = Kp / CBK;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        store_ab(buf, ra, rb);
+        __syncthreads();
+        if (c + 1 < nchunks) {           // next chunk's global loads overlap this chunk's MFMAs
+            load_a((c + 1) * CBK, ra);
+            load_b((c + 1) * CBK, rb);
+        }
+#pragma unroll
+        for (int k = 0; k < CBK; k += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = sA[buf][wm0 + i * 32 + il][k + kl];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = sB[buf][k + kl][wn0 + j * 32 + il];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: BN (scale, shift), residual, ReLU; C layout col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = n0 + wn0 + j * 32 + il;
+        const float sc = scale[co], sh = shift[co];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                if (m < Mtot) {
+                    float v = acc[i][j][r] * sc + sh;
+                    if (residual) v += residual[(size_t)m * Cout + co];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    y[(size_t)m * Cout + co] = v;
+                }
+            }
+        }
+    }
+}
+
+// (B,C,H,W) -> (B,H,W,Cp): lanes along w read each channel plane coalesced; every lane assembles its
+// pixel's Cp channels and stores them as float4s.
+template <int CP>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                                           int HW, long total) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;   // pixel index over B*H*W
+    if (p >= total) return;
+    const long b = p / HW, hw = p % HW;
+    float v[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) v[c] = (c < C) ? x[(b * C + c) * HW + hw] : 0.0f;
+    float4* d = reinterpret_cast<float4*>(y + p * CP);
+#pragma unroll
+    for (int q = 0; q < CP / 4; ++q) d[q] = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
+}
+
+// MaxPool2d(3, 2, 1), NHWC, thread per (output pixel, 4 channels)
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
+                                                      int C, int Ho, int Wo, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = C / 4;
+    const int cq = (int)(i % c4);
+    long p = i / c4;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho);
+    const long b = p / Ho;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hi = ho * 2 - 1 + kh;
+        if (hi < 0 || hi >= H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int wi = wo * 2 - 1 + kw;
+            if (wi < 0 || wi >= W) continue;
+            const float4 v = *reinterpret_cast<const float4*>(x + ((b * H + hi) * W + wi) * C + cq * 4);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    *reinterpret_cast<float4*>(y + i * 4) = m;
+}
+
+// global average pool: thread per (b, c), coalesced over c
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C,
+                                                      int total) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int b = i / C, c = i % C;
+    const float* s = x + (size_t)b * HW * C + c;
+    float acc = 0.0f;
+    for (int p = 0; p < HW; ++p) acc += s[(size_t)p * C];
+    y[i] = acc / (float)HW;
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_conv(const float* x, const float* wk, const float* scale, const float* shift, const float* residual,
+                       float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
+                       hipStream_t s) {
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    const int Mtot = B * Ho * Wo, Kreal = KH * KW * Cin, Kp = ceil_div(Kreal, CBK) * CBK;
+    const int tiles_m = ceil_div(Mtot, BM), tiles_n = Cout / BN;
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(tiles_m * tiles_n), dim3(256), 0, s, x, wk, scale,
+                       shift, residual, y, H, W, Cin, Cout, KW, stride, pad, Ho, Wo, Mtot, Kreal, Kp, relu, tiles_m);
+    return check_launch("hps_conv2d_bn_act");
+}
+
+}  // namespace hps
+
+using namespace hps;
+
+extern "C" int hps_conv2d_bn_act(const float* x, const float* wk, const float* scale, const float* shift,
+                                 const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int KH,
+                                 int KW, int stride, int pad, int relu, hps_stream_t stream) {
+    if (!x || !wk || !scale || !shift || !y) return bad_arg("hps_conv2d_bn_act: null pointer");
+    if (Cin % 4 != 0 || Cout % 64 != 0) return bad_arg("hps_conv2d_bn_act: Cin % 4 == 0 and Cout % 64 == 0 required");
+    if (B <= 0) return HPS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    const long Mtot = (long)B * Ho * Wo;
+    // largest tile that still gives every CU (256) at least two workgroups
+    if (Cout % 128 == 0 && (Mtot / 128) * (Cout / 128) >= 512)
+        return launch_conv<128, 128, 64, 64>(x, wk, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
+    if ((Mtot / 128) * (Cout / 64) >= 512)
+        return launch_conv<128, 64, 64, 32>(x, wk, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
+    return launch_conv<64, 64, 32, 32>(x, wk, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
+}
+
+extern "C" int hps_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, int Cp, hps_stream_t stream) {
+    if (!x || !y) return bad_arg("hps_nchw_to_nhwc: null pointer");
+    if (C > Cp) return bad_arg("hps_nchw_to_nhwc: Cp < C");
+    if (B <= 0) return HPS_OK;
+    const long total = (long)B * H * W;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    hipStream_t s = (hipStream_t)stream;
+    switch (Cp) {
+        case 4: hipLaunchKernelGGL(nchw_to_nhwc_kernel<4>, grid, dim3(256), 0, s, x, y, C, H * W, total); break;
+        case 20: hipLaunchKernelGGL(nchw_to_nhwc_kernel<20>, grid, dim3(256), 0, s, x, y, C, H * W, total); break;
+        case 64: hipLaunchKernelGGL(nchw_to_nhwc_kernel<64>, grid, dim3(256), 0, s, x, y, C, H * W, total); break;
+        default: set_error("hps_nchw_to_nhwc: Cp=%d unsupported (4, 20, 64)", Cp); return HPS_E_UNSUPPORTED;
+    }
+    return check_launch("hps_nchw_to_nhwc");
+}
+
+extern "C" int hps_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, hps_stream_t stream) {
+    if (!x || !y) return bad_arg("hps_maxpool3x3s2: null pointer");
+    if (C % 4 != 0) return bad_arg("hps_maxpool3x3s2: C % 4 == 0 required");
+    if (B <= 0) return HPS_OK;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long total = (long)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, H,
+                       W, C, Ho, Wo, total);
+    return check_launch("hps_maxpool3x3s2");
+}
+
+extern "C" int hps_global_avgpool(const float* x, float* y, int B, int HW, int C, hps_stream_t stream) {
+    if (!x || !y) return bad_arg("hps_global_avgpool: null pointer");
+    if (B <= 0) return HPS_OK;
+    hipLaunchKernelGGL(avgpool_kernel, dim3(ceil_div(B * C, 256)), dim3(256), 0, (hipStream_t)stream, x, y, HW, C, B * C);
+    return check_launch("hps_global_avgpool");
+}

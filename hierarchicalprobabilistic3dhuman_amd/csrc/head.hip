@@ -1,0 +1,209 @@
+// Distribution-prediction head: FC trunk and the hierarchical per-joint MLPs
+// (models/poseMF_shapeGaussian_net.py:95-162).
+// The 23 sequential joints of the reference loop (:121-160) are grouped by kinematic depth; one
+// launch evaluates every joint of a level for the whole batch.
+#include "hps_common.h"
+
+namespace hps {
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x); }
+
+constexpr int TB = 16;  // batch rows per workgroup
+
+// out[b, n] = act(x[b, :] . wt[:, n] + bias[n] + addend[n]);  256 threads = 4 K-slices x 64 columns
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ wt,
+                                                     const float* __restrict__ bias, const float* __restrict__ addend,
+                                                     float* __restrict__ out, int ldo, int B, int K, int N, int act) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // xs[K][TB] then red[4][TB][64]
+    float* xs = smem;
+    float* red = smem + (size_t)((K * TB + 3) & ~3);
+    const int b0 = blockIdx.y * TB;
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ks = threadIdx.x >> 6;
+
+    for (int i = threadIdx.x; i < K * TB; i += 256) {
+        const int r = i / K, k = i % K;                      // coalesced along k
+        xs[k * TB + r] = (b0 + r < B) ? x[(size_t)(b0 + r) * ldx + k] : 0.0f;
+    }
+    __syncthreads();
+
+    float acc[TB];
+#pragma unroll
+    for (int r = 0; r < TB; ++r) acc[r] = 0.0f;
+    const int kchunk = ceil_div(K, 4);
+    const int k_lo = ks * kchunk, k_hi = min(K, k_lo + kchunk);
+    if (n < N) {
+        for (int k = k_lo; k < k_hi; ++k) {
+            const float wv = wt[(size_t)k * N + n];
+            const float4* xr = reinterpret_cast<const float4*>(xs + k * TB);
+#pragma unroll
+            for (int q = 0; q < TB / 4; ++q) {
+                const float4 xv = xr[q];
+                acc[q * 4 + 0] += xv.x * wv; acc[q * 4 + 1] += xv.y * wv;
+                acc[q * 4 + 2] += xv.z * wv; acc[q * 4 + 3] += xv.w * wv;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < TB; ++r) red[(ks * TB + r) * 64 + (threadIdx.x & 63)] = acc[r];
+    __syncthreads();
+    if (ks == 0 && n < N) {
+        const float add = bias[n] + (addend ? addend[n] : 0.0f);
+        for (int r = 0; r < TB && b0 + r < B; ++r) {
+            const int c = threadIdx.x & 63;
+            float v = red[(0 * TB + r) * 64 + c] + red[(1 * TB + r) * 64 + c] + red[(2 * TB + r) * 64 + c] +
+                      red[(3 * TB + r) * 64 + c] + add;
+            if (act == HPS_ACT_ELU) v = elu1(v);
+            else if (act == HPS_ACT_RELU) v = fmaxf(v, 0.0f);
+            out[(size_t)(b0 + r) * ldo + n] = v;
+        }
+    }
+}
+
+// One kinematic level: grid = (n_level joints, batch tiles).  hidden == 128 (EMBED_DIM / 2).
+template <int HID>
+__global__ __launch_bounds__(256) void joint_level_kernel(
+    const float* __restrict__ embed, int embed_dim, const int32_t* __restrict__ joint_ids,
+    const int32_t* __restrict__ anc_ptr, const int32_t* __restrict__ anc_idx, const float* const* __restrict__ w1t_ptrs,
+    const float* const* __restrict__ b1_ptrs, const float* const* __restrict__ w2_ptrs,
+    const float* const* __restrict__ b2_ptrs, const float* __restrict__ u_proper, const float* __restrict__ s_proper,
+    const float* __restrict__ mode, float delta_i_weight, float* __restrict__ pose_f, int B, int NJ) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int joint = joint_ids[blockIdx.x];
+    const int a_lo = anc_ptr[joint], P = anc_ptr[joint + 1] - a_lo;
+    const int in_dim = embed_dim + 21 * P;
+    float* xs = smem;                                        // [in_dim][TB]
+    float* hs = smem + (size_t)((in_dim * TB + 3) & ~3);     // [HID][TB]
+    float* red = hs + HID * TB;                              // [TB][HID]  partial sums of K-slice 1
+    const int b0 = blockIdx.y * TB;
+
+    // gather: cat[embed, U_proper[anc] (9P), S_proper[anc] (3P), mode[anc] (9P)]   (:126-132)
+    for (int i = threadIdx.x; i < in_dim * TB; i += 256) {
+        const int r = i / in_dim, k = i % in_dim;
+        const int b = b0 + r;
+        float v = 0.0f;
+        if (b < B) {
+            if (k < embed_dim) v = embed[(size_t)b * embed_dim + k];
+            else {
+                int t = k - embed_dim;
+                if (t < 9 * P) v = u_proper[((size_t)b * NJ + anc_idx[a_lo + t / 9]) * 9 + t % 9];
+                else if ((t -= 9 * P) < 3 * P) v = s_proper[((size_t)b * NJ + anc_idx[a_lo + t / 3]) * 3 + t % 3];
+                else { t -= 3 * P; v = mode[((size_t)b * NJ + anc_idx[a_lo + t / 9]) * 9 + t % 9]; }
+            }
+        }
+        xs[k * TB + r] = v;
+    }
+    __syncthreads();
+
+    // hidden layer: 2 K-slices x HID columns
+    const float* w1t = w1t_ptrs[joint];
+    const int n = threadIdx.x % HID, ks = threadIdx.x / HID;     // HID == 128 -> ks in {0,1}
+    float acc[TB];
+#pragma unroll
+    for (int r = 0; r < TB; ++r) acc[r] = 0.0f;
+    const int kh = (in_dim + 1) / 2;
+    const int k_lo = ks * kh, k_hi = min(in_dim, k_lo + kh);
+    for (int k = k_lo; k < k_hi; ++k) {
+        const float wv = w1t[(size_t)k * HID + n];
+        const float4* xr = reinterpret_cast<const float4*>(xs + k * TB);
+#pragma unroll
+        for (int q = 0; q < TB / 4; ++q) {
+            const float4 xv = xr[q];
+            acc[q * 4 + 0] += xv.x * wv; acc[q * 4 + 1] += xv.y * wv;
+            acc[q * 4 + 2] += xv.z * wv; acc[q * 4 + 3] += xv.w * wv;
+        }
+    }
+    if (ks == 1) {
+#pragma unroll
+        for (int r = 0; r < TB; ++r) red[r * HID + n] = acc[r];
+    }
+    __syncthreads();
+    if (ks == 0) {
+        const float bv = b1_ptrs[joint][n];
+#pragma unroll
+        for (int r = 0; r < TB; ++r) hs[n * TB + r] = elu1(acc[r] + red[r * HID + n] + bv);
+    }
+    __syncthreads();
+
+    // output layer: 9 x TB dot products of length HID, + bias + delta_i_weight * I   (:134-135)
+    if (threadIdx.x < 9 * TB) {
+        const int e = threadIdx.x / TB, r = threadIdx.x % TB;
+        const float* w2 = w2_ptrs[joint] + (size_t)e * HID;
+        float v = 0.0f;
+        for (int k = 0; k < HID; ++k) v += w2[k] * hs[k * TB + r];
+        v += b2_ptrs[joint][e];
+        if (e % 4 == 0) v += delta_i_weight;
+        if (b0 + r < B) pose_f[((size_t)(b0 + r) * NJ + joint) * 9 + e] = v;
+    }
+}
+
+// proper SVD + mode (:139-152): thread per (image, joint of the level)
+__global__ void svd_finish_kernel(const float* __restrict__ pose_u, const float* __restrict__ pose_s,
+                                  const float* __restrict__ pose_v, const int32_t* __restrict__ joint_ids, int n_level,
+                                  float* __restrict__ u_proper, float* __restrict__ s_proper, float* __restrict__ mode,
+                                  int B, int NJ) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * n_level) return;
+    const int b = i / n_level, joint = joint_ids[i % n_level];
+    const size_t o = (size_t)b * NJ + joint;
+    float U[9], V[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { U[e] = pose_u[o * 9 + e]; V[e] = pose_v[o * 9 + e]; }
+    const float dU = det3(U), dV = det3(V);
+    U[2] *= dU; U[5] *= dU; U[8] *= dU;
+    V[2] *= dV; V[5] *= dV; V[8] *= dV;
+    float Mo[9];
+    mat3_mul_bt(U, V, Mo);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { u_proper[o * 9 + e] = U[e]; mode[o * 9 + e] = Mo[e]; }
+    s_proper[o * 3 + 0] = pose_s[o * 3 + 0];
+    s_proper[o * 3 + 1] = pose_s[o * 3 + 1];
+    s_proper[o * 3 + 2] = pose_s[o * 3 + 2] * (dU * dV);
+}
+
+}  // namespace hps
+
+using namespace hps;
+
+extern "C" int hps_linear(const float* x, int ldx, const float* wt, const float* bias, const float* addend, float* out,
+                          int ldo, int B, int K, int N, int act, hps_stream_t stream) {
+    if (!x || !wt || !bias || !out) return bad_arg("hps_linear: null pointer");
+    if (K <= 0 || N <= 0 || ldx < K || ldo < N) return bad_arg("hps_linear: dims");
+    if (B <= 0) return HPS_OK;
+    size_t lds = ((size_t)((K * TB + 3) & ~3) + 4 * TB * 64) * sizeof(float);
+    if (lds > 160 * 1024) { set_error("hps_linear: K=%d too large for the LDS tile", K); return HPS_E_UNSUPPORTED; }
+    hipLaunchKernelGGL(linear_kernel, dim3(ceil_div(N, 64), ceil_div(B, TB)), dim3(256), lds, (hipStream_t)stream, x,
+                       ldx, wt, bias, addend, out, ldo, B, K, N, act);
+    return check_launch("hps_linear");
+}
+
+extern "C" int hps_head_joint_level(const float* embed, int embed_dim, int hidden, const int32_t* joint_ids,
+                                    int n_level, const int32_t* anc_ptr, const int32_t* anc_idx,
+                                    const float* const* w1t_ptrs, const float* const* b1_ptrs,
+                                    const float* const* w2_ptrs, const float* const* b2_ptrs, const float* u_proper,
+                                    const float* s_proper, const float* mode, float delta_i_weight, float* pose_f,
+                                    int B, int num_body_joints, hps_stream_t stream) {
+    if (!embed || !joint_ids || !anc_ptr || !anc_idx || !w1t_ptrs || !b1_ptrs || !w2_ptrs || !b2_ptrs || !u_proper ||
+        !s_proper || !mode || !pose_f)
+        return bad_arg("hps_head_joint_level: null pointer");
+    if (hidden != 128) { set_error("hps_head_joint_level: hidden=%d unsupported (128 = EMBED_DIM/2)", hidden); return HPS_E_UNSUPPORTED; }
+    if (B <= 0 || n_level <= 0) return HPS_OK;
+    const int max_in = embed_dim + 21 * num_body_joints;
+    size_t lds = ((size_t)((max_in * TB + 3) & ~3) + 2 * 128 * TB) * sizeof(float);
+    if (lds > 160 * 1024) { set_error("hps_head_joint_level: embed_dim=%d too large", embed_dim); return HPS_E_UNSUPPORTED; }
+    hipLaunchKernelGGL((joint_level_kernel<128>), dim3(n_level, ceil_div(B, TB)), dim3(256), lds, (hipStream_t)stream,
+                       embed, embed_dim, joint_ids, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper,
+                       s_proper, mode, delta_i_weight, pose_f, B, num_body_joints);
+    return check_launch("hps_head_joint_level");
+}
+
+extern "C" int hps_head_svd_finish(const float* pose_u, const float* pose_s, const float* pose_v,
+                                   const int32_t* joint_ids, int n_level, float* u_proper, float* s_proper, float* mode,
+                                   int B, int num_body_joints, hps_stream_t stream) {
+    if (!pose_u || !pose_s || !pose_v || !joint_ids || !u_proper || !s_proper || !mode)
+        return bad_arg("hps_head_svd_finish: null pointer");
+    if (B <= 0 || n_level <= 0) return HPS_OK;
+    hipLaunchKernelGGL(svd_finish_kernel, dim3(ceil_div(B * n_level, 128)), dim3(128), 0, (hipStream_t)stream, pose_u,
+                       pose_s, pose_v, joint_ids, n_level, u_proper, s_proper, mode, B, num_body_joints);
+    return check_launch("hps_head_svd_finish");
+}

@@ -1,0 +1,83 @@
+// Shared helpers for the libhps.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "hps.h"
+
+namespace hps {
+
+// thread-local last-error text returned by hps_last_error()
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return HPS_OK;
+}
+
+inline int bad_arg(const char* what) {
+    set_error("bad argument: %s", what);
+    return HPS_E_BADARG;
+}
+
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// 12-byte vertex record: one global_load_dwordx3 / global_store_dwordx3 per lane, lane-contiguous.
+struct __attribute__((packed, aligned(4))) f3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ float det3(const float* m) {
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
+           m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+// C = A * B, 3x3 row-major
+__device__ __forceinline__ void mat3_mul(const float* a, const float* b, float* c) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            c[i * 3 + j] = a[i * 3 + 0] * b[0 * 3 + j] + a[i * 3 + 1] * b[1 * 3 + j] + a[i * 3 + 2] * b[2 * 3 + j];
+}
+
+// C = A * B^T, 3x3 row-major
+__device__ __forceinline__ void mat3_mul_bt(const float* a, const float* b, float* c) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            c[i * 3 + j] = a[i * 3 + 0] * b[j * 3 + 0] + a[i * 3 + 1] * b[j * 3 + 1] + a[i * 3 + 2] * b[j * 3 + 2];
+}
+
+// utils/rigid_transform_utils.py:113-133 -- q = (w,x,y,z), re-normalised, row-major 3x3 out
+__device__ __forceinline__ void quat_to_rotmat_dev(float qw, float qx, float qy, float qz, float* r) {
+    float n = sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+    float w = qw / n, x = qx / n, y = qy / n, z = qz / n;
+    float w2 = w * w, x2 = x * x, y2 = y * y, z2 = z * z;
+    float wx = w * x, wy = w * y, wz = w * z, xy = x * y, xz = x * z, yz = y * z;
+    r[0] = w2 + x2 - y2 - z2; r[1] = 2 * xy - 2 * wz;     r[2] = 2 * wy + 2 * xz;
+    r[3] = 2 * wz + 2 * xy;   r[4] = w2 - x2 + y2 - z2;   r[5] = 2 * yz - 2 * wx;
+    r[6] = 2 * xz - 2 * wy;   r[7] = 2 * wx + 2 * yz;     r[8] = w2 - x2 - y2 + z2;
+}
+
+// smplx.lbs.batch_rodrigues: angle = ||r + 1e-8||, R = I + sin K + (1 - cos) K^2, K = [r/angle]_x
+__device__ __forceinline__ void rodrigues_dev(float rx, float ry, float rz, float* r) {
+    float ex = rx + 1e-8f, ey = ry + 1e-8f, ez = rz + 1e-8f;
+    float angle = sqrtf(ex * ex + ey * ey + ez * ez);
+    float dx = rx / angle, dy = ry / angle, dz = rz / angle;
+    float s = sinf(angle), c = 1.0f - cosf(angle);
+    // K = [[0,-dz,dy],[dz,0,-dx],[-dy,dx,0]];  K^2 computed as the matrix product
+    float k[9] = {0.f, -dz, dy, dz, 0.f, -dx, -dy, dx, 0.f};
+    float k2[9];
+    mat3_mul(k, k, k2);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r[i] = ((i % 4 == 0) ? 1.0f : 0.0f) + s * k[i] + c * k2[i];
+}
+
+}  // namespace hps

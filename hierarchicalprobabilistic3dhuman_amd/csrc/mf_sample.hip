@@ -1,0 +1,228 @@
+// Matrix-Fisher rotation sampling by Bingham / angular-central-Gaussian rejection sampling, one
+// wavefront per (image, joint) call.  Replaces utils/sampling_utils.py:10-143:
+// the per-call Python loop (:128-137), the boolean-mask compaction (:64-65) and the host
+// synchronisation per round (:62) become ballot + prefix-popcount inside one wave.
+#include "hps_common.h"
+
+namespace hps {
+
+// ---- Philox4x32-10 (Salmon et al. 2011), counter-based: no state to carry between launches -------
+struct u4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u4 philox4x32_10(u4 ctr, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * ctr.x;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * ctr.z;
+        u4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ ctr.y ^ k0;
+        n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ ctr.w ^ k1;
+        n.w = (uint32_t)p0;
+        ctr = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return ctr;
+}
+
+// (0,1] uniform from 32 bits (never 0, so log() is finite); [0,1) uniform from the top 24 bits
+__device__ __forceinline__ float u01_open0(uint32_t x) { return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float r = sqrtf(-2.0f * logf(u01_open0(a)));
+    const float t = 6.28318530717958647692f * u01(b);
+    n0 = r * cosf(t);
+    n1 = r * sinf(t);
+}
+
+__global__ __launch_bounds__(64) void mf_sample_kernel(
+    const float* __restrict__ pose_u, const float* __restrict__ pose_s, const float* __restrict__ pose_v,
+    const float* __restrict__ bingham_a, int nj, int N, int n_prop, float b, float m_star, const float* __restrict__ eps, const float* __restrict__ wun,
+    const int32_t* __restrict__ draw_idx, uint64_t seed, int64_t call_offset, int max_rounds,
+    float* __restrict__ r_out, float* __restrict__ quat_out, int32_t* __restrict__ accepted) {
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int img = c / nj, joint = c % nj;
+
+    // ---- per-call parameters (wave-uniform; every lane computes them redundantly) ----
+    float U[9], V[9], S[3];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { U[e] = pose_u[(size_t)c * 9 + e]; V[e] = pose_v[(size_t)c * 9 + e]; }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) S[e] = pose_s[(size_t)c * 3 + e];
+    const float detU = det3(U), detV = det3(V);                 // sampling_utils.py:105
+    S[2] *= detU * detV;                                        // :109
+    U[2] *= detU; U[5] *= detU; U[8] *= detU;                   // :110  (third column)
+    V[2] *= detV; V[5] *= detV; V[8] *= detV;                   // :111
+    float A[4], Om[4], sd[4];
+    A[0] = 0.0f;
+    A[1] = 2.0f * (S[1] + S[2]);                                // :119-121
+    A[2] = 2.0f * (S[0] + S[2]);
+    A[3] = 2.0f * (S[0] + S[1]);
+    if (bingham_a) {                                            // bingham_sampling_for_matrix_fisher_torch(A=...)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) A[e] = bingham_a[(size_t)c * 4 + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        Om[e] = 1.0f + 2.0f * A[e] / b;                         // :123
+        sd[e] = 1.0f / sqrtf(Om[e]);                            // :124  Omega ** -0.5
+    }
+
+    const bool host_noise = (eps != nullptr);
+    const float* eps_c = nullptr;
+    const float* w_c = nullptr;
+    if (host_noise) {
+        const size_t d = (size_t)draw_idx[c];
+        eps_c = eps + d * (size_t)n_prop * 4;
+        w_c = wun + d * (size_t)n_prop;
+    }
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const uint64_t gcall = (uint64_t)(call_offset + c);
+
+    int total = 0;
+    for (int round = 0; round < max_rounds; ++round) {
+        // pass 1 counts the accepted proposals of this round; pass 2 (only if >= N) regenerates the
+        // same proposals and emits the first N accepted in proposal order (:63-65).  A failed round
+        // writes nothing, exactly like the reference's discard-and-redraw (:68-69).
+        for (int pass = 0; pass < 2; ++pass) {
+            int base = 0;
+            for (int p0 = 0; p0 < n_prop; p0 += 64) {
+                const int p = p0 + lane;
+                const bool in_range = p < n_prop;
+                float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 1.f, wu = 2.0f;
+                if (in_range) {
+                    if (host_noise) {
+                        const float4 e4 = *reinterpret_cast<const float4*>(eps_c + (size_t)p * 4);
+                        e0 = e4.x; e1 = e4.y; e2 = e4.z; e3 = e4.w;
+                        wu = w_c[p];
+                    } else {
+                        u4 ctr;
+                        ctr.x = (uint32_t)p; ctr.y = (uint32_t)round;
+                        ctr.z = (uint32_t)gcall; ctr.w = (uint32_t)(gcall >> 32) & 0x7fffffffu;
+                        const u4 r0 = philox4x32_10(ctr, k0, k1);
+                        ctr.w |= 0x80000000u;
+                        const u4 r1 = philox4x32_10(ctr, k0, k1);
+                        box_muller(r0.x, r0.y, e0, e1);
+                        box_muller(r0.z, r0.w, e2, e3);
+                        wu = u01(r1.x);
+                    }
+                }
+                // y = std * eps ; x = y / ||y||                       (:52-53)
+                const float y0 = sd[0] * e0, y1 = sd[1] * e1, y2 = sd[2] * e2, y3 = sd[3] * e3;
+                const float nrm = sqrtf(y0 * y0 + y1 * y1 + y2 * y2 + y3 * y3);
+                const float x0 = y0 / nrm, x1 = y1 / nrm, x2 = y2 / nrm, x3 = y3 / nrm;
+                // p_Bing* = exp(-x^T A x); p_ACG* = (x^T Omega x)^-2   (:56-57)
+                const float qa = x0 * A[0] * x0 + x1 * A[1] * x1 + x2 * A[2] * x2 + x3 * A[3] * x3;
+                const float qo = x0 * Om[0] * x0 + x1 * Om[1] * x1 + x2 * Om[2] * x2 + x3 * Om[3] * x3;
+                const float p_bing = expf(-qa);
+                const float p_acg = 1.0f / (qo * qo);
+                const bool acc = in_range && (wu < p_bing / (m_star * p_acg));          // :61
+                const unsigned long long mask = __ballot(acc);
+                if (pass == 1) {
+                    const int rank = base + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (acc && rank < N) {
+                        float Rq[9], T[9], Ro[9];
+                        quat_to_rotmat_dev(x0, x1, x2, x3, Rq);                          // :139
+                        mat3_mul_bt(Rq, V, T);                                           // R V_p^T
+                        mat3_mul(U, T, Ro);                                              // U_p (R V_p^T)   :140-141
+                        const size_t o = ((size_t)img * N + rank) * nj + joint;
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) r_out[o * 9 + e] = Ro[e];
+                        if (quat_out) {
+                            quat_out[o * 4 + 0] = x0; quat_out[o * 4 + 1] = x1;
+                            quat_out[o * 4 + 2] = x2; quat_out[o * 4 + 3] = x3;
+                        }
+                    }
+                }
+                base += __popcll(mask);
+                if (pass == 1 && base >= N) break;   // every kept proposal has been written
+            }
+            if (pass == 0) {
+                total = base;
+                if (total < N) break;                // round failed: no emit pass
+            }
+        }
+        if (total >= N || host_noise) break;         // host noise: the caller supplies the next draw
+    }
+    if (lane == 0) accepted[c] = total;
+}
+
+__global__ void quat_to_rotmat_kernel(const float* __restrict__ q, float* __restrict__ r, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float R[9];
+    quat_to_rotmat_dev(q[i * 4 + 0], q[i * 4 + 1], q[i * 4 + 2], q[i * 4 + 3], R);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) r[(size_t)i * 9 + e] = R[e];
+}
+
+// utils/rigid_transform_utils.py:80-94.  F.normalize: v / max(||v||, 1e-12).
+__global__ void rot6d_to_rotmat_kernel(const float* __restrict__ x, float* __restrict__ r, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* s = x + (size_t)i * 6;                 // view(-1,3,2): a1 = s[0],s[2],s[4]; a2 = s[1],s[3],s[5]
+    float a1[3] = {s[0], s[2], s[4]}, a2[3] = {s[1], s[3], s[5]};
+    float n1 = fmaxf(sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]), 1e-12f);
+    float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+    float d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+    float u[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+    float n2 = fmaxf(sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1e-12f);
+    float b2[3] = {u[0] / n2, u[1] / n2, u[2] / n2};
+    float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
+    float* o = r + (size_t)i * 9;                       // stack((b1,b2,b3), dim=-1): columns
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o[k * 3 + 0] = b1[k]; o[k * 3 + 1] = b2[k]; o[k * 3 + 2] = b3[k]; }
+}
+
+__global__ void rodrigues_kernel(const float* __restrict__ aa, float* __restrict__ r, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float R[9];
+    rodrigues_dev(aa[i * 3 + 0], aa[i * 3 + 1], aa[i * 3 + 2], R);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) r[(size_t)i * 9 + e] = R[e];
+}
+
+}  // namespace hps
+
+using namespace hps;
+
+extern "C" int hps_mf_sample(const float* pose_u, const float* pose_s, const float* pose_v, const float* bingham_a,
+                             int C, int num_joints, int num_samples, int n_prop, float b, float m_star, const float* eps, const float* w,
+                             const int32_t* draw_idx, uint64_t seed, int64_t call_offset, int max_rounds,
+                             float* r_out, float* quat_out, int32_t* accepted, hps_stream_t stream) {
+    if (!pose_u || !pose_s || !pose_v || !r_out || !accepted) return bad_arg("hps_mf_sample: null pointer");
+    if ((eps != nullptr) != (w != nullptr) || (eps && !draw_idx)) return bad_arg("hps_mf_sample: eps, w and draw_idx go together");
+    if (num_joints <= 0 || C % num_joints != 0) return bad_arg("hps_mf_sample: C must be a multiple of num_joints");
+    if (num_samples <= 0 || n_prop < num_samples || !(b > 0.f)) return bad_arg("hps_mf_sample: num_samples / n_prop / b");
+    if (max_rounds < 1) max_rounds = 1;
+    if (C == 0) return HPS_OK;
+    hipLaunchKernelGGL(mf_sample_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, pose_u, pose_s, pose_v,
+                       bingham_a, num_joints, num_samples, n_prop, b, m_star, eps, w, draw_idx, seed, call_offset, max_rounds,
+                       r_out, quat_out, accepted);
+    return check_launch("hps_mf_sample");
+}
+
+extern "C" int hps_quat_to_rotmat(const float* quat, float* rotmat, int n, hps_stream_t stream) {
+    if (!quat || !rotmat) return bad_arg("hps_quat_to_rotmat: null pointer");
+    if (n <= 0) return HPS_OK;
+    hipLaunchKernelGGL(quat_to_rotmat_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, quat, rotmat, n);
+    return check_launch("hps_quat_to_rotmat");
+}
+
+extern "C" int hps_rot6d_to_rotmat(const float* x6, float* rotmat, int n, hps_stream_t stream) {
+    if (!x6 || !rotmat) return bad_arg("hps_rot6d_to_rotmat: null pointer");
+    if (n <= 0) return HPS_OK;
+    hipLaunchKernelGGL(rot6d_to_rotmat_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, x6, rotmat, n);
+    return check_launch("hps_rot6d_to_rotmat");
+}
+
+extern "C" int hps_batch_rodrigues(const float* aa, float* rotmat, int n, hps_stream_t stream) {
+    if (!aa || !rotmat) return bad_arg("hps_batch_rodrigues: null pointer");
+    if (n <= 0) return HPS_OK;
+    hipLaunchKernelGGL(rodrigues_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, aa, rotmat, n);
+    return check_launch("hps_batch_rodrigues");
+}

@@ -1,0 +1,173 @@
+"""``PoseMFShapeGaussianNet`` with the constructor, state-dict layout and forward contract of the
+reference's models/poseMF_shapeGaussian_net.py, executed by libhps.so.
+
+    net = PoseMFShapeGaussianNet(smpl_parents=smpl.parents.tolist(), config=cfg).to(device).eval()
+    net.load_state_dict(checkpoint['best_model_state_dict'])
+    pose_F, pose_U, pose_S, pose_V, pose_rotmats_mode, shape_dist, glob, cam = net(proxy_rep_input)
+
+Execution: ResNet-18 encoder (resnet.py) -> FC trunk (hps_linear) -> the 23 per-joint MLPs grouped into
+kinematic depth levels (hps_head_joint_level; 8 levels for the SMPL tree instead of 23 sequential steps)
+-> 3x3 SVD -> proper-SVD fix and mode (hps_head_svd_finish).
+
+3x3 SVD: like the reference (models/poseMF_shapeGaussian_net.py:137, "SVD is faster on CPU") the SVD
+itself runs on the host through LAPACK -- one batched call per level.  This is deliberate, not a
+fallback: the column signs LAPACK returns are not determined by the mathematics, they feed the child
+joints' MLPs through U_proper (:126-130), and the trained weights were fitted to them (SURVEY.md section 7
+hard part 1).  Everything around it (MLPs, determinants, proper fix, mode) runs on the device.
+"""
+import torch
+from torch import nn
+from torch.distributions import Normal
+
+from . import _capi
+from .resnet import resnet18
+from .rigid_transform_utils import rotmat_to_rot6d
+
+
+def immediate_parents_to_all_parents(immediate_parents):
+    """models/poseMF_shapeGaussian_net.py:14-21: for every body joint (SMPL joint - 1) the list of its
+    ancestors, nearest first, the root excluded.  Returned as a plain dict joint -> list."""
+    all_parents = {}
+    for smpl_idx in range(1, len(immediate_parents)):
+        joint, parent = smpl_idx - 1, immediate_parents[smpl_idx] - 1
+        all_parents[joint] = [parent] + all_parents[parent] if parent >= 0 else []
+    return all_parents
+
+
+class PoseMFShapeGaussianNet(nn.Module):
+    def __init__(self, smpl_parents, config):
+        super().__init__()
+        self.config = config
+        self.parents_dict = immediate_parents_to_all_parents(smpl_parents)
+        self.num_joints = len(self.parents_dict)
+        self.num_pose_params = self.num_joints * 9
+        self.num_shape_params = config.MODEL.NUM_SMPL_BETAS
+        self.num_glob_params = 6
+        self.num_cam_params = 3
+        self.register_buffer("init_glob", rotmat_to_rot6d(torch.eye(3)[None, :].float()))
+        self.register_buffer("init_cam", torch.tensor([0.9, 0.0, 0.0]).float())
+
+        if config.MODEL.NUM_RESNET_LAYERS != 18:
+            raise NotImplementedError("only the ResNet-18 encoder of the released model is implemented")
+        self.image_encoder = resnet18(in_channels=config.MODEL.NUM_IN_CHANNELS, pretrained=False)
+        num_image_features, fc1_dim = 512, 512
+        embed_dim = config.MODEL.EMBED_DIM
+
+        self.activation = nn.ELU()
+        self.fc1 = nn.Linear(num_image_features, fc1_dim)
+        self.fc_shape = nn.Linear(fc1_dim, self.num_shape_params * 2)
+        self.fc_glob = nn.Linear(fc1_dim, self.num_glob_params)
+        self.fc_cam = nn.Linear(fc1_dim, self.num_cam_params)
+        self.fc_embed = nn.Linear(num_image_features + self.num_shape_params * 2 + self.num_glob_params
+                                  + self.num_cam_params, embed_dim)
+        self.fc_pose = nn.ModuleList()
+        for joint in range(self.num_joints):
+            in_dim = embed_dim + len(self.parents_dict[joint]) * (9 + 3 + 9)
+            self.fc_pose.append(nn.Sequential(nn.Linear(in_dim, embed_dim // 2), self.activation,
+                                              nn.Linear(embed_dim // 2, 9)))
+        # kinematic depth levels: joints whose ancestors are all in earlier levels
+        depth = [len(self.parents_dict[j]) for j in range(self.num_joints)]
+        self.levels = [[j for j in range(self.num_joints) if depth[j] == d] for d in range(max(depth) + 1)]
+        self._prepared = None
+
+    # ---- kernel-side weights; rebuilt after .to() / load_state_dict ----
+    def _apply(self, fn, *args, **kwargs):
+        self._prepared = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._prepared = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def prepare(self):
+        dev = self.fc1.weight.device
+        t = lambda w: w.detach().float().t().contiguous()
+        c = lambda w: w.detach().float().contiguous()
+        nsh, ng, nc = self.num_shape_params * 2, self.num_glob_params, self.num_cam_params
+        p = {}
+        p["fc1_wt"], p["fc1_b"] = t(self.fc1.weight), c(self.fc1.bias)
+        # fc_shape | fc_glob | fc_cam fused into one (512 -> 29) layer; init_glob / init_cam as addend
+        p["sgc_wt"] = t(torch.cat([self.fc_shape.weight, self.fc_glob.weight, self.fc_cam.weight], dim=0))
+        p["sgc_b"] = c(torch.cat([self.fc_shape.bias, self.fc_glob.bias, self.fc_cam.bias]))
+        p["sgc_add"] = c(torch.cat([torch.zeros(nsh, device=dev), self.init_glob.reshape(-1), self.init_cam.reshape(-1)]))
+        p["embed_wt"], p["embed_b"] = t(self.fc_embed.weight), c(self.fc_embed.bias)
+        w1t = [t(m[0].weight) for m in self.fc_pose]
+        b1 = [c(m[0].bias) for m in self.fc_pose]
+        w2 = [c(m[2].weight) for m in self.fc_pose]
+        b2 = [c(m[2].bias) for m in self.fc_pose]
+        p["keep"] = (w1t, b1, w2, b2)                      # owners of the device memory behind the pointer tables
+        ptrs = lambda ts: torch.tensor([x.data_ptr() for x in ts], dtype=torch.int64, device=dev)
+        p["w1t_ptrs"], p["b1_ptrs"], p["w2_ptrs"], p["b2_ptrs"] = ptrs(w1t), ptrs(b1), ptrs(w2), ptrs(b2)
+        anc_ptr, anc_idx = [0], []
+        for j in range(self.num_joints):
+            anc_idx.extend(self.parents_dict[j])
+            anc_ptr.append(len(anc_idx))
+        p["anc_ptr"] = torch.tensor(anc_ptr, dtype=torch.int32, device=dev)
+        p["anc_idx"] = torch.tensor(anc_idx if anc_idx else [0], dtype=torch.int32, device=dev)
+        p["levels"] = [torch.tensor(l, dtype=torch.int32, device=dev) for l in self.levels]
+        p["levels_long"] = [torch.tensor(l, dtype=torch.long, device=dev) for l in self.levels]
+        self._prepared = p
+        return p
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, input, input_feats=None):
+        """models/poseMF_shapeGaussian_net.py:85-162.  input: (B,C,D,D); ``input_feats`` skips the encoder."""
+        if input_feats is None:
+            input_feats = self.image_encoder(input)
+        _capi.require_device(input_feats, "input_feats")
+        p = self._prepared or self.prepare()
+        feats = _capi.f32c(input_feats)
+        B = feats.shape[0]
+        dev = feats.device
+        nj = self.num_joints
+        nsh, ng, nc = self.num_shape_params * 2, self.num_glob_params, self.num_cam_params
+        embed_dim = self.config.MODEL.EMBED_DIM
+        P, s = _capi.ptr, _capi.stream()
+        f32 = dict(device=dev, dtype=torch.float32)
+
+        # trunk (:95-110).  cat_buf = [feats | shape_params | glob | cam] is fc_embed's input.
+        nf = feats.shape[1]
+        ld = nf + nsh + ng + nc
+        cat_buf = torch.empty(B, ld, **f32)
+        cat_buf[:, :nf] = feats
+        x = torch.empty(B, p["fc1_wt"].shape[1], **f32)
+        _capi.call("hps_linear", P(feats), nf, P(p["fc1_wt"]), P(p["fc1_b"]), None, P(x), x.shape[1], B, nf,
+                   x.shape[1], 1, s)
+        sgc_view = cat_buf[:, nf:]                         # written in place with row stride ld
+        _capi.call("hps_linear", P(x), x.shape[1], P(p["sgc_wt"]), P(p["sgc_b"]), P(p["sgc_add"]),
+                   _capi._P(sgc_view.data_ptr()), ld, B, x.shape[1], nsh + ng + nc, 0, s)
+        embed = torch.empty(B, embed_dim, **f32)
+        _capi.call("hps_linear", P(cat_buf), ld, P(p["embed_wt"]), P(p["embed_b"]), None, P(embed), embed_dim, B,
+                   ld, embed_dim, 1, s)
+        shape_params = cat_buf[:, nf:nf + nsh]
+        shape_mean = shape_params[:, :self.num_shape_params]
+        shape_log_std = shape_params[:, self.num_shape_params:]
+        shape_dist = Normal(loc=shape_mean, scale=torch.exp(shape_log_std), validate_args=False)
+        glob = cat_buf[:, nf + nsh:nf + nsh + ng].clone()
+        cam = cat_buf[:, nf + nsh + ng:].clone()
+
+        # hierarchical pose prediction (:121-160), one kinematic level at a time
+        pose_F = torch.zeros(B, nj, 3, 3, **f32)
+        pose_U = torch.zeros(B, nj, 3, 3, **f32)
+        pose_S = torch.zeros(B, nj, 3, **f32)
+        pose_V = torch.zeros(B, nj, 3, 3, **f32)
+        U_proper = torch.zeros(B, nj, 3, 3, **f32)
+        S_proper = torch.zeros(B, nj, 3, **f32)
+        mode = torch.zeros(B, nj, 3, 3, **f32)
+        delta = float(self.config.MODEL.DELTA_I_WEIGHT) if self.config.MODEL.DELTA_I else 0.0
+        for lvl, lvl_long in zip(p["levels"], p["levels_long"]):
+            n_level = lvl.numel()
+            _capi.call("hps_head_joint_level", P(embed), embed_dim, embed_dim // 2, _capi.iptr(lvl), n_level,
+                       _capi.iptr(p["anc_ptr"]), _capi.iptr(p["anc_idx"]),
+                       _capi._P(p["w1t_ptrs"].data_ptr()), _capi._P(p["b1_ptrs"].data_ptr()),
+                       _capi._P(p["w2_ptrs"].data_ptr()), _capi._P(p["b2_ptrs"].data_ptr()),
+                       P(U_proper), P(S_proper), P(mode), delta, P(pose_F), B, nj, s)
+            # host LAPACK SVD of the level's (B * n_level) 3x3 matrices (:137), see module docstring
+            F_host = pose_F[:, lvl_long].cpu()
+            U_h, S_h, Vh_h = torch.linalg.svd(F_host)
+            pose_U[:, lvl_long] = U_h.to(dev, non_blocking=True)
+            pose_S[:, lvl_long] = S_h.to(dev, non_blocking=True)
+            pose_V[:, lvl_long] = Vh_h.transpose(-1, -2).contiguous().to(dev, non_blocking=True)
+            _capi.call("hps_head_svd_finish", P(pose_U), P(pose_S), P(pose_V), _capi.iptr(lvl), n_level,
+                       P(U_proper), P(S_proper), P(mode), B, nj, s)
+        return pose_F, pose_U, pose_S, pose_V, mode, shape_dist, glob, cam

@@ -1,0 +1,101 @@
+"""Per-image inference harness: the batched core of the reference's
+predict/predict_poseMF_shapeGaussian_net.py:103-165 (``infer``) and a ``predict_poseMF_shapeGaussian_net``
+with the reference's signature (:19-32) that feeds it.
+
+Everything between the proxy representation and the sampled meshes runs on the device through
+libhps.so.  The stages before it (image IO, HRNet keypoints, cropping, Canny edges, heatmaps; :61-100) and
+after it (rendering, PNG writing; :167-333) are out of scope and stay
+injected objects: ``hrnet_model`` / ``edge_detect_model`` / ``object_detect_model`` are whatever the caller
+built, and ``proxy_rep_fn`` may replace the whole front end.
+"""
+import os
+
+import torch
+
+from . import _capi
+from .rigid_transform_utils import rot6d_to_rotmat, batch_rodrigues
+from .sampling_utils import compute_vertex_uncertainties_by_poseMF_shapeGaussian_sampling
+
+
+@torch.no_grad()
+def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mean_shape=True,
+          sample_on_cpu=False, seed=None, image_offset=0, input_feats=None):
+    """predict/predict_poseMF_shapeGaussian_net.py:103-165 for a batch of B proxy representations.
+
+    proxy_rep_input: (B,18,256,256) on the device.  Returns a dict of device tensors; every entry equals
+    what looping the reference's batch-1 code over the images yields:
+      pose_F/U/V (B,23,3,3), pose_S (B,23,3), pose_rotmats_mode (B,23,3,3), shape_loc/shape_scale (B,10),
+      glob (B,6), cam (B,3), glob_rotmats (B,3,3), verts_mode (B,6890,3), joints_mode (B,90,3),
+      verts_tpose (B,6890,3), R_samples (B,N,23,3,3), verts_samples (B,N,6890,3),
+      joints_samples (B,N,90,3), unc (B,6890).
+    """
+    pose_F, pose_U, pose_S, pose_V, mode, shape_dist, glob, cam = pose_shape_model(proxy_rep_input,
+                                                                                   input_feats=input_feats)
+    B = pose_F.shape[0]
+    if glob.shape[-1] == 3:                                                       # :107-110
+        glob_rotmats = batch_rodrigues(glob)
+    else:
+        glob_rotmats = rot6d_to_rotmat(glob)
+    out_mode = smpl_model(body_pose=mode, global_orient=glob_rotmats.unsqueeze(1), betas=shape_dist.loc,
+                          pose2rot=False)                                         # :112-115
+    dev = pose_F.device
+    out_tpose = smpl_model(betas=shape_dist.loc, global_orient=torch.zeros(B, 3, device=dev),
+                           body_pose=torch.zeros(B, 69, device=dev))             # :136 (zero pose), per image
+    unc, verts_s, joints_s, R = compute_vertex_uncertainties_by_poseMF_shapeGaussian_sampling(
+        pose_U=pose_U, pose_S=pose_S, pose_V=pose_V, shape_distribution=shape_dist, glob_rotmats=glob_rotmats,
+        num_samples=num_samples, smpl_model=smpl_model, use_mean_shape=use_mean_shape,
+        sample_on_cpu=sample_on_cpu, seed=seed, image_offset=image_offset, return_rotmats=True)   # :157-165
+    if B == 1:
+        unc, verts_s, joints_s = unc[None], verts_s[None], joints_s[None]
+    return dict(pose_F=pose_F, pose_U=pose_U, pose_S=pose_S, pose_V=pose_V, pose_rotmats_mode=mode,
+                shape_loc=shape_dist.loc, shape_scale=shape_dist.scale, glob=glob, cam=cam,
+                glob_rotmats=glob_rotmats, verts_mode=out_mode.vertices, joints_mode=out_mode.joints,
+                verts_tpose=out_tpose.vertices, R_samples=R, verts_samples=verts_s, joints_samples=joints_s,
+                unc=unc)
+
+
+def predict_poseMF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_model, hrnet_model, hrnet_cfg,
+                                     edge_detect_model, device, image_dir, save_dir, object_detect_model=None,
+                                     joints2Dvisib_threshold=0.75, visualise_wh=512, visualise_uncropped=True,
+                                     visualise_samples=False, proxy_rep_fn=None, num_samples=50, batch_size=1,
+                                     result_fn=None):
+    """Signature of predict/predict_poseMF_shapeGaussian_net.py:19-32 plus three keyword extensions.
+
+    proxy_rep_fn(image_path) -> (1,18,D,D) tensor replaces the reference's front end (:61-100: cv2 image
+    load, HRNet, crop, Canny, heatmaps), which depends on cv2 / torchvision detectors that are outside the
+    hot path; without it the injected hrnet_model / edge_detect_model must be callables with the
+    reference's interfaces and cv2 must be importable.  result_fn(image_name, result_dict) receives the
+    outputs instead of the reference's pytorch3d renderer; by default vertices / joints / uncertainties are
+    saved as <save_dir>/<image>.pt.
+    """
+    pose_shape_model.eval()
+    image_fnames = sorted(f for f in os.listdir(image_dir) if f.lower().endswith((".png", ".jpg", ".jpeg")))
+    if proxy_rep_fn is None:
+        proxy_rep_fn = _reference_front_end(pose_shape_cfg, hrnet_model, hrnet_cfg, edge_detect_model,
+                                            object_detect_model, joints2Dvisib_threshold, device)
+    os.makedirs(save_dir, exist_ok=True)
+    for i0 in range(0, len(image_fnames), batch_size):
+        names = image_fnames[i0:i0 + batch_size]
+        proxy = torch.cat([proxy_rep_fn(os.path.join(image_dir, n)).to(device).float() for n in names], dim=0)
+        res = infer(pose_shape_model, smpl_model, proxy, num_samples=num_samples, use_mean_shape=True)
+        for k, n in enumerate(names):
+            item = {key: val[k] for key, val in res.items()}
+            if result_fn is not None:
+                result_fn(n, item)
+            else:
+                keep = ("verts_mode", "joints_mode", "verts_tpose", "unc", "cam", "glob_rotmats")
+                torch.save({key: item[key].cpu() for key in keep},
+                           os.path.join(save_dir, os.path.splitext(n)[0] + ".pt"))
+
+
+def _reference_front_end(pose_shape_cfg, hrnet_model, hrnet_cfg, edge_detect_model, object_detect_model,
+                         joints2Dvisib_threshold, device):
+    """Front end of predict/...:61-100 assembled from the injected reference-interface objects."""
+    try:
+        import cv2  # noqa: F401
+    except ImportError as e:
+        raise _capi.HpsError(
+            "the image front end (cv2 + HRNet + Canny, predict/predict_poseMF_shapeGaussian_net.py:61-100) is "
+            "outside this package's hot path; pass proxy_rep_fn= or install cv2 and inject the reference's "
+            "hrnet_model / edge_detect_model") from e
+    raise _capi.HpsError("pass proxy_rep_fn=: the HRNet/Canny front end is not part of this package")

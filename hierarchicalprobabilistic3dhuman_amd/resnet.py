@@ -1,0 +1,155 @@
+"""ResNet-18 image encoder (final FC removed) with the module tree and state-dict keys of the reference's
+models/resnet.py, executed as implicit-GEMM convolutions on the gfx950 fp32 matrix cores.
+
+The ``nn.Conv2d`` / ``nn.BatchNorm2d`` children only hold parameters (so that
+``load_state_dict(checkpoint['best_model_state_dict'])`` and default initialisation behave exactly as in
+the reference); their own forward is never used.  Inference only: BatchNorm uses running statistics
+(the reference runs the encoder under ``model.eval()``, predict/...:55) and is fused, together with the
+residual add and ReLU, into the convolution epilogue.
+"""
+import torch
+from torch import nn
+
+from . import _capi
+
+
+class _ConvBN:
+    """Kernel-side form of conv + eval BatchNorm: k-major filter (ceil16(KH*KW*Cin_p), Cout), scale, shift."""
+
+    def __init__(self, conv, bn, cin_pad=None):
+        w = conv.weight.detach().float()                      # (Cout, Cin, KH, KW)
+        cout, cin, kh, kw = w.shape
+        cin_p = cin if cin_pad is None else cin_pad
+        wk = torch.zeros(kh, kw, cin_p, cout, device=w.device, dtype=torch.float32)
+        wk[:, :, :cin, :] = w.permute(2, 3, 1, 0)
+        k_real = kh * kw * cin_p
+        k_pad = (k_real + 15) // 16 * 16
+        flat = torch.zeros(k_pad, cout, device=w.device, dtype=torch.float32)
+        flat[:k_real] = wk.reshape(k_real, cout)
+        self.wk = flat.contiguous()
+        inv_std = torch.rsqrt(bn.running_var.detach().double() + bn.eps)
+        scale = bn.weight.detach().double() * inv_std
+        self.scale = scale.float().contiguous()
+        self.shift = (bn.bias.detach().double() - bn.running_mean.detach().double() * scale).float().contiguous()
+        self.cin_p, self.cout, self.kh, self.kw = cin_p, cout, kh, kw
+        self.stride, self.pad = conv.stride[0], conv.padding[0]
+
+    def __call__(self, x, residual=None, relu=True):
+        B, H, W, C = x.shape
+        assert C == self.cin_p
+        Ho = (H + 2 * self.pad - self.kh) // self.stride + 1
+        Wo = (W + 2 * self.pad - self.kw) // self.stride + 1
+        y = torch.empty(B, Ho, Wo, self.cout, device=x.device, dtype=torch.float32)
+        P = _capi.ptr
+        _capi.call("hps_conv2d_bn_act", P(x), P(self.wk), P(self.scale), P(self.shift),
+                   P(residual) if residual is not None else None, P(y), B, H, W, C, self.cout, self.kh, self.kw,
+                   self.stride, self.pad, 1 if relu else 0, _capi.stream())
+        return y
+
+
+class BasicBlock(nn.Module):
+    """models/resnet.py:40-78 (parameter container; executed by ResNet._run_block)."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class ResNet(nn.Module):
+    """models/resnet.py:125-217 for BasicBlock stacks."""
+
+    def __init__(self, layers, in_channels):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(in_channels, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, layers[0])
+        self.layer2 = self._make_layer(128, layers[1], stride=2)
+        self.layer3 = self._make_layer(256, layers[2], stride=2)
+        self.layer4 = self._make_layer(512, layers[3], stride=2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        # same initialisation, in the same module order, as models/resnet.py:161-166
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        self._prepared = None
+
+    def _make_layer(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes, kernel_size=1, stride=stride, bias=False),
+                                       nn.BatchNorm2d(planes))
+        blks = [BasicBlock(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes
+        for _ in range(1, blocks):
+            blks.append(BasicBlock(planes, planes))
+        return nn.Sequential(*blks)
+
+    # ---- weight preparation (BN folding, k-major filters); redone after .to() / load_state_dict ----
+    def _apply(self, fn, *args, **kwargs):
+        self._prepared = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._prepared = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def prepare(self):
+        cin = self.conv1.in_channels
+        self._cin_pad = (cin + 3) // 4 * 4
+        prep = {"stem": _ConvBN(self.conv1, self.bn1, cin_pad=self._cin_pad), "blocks": []}
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                down = _ConvBN(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
+                prep["blocks"].append((_ConvBN(blk.conv1, blk.bn1), _ConvBN(blk.conv2, blk.bn2), down))
+        self._prepared = prep
+        return prep
+
+    def forward(self, x):
+        """models/resnet.py:202-217: (B,C,H,W) NCHW fp32 -> (B,512)."""
+        _capi.require_device(x, "encoder input")
+        if self.training:
+            raise RuntimeError("the MI355X encoder path is inference-only (eval-mode BatchNorm); call .eval()")
+        prep = self._prepared or self.prepare()
+        x = _capi.f32c(x)
+        B, C, H, W = x.shape
+        s = _capi.stream()
+        P = _capi.ptr
+        cp = self._cin_pad
+        if cp not in (4, 20, 64):
+            raise _capi.HpsError("in_channels=%d unsupported by hps_nchw_to_nhwc (padded %d)" % (C, cp))
+        xh = torch.empty(B, H, W, cp, device=x.device, dtype=torch.float32)
+        _capi.call("hps_nchw_to_nhwc", P(x), P(xh), B, C, H, W, cp, s)
+        y = prep["stem"](xh, relu=True)                                    # conv1 + bn1 + relu
+        Bh, Hh, Wh, Ch = y.shape
+        Hp, Wp = (Hh + 2 - 3) // 2 + 1, (Wh + 2 - 3) // 2 + 1
+        yp = torch.empty(B, Hp, Wp, Ch, device=x.device, dtype=torch.float32)
+        _capi.call("hps_maxpool3x3s2", P(y), P(yp), B, Hh, Wh, Ch, s)
+        y = yp
+        for c1, c2, down in prep["blocks"]:                                # BasicBlock.forward :62-78
+            identity = down(y, relu=False) if down is not None else y
+            out = c1(y, relu=True)
+            y = c2(out, residual=identity, relu=True)
+        Bq, Hq, Wq, Cq = y.shape
+        feats = torch.empty(B, Cq, device=x.device, dtype=torch.float32)
+        _capi.call("hps_global_avgpool", P(y), P(feats), B, Hq * Wq, Cq, s)
+        return feats
+
+
+def resnet18(in_channels, pretrained=False, progress=True, **kwargs):
+    """models/resnet.py:229-237 (pretrained ImageNet weights are never used by the reference's nets)."""
+    if pretrained:
+        raise NotImplementedError("no network access: pretrained weights are not available")
+    return ResNet([2, 2, 2, 2], in_channels)

@@ -1,0 +1,168 @@
+"""Matrix-Fisher sampling and sample-mesh uncertainty with the call surface of the reference's
+utils/sampling_utils.py, executed by libhps.so (hps_mf_sample: one wavefront per (image, joint)).
+
+Random numbers
+  ``sample_on_cpu=True``  -- the reference's seed-reproducible route (run_evaluate.py:83-94): the
+      proposal noise is drawn on the host from torch's global CPU generator in exactly the reference's
+      order (per image, per joint: randn(8N,4) then rand(8N); one more pair per discarded round,
+      utils/sampling_utils.py:51,60,128-137) and uploaded; the rejection test, compaction, quaternion ->
+      rotation and U R V^T run on the device.  Same torch.manual_seed => same samples as the reference's
+      CPU path, up to accept decisions that sit on an fp32 rounding tie.
+  ``sample_on_cpu=False`` -- counter-based Philox4x32-10 inside the kernel, keyed by
+      (seed, global image index, joint, round, proposal): independent of batch size and of how images
+      are sharded over GPUs.  ``seed=None`` takes the seed from torch's global CPU generator, so
+      torch.manual_seed() still controls it.
+"""
+import numpy as np
+import torch
+
+from . import _capi
+
+_MAX_ROUNDS = 64
+
+
+def _m_star(b):
+    # utils/sampling_utils.py:46 / :125
+    return float(np.exp(-(4 - b) / 2) * ((4 / b) ** 2))
+
+
+def _launch(pose_U, pose_S, pose_V, num_samples, n_prop, b, eps=None, w=None, draw_idx=None, seed=0,
+            call_offset=0, bingham_a=None, want_quat=False):
+    B, nj = pose_U.shape[:2]
+    C = B * nj
+    dev = pose_U.device
+    R = torch.empty(B, num_samples, nj, 3, 3, device=dev, dtype=torch.float32)
+    quat = torch.empty(B, num_samples, nj, 4, device=dev, dtype=torch.float32) if want_quat else None
+    accepted = torch.empty(C, device=dev, dtype=torch.int32)
+    P = _capi.ptr
+    _capi.call("hps_mf_sample", P(pose_U), P(pose_S), P(pose_V), P(bingham_a) if bingham_a is not None else None,
+               C, nj, num_samples, n_prop, float(b), _m_star(b),
+               P(eps) if eps is not None else None, P(w) if w is not None else None,
+               _capi.iptr(draw_idx) if draw_idx is not None else None,
+               int(seed) & 0xFFFFFFFFFFFFFFFF, int(call_offset), _MAX_ROUNDS,
+               P(R), P(quat) if quat is not None else None, _capi.iptr(accepted), _capi.stream())
+    return R, quat, accepted
+
+
+def _host_stream_sampling(pose_U, pose_S, pose_V, num_samples, n_prop, b, bingham_a=None, want_quat=False):
+    """Reference-order host noise; rare discarded rounds (fewer than N accepted, :68-69) shift every later
+    call one draw further down the stream, exactly as the sequential reference loop would."""
+    B, nj = pose_U.shape[:2]
+    C = B * nj
+    dev = pose_U.device
+    eps_l, w_l = [], []
+
+    def draw(n):
+        for _ in range(n):
+            eps_l.append(torch.randn(n_prop, 4).float())      # :51
+            w_l.append(torch.rand(n_prop))                      # :60
+
+    draw(C)
+    assign = torch.arange(C, dtype=torch.int32)
+    while True:
+        eps = torch.stack(eps_l).to(dev)
+        w = torch.stack(w_l).to(dev)
+        R, quat, accepted = _launch(pose_U, pose_S, pose_V, num_samples, n_prop, b, eps=eps, w=w,
+                                    draw_idx=assign.to(dev), bingham_a=bingham_a, want_quat=want_quat)
+        fails = (accepted.cpu() < num_samples).nonzero().flatten()
+        if fails.numel() == 0:
+            return R, quat, accepted
+        first = int(fails[0])
+        assign[first:] += 1          # call `first` retries with the next pair; later calls shift along
+        draw(1)
+
+
+def _philox_seed(seed):
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    return seed
+
+
+def bingham_sampling_for_matrix_fisher_torch(A, num_samples, Omega=None, Gaussian_std=None, b=1.5, M_star=None,
+                                             oversampling_ratio=8, sample_on_cpu=False, seed=None):
+    """utils/sampling_utils.py:10-71: A (4,) diagonal Bingham parameter -> (samples (N,4), accept_ratio).
+
+    Omega / Gaussian_std / M_star are derived from A and b in the kernel (their defaults at :42-46);
+    passing different values is not supported."""
+    _capi.require_device(A, "A")
+    assert A.shape == (4,)
+    assert A.min() >= 0
+    for given, derived, name in ((Omega, 1 + 2 * A / b, "Omega"),
+                                 (Gaussian_std, (1 + 2 * A / b) ** -0.5, "Gaussian_std")):
+        if given is not None and not torch.allclose(given.to(A.device), derived, rtol=1e-5, atol=1e-6):
+            raise NotImplementedError("%s must be the value derived from A and b" % name)
+    if M_star is not None and abs(float(M_star) - _m_star(b)) > 1e-6:
+        raise NotImplementedError("M_star must be the value derived from b")
+    dev = A.device
+    eye = torch.eye(3, device=dev).reshape(1, 1, 3, 3).contiguous()
+    S = torch.zeros(1, 1, 3, device=dev)
+    a = _capi.f32c(A).reshape(1, 4)
+    n_prop = num_samples * oversampling_ratio
+    if sample_on_cpu:
+        _, quat, accepted = _host_stream_sampling(eye, S, eye, num_samples, n_prop, b, bingham_a=a, want_quat=True)
+    else:
+        _, quat, accepted = _launch(eye, S, eye, num_samples, n_prop, b, seed=_philox_seed(seed), bingham_a=a,
+                                    want_quat=True)
+    accept_ratio = int(accepted[0].item()) / num_samples * 4            # :67 (as meaningless as the original)
+    return quat[0, :, 0, :], accept_ratio
+
+
+def pose_matrix_fisher_sampling_torch(pose_U, pose_S, pose_V, num_samples, b=1.5, oversampling_ratio=8,
+                                      sample_on_cpu=False, seed=None, image_offset=0):
+    """utils/sampling_utils.py:74-143: (B,23,3,3), (B,23,3), (B,23,3,3) -> R_samples (B,N,23,3,3).
+
+    ``image_offset``: global index of the first image of this batch (multi-GPU sharding); only used by
+    the Philox route."""
+    for t, name in ((pose_U, "pose_U"), (pose_S, "pose_S"), (pose_V, "pose_V")):
+        _capi.require_device(t, name)
+    U, S, V = _capi.f32c(pose_U), _capi.f32c(pose_S), _capi.f32c(pose_V)
+    n_prop = num_samples * oversampling_ratio
+    if sample_on_cpu:
+        R, _, _ = _host_stream_sampling(U, S, V, num_samples, n_prop, b)
+    else:
+        nj = U.shape[1]
+        R, _, _ = _launch(U, S, V, num_samples, n_prop, b, seed=_philox_seed(seed), call_offset=image_offset * nj)
+    return R
+
+
+def vertex_uncertainty(vertices_samples):
+    """utils/sampling_utils.py:189-190, batched: (B,N,V,3) -> (B,V)."""
+    _capi.require_device(vertices_samples, "vertices_samples")
+    v = _capi.f32c(vertices_samples)
+    B, N, V = v.shape[:3]
+    unc = torch.empty(B, V, device=v.device, dtype=torch.float32)
+    _capi.call("hps_vertex_uncertainty", _capi.ptr(v), _capi.ptr(unc), B, N, V, _capi.stream())
+    return unc
+
+
+def compute_vertex_uncertainties_by_poseMF_shapeGaussian_sampling(pose_U, pose_S, pose_V, shape_distribution,
+                                                                  glob_rotmats, num_samples, smpl_model,
+                                                                  use_mean_shape=False, sample_on_cpu=False,
+                                                                  seed=None, image_offset=0, return_rotmats=False):
+    """utils/sampling_utils.py:146-192.  The reference asserts batch size 1 (:171); here any B is accepted
+    and the result equals looping the B = 1 function over the images (the flattened (B*N) SMPL call is the
+    reference's own training-path precedent, train/train_poseMF_shapeGaussian_net.py:304-308).
+
+    B == 1 returns the reference's shapes: unc (6890,), vertices (N,6890,3), joints (N,90,3);
+    B > 1 returns unc (B,6890), vertices (B,N,6890,3), joints (B,N,90,3)."""
+    B = pose_U.shape[0]
+    assert pose_U.shape[0] == pose_S.shape[0] == pose_V.shape[0]
+    R = pose_matrix_fisher_sampling_torch(pose_U, pose_S, pose_V, num_samples, b=1.5, oversampling_ratio=8,
+                                          sample_on_cpu=sample_on_cpu, seed=seed, image_offset=image_offset)
+    if use_mean_shape:
+        shape = shape_distribution.loc[:, None, :].expand(B, num_samples, -1)                   # :178-179
+    else:
+        shape = shape_distribution.sample([num_samples]).transpose(0, 1)                        # :180-181, (B,N,nb)
+    glob = glob_rotmats.reshape(B, 1, 1, 3, 3).expand(B, num_samples, 1, 3, 3)
+    out = smpl_model(body_pose=R.reshape(B * num_samples, -1, 3, 3),
+                     global_orient=glob.reshape(B * num_samples, 1, 3, 3),
+                     betas=shape.reshape(B * num_samples, -1), pose2rot=False)                  # :182-185
+    V = out.vertices.shape[1]
+    verts = out.vertices.view(B, num_samples, V, 3)
+    joints = out.joints.view(B, num_samples, -1, 3)
+    unc = vertex_uncertainty(verts)                                                             # :189-190
+    if B == 1:
+        res = (unc[0], verts[0], joints[0])
+    else:
+        res = (unc, verts, joints)
+    return res + (R,) if return_rotmats else res

@@ -1,0 +1,181 @@
+"""``SMPL`` with the call surface of the reference's models/smpl_official.py (a thin subclass of
+smplx.SMPL that appends 9 + 19 + 17 regressed joints -> 90), executed by hand-written gfx950 kernels.
+
+    smpl = SMPL(model_path, batch_size=1, gender='neutral', num_betas=10).to(device)
+    out = smpl(body_pose=(M,23,3,3), global_orient=(M,1,3,3), betas=(M,10), pose2rot=False)
+    out.vertices (M,6890,3), out.joints (M,90,3)
+
+Kernel sequence per call (all on the current HIP stream, no host synchronisation):
+  hps_smpl_pose_prep  Rodrigues, rest joints, forward kinematics, blend-GEMM operand
+  hps_smpl_blend      v_template + [betas | pose feature] @ [shapedirs ; posedirs]   (fp32 MFMA)
+  hps_smpl_lbs        linear blend skinning over 6890 vertices                     (HBM bound)
+  hps_smpl_joints     24 kinematic joints + 21 vertex picks + 45 regressed joints
+"""
+from collections import namedtuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _capi
+from .configs import SMPLX_EXTRA_VERTEX_IDS
+from .smpl_data import resolve_smpl_model, load_extra_joint_regressors, parents_from_kintree
+
+SMPLOutput = namedtuple("SMPLOutput", ["vertices", "joints", "full_pose", "betas", "global_orient", "body_pose"])
+SMPLOutput.__new__.__defaults__ = (None,) * 6
+
+_LBS_K_CHOICES = (4, 8, 12, 24)
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class SMPL(nn.Module):
+    """models/smpl_official.py:12-41.  ``model_path``: directory holding SMPL_<GENDER>.pkl, a pkl path,
+    or a dict of arrays (e.g. ``smpl_data.synthetic_smpl_model()``).  ``model_files_dir`` may point at the
+    reference's model_files/ (extra joint regressors); the packaged copies are used otherwise."""
+
+    NUM_JOINTS = 24
+    NUM_BODY_JOINTS = 23
+
+    def __init__(self, model_path, batch_size=1, gender="neutral", num_betas=10, model_files_dir=None,
+                 dtype=torch.float32, **kwargs):
+        super().__init__()
+        if dtype != torch.float32:
+            raise ValueError("the gfx950 kernels compute in fp32 (the reference never changes dtype)")
+        model = resolve_smpl_model(model_path, gender=gender, num_betas=num_betas)
+        self.gender = gender
+        self.batch_size = batch_size
+        self.num_betas = num_betas
+        self.dtype = dtype
+        self.keep_intermediates = False
+
+        f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
+        v_template = np.asarray(model["v_template"], np.float64)
+        shapedirs = np.asarray(model["shapedirs"], np.float64)[:, :, :num_betas]
+        posedirs_v3k = np.asarray(model["posedirs"], np.float64)                  # (V,3,207)
+        J_regressor = np.asarray(model["J_regressor"], np.float64)
+        weights = np.asarray(model["weights"], np.float64)
+        parents = parents_from_kintree(model["kintree_table"])
+        V, J = v_template.shape[0], J_regressor.shape[0]
+        self.num_verts = V
+
+        # ---- buffers with smplx's names / layouts (what a user of the reference can inspect) ----
+        self.register_buffer("v_template", f32(v_template))
+        self.register_buffer("shapedirs", f32(shapedirs))
+        self.register_buffer("posedirs", f32(posedirs_v3k.reshape(-1, posedirs_v3k.shape[-1]).T))   # (207,3V)
+        self.register_buffer("J_regressor", f32(J_regressor))
+        self.register_buffer("lbs_weights", f32(weights))
+        self.register_buffer("parents", torch.tensor(parents, dtype=torch.long))
+        extra, cocoplus, h36m = load_extra_joint_regressors(model_files_dir)      # smpl_official.py:17-25
+        self.register_buffer("J_regressor_extra", f32(extra))
+        self.register_buffer("J_regressor_cocoplus", f32(cocoplus))
+        self.register_buffer("J_regressor_h36m", f32(h36m))
+        # zero-initialised module parameters of `batch_size` rows, the defaults smplx falls back to
+        self.betas = nn.Parameter(torch.zeros(batch_size, num_betas), requires_grad=False)
+        self.global_orient = nn.Parameter(torch.zeros(batch_size, 3), requires_grad=False)
+        self.body_pose = nn.Parameter(torch.zeros(batch_size, 69), requires_grad=False)
+
+        # ---- kernel-side constants (derived in float64, stored fp32; not part of the state dict) ----
+        nb = num_betas
+        n_pose = posedirs_v3k.shape[-1]
+        self._N = 3 * V
+        self._kp = _round_up(nb + n_pose, 16)
+        self._np = _round_up(self._N, 128)
+        bmat = np.zeros((self._kp, self._np), np.float64)
+        bmat[:nb, :self._N] = shapedirs.reshape(self._N, nb).T                    # row l: d v[n] / d beta_l
+        bmat[nb:nb + n_pose, :self._N] = posedirs_v3k.reshape(self._N, n_pose).T
+        self.register_buffer("_bmat", f32(bmat), persistent=False)
+        self.register_buffer("_v_template_flat", f32(v_template.reshape(-1)), persistent=False)
+        # joint regression folded through the linear shape blend: J = J_reg (v_t + S beta)
+        self.register_buffer("_j_template", f32(J_regressor @ v_template), persistent=False)                 # (J,3)
+        self.register_buffer("_j_shapedirs", f32(np.einsum("jv,vcl->jcl", J_regressor, shapedirs)), persistent=False)
+        depth = np.zeros(J, np.int32)
+        for j in range(1, J):
+            depth[j] = depth[parents[j]] + 1
+        self.register_buffer("_parents_i32", torch.tensor(parents, dtype=torch.int32), persistent=False)
+        self.register_buffer("_depth_i32", torch.tensor(depth, dtype=torch.int32), persistent=False)
+        # compressed skinning weights: K entries per vertex, exact when K >= max non-zeros per row
+        nnz = int((weights != 0).sum(1).max())
+        K = next(k for k in _LBS_K_CHOICES if k >= nnz)
+        order = np.argsort(-(weights != 0).astype(np.int8), axis=1, kind="stable")[:, :K]   # non-zeros first, index order
+        w_val = np.take_along_axis(weights, order, axis=1)
+        w_idx = np.where(w_val != 0, order, 0)
+        self._lbs_k = K
+        self.register_buffer("_w_idx", torch.tensor(w_idx, dtype=torch.int32).contiguous(), persistent=False)
+        self.register_buffer("_w_val", f32(w_val).contiguous(), persistent=False)
+        # joint rows after the 24 kinematic joints: 21 vertex picks (smplx VertexJointSelector), then the
+        # extra / cocoplus / h36m regressors (smpl_official.py:30-34) -- one CSR matrix over the vertices
+        picks = np.zeros((len(SMPLX_EXTRA_VERTEX_IDS), V))
+        picks[np.arange(len(SMPLX_EXTRA_VERTEX_IDS)), SMPLX_EXTRA_VERTEX_IDS] = 1.0
+        rows = [picks, extra, cocoplus, h36m]
+        dense = np.concatenate(rows, axis=0)
+        ptr_, col_, val_ = [0], [], []
+        for r in range(dense.shape[0]):
+            nz = np.nonzero(dense[r])[0]
+            col_.extend(nz.tolist())
+            val_.extend(dense[r, nz].tolist())
+            ptr_.append(len(col_))
+        self._n_joint_rows = dense.shape[0]
+        self.register_buffer("_csr_ptr", torch.tensor(ptr_, dtype=torch.int32), persistent=False)
+        self.register_buffer("_csr_col", torch.tensor(col_, dtype=torch.int32), persistent=False)
+        self.register_buffer("_csr_val", torch.tensor(val_, dtype=torch.float32), persistent=False)
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, betas=None, body_pose=None, global_orient=None, transl=None, pose2rot=True,
+                return_verts=True, return_full_pose=False, **kwargs):
+        """smplx SMPL.forward semantics as used by the reference (models/smpl_official.py:27-41):
+        omitted arguments default to the zero module parameters; betas with fewer rows than the pose
+        are expanded; ``pose2rot=False`` takes rotation matrices, otherwise axis-angle."""
+        dev = self.v_template.device
+        _capi.require_device(self.v_template, "SMPL buffers (call .to('cuda'))")
+        J = self.NUM_JOINTS
+        global_orient = self.global_orient if global_orient is None else global_orient
+        body_pose = self.body_pose if body_pose is None else body_pose
+        betas = self.betas if betas is None else betas
+        for name, t in (("betas", betas), ("body_pose", body_pose), ("global_orient", global_orient)):
+            _capi.require_device(t, name)
+        M = max(betas.shape[0], global_orient.shape[0], body_pose.shape[0])
+        if betas.shape[0] != M:
+            betas = betas.expand(int(M / betas.shape[0]), -1) if betas.shape[0] == 1 else betas.repeat(int(M / betas.shape[0]), 1)
+        if global_orient.shape[0] != M or body_pose.shape[0] != M:
+            raise ValueError("global_orient / body_pose must have the same number of rows")
+
+        g = _capi.f32c(global_orient).reshape(M, -1)
+        b = _capi.f32c(body_pose).reshape(M, -1)
+        is_rotmat = 0 if pose2rot else 1
+        exp_g, exp_b = (9, 9 * (J - 1)) if is_rotmat else (3, 3 * (J - 1))
+        if g.shape[1] != exp_g or b.shape[1] != exp_b:
+            raise ValueError("pose2rot=%s expects global_orient with %d and body_pose with %d values per mesh, got %d / %d"
+                             % (pose2rot, exp_g, exp_b, g.shape[1], b.shape[1]))
+        be = _capi.f32c(betas)
+        if be.shape[1] != self.num_betas:
+            raise ValueError("betas must have %d columns" % self.num_betas)
+        tr = None if transl is None else _capi.f32c(transl).reshape(M, 3)
+
+        V, N = self.num_verts, self._N
+        mp = _round_up(M, 128)
+        f32 = dict(device=dev, dtype=torch.float32)
+        xt = torch.empty(self._kp, mp, **f32)
+        a = torch.empty(M, J, 12, **f32)
+        j_posed = torch.empty(M, J, 3, **f32)
+        v_posed = torch.empty(M, V, 3, **f32)
+        verts = torch.empty(M, V, 3, **f32)
+        joints = torch.empty(M, J + self._n_joint_rows, 3, **f32)
+        s = _capi.stream()
+        P = _capi.ptr
+        _capi.call("hps_smpl_pose_prep", P(g), P(b), is_rotmat, P(be), self.num_betas, P(self._j_template),
+                   P(self._j_shapedirs), _capi.iptr(self._parents_i32), _capi.iptr(self._depth_i32), J, P(xt),
+                   self._kp, mp, P(a), P(j_posed), None, M, s)
+        _capi.call("hps_smpl_blend", P(xt), P(self._bmat), P(self._v_template_flat), P(v_posed), M, N, self._kp,
+                   mp, self._np, s)
+        _capi.call("hps_smpl_lbs", P(v_posed), P(a), _capi.iptr(self._w_idx), P(self._w_val), self._lbs_k, J,
+                   P(tr) if tr is not None else None, P(verts), M, V, s)
+        _capi.call("hps_smpl_joints", P(verts), P(j_posed), _capi.iptr(self._csr_ptr), _capi.iptr(self._csr_col),
+                   P(self._csr_val), self._n_joint_rows, J, P(tr) if tr is not None else None, P(joints), M, V, s)
+        full_pose = torch.cat([g, b], dim=1) if return_full_pose else None
+        if self.keep_intermediates:                                         # tests / profiling only
+            self._last = dict(xt=xt, a=a, j_posed=j_posed, v_posed=v_posed)
+        return SMPLOutput(vertices=verts if return_verts else None, joints=joints, full_pose=full_pose,
+                          betas=betas, global_orient=global_orient, body_pose=body_pose)

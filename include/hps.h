@@ -1,0 +1,188 @@
+/*
+ * hps.h -- C ABI of libhps.so: the MI355X (gfx950) hot path of HierarchicalProbabilistic3DHuman.
+ *
+ * The reference is pure Python and has no FFI layer; these entry points are what a
+ * binding for its per-image inference path would call.  Each declaration cites the reference
+ * code (file:line, relative to the reference repo) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; row-major contiguous fp32
+ *     (int32 for indices); the caller owns all memory (PyTorch tensors in the shipped binding);
+ *   - stream is a hipStream_t passed as void*; calls only enqueue work (no allocation, no
+ *     synchronisation, no host round trip);
+ *   - return value: 0 on success, otherwise a hipError_t value (> 0) or a negative HPS_E_* code;
+ *     hps_last_error() returns a thread-local description of the last failure;
+ *   - no mutable global state: safe to call from several host threads on different streams.
+ */
+#ifndef HPS_H_
+#define HPS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hps_stream_t; /* hipStream_t */
+
+#define HPS_OK 0
+#define HPS_E_BADARG (-1)      /* null pointer / size out of range */
+#define HPS_E_UNSUPPORTED (-2) /* shape not implemented by this build */
+
+#define HPS_ACT_NONE 0
+#define HPS_ACT_ELU 1
+#define HPS_ACT_RELU 2
+
+int hps_version(void);
+const char* hps_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * SMPL forward  (models/smpl_official.py:27-41 -> smplx 0.1.26 SMPL.forward / lbs)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Rodrigues / rest joints / forward kinematics / blend-GEMM operand, one launch.
+ *   glob, body : global_orient and body_pose of M meshes; rotation matrices (M,1,3,3)/(M,J-1,3,3)
+ *                if is_rotmat != 0 (pose2rot=False), else axis-angle (M,3)/(M,(J-1)*3) converted by
+ *                smplx batch_rodrigues (angle = ||r + 1e-8||).
+ *   betas      : (M, num_betas).
+ *   j_template : (J,3)   = J_regressor @ v_template          } joint regression folded through the
+ *   j_shapedirs: (J,3,nb)= J_regressor @ shapedirs           } linear shape blend (exact algebra)
+ *   parents    : (J,) int32, parents[0] = -1;  depth: (J,) int32 tree depth of each joint.
+ * outputs
+ *   xt   : (kp, mp) blend-GEMM operand, k-major: rows [0,nb) betas, [nb, nb+9(J-1)) pose feature
+ *          (R_j - I, j = 1..J-1), remaining rows zero.  Only columns < M are written.
+ *   a    : (M,J,12) skinning transforms, top 3 rows of smplx's "A" (world transform with the rest
+ *          pose removed), row-major 3x4.
+ *   j_posed : (M,J,3) posed joint locations.   rot_out: optional (M,J,3,3) rotation matrices used.
+ */
+int hps_smpl_pose_prep(const float* glob, const float* body, int is_rotmat, const float* betas,
+                       int num_betas, const float* j_template, const float* j_shapedirs,
+                       const int32_t* parents, const int32_t* depth, int num_joints, float* xt,
+                       int kp, int mp, float* a, float* j_posed, float* rot_out, int M,
+                       hps_stream_t stream);
+
+/* Shape + pose blend shapes as one fp32-MFMA GEMM:
+ *   v_posed[m, n] = v_template[n] + sum_k xt[k, m] * bmat[k, n]      (n = 3*vertex + coord)
+ * bmat: (kp, np) = [shapedirs ; posedirs ; 0] with np = N rounded up to 128 (zero padded),
+ * xt: (kp, mp) from hps_smpl_pose_prep, mp = M rounded up to 128, kp a multiple of 16.
+ * Replaces lbs steps (1) and (3): blend_shapes einsum + pose_feature @ posedirs. */
+int hps_smpl_blend(const float* xt, const float* bmat, const float* v_template, float* v_posed,
+                   int M, int N, int kp, int mp, int np, hps_stream_t stream);
+
+/* Linear blend skinning, lbs step (5):  verts[m,v] = (sum_k w[v,k] * A[m, idx[v,k]]) . [v_posed[m,v]; 1]
+ * Skinning weights in compressed form: w_idx/w_val (V, K) -- the K largest-support entries of each
+ * row of lbs_weights, padded with (0, 0.0f); exact for any model with <= K non-zeros per row.
+ * transl: optional (M,3) added to the result (smplx SMPL.forward step (7)), may be NULL.
+ * Algorithmic HBM bytes per mesh: 12 V (v_posed) + 48 J.. (A) + 12 V (verts); SURVEY section 8(d). */
+int hps_smpl_lbs(const float* v_posed, const float* a, const int32_t* w_idx, const float* w_val,
+                 int K, int num_joints, const float* transl, float* verts, int M, int V,
+                 hps_stream_t stream);
+
+/* Joints: out[m, 0:J] = j_posed[m] ; out[m, J + r] = sum_e csr_val[e] * verts[m, csr_col[e]]
+ * for CSR rows r = 0..n_rows-1 (the 21 smplx vertex picks as 1-entry rows, then the extra / cocoplus /
+ * h36m regressors of models/smpl_official.py:30-34).  transl optional (M,3). out: (M, J+n_rows, 3). */
+int hps_smpl_joints(const float* verts, const float* j_posed, const int32_t* csr_ptr,
+                    const int32_t* csr_col, const float* csr_val, int n_rows, int num_joints,
+                    const float* transl, float* joints, int M, int V, hps_stream_t stream);
+
+/* Per-vertex uncertainty of utils/sampling_utils.py:189-190, batched over images:
+ * verts (B,N,V,3) -> unc (B,V) = mean_s || verts[b,s,v] - mean_s' verts[b,s',v] ||. */
+int hps_vertex_uncertainty(const float* verts, float* unc, int B, int N, int V, hps_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Matrix-Fisher sampling  (utils/sampling_utils.py:10-143)
+ * ---------------------------------------------------------------------------------------- */
+
+/* One wavefront per (image, joint) call c = image*num_joints + joint, C calls in total.
+ * pose_u/pose_v (C,3,3), pose_s (C,3): raw SVD factors; the proper-SVD fix (:104-111), Bingham A,
+ * ACG Omega, Gaussian std (:118-124), the 8N-proposal rejection test (:51-61), in-order compaction
+ * of the first N accepted proposals (:64-65), quat_to_rotmat (:139) and U_p R V_p^T (:140-141) are
+ * all done in the kernel.  r_out is (B, N, num_joints, 3, 3); quat_out optional (B,N,num_joints,4).
+ * accepted (C,) int32 receives the number of accepted proposals of the round that was used.
+ * bingham_a: optional (C,4) Bingham parameter used instead of the one derived from pose_s -- the
+ * entry point of bingham_sampling_for_matrix_fisher_torch (:10-71), which takes A directly.
+ *
+ * Noise source
+ *   eps/w != NULL : proposals come from host-drawn noise, eps (D, n_prop, 4) standard normals and
+ *                   w (D, n_prop) uniforms (the reference's torch.randn / torch.rand stream, :51/:60);
+ *                   call c reads draw slot draw_idx[c].  A call with fewer than N accepted proposals
+ *                   leaves its outputs untouched and reports accepted[c] < N (the caller retries with
+ *                   the next draw, as the reference does at :68-69).
+ *   eps == NULL   : counter-based Philox4x32-10 in the kernel, keyed by (seed, call_offset + c,
+ *                   round, proposal) so results do not depend on how images are sharded over GPUs;
+ *                   rounds are redrawn in-kernel until N proposals are accepted (max_rounds bound).
+ */
+int hps_mf_sample(const float* pose_u, const float* pose_s, const float* pose_v,
+                  const float* bingham_a, int C, int num_joints, int num_samples, int n_prop,
+                  float b, float m_star,
+                  const float* eps, const float* w, const int32_t* draw_idx, uint64_t seed,
+                  int64_t call_offset, int max_rounds, float* r_out, float* quat_out,
+                  int32_t* accepted, hps_stream_t stream);
+
+/* utils/rigid_transform_utils.py:113-133 */
+int hps_quat_to_rotmat(const float* quat, float* rotmat, int n, hps_stream_t stream);
+/* utils/rigid_transform_utils.py:80-94 (cross product along dim 1 for every batch size) */
+int hps_rot6d_to_rotmat(const float* x6, float* rotmat, int n, hps_stream_t stream);
+/* smplx.lbs.batch_rodrigues (reference import: predict/predict_poseMF_shapeGaussian_net.py:7) */
+int hps_batch_rodrigues(const float* aa, float* rotmat, int n, hps_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Distribution-prediction head  (models/poseMF_shapeGaussian_net.py:95-162)
+ * ---------------------------------------------------------------------------------------- */
+
+/* out[b, n] = act( sum_k x[b, k] * wt[k, n] + bias[n] (+ addend[n]) ),  wt = weight^T (K,N).
+ * x rows have stride ldx, out rows stride ldo (lets the trunk write straight into the fc_embed
+ * input buffer).  addend optional (init_glob / init_cam, :106-107). */
+int hps_linear(const float* x, int ldx, const float* wt, const float* bias, const float* addend,
+               float* out, int ldo, int B, int K, int N, int act, hps_stream_t stream);
+
+/* One kinematic level of the joint loop (:121-135): for every joint g in the level
+ *   in  = cat[embed(b), U_proper[b, anc].flat, S_proper[b, anc].flat, mode[b, anc].flat]
+ *   F   = W2 . ELU(W1 . in + b1) + b2 + delta_i_weight * I
+ * joint_ids (n_level,) int32; anc_ptr (23+1,) / anc_idx: CSR list of ancestors (nearest first);
+ * w1t_ptrs[joint] -> (in_dim, hidden) = fc_pose[j].0.weight^T, b1_ptrs -> (hidden,),
+ * w2_ptrs -> (9, hidden), b2_ptrs -> (9,)  (device arrays of device pointers, indexed by joint id).
+ * u_proper/mode (B,23,9), s_proper (B,23,3) hold the ancestors' results; pose_f (B,23,9) output. */
+int hps_head_joint_level(const float* embed, int embed_dim, int hidden, const int32_t* joint_ids,
+                         int n_level, const int32_t* anc_ptr, const int32_t* anc_idx,
+                         const float* const* w1t_ptrs, const float* const* b1_ptrs,
+                         const float* const* w2_ptrs, const float* const* b2_ptrs,
+                         const float* u_proper, const float* s_proper, const float* mode,
+                         float delta_i_weight, float* pose_f, int B, int num_body_joints,
+                         hps_stream_t stream);
+
+/* Proper-SVD fix and mode (:139-152) for the joints of one level, given U,S,V of those joints
+ * already stored in pose_u/pose_s/pose_v (B,23,..): writes u_proper, s_proper, mode = U_p V_p^T. */
+int hps_head_svd_finish(const float* pose_u, const float* pose_s, const float* pose_v,
+                        const int32_t* joint_ids, int n_level, float* u_proper, float* s_proper,
+                        float* mode, int B, int num_body_joints, hps_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ResNet-18 encoder  (models/resnet.py:202-217) -- NHWC activations
+ * ---------------------------------------------------------------------------------------- */
+
+/* (B,C,H,W) -> (B,H,W,Cp) with channels zero-padded to Cp. */
+int hps_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, int Cp,
+                     hps_stream_t stream);
+
+/* Implicit-GEMM convolution on fp32 MFMA with fused eval-mode BatchNorm, residual add and ReLU:
+ *   y[b,ho,wo,co] = act( scale[co] * sum_{kh,kw,ci} x[b, ho*s-p+kh, wo*s-p+kw, ci] * wk[(kh,kw,ci), co]
+ *                        + shift[co] (+ residual[b,ho,wo,co]) )
+ * x (B,H,W,Cin) NHWC, wk (ceil16(KH*KW*Cin), Cout) k-major filter (rows zero-padded to a multiple of
+ * 16), scale/shift (Cout,) from BN running stats
+ * (models/resnet.py:62-78, :202-206).  Cin % 4 == 0 (pad), Cout % 64 == 0. */
+int hps_conv2d_bn_act(const float* x, const float* wk, const float* scale, const float* shift,
+                      const float* residual, float* y, int B, int H, int W, int Cin, int Cout,
+                      int KH, int KW, int stride, int pad, int relu, hps_stream_t stream);
+
+/* nn.MaxPool2d(3, stride 2, pad 1) on NHWC (models/resnet.py:152, :207). */
+int hps_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, hps_stream_t stream);
+
+/* AdaptiveAvgPool2d((1,1)) + flatten on NHWC (models/resnet.py:214-215): (B,H,W,C) -> (B,C). */
+int hps_global_avgpool(const float* x, float* y, int B, int HW, int C, hps_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPS_H_ */

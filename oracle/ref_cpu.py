@@ -1,0 +1,396 @@
+"""TEST INFRASTRUCTURE -- fp32 PyTorch-CPU restatement of the reference's per-image inference path.
+
+This module is the parity oracle and the timed CPU baseline.  It is NOT part of the product: only
+tests/, __graft_entry__.smoke() and bench.py's ``cpu_baseline`` leg may import it.  The product
+(hierarchicalprobabilistic3dhuman_amd/) never falls back to it.
+
+Every function follows the reference file:line it cites (paths relative to the reference repo).
+
+Parity status
+  * encoder / head / sampler / rotation conversions: PINNED -- checked against the imported
+    reference and against golden vectors generated from it (tests/golden/make_golden.py,
+    tests/test_oracle_golden.py).
+  * SMPL arithmetic (smplx 0.1.26 ``SMPL.forward`` / ``lbs``; requirements.txt:10): the smplx source
+    and the SMPL pkl assets are absent from the reference checkout, so this part restates smplx's
+    published algorithm (Loper et al. 2015; op list in SURVEY.md section 8 row A11) and is anchored on the
+    reference's call sites (models/smpl_official.py:27-41), the joint-layout contract
+    (utils/label_conversions.py:17-20) and analytic known-answer tests plus a float64 twin
+    (oracle/smpl_np64.py).  PARITY UNPINNED for that part.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------------------------
+# Rotation conversions -- utils/rigid_transform_utils.py
+# ----------------------------------------------------------------------------------------------
+
+
+def rot6d_to_rotmat(x):
+    """utils/rigid_transform_utils.py:80-94 (Gram-Schmidt on the two columns of x.view(-1,3,2)).
+
+    The reference calls ``torch.cross(b1, b2)`` without ``dim`` (line 93), which picks the first
+    dimension of size 3 and is therefore wrong at exactly B == 3; the cross product meant is along
+    dim 1, which is what is restated here (identical for every B != 3).
+    """
+    x = x.reshape(-1, 3, 2)
+    a1, a2 = x[:, :, 0], x[:, :, 1]
+    b1 = F.normalize(a1)
+    b2 = F.normalize(a2 - torch.einsum('bi,bi->b', b1, a2).unsqueeze(-1) * b1)
+    b3 = torch.cross(b1, b2, dim=1)
+    return torch.stack((b1, b2, b3), dim=-1)
+
+
+def rotmat_to_rot6d(R, stack_columns=False):
+    """utils/rigid_transform_utils.py:97-110."""
+    if stack_columns:
+        return torch.cat([R[:, :, 0], R[:, :, 1]], dim=1)
+    return R[:, :, :2].contiguous().view(-1, 6)
+
+
+def quat_to_rotmat(quat):
+    """utils/rigid_transform_utils.py:113-133; quat is (w, x, y, z), re-normalised first."""
+    q = quat / quat.norm(p=2, dim=1, keepdim=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    w2, x2, y2, z2 = w.pow(2), x.pow(2), y.pow(2), z.pow(2)
+    wx, wy, wz = w * x, w * y, w * z
+    xy, xz, yz = x * y, x * z, y * z
+    return torch.stack([w2 + x2 - y2 - z2, 2 * xy - 2 * wz, 2 * wy + 2 * xz,
+                        2 * wz + 2 * xy, w2 - x2 + y2 - z2, 2 * yz - 2 * wx,
+                        2 * xz - 2 * wy, 2 * wx + 2 * yz, w2 - x2 - y2 + z2], dim=1).view(-1, 3, 3)
+
+
+def batch_rodrigues(rot_vecs):
+    """smplx.lbs.batch_rodrigues (imported by the reference at predict/...:7, evaluate/...:6):
+    angle = ||r + 1e-8||, R = I + sin(a) K + (1 - cos(a)) K^2 with K the cross-product matrix of r/angle."""
+    n = rot_vecs.shape[0]
+    angle = torch.norm(rot_vecs + 1e-8, dim=1, keepdim=True)
+    rot_dir = rot_vecs / angle
+    cos = torch.cos(angle).unsqueeze(1)
+    sin = torch.sin(angle).unsqueeze(1)
+    rx, ry, rz = torch.split(rot_dir, 1, dim=1)
+    zeros = torch.zeros((n, 1), dtype=rot_vecs.dtype)
+    K = torch.cat([zeros, -rz, ry, rz, zeros, -rx, -ry, rx, zeros], dim=1).view(n, 3, 3)
+    ident = torch.eye(3, dtype=rot_vecs.dtype).unsqueeze(0)
+    return ident + sin * K + (1 - cos) * torch.bmm(K, K)
+
+
+# ----------------------------------------------------------------------------------------------
+# Encoder -- models/resnet.py (ResNet-18, final FC removed, eval-mode BatchNorm)
+# ----------------------------------------------------------------------------------------------
+
+def _bn(x, sd, prefix):
+    return F.batch_norm(x, sd[prefix + '.running_mean'], sd[prefix + '.running_var'],
+                        sd[prefix + '.weight'], sd[prefix + '.bias'], training=False, eps=1e-5)
+
+
+def _basic_block(x, sd, prefix, stride, has_down):
+    """models/resnet.py:62-78."""
+    out = F.conv2d(x, sd[prefix + '.conv1.weight'], stride=stride, padding=1)
+    out = F.relu(_bn(out, sd, prefix + '.bn1'))
+    out = F.conv2d(out, sd[prefix + '.conv2.weight'], stride=1, padding=1)
+    out = _bn(out, sd, prefix + '.bn2')
+    if has_down:
+        x = _bn(F.conv2d(x, sd[prefix + '.downsample.0.weight'], stride=stride), sd, prefix + '.downsample.1')
+    return F.relu(out + x)
+
+
+def resnet18_forward(sd, x, prefix='image_encoder'):
+    """models/resnet.py:202-217 with layers [2,2,2,2] (:229-237). ``sd`` = state dict of the net."""
+    p = prefix
+    x = F.conv2d(x, sd[p + '.conv1.weight'], stride=2, padding=3)
+    x = F.relu(_bn(x, sd, p + '.bn1'))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    for li in range(1, 5):
+        stride = 1 if li == 1 else 2
+        x = _basic_block(x, sd, '%s.layer%d.0' % (p, li), stride, li != 1)
+        x = _basic_block(x, sd, '%s.layer%d.1' % (p, li), 1, False)
+    return torch.flatten(F.adaptive_avg_pool2d(x, (1, 1)), 1)
+
+
+# ----------------------------------------------------------------------------------------------
+# Head -- models/poseMF_shapeGaussian_net.py
+# ----------------------------------------------------------------------------------------------
+
+def all_ancestors(smpl_parents):
+    """models/poseMF_shapeGaussian_net.py:14-21: per body joint (0..22) the ancestor list, nearest
+    first, in body-joint numbering (SMPL joint index - 1; the root is not a body joint)."""
+    anc = {}
+    for i in range(1, len(smpl_parents)):
+        joint, parent = i - 1, smpl_parents[i] - 1
+        anc[joint] = ([parent] + anc[parent]) if parent >= 0 else []
+    return [anc[j] for j in range(len(smpl_parents) - 1)]
+
+
+def head_forward(sd, feats, smpl_parents, delta_i=True, delta_i_weight=1.0, num_betas=10):
+    """models/poseMF_shapeGaussian_net.py:95-162 from image features (B,512).
+
+    Returns pose_F, pose_U, pose_S, pose_V, pose_rotmats_mode, (shape_loc, shape_scale), glob, cam.
+    """
+    B = feats.shape[0]
+    ancestors = all_ancestors(smpl_parents)
+    nj = len(ancestors)
+    x = F.elu(F.linear(feats, sd['fc1.weight'], sd['fc1.bias']))
+    shape_params = F.linear(x, sd['fc_shape.weight'], sd['fc_shape.bias'])
+    shape_loc = shape_params[:, :num_betas]
+    shape_scale = torch.exp(shape_params[:, num_betas:])
+    glob = F.linear(x, sd['fc_glob.weight'], sd['fc_glob.bias']) + sd['init_glob']
+    cam = F.linear(x, sd['fc_cam.weight'], sd['fc_cam.bias']) + sd['init_cam']
+    embed = F.elu(F.linear(torch.cat([feats, shape_params, glob, cam], dim=1),
+                           sd['fc_embed.weight'], sd['fc_embed.bias']))
+
+    pose_F = torch.zeros(B, nj, 3, 3)
+    pose_U = torch.zeros(B, nj, 3, 3)
+    pose_S = torch.zeros(B, nj, 3)
+    pose_V = torch.zeros(B, nj, 3, 3)
+    U_proper = torch.zeros(B, nj, 3, 3)
+    S_proper = torch.zeros(B, nj, 3)
+    mode = torch.zeros(B, nj, 3, 3)
+    for j in range(nj):
+        anc = ancestors[j]
+        if anc:
+            inp = torch.cat([embed, U_proper[:, anc].reshape(B, -1), S_proper[:, anc].reshape(B, -1),
+                             mode[:, anc].reshape(B, -1)], dim=1)
+        else:
+            inp = embed
+        h = F.elu(F.linear(inp, sd['fc_pose.%d.0.weight' % j], sd['fc_pose.%d.0.bias' % j]))
+        Fj = F.linear(h, sd['fc_pose.%d.2.weight' % j], sd['fc_pose.%d.2.bias' % j]).view(-1, 3, 3)
+        if delta_i:
+            Fj = Fj + delta_i_weight * torch.eye(3)[None].expand_as(Fj)
+        U, S, V = torch.svd(Fj)                                   # :137 (CPU LAPACK in the reference too)
+        detU, detV = torch.det(U), torch.det(V)                   # :139-140
+        Up, Sp, Vp = U.clone(), S.clone(), V.clone()
+        Up[:, :, 2] *= detU.unsqueeze(-1)                         # :147-150
+        Sp[:, 2] *= detU * detV
+        Vp[:, :, 2] *= detV.unsqueeze(-1)
+        pose_F[:, j], pose_U[:, j], pose_S[:, j], pose_V[:, j] = Fj, U, S, V
+        U_proper[:, j], S_proper[:, j] = Up, Sp
+        mode[:, j] = torch.matmul(Up, Vp.transpose(-1, -2))       # :152
+    return pose_F, pose_U, pose_S, pose_V, mode, (shape_loc, shape_scale), glob, cam
+
+
+def net_forward(sd, proxy_rep_input, smpl_parents, **kw):
+    """models/poseMF_shapeGaussian_net.py:85-162 end to end."""
+    return head_forward(sd, resnet18_forward(sd, proxy_rep_input), smpl_parents, **kw)
+
+
+# ----------------------------------------------------------------------------------------------
+# Matrix-Fisher sampling -- utils/sampling_utils.py
+# ----------------------------------------------------------------------------------------------
+
+def m_star(b):
+    """utils/sampling_utils.py:46 / :125 (evaluated in float64 by numpy, then used as a Python float)."""
+    return float(np.exp(-(4 - b) / 2) * ((4 / b) ** 2))
+
+
+def bingham_sampling(A, num_samples, Omega, Gaussian_std, M_star, oversampling_ratio=8, log=None):
+    """utils/sampling_utils.py:48-69. Draws from the global torch CPU generator in the reference's
+    order: randn(8N,4) then rand(8N), once per rejection round.  ``log`` (a dict) receives the noise
+    of the accepted round and the number of discarded rounds."""
+    n_prop = num_samples * oversampling_ratio
+    rounds = 0
+    while True:
+        eps = torch.randn(n_prop, 4).float()                                   # :51
+        y = Gaussian_std * eps                                                  # :52
+        samples = y / torch.norm(y, dim=1, keepdim=True)                        # :53
+        p_bing = torch.exp(-torch.einsum('bn,n,bn->b', samples, A, samples))    # :56
+        p_acg = torch.einsum('bn,n,bn->b', samples, Omega, samples) ** (-2)     # :57
+        w = torch.rand(n_prop)                                                  # :60
+        accept = w < p_bing / (M_star * p_acg)                                  # :61
+        if int(accept.sum().item()) >= num_samples:                             # :62-63
+            if log is not None:
+                log['eps'], log['w'], log['discarded_rounds'] = eps, w, rounds
+                log['accept'] = accept
+            return samples[accept][:num_samples]                                # :64-65
+        rounds += 1
+
+
+def proper_svd(pose_U, pose_S, pose_V):
+    """utils/sampling_utils.py:104-111."""
+    detU, detV = torch.det(pose_U), torch.det(pose_V)
+    Up, Sp, Vp = pose_U.clone(), pose_S.clone(), pose_V.clone()
+    Sp[..., 2] *= detU * detV
+    Up[..., :, 2] *= detU.unsqueeze(-1)
+    Vp[..., :, 2] *= detV.unsqueeze(-1)
+    return Up, Sp, Vp
+
+
+def pose_matrix_fisher_sampling(pose_U, pose_S, pose_V, num_samples, b=1.5, oversampling_ratio=8,
+                                return_noise=False):
+    """utils/sampling_utils.py:74-143 on CPU tensors (the ``sample_on_cpu`` route).
+
+    With ``return_noise`` also returns (eps (B,23,8N,4), w (B,23,8N), discarded_rounds (B,23)): the
+    noise of the accepted round of every (image, joint) call, for replay through the HIP kernel.
+    """
+    B, nj = pose_U.shape[:2]
+    Up, Sp, Vp = proper_svd(pose_U, pose_S, pose_V)
+    A = torch.zeros(B, nj, 4)
+    A[:, :, 1] = 2 * (Sp[:, :, 1] + Sp[:, :, 2])                                # :118-121
+    A[:, :, 2] = 2 * (Sp[:, :, 0] + Sp[:, :, 2])
+    A[:, :, 3] = 2 * (Sp[:, :, 0] + Sp[:, :, 1])
+    Omega = torch.ones(B, nj, 4) + 2 * A / b                                    # :123
+    std = Omega ** (-0.5)                                                       # :124
+    Ms = m_star(b)
+    quats = torch.zeros(B, num_samples, nj, 4)
+    n_prop = num_samples * oversampling_ratio
+    eps_all = torch.zeros(B, nj, n_prop, 4) if return_noise else None
+    w_all = torch.zeros(B, nj, n_prop) if return_noise else None
+    disc = torch.zeros(B, nj, dtype=torch.int64) if return_noise else None
+    for i in range(B):                                                          # :128-137
+        for j in range(nj):
+            log = {} if return_noise else None
+            quats[i, :, j] = bingham_sampling(A[i, j], num_samples, Omega[i, j], std[i, j], Ms,
+                                              oversampling_ratio, log)
+            if return_noise:
+                eps_all[i, j], w_all[i, j], disc[i, j] = log['eps'], log['w'], log['discarded_rounds']
+    R = quat_to_rotmat(quats.view(-1, 4)).view(B, num_samples, nj, 3, 3)        # :139
+    R = torch.matmul(Up[:, None], torch.matmul(R, Vp[:, None].transpose(-1, -2)))  # :140-141
+    if return_noise:
+        return R, (eps_all, w_all, disc)
+    return R
+
+
+# ----------------------------------------------------------------------------------------------
+# SMPL forward -- models/smpl_official.py:27-41 over smplx 0.1.26 SMPL.forward / lbs (restated)
+# ----------------------------------------------------------------------------------------------
+
+class SMPLParams:
+    """fp32 CPU tensors of one SMPL model, laid out like smplx's buffers.
+
+    model: dict as returned by smpl_data.synthetic_smpl_model / load_smpl_pkl;
+    extra_regressors: (extra (9,V), cocoplus (19,V), h36m (17,V)) float64 arrays
+    (models/smpl_official.py:17-25)."""
+
+    def __init__(self, model, extra_regressors, extra_vertex_ids, num_betas=10, dtype=torch.float32):
+        t = lambda a: torch.tensor(np.asarray(a), dtype=dtype)
+        self.dtype = dtype
+        self.v_template = t(model['v_template'])                                   # (V,3)
+        self.shapedirs = t(np.asarray(model['shapedirs'])[:, :, :num_betas])       # (V,3,nb)
+        pd = np.asarray(model['posedirs'])
+        self.posedirs = t(pd.reshape(-1, pd.shape[-1]).T)                          # (207, 3V)
+        self.J_regressor = t(model['J_regressor'])                                 # (24,V)
+        self.lbs_weights = t(model['weights'])                                     # (V,24)
+        parents = np.asarray(model['kintree_table'])[0].astype(np.int64).copy()
+        parents[0] = -1
+        self.parents = torch.tensor(parents)
+        self.J_regressor_extra, self.J_regressor_cocoplus, self.J_regressor_h36m = (t(a) for a in extra_regressors)
+        self.extra_vertex_ids = torch.tensor(list(extra_vertex_ids), dtype=torch.long)
+        self.num_betas = num_betas
+
+
+def _rigid_transform(rot_mats, joints, parents):
+    """smplx.lbs.batch_rigid_transform: chain G_i = G_parent(i) . [R_i | J_i - J_parent(i)] in joint-index
+    order; returns posed joints (M,24,3) and A = G with the rest pose removed (M,24,4,4)."""
+    M, nj = joints.shape[:2]
+    joints = joints.unsqueeze(-1)
+    rel = joints.clone()
+    rel[:, 1:] -= joints[:, parents[1:]]
+    T = torch.cat([F.pad(rot_mats.reshape(-1, 3, 3), [0, 0, 0, 1]),
+                   F.pad(rel.reshape(-1, 3, 1), [0, 0, 0, 1], value=1.0)], dim=2).view(M, nj, 4, 4)
+    chain = [T[:, 0]]
+    for i in range(1, nj):
+        chain.append(torch.matmul(chain[int(parents[i])], T[:, i]))
+    G = torch.stack(chain, dim=1)
+    posed = G[:, :, :3, 3]
+    jh = F.pad(joints, [0, 0, 0, 1])
+    A = G - F.pad(torch.matmul(G, jh), [3, 0, 0, 0, 0, 0, 0, 0])
+    return posed, A
+
+
+def smpl_forward(p, betas=None, body_pose=None, global_orient=None, pose2rot=True, transl=None,
+                 return_intermediates=False):
+    """models/smpl_official.py:27-41 -> smplx SMPL.forward -> lbs.
+
+    Omitted arguments fall back to zero tensors with one row (the module parameters of a
+    ``batch_size=1`` SMPL, run_predict.py:61-64).  Returns dict(vertices (M,6890,3), joints (M,90,3), ...).
+    """
+    dt = p.dtype
+    if betas is None:
+        betas = torch.zeros(1, p.num_betas, dtype=dt)
+    if global_orient is None:
+        global_orient = torch.zeros(1, 3, dtype=dt)
+    if body_pose is None:
+        body_pose = torch.zeros(1, 69, dtype=dt)
+    full_pose = torch.cat([global_orient, body_pose], dim=1)
+    M = max(betas.shape[0], global_orient.shape[0], body_pose.shape[0])
+    if betas.shape[0] != M:
+        betas = betas.expand(int(M / betas.shape[0]), -1)
+
+    V = p.v_template.shape[0]
+    v_shaped = p.v_template + torch.einsum('bl,mkl->bmk', betas, p.shapedirs)       # (1)
+    J = torch.einsum('bik,ji->bjk', v_shaped, p.J_regressor)                        # (2)
+    ident = torch.eye(3, dtype=dt)
+    if pose2rot:                                                                    # (3)
+        rot_mats = batch_rodrigues(full_pose.reshape(-1, 3)).view(M, -1, 3, 3)
+    else:
+        rot_mats = full_pose.reshape(M, -1, 3, 3)
+    pose_feature = (rot_mats[:, 1:] - ident).reshape(M, -1)
+    v_posed = v_shaped + torch.matmul(pose_feature, p.posedirs).view(M, V, 3)
+    J_posed, A = _rigid_transform(rot_mats, J, p.parents)                           # (4)
+    nj = p.J_regressor.shape[0]
+    T = torch.matmul(p.lbs_weights.unsqueeze(0).expand(M, -1, -1), A.view(M, nj, 16)).view(M, V, 4, 4)  # (5)
+    v_h = torch.cat([v_posed, torch.ones(M, V, 1, dtype=dt)], dim=2)
+    verts = torch.matmul(T, v_h.unsqueeze(-1))[:, :, :3, 0]
+    joints = torch.cat([J_posed, verts[:, p.extra_vertex_ids]], dim=1)              # (6) 24 + 21 = 45
+    if transl is not None:                                                          # (7)
+        joints = joints + transl.unsqueeze(1)
+        verts = verts + transl.unsqueeze(1)
+    v2j = lambda R: torch.einsum('bik,ji->bjk', verts, R)                           # smpl_official.py:30-32
+    all_joints = torch.cat([joints, v2j(p.J_regressor_extra), v2j(p.J_regressor_cocoplus),
+                            v2j(p.J_regressor_h36m)], dim=1)                        # :33-34  -> 90
+    out = dict(vertices=verts, joints=all_joints, betas=betas, body_pose=body_pose,
+               global_orient=global_orient, full_pose=full_pose)
+    if return_intermediates:
+        out.update(v_shaped=v_shaped, v_posed=v_posed, J=J, A=A, rot_mats=rot_mats, J_posed=J_posed)
+    return out
+
+
+def vertex_uncertainty(verts_samples):
+    """utils/sampling_utils.py:189-190 for one image: (N,V,3) -> (V,)."""
+    mean_v = verts_samples.mean(dim=0)
+    return torch.norm(verts_samples - mean_v, dim=-1).mean(dim=0)
+
+
+# ----------------------------------------------------------------------------------------------
+# The batched per-image path (predict/predict_poseMF_shapeGaussian_net.py:103-165, looped over B)
+# ----------------------------------------------------------------------------------------------
+
+def infer(sd, smpl_params, smpl_parents, proxy_rep_input, num_samples, use_mean_shape=True, feats=None,
+          return_noise=False):
+    """What predict/predict_poseMF_shapeGaussian_net.py:103-165 computes, for a batch of B images,
+    identical to looping the reference's B=1 calls (same RNG draw order: image outer, joint inner).
+    """
+    if feats is None:
+        feats = resnet18_forward(sd, proxy_rep_input)
+    pose_F, pose_U, pose_S, pose_V, mode, (loc, scale), glob, cam = head_forward(sd, feats, smpl_parents)
+    B = feats.shape[0]
+    glob_R = rot6d_to_rotmat(glob)                                                 # predict:107-110
+    out_mode = smpl_forward(smpl_params, body_pose=mode, global_orient=glob_R.unsqueeze(1), betas=loc,
+                            pose2rot=False)                                        # predict:112-115
+    out_tpose = smpl_forward(smpl_params, betas=loc, global_orient=torch.zeros(B, 3),
+                             body_pose=torch.zeros(B, 69))                         # predict:136 per image
+    R = pose_matrix_fisher_sampling(pose_U, pose_S, pose_V, num_samples, return_noise=return_noise)
+    noise = None
+    if return_noise:
+        R, noise = R
+    if use_mean_shape:
+        betas_s = loc[:, None, :].expand(B, num_samples, -1)                       # sampling_utils:178-179
+    else:
+        betas_s = torch.stack([torch.distributions.Normal(loc[i:i + 1], scale[i:i + 1]).sample([num_samples])[:, 0]
+                               for i in range(B)])
+    out_s = smpl_forward(smpl_params, body_pose=R.reshape(B * num_samples, 23, 3, 3),
+                         global_orient=glob_R[:, None, None].expand(B, num_samples, 1, 3, 3).reshape(-1, 1, 3, 3),
+                         betas=betas_s.reshape(B * num_samples, -1), pose2rot=False)  # sampling_utils:182-185
+    V = out_s['vertices'].shape[1]
+    verts_s = out_s['vertices'].view(B, num_samples, V, 3)
+    unc = torch.stack([vertex_uncertainty(verts_s[i]) for i in range(B)])
+    res = dict(pose_F=pose_F, pose_U=pose_U, pose_S=pose_S, pose_V=pose_V, pose_rotmats_mode=mode,
+               shape_loc=loc, shape_scale=scale, glob=glob, cam=cam, glob_rotmats=glob_R, feats=feats,
+               verts_mode=out_mode['vertices'], joints_mode=out_mode['joints'],
+               verts_tpose=out_tpose['vertices'], R_samples=R, verts_samples=verts_s,
+               joints_samples=out_s['joints'].view(B, num_samples, -1, 3), betas_samples=betas_s, unc=unc)
+    if return_noise:
+        res['noise'] = noise
+    return res

@@ -1,0 +1,288 @@
+"""Developer bring-up / micro-benchmark script for a GPU box (not part of the product or the test-suite).
+
+    python tools/gpu_bringup.py <section> [...]      sections: rot smpl smpl_perf sampler head encoder encoder_perf e2e
+Each section compares the HIP path with the CPU oracle and prints max-abs errors and timings.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from hierarchicalprobabilistic3dhuman_amd import configs, smpl_data  # noqa: E402
+from hierarchicalprobabilistic3dhuman_amd import rigid_transform_utils as rtu  # noqa: E402
+from hierarchicalprobabilistic3dhuman_amd import sampling_utils as su  # noqa: E402
+from hierarchicalprobabilistic3dhuman_amd.smpl_official import SMPL  # noqa: E402
+from hierarchicalprobabilistic3dhuman_amd.poseMF_shapeGaussian_net import PoseMFShapeGaussianNet  # noqa: E402
+from hierarchicalprobabilistic3dhuman_amd.predict_poseMF_shapeGaussian_net import infer  # noqa: E402
+from oracle import ref_cpu as O  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def err(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+
+
+def timeit(fn, iters=10, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def make_smpl():
+    model = smpl_data.synthetic_smpl_model(0)
+    ex = smpl_data.load_extra_joint_regressors(None)
+    params = O.SMPLParams(model, ex, configs.SMPLX_EXTRA_VERTEX_IDS)
+    smpl = SMPL(model).to(dev)
+    return model, params, smpl
+
+
+def sec_rot():
+    g = torch.randn(5, 6)
+    print("rot6d", err(rtu.rot6d_to_rotmat(g.to(dev)), O.rot6d_to_rotmat(g)))
+    g3 = torch.randn(3, 6)
+    print("rot6d B=3", err(rtu.rot6d_to_rotmat(g3.to(dev)), O.rot6d_to_rotmat(g3)))
+    q = torch.randn(7, 4)
+    print("quat", err(rtu.quat_to_rotmat(q.to(dev)), O.quat_to_rotmat(q)))
+    a = torch.randn(9, 3)
+    a[0] = 0
+    print("rodrigues", err(rtu.batch_rodrigues(a.to(dev)), O.batch_rodrigues(a)))
+
+
+def sec_smpl():
+    model, params, smpl = make_smpl()
+    smpl.keep_intermediates = True
+    for M in (1, 37, 130):
+        g = torch.Generator().manual_seed(M)
+        betas = torch.randn(M, 10, generator=g)
+        aa = torch.randn(M, 24, 3, generator=g) * 0.5
+        R = O.batch_rodrigues(aa.view(-1, 3)).view(M, 24, 3, 3)
+        transl = torch.randn(M, 3, generator=g)
+        ref = O.smpl_forward(params, betas=betas, body_pose=R[:, 1:], global_orient=R[:, :1], pose2rot=False,
+                             transl=transl, return_intermediates=True)
+        out = smpl(betas=betas.to(dev), body_pose=R[:, 1:].to(dev), global_orient=R[:, :1].to(dev), pose2rot=False,
+                   transl=transl.to(dev))
+        L = smpl._last
+        print("M=%d rotmat: v_posed %.2e A %.2e J_posed %.2e verts %.2e joints %.2e" % (
+            M, err(L["v_posed"], ref["v_posed"]), err(L["a"].view(M, 24, 3, 4), ref["A"][:, :, :3, :]),
+            err(L["j_posed"], ref["J_posed"]), err(out.vertices, ref["vertices"]), err(out.joints, ref["joints"])))
+        ref2 = O.smpl_forward(params, betas=betas, body_pose=aa[:, 1:].reshape(M, 69), global_orient=aa[:, 0],
+                              pose2rot=True)
+        out2 = smpl(betas=betas.to(dev), body_pose=aa[:, 1:].reshape(M, 69).to(dev), global_orient=aa[:, 0].to(dev))
+        print("M=%d axis-angle: verts %.2e joints %.2e" % (M, err(out2.vertices, ref2["vertices"]),
+                                                            err(out2.joints, ref2["joints"])))
+    # defaults: zero pose via module parameters
+    b1 = torch.randn(1, 10)
+    print("tpose", err(smpl(betas=b1.to(dev)).vertices, O.smpl_forward(params, betas=b1)["vertices"]))
+
+
+def sec_smpl_perf():
+    model, params, smpl = make_smpl()
+    from hierarchicalprobabilistic3dhuman_amd import _capi
+    P = _capi.ptr
+    for M in (6528, 16000):
+        betas = torch.randn(M, 10, device=dev)
+        aa = torch.randn(M * 24, 3, device=dev) * 0.5
+        R = rtu.batch_rodrigues(aa).view(M, 24, 3, 3)
+        gl, bo = R[:, :1].contiguous(), R[:, 1:].contiguous()
+        smpl.keep_intermediates = True
+        smpl(betas=betas, body_pose=bo, global_orient=gl, pose2rot=False)
+        L = smpl._last
+        V, J = 6890, 24
+        verts = torch.empty(M, V, 3, device=dev)
+        joints = torch.empty(M, 90, 3, device=dev)
+        s = _capi.stream()
+        t_all = timeit(lambda: smpl(betas=betas, body_pose=bo, global_orient=gl, pose2rot=False), 5, 2)
+        t_prep = timeit(lambda: _capi.call("hps_smpl_pose_prep", P(gl), P(bo), 1, P(betas), 10, P(smpl._j_template),
+                                           P(smpl._j_shapedirs), _capi.iptr(smpl._parents_i32), _capi.iptr(smpl._depth_i32),
+                                           J, P(L["xt"]), smpl._kp, L["xt"].shape[1], P(L["a"]), P(L["j_posed"]), None, M, s))
+        t_blend = timeit(lambda: _capi.call("hps_smpl_blend", P(L["xt"]), P(smpl._bmat), P(smpl._v_template_flat),
+                                            P(L["v_posed"]), M, 3 * V, smpl._kp, L["xt"].shape[1], smpl._np, s))
+        t_lbs = timeit(lambda: _capi.call("hps_smpl_lbs", P(L["v_posed"]), P(L["a"]), _capi.iptr(smpl._w_idx),
+                                          P(smpl._w_val), smpl._lbs_k, J, None, P(verts), M, V, s), 20, 5)
+        t_j = timeit(lambda: _capi.call("hps_smpl_joints", P(verts), P(L["j_posed"]), _capi.iptr(smpl._csr_ptr),
+                                        _capi.iptr(smpl._csr_col), P(smpl._csr_val), smpl._n_joint_rows, J, None,
+                                        P(joints), M, V, s))
+        gb = 166896.0 * M / 1e9
+        print("M=%d: forward %.3f ms | prep %.3f blend %.3f (%.1f TF) lbs %.3f (%.2f TB/s alg, %.1f%% of 8) joints %.3f" % (
+            M, t_all, t_prep, t_blend, 2.0 * M * 217 * 20670 / t_blend / 1e9, t_lbs, gb / t_lbs, gb / t_lbs / 8 * 100, t_j))
+        if M == 6528:
+            B, N = 64, 102
+            vs = verts[:B * N].view(B, N, V, 3)
+            t_u = timeit(lambda: su.vertex_uncertainty(vs))
+            print("uncertainty B=64 N=102: %.3f ms (%.2f TB/s single-read)" % (t_u, B * N * V * 12 / t_u / 1e9))
+            ref_u = O.vertex_uncertainty(vs[3].cpu())
+            print("unc err", err(su.vertex_uncertainty(vs)[3], ref_u))
+
+
+def sec_sampler():
+    g = torch.Generator().manual_seed(1)
+    for (B, N) in ((2, 4), (2, 100), (64, 1), (3, 1000)):
+        F = torch.randn(B, 23, 3, 3, generator=g) * (3.0 if N != 1 else 0.3) + torch.eye(3)
+        U, S, Vh = torch.linalg.svd(F)
+        V = Vh.transpose(-1, -2).contiguous()
+        torch.manual_seed(5)
+        Rref, (eps, w, disc) = O.pose_matrix_fisher_sampling(U, S, V, N, return_noise=True)
+        torch.manual_seed(5)
+        t0 = time.time()
+        R = su.pose_matrix_fisher_sampling_torch(U.to(dev), S.to(dev), V.to(dev), N, sample_on_cpu=True)
+        torch.cuda.synchronize()
+        d = (R.cpu() - Rref).abs().amax(dim=(-1, -2))
+        print("sampler host-stream B=%d N=%d: max err %.2e, entries>1e-4: %d of %d, discarded rounds %d, %.1f ms" % (
+            B, N, float(d.max()), int((d > 1e-4).sum()), d.numel(), int(disc.sum()), (time.time() - t0) * 1e3))
+    # philox route
+    B, N = 64, 100
+    F = torch.randn(B, 23, 3, 3, generator=g) * 2 + torch.eye(3)
+    U, S, Vh = torch.linalg.svd(F)
+    V = Vh.transpose(-1, -2).contiguous()
+    Ud, Sd, Vd = U.to(dev), S.to(dev), V.to(dev)
+    R = su.pose_matrix_fisher_sampling_torch(Ud, Sd, Vd, N, seed=123)
+    RtR = torch.matmul(R.transpose(-1, -2), R) - torch.eye(3, device=dev)
+    print("philox: orth err %.2e det min %.6f" % (float(RtR.abs().max()), float(torch.det(R.cpu()).min())))
+    R2a = su.pose_matrix_fisher_sampling_torch(Ud[:32], Sd[:32], Vd[:32], N, seed=123, image_offset=0)
+    R2b = su.pose_matrix_fisher_sampling_torch(Ud[32:], Sd[32:], Vd[32:], N, seed=123, image_offset=32)
+    print("philox sharding invariance (bitwise):", bool(torch.equal(R, torch.cat([R2a, R2b]))))
+    print("philox B=64 N=100: %.3f ms" % timeit(lambda: su.pose_matrix_fisher_sampling_torch(Ud, Sd, Vd, N, seed=123)))
+    # first-moment check against the mode direction: E[R] ~ U diag(d) V^T with d in (0,1): check U^T E[R] V is ~diagonal
+    Nbig = 4000
+    Rb = su.pose_matrix_fisher_sampling_torch(Ud[:2], Sd[:2], Vd[:2], Nbig, seed=7)
+    Up, Sp, Vp = O.proper_svd(U[:2], S[:2], V[:2])
+    Em = Rb.mean(dim=1).cpu()
+    D = torch.matmul(Up.transpose(-1, -2), torch.matmul(Em, Vp))
+    off = D - torch.diag_embed(torch.diagonal(D, dim1=-2, dim2=-1))
+    print("philox E[R] off-diagonal max %.3f (MC sigma ~%.3f); diag sample" % (float(off.abs().max()), 1 / np.sqrt(Nbig)),
+          D[0, 0].diagonal().tolist(), "S", Sp[0, 0].tolist())
+
+
+def make_net():
+    cfg = configs.get_cfg_defaults()
+    torch.manual_seed(0)
+    net = PoseMFShapeGaussianNet(configs.SMPL_PARENTS, cfg).eval()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    return net.to(dev), sd
+
+
+def sec_head():
+    net, sd = make_net()
+    g = torch.Generator().manual_seed(3)
+    for B in (2, 64):
+        feats = torch.rand(B, 512, generator=g) * 2
+        ref = O.head_forward(sd, feats, configs.SMPL_PARENTS)
+        out = net(None, input_feats=feats.to(dev))
+        names = "F U S V mode".split()
+        print("head B=%d:" % B, " ".join("%s %.2e" % (n, err(a, b)) for n, a, b in zip(names, out[:5], ref[:5])),
+              "loc %.2e scale %.2e glob %.2e cam %.2e" % (err(out[5].loc, ref[5][0]), err(out[5].scale, ref[5][1]),
+                                                           err(out[6], ref[6]), err(out[7], ref[7])))
+        fd = feats.to(dev)
+        print("head B=%d time %.3f ms" % (B, timeit(lambda: net(None, input_feats=fd), 5, 2)))
+
+
+def sec_encoder():
+    net, sd = make_net()
+    import torch.nn.functional as F
+    enc = net.image_encoder
+    prep = enc.prepare()
+    from hierarchicalprobabilistic3dhuman_amd import _capi
+    P = _capi.ptr
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 18, 256, 256, generator=g)
+    # stem only
+    xh = torch.empty(2, 256, 256, 20, device=dev)
+    _capi.call("hps_nchw_to_nhwc", P(x.to(dev)), P(xh), 2, 18, 256, 256, 20, _capi.stream())
+    print("nhwc", err(xh[..., :18].permute(0, 3, 1, 2), x), float(xh[..., 18:].abs().max()))
+    y = prep["stem"](xh, relu=True)
+    ref = F.relu(O._bn(F.conv2d(x, sd["image_encoder.conv1.weight"], stride=2, padding=3), sd, "image_encoder.bn1"))
+    print("stem", err(y.permute(0, 3, 1, 2), ref), "ref max", float(ref.abs().max()))
+    yp = torch.empty(2, 64, 64, 64, device=dev)
+    _capi.call("hps_maxpool3x3s2", P(y), P(yp), 2, 128, 128, 64, _capi.stream())
+    refp = F.max_pool2d(ref, 3, 2, 1)
+    print("maxpool", err(yp.permute(0, 3, 1, 2), refp))
+    # random conv checks for each tile config / stride / 1x1
+    for (B, H, Cin, Cout, k, s, p) in ((2, 64, 64, 64, 3, 1, 1), (2, 64, 64, 128, 3, 2, 1), (2, 64, 64, 128, 1, 2, 0),
+                                       (64, 8, 512, 512, 3, 1, 1), (3, 16, 256, 256, 3, 1, 1), (1, 8, 512, 512, 3, 1, 1)):
+        conv = torch.nn.Conv2d(Cin, Cout, k, s, p, bias=False)
+        bn = torch.nn.BatchNorm2d(Cout).eval()
+        bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_()
+        xin = torch.randn(B, Cin, H, H)
+        res = torch.randn(B, Cout, (H + 2 * p - k) // s + 1, (H + 2 * p - k) // s + 1)
+        with torch.no_grad():
+            r = F.relu(bn(conv(xin)) + res)
+        from hierarchicalprobabilistic3dhuman_amd.resnet import _ConvBN
+        cb = _ConvBN(conv.to(dev), bn.to(dev))
+        yo = cb(xin.to(dev).permute(0, 2, 3, 1).contiguous(), residual=res.to(dev).permute(0, 2, 3, 1).contiguous())
+        print("conv B%d H%d %d->%d k%d s%d: err %.2e (ref max %.1f)" % (B, H, Cin, Cout, k, s, err(yo.permute(0, 3, 1, 2), r), float(r.abs().max())))
+    feats_ref = O.resnet18_forward(sd, x)
+    feats = enc(x.to(dev))
+    print("encoder feats err %.2e rel %.2e" % (err(feats, feats_ref), err(feats, feats_ref) / float(feats_ref.abs().max())))
+
+
+def sec_encoder_perf():
+    net, sd = make_net()
+    enc = net.image_encoder
+    x = torch.rand(64, 18, 256, 256, device=dev)
+    t = timeit(lambda: enc(x), 5, 2)
+    print("encoder B=64: %.3f ms  (%.1f TFLOP/s on 6.279 GFLOP/img)" % (t, 64 * 6.279 / t))
+    # per-layer timing
+    prep = enc._prepared
+    xh = torch.empty(64, 256, 256, 20, device=dev)
+    from hierarchicalprobabilistic3dhuman_amd import _capi
+    P = _capi.ptr
+    t = timeit(lambda: _capi.call("hps_nchw_to_nhwc", P(x), P(xh), 64, 18, 256, 256, 20, _capi.stream()))
+    print("  nchw->nhwc %.3f ms" % t)
+    t = timeit(lambda: prep["stem"](xh), 5, 2)
+    print("  stem conv7x7 %.3f ms (%.1f TF)" % (t, 64 * 2 * 0.925 / t))
+    y = prep["stem"](xh)
+    yp = torch.empty(64, 64, 64, 64, device=dev)
+    t = timeit(lambda: _capi.call("hps_maxpool3x3s2", P(y), P(yp), 64, 128, 128, 64, _capi.stream()))
+    print("  maxpool %.3f ms" % t)
+    cur = yp
+    for bi, (c1, c2, down) in enumerate(prep["blocks"]):
+        t1 = timeit(lambda: c1(cur), 5, 2)
+        o = c1(cur)
+        idn = down(cur, relu=False) if down is not None else cur
+        t2 = timeit(lambda: c2(o, residual=idn), 5, 2)
+        fl1 = 2.0 * o.numel() * c1.kh * c1.kw * c1.cin_p / 1e9
+        o2 = c2(o, residual=idn)
+        fl2 = 2.0 * o2.numel() * c2.kh * c2.kw * c2.cin_p / 1e9
+        td = timeit(lambda: down(cur, relu=False), 5, 2) if down is not None else 0.0
+        print("  block %d: conv1 %.3f ms (%.1f TF) conv2 %.3f ms (%.1f TF) down %.3f ms" % (bi, t1, fl1 / t1, t2, fl2 / t2, td))
+        cur = o2
+
+
+def sec_e2e():
+    model, params, smpl = make_smpl()
+    net, sd = make_net()
+    g = torch.Generator().manual_seed(0)
+    B, N = 2, 4
+    x = torch.rand(B, 18, 256, 256, generator=g)
+    torch.manual_seed(11)
+    ref = O.infer(sd, params, configs.SMPL_PARENTS, x, N)
+    torch.manual_seed(11)
+    out = infer(net, smpl, x.to(dev), num_samples=N, sample_on_cpu=True)
+    for k in ("pose_F", "pose_S", "pose_rotmats_mode", "shape_loc", "glob_rotmats", "verts_mode", "joints_mode",
+              "verts_tpose", "R_samples", "verts_samples", "joints_samples", "unc"):
+        print("e2e %s: %.2e" % (k, err(out[k], ref[k])))
+    xb = torch.rand(64, 18, 256, 256, device=dev)
+    for Ns in (100,):
+        t = timeit(lambda: infer(net, smpl, xb, num_samples=Ns, seed=1), 3, 1)
+        print("e2e B=64 N=%d: %.2f ms -> %.0f img/s" % (Ns, t, 64 / t * 1e3))
+
+
+if __name__ == "__main__":
+    for name in sys.argv[1:]:
+        print("==== %s ====" % name, flush=True)
+        t0 = time.time()
+        globals()["sec_" + name]()
+        print("---- %s done in %.1f s" % (name, time.time() - t0), flush=True)
