@@ -1,0 +1,150 @@
+#!/usr/bin/env python
+"""Benchmark of the per-image inference hot path on MI355X (contract: see the round prompt / DESIGN.md).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of synthetic proxy representations per GPU:
+ResNet-18 encoder -> distribution head -> matrix-Fisher sampling (num_samples=100) -> SMPL forward over
+B*(N+2) meshes -> per-vertex uncertainty (BASELINE.json configs[1]: batch 64, 256x256, num_samples 100).
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from hierarchicalprobabilistic3dhuman_amd import configs, smpl_data, sharding  # noqa: E402
+from hierarchicalprobabilistic3dhuman_amd.poseMF_shapeGaussian_net import PoseMFShapeGaussianNet  # noqa: E402
+from hierarchicalprobabilistic3dhuman_amd.predict_poseMF_shapeGaussian_net import infer  # noqa: E402
+from hierarchicalprobabilistic3dhuman_amd.smpl_official import SMPL  # noqa: E402
+
+LBS_BYTES_PER_MESH = 166896          # 82,680 (v_posed) + 1,536 (A) + 82,680 (verts)
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def synthetic_inputs(lo, hi):
+    """Proxy representations of global images lo..hi-1; each image has its own seed so the data of image i
+    does not depend on how the batch is sharded."""
+    xs = [torch.rand(18, 256, 256, generator=torch.Generator().manual_seed(1000 + i)) for i in range(lo, hi)]
+    return torch.stack(xs)
+
+
+def cpu_baseline(net_state, parents, num_samples, n_images):
+    """The CPU oracle (a port of the reference's PyTorch-CPU path, validated against the imported reference)
+    timed on this host's cores on a bounded sample of the same workload."""
+    from oracle import ref_cpu as O
+    model = smpl_data.synthetic_smpl_model(0)
+    params = O.SMPLParams(model, smpl_data.load_extra_joint_regressors(None), configs.SMPLX_EXTRA_VERTEX_IDS)
+    x = synthetic_inputs(0, n_images)
+    with torch.no_grad():
+        torch.manual_seed(0)
+        O.infer(net_state, params, parents, x[:1], num_samples)          # warm (thread pools, allocator)
+        t0 = time.perf_counter()
+        O.infer(net_state, params, parents, x, num_samples)
+        dt = time.perf_counter() - t0
+    return {"value": n_images / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d images, num_samples=%d, oracle/ref_cpu.infer timed once after a 1-image warm-up (%.2f s)"
+                      % (n_images, num_samples, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--num-samples", type=int, default=100)
+    ap.add_argument("--cpu-images", type=int, default=16, help="images in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank, world, local_rank = sharding.init_distributed("nccl" if args.gpus > 1 else None)
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d must be launched with %d ranks (torch.distributed.run), got WORLD_SIZE=%d"
+                         % (args.gpus, args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (HIP) device; there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    B, N = args.batch, args.num_samples
+
+    cfg = configs.get_cfg_defaults()
+    torch.manual_seed(0)
+    net = PoseMFShapeGaussianNet(configs.SMPL_PARENTS, cfg).eval()     # default init under seed 0 (random weights)
+    net_state = {k: v.clone() for k, v in net.state_dict().items()} if rank == 0 else None
+    net = net.to(dev)
+    smpl = SMPL(smpl_data.synthetic_smpl_model(0), batch_size=1, gender="neutral", num_betas=10).to(dev)
+
+    lo, hi = sharding.shard_range(B * world, rank, world)               # weak scaling: B images per GPU
+    x = synthetic_inputs(lo, hi).to(dev)
+
+    def step(i):
+        return infer(net, smpl, x, num_samples=N, use_mean_shape=True, seed=1234 + i, image_offset=lo)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for i in range(args.warmup):
+        res = step(i)
+    torch.cuda.synchronize()
+    smpl.lbs_events = []
+    sums = torch.zeros(4, dtype=torch.float64, device=dev)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        res = step(args.warmup + i)
+        sums += sharding.batch_metric_sums(res)
+    per_rank, total = sharding.gather_metric_sums(sums)                 # the one collective of the run
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(dt_t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(dt_t.item())
+
+    # LBS kernel time from HIP events recorded around each launch on the launch stream
+    M = B * (N + 2)
+    lbs_ms = [e0.elapsed_time(e1) for (m, e0, e1) in smpl.lbs_events if m == M]
+    smpl.lbs_events = None
+    lbs_avg_ms = sum(lbs_ms) / max(1, len(lbs_ms))
+    achieved = LBS_BYTES_PER_MESH * M / (lbs_avg_ms * 1e-3) / 1e9 if lbs_ms else None
+
+    if rank == 0:
+        images = B * world * args.steps
+        out = {
+            "metric": "images/sec end-to-end (num_samples=%d)" % N,
+            "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: batch=%d synthetic 18x256x256 proxy representations per GPU, "
+                                   "num_samples=%d, neutral synthetic SMPL (6890 verts), random-init ResNet-18 + "
+                                   "poseMF_shapeGaussian head (seed 0), Philox sampling" % (B, N),
+                       "images_per_gpu": B, "global_batch": B * world, "num_samples": N,
+                       "meshes_per_step_per_gpu": M, "parallelism": "images sharded over %d GPU(s)" % world},
+            "roofline": {"bound": "hbm", "kernel": "hps::lbs_kernel<4,4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "avg_launch_ms": lbs_avg_ms, "launches": len(lbs_ms),
+                         "algorithmic_bytes_per_launch": LBS_BYTES_PER_MESH * M},
+            "metric_checksums": {"images": float(total[0]), "sum_unc": float(total[1]),
+                                 "sum_abs_verts_mode": float(total[2]), "sum_abs_joints_samples": float(total[3])},
+        }
+        if world == 1 and args.cpu_images > 0:
+            out["cpu_baseline"] = cpu_baseline(net_state, configs.SMPL_PARENTS, N, args.cpu_images)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

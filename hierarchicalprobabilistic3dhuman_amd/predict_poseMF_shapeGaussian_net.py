@@ -14,7 +14,7 @@ import torch
 
 from . import _capi
 from .rigid_transform_utils import rot6d_to_rotmat, batch_rodrigues
-from .sampling_utils import compute_vertex_uncertainties_by_poseMF_shapeGaussian_sampling
+from .sampling_utils import pose_matrix_fisher_sampling_torch, vertex_uncertainty
 
 
 @torch.no_grad()
@@ -31,26 +31,37 @@ def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mea
     """
     pose_F, pose_U, pose_S, pose_V, mode, shape_dist, glob, cam = pose_shape_model(proxy_rep_input,
                                                                                    input_feats=input_feats)
-    B = pose_F.shape[0]
+    B, nj = pose_F.shape[:2]
+    N = num_samples
+    dev = pose_F.device
     if glob.shape[-1] == 3:                                                       # :107-110
         glob_rotmats = batch_rodrigues(glob)
     else:
         glob_rotmats = rot6d_to_rotmat(glob)
-    out_mode = smpl_model(body_pose=mode, global_orient=glob_rotmats.unsqueeze(1), betas=shape_dist.loc,
-                          pose2rot=False)                                         # :112-115
-    dev = pose_F.device
-    out_tpose = smpl_model(betas=shape_dist.loc, global_orient=torch.zeros(B, 3, device=dev),
-                           body_pose=torch.zeros(B, 69, device=dev))             # :136 (zero pose), per image
-    unc, verts_s, joints_s, R = compute_vertex_uncertainties_by_poseMF_shapeGaussian_sampling(
-        pose_U=pose_U, pose_S=pose_S, pose_V=pose_V, shape_distribution=shape_dist, glob_rotmats=glob_rotmats,
-        num_samples=num_samples, smpl_model=smpl_model, use_mean_shape=use_mean_shape,
-        sample_on_cpu=sample_on_cpu, seed=seed, image_offset=image_offset, return_rotmats=True)   # :157-165
-    if B == 1:
-        unc, verts_s, joints_s = unc[None], verts_s[None], joints_s[None]
+    R = pose_matrix_fisher_sampling_torch(pose_U, pose_S, pose_V, N, b=1.5, oversampling_ratio=8,
+                                          sample_on_cpu=sample_on_cpu, seed=seed, image_offset=image_offset)
+    loc = shape_dist.loc
+    if use_mean_shape:                                                            # sampling_utils.py:178-181
+        betas_s = loc[:, None, :].expand(B, N, -1)
+    else:
+        betas_s = shape_dist.sample([N]).transpose(0, 1)
+    # One flattened SMPL call over B*(N+2) meshes: [mode | T-pose | samples].  The reference makes three
+    # calls per image (:112-115, :136, sampling_utils.py:182-185); SMPL is per-mesh so the results are the
+    # same, and the zero axis-angle pose of :136 is exactly the identity rotation under smplx's Rodrigues.
+    eye = torch.eye(3, device=dev)
+    body = torch.cat([mode, eye.expand(B, nj, 3, 3), R.reshape(B * N, nj, 3, 3)], dim=0)
+    glob_all = torch.cat([glob_rotmats, eye.expand(B, 3, 3),
+                          glob_rotmats[:, None].expand(B, N, 3, 3).reshape(B * N, 3, 3)], dim=0).unsqueeze(1)
+    betas_all = torch.cat([loc, loc, betas_s.reshape(B * N, -1)], dim=0)
+    out = smpl_model(body_pose=body, global_orient=glob_all, betas=betas_all, pose2rot=False)
+    V = out.vertices.shape[1]
+    verts_s = out.vertices[2 * B:].view(B, N, V, 3)
+    joints_s = out.joints[2 * B:].view(B, N, -1, 3)
+    unc = vertex_uncertainty(verts_s)                                             # sampling_utils.py:189-190
     return dict(pose_F=pose_F, pose_U=pose_U, pose_S=pose_S, pose_V=pose_V, pose_rotmats_mode=mode,
-                shape_loc=shape_dist.loc, shape_scale=shape_dist.scale, glob=glob, cam=cam,
-                glob_rotmats=glob_rotmats, verts_mode=out_mode.vertices, joints_mode=out_mode.joints,
-                verts_tpose=out_tpose.vertices, R_samples=R, verts_samples=verts_s, joints_samples=joints_s,
+                shape_loc=loc, shape_scale=shape_dist.scale, glob=glob, cam=cam,
+                glob_rotmats=glob_rotmats, verts_mode=out.vertices[:B], joints_mode=out.joints[:B],
+                verts_tpose=out.vertices[B:2 * B], R_samples=R, verts_samples=verts_s, joints_samples=joints_s,
                 unc=unc)
 
 

@@ -1,0 +1,63 @@
+"""Image sharding over the GPUs of one node and the single metric reduction.
+
+Every image is independent through the whole path (eval-mode BatchNorm, per-image sampling, per-mesh
+SMPL), so rank r of R simply owns the contiguous block [r*B/R, (r+1)*B/R) of the global batch; weights and
+SMPL constants are replicated.  Nothing on the data path is exchanged.  The only collective is one
+all-gather of each rank's small metric accumulator at the end of a run (RCCL over xGMI when the backend is
+"nccl"; latency-bound, O(100) bytes), reduced in rank order so the result does not depend on arrival order.
+The Philox sampler is keyed by the global image index, so per-image outputs are identical for any R.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them).
+    Returns (rank, world_size, local_rank).  A single process without those variables is world size 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def shard_range(total, rank, world):
+    """Contiguous block of ``total`` items owned by ``rank``; the first ``total % world`` ranks get one extra."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_metric_sums(local_sums):
+    """One all-gather of a rank's 1-D accumulator (sums and a count).  Returns (per_rank (R,K), total (K,)),
+    the total being the rank-ordered sum -- bit-identical on every rank and to a single-process run that adds
+    the same per-shard sums in the same order."""
+    local_sums = local_sums.reshape(-1)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        per_rank = local_sums[None].clone()
+    else:
+        bufs = [torch.empty_like(local_sums) for _ in range(dist.get_world_size())]
+        dist.all_gather(bufs, local_sums.contiguous())
+        per_rank = torch.stack(bufs)
+    total = torch.zeros_like(local_sums)
+    for r in range(per_rank.shape[0]):
+        total = total + per_rank[r]
+    return per_rank, total
+
+
+def batch_metric_sums(result):
+    """Accumulator of one ``infer`` result: [image count, sum of per-vertex uncertainty, sum |mode vertices|,
+    sum |sample joints|] in float64 -- the checksum-of-checksums the scaling tests compare across world sizes."""
+    B = result["unc"].shape[0]
+    vals = [float(B), result["unc"].double().sum(), result["verts_mode"].double().abs().sum(),
+            result["joints_samples"].double().abs().sum()]
+    return torch.stack([torch.as_tensor(v, dtype=torch.float64, device=result["unc"].device) for v in vals])

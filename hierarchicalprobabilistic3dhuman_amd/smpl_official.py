@@ -50,6 +50,7 @@ class SMPL(nn.Module):
         self.num_betas = num_betas
         self.dtype = dtype
         self.keep_intermediates = False
+        self.lbs_events = None
 
         f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
         v_template = np.asarray(model["v_template"], np.float64)
@@ -170,8 +171,15 @@ class SMPL(nn.Module):
                    self._kp, mp, P(a), P(j_posed), None, M, s)
         _capi.call("hps_smpl_blend", P(xt), P(self._bmat), P(self._v_template_flat), P(v_posed), M, N, self._kp,
                    mp, self._np, s)
+        ev = None
+        if self.lbs_events is not None:      # bench.py: HIP events around the LBS launch, on its own stream
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         _capi.call("hps_smpl_lbs", P(v_posed), P(a), _capi.iptr(self._w_idx), P(self._w_val), self._lbs_k, J,
                    P(tr) if tr is not None else None, P(verts), M, V, s)
+        if ev is not None:
+            ev[1].record()
+            self.lbs_events.append((M, ev[0], ev[1]))
         _capi.call("hps_smpl_joints", P(verts), P(j_posed), _capi.iptr(self._csr_ptr), _capi.iptr(self._csr_col),
                    P(self._csr_val), self._n_joint_rows, J, P(tr) if tr is not None else None, P(joints), M, V, s)
         full_pose = torch.cat([g, b], dim=1) if return_full_pose else None

@@ -1,0 +1,92 @@
+"""Generates the golden vectors under tests/golden/ by IMPORTING THE REFERENCE (only possible in the build
+container, where /root/reference exists).  The reference's source never leaves that container: what is
+committed is data -- seeded inputs' recipes and the reference's outputs.
+
+    python tests/golden/make_golden.py
+
+Recipes (so that tests can rebuild the inputs without the reference):
+  net weights : default initialisation of PoseMFShapeGaussianNet under torch.manual_seed(0)
+                (asserted here to be identical, tensor for tensor, between the reference class and ours)
+  net input   : torch.rand(2,18,256,256, generator=torch.Generator().manual_seed(0))
+  sampler     : torch.manual_seed(0) then pose_matrix_fisher_sampling_torch(U,S,V, N, sample_on_cpu=True)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))     # utils/rigid_transform_utils.py:1 imports cv2; unused on the path
+sys.path.insert(0, REF)
+sys.path.insert(1, ROOT)
+
+from models.poseMF_shapeGaussian_net import PoseMFShapeGaussianNet as RefNet  # noqa: E402
+from utils.sampling_utils import pose_matrix_fisher_sampling_torch as ref_sampling  # noqa: E402
+from utils.sampling_utils import bingham_sampling_for_matrix_fisher_torch as ref_bingham  # noqa: E402
+import utils.rigid_transform_utils as ref_rtu  # noqa: E402
+from losses.matrix_fisher_loss import LogMFNormConstant  # noqa: E402
+
+from hierarchicalprobabilistic3dhuman_amd import configs  # noqa: E402
+from hierarchicalprobabilistic3dhuman_amd.poseMF_shapeGaussian_net import PoseMFShapeGaussianNet as OurNet  # noqa: E402
+
+
+def main():
+    cfg = configs.get_cfg_defaults()
+    parents = configs.SMPL_PARENTS
+    torch.manual_seed(0)
+    ref = RefNet(parents, cfg).eval()
+    torch.manual_seed(0)
+    ours = OurNet(parents, cfg).eval()
+    a, b = ref.state_dict(), ours.state_dict()
+    assert list(a.keys()) == list(b.keys()) and all(torch.equal(a[k], b[k]) for k in a), "weight recipe broken"
+    assert {int(k): list(v) for k, v in ref.parents_dict.items()} == {int(k): list(v) for k, v in ours.parents_dict.items()}
+
+    out = {}
+    # ---- net: encoder features + 8-tuple on a seeded (2,18,256,256) input; plus the B=1 plumbing case ----
+    x = torch.rand(2, 18, 256, 256, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        feats = ref.image_encoder(x)
+        F_, U, S, V, mode, sd, glob, cam = ref(x)
+    out.update(net_feats=feats, net_F=F_, net_U=U, net_S=S, net_V=V, net_mode=mode, net_shape_loc=sd.loc,
+               net_shape_scale=sd.scale, net_glob=glob, net_cam=cam)
+    # ---- sampler given those U,S,V, for N = 1 (config #1), 4 and 100 ----
+    for N in (1, 4, 100):
+        torch.manual_seed(0)
+        out["sampler_R_N%d" % N] = ref_sampling(U, S, V, N, sample_on_cpu=True)
+    # a concentration sweep with random proper U, V (SURVEY.md section 8(d) stress set)
+    S_sweep = torch.tensor([[0., 0., 0.], [1.9, .78, .6], [5., 5., 5.], [20., 15., 10.], [100., 80., 50.],
+                            [500., 400., 300.], [50., 1., .1]])
+    g = torch.Generator().manual_seed(7)
+    Q1, _ = torch.linalg.qr(torch.randn(7, 3, 3, generator=g))
+    Q2, _ = torch.linalg.qr(torch.randn(7, 3, 3, generator=g))
+    Q1[:, :, 2] *= torch.det(Q1)[:, None]
+    Q2[:, :, 2] *= torch.det(Q2)[:, None]
+    torch.manual_seed(1)
+    out["sweep_U"], out["sweep_S"], out["sweep_V"] = Q1[None], S_sweep[None], Q2[None]
+    out["sweep_R_N50"] = ref_sampling(Q1[None], S_sweep[None], Q2[None], 50, sample_on_cpu=True)
+    # E[R] = U diag(d log c / d s) V^T: the reference's own normalising-constant gradient (losses/matrix_fisher_loss.py:172-192)
+    Sg = S_sweep.clone().requires_grad_(True)
+    LogMFNormConstant.apply(Sg).sum().backward()
+    out["sweep_dlogc_dS"] = Sg.grad.detach()
+    # bingham entry point
+    A = torch.tensor([0., 2.76, 5., 5.36])
+    torch.manual_seed(2)
+    q, _ = ref_bingham(A, 16)
+    out["bingham_A"], out["bingham_q_N16"] = A, q
+    # ---- rotation conversions ----
+    g = torch.Generator().manual_seed(3)
+    x6 = torch.randn(5, 6, generator=g)
+    quat = torch.randn(7, 4, generator=g)
+    out.update(rot6d_in=x6, rot6d_out=ref_rtu.rot6d_to_rotmat(x6), quat_in=quat, quat_out=ref_rtu.quat_to_rotmat(quat),
+               rotmat_to_rot6d_out=ref_rtu.rotmat_to_rot6d(ref_rtu.quat_to_rotmat(quat)))
+    np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"),
+                        **{k: v.detach().numpy() for k, v in out.items()})
+    print("wrote", os.path.join(HERE, "reference_vectors.npz"), {k: tuple(v.shape) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

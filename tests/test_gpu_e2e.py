@@ -1,0 +1,72 @@
+"""GPU parity, end to end: proxy representation -> sampled meshes and uncertainty, HIP path vs CPU oracle on
+the same seeded inputs (sample_on_cpu route = the reference's seed-reproducible route), BASELINE configs[0]
+(B=1, N=1) and a small batch; full-size BASELINE configs[1] (B=64, N=100) through properties.
+
+Stated tolerance: image -> vertices <= 1e-3 m end to end; observed ~5e-6."""
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+from hierarchicalprobabilistic3dhuman_amd import configs, sharding
+from hierarchicalprobabilistic3dhuman_amd.predict_poseMF_shapeGaussian_net import infer
+from hierarchicalprobabilistic3dhuman_amd import sampling_utils as su
+from hierarchicalprobabilistic3dhuman_amd import rigid_transform_utils as rtu
+from conftest import maxerr
+
+pytestmark = pytest.mark.gpu
+KEYS = ("pose_F", "pose_S", "pose_rotmats_mode", "shape_loc", "shape_scale", "glob", "cam", "glob_rotmats",
+        "verts_mode", "joints_mode", "verts_tpose", "R_samples", "verts_samples", "joints_samples", "unc")
+
+
+@pytest.mark.parametrize("B,N", [(1, 1), (2, 4)])
+def test_infer_matches_oracle(B, N, dev, net_gpu, net_cpu, smpl_gpu, smpl_assets, golden_input):
+    x = golden_input[:B]
+    torch.manual_seed(11)
+    ref = O.infer(net_cpu[1], smpl_assets[2], configs.SMPL_PARENTS, x, N)
+    torch.manual_seed(11)
+    out = infer(net_gpu, smpl_gpu, x.to(dev), num_samples=N, sample_on_cpu=True)
+    for k in KEYS:
+        assert out[k].shape == ref[k].shape, k
+        assert maxerr(out[k], ref[k]) <= 1e-3, k
+    assert maxerr(out["verts_samples"], ref["verts_samples"]) <= 1e-4
+
+
+def test_reference_call_sequence_batch_one(dev, net_gpu, net_cpu, smpl_gpu, smpl_assets, golden_input):
+    """The calls of predict/predict_poseMF_shapeGaussian_net.py:103-165, written as the reference writes them."""
+    x = golden_input[:1].to(dev)
+    pose_F, pose_U, pose_S, pose_V, mode, shape_dist, glob, cam = net_gpu(x)
+    glob_rotmats = rtu.rot6d_to_rotmat(glob)
+    out_mode = smpl_gpu(body_pose=mode, global_orient=glob_rotmats.unsqueeze(1), betas=shape_dist.loc, pose2rot=False)
+    out_rest = smpl_gpu(betas=shape_dist.loc)
+    torch.manual_seed(2)
+    unc, verts, joints = su.compute_vertex_uncertainties_by_poseMF_shapeGaussian_sampling(
+        pose_U=pose_U, pose_S=pose_S, pose_V=pose_V, shape_distribution=shape_dist, glob_rotmats=glob_rotmats,
+        num_samples=6, smpl_model=smpl_gpu, use_mean_shape=True, sample_on_cpu=True)
+    assert unc.shape == (6890,) and verts.shape == (6, 6890, 3) and joints.shape == (6, 90, 3)
+    torch.manual_seed(2)
+    ref = O.infer(net_cpu[1], smpl_assets[2], configs.SMPL_PARENTS, golden_input[:1], 6)
+    assert maxerr(out_mode.vertices, ref["verts_mode"]) <= 1e-3 and maxerr(out_rest.vertices, ref["verts_tpose"]) <= 1e-3
+    assert maxerr(verts, ref["verts_samples"][0]) <= 1e-3 and maxerr(unc, ref["unc"][0]) <= 1e-3
+
+
+def test_full_size_config_properties(dev, net_gpu, smpl_gpu):
+    """BASELINE configs[1]: B=64, N=100 on one GPU (6528 meshes): finite outputs, batch independence and
+    sharding invariance of per-image outputs and of the reduced metric sums."""
+    B, N = 64, 100
+    x = torch.stack([torch.rand(18, 256, 256, generator=torch.Generator().manual_seed(1000 + i)) for i in range(B)]).to(dev)
+    whole = infer(net_gpu, smpl_gpu, x, num_samples=N, seed=5)
+    assert whole["verts_samples"].shape == (B, N, 6890, 3) and whole["unc"].shape == (B, 6890)
+    for k in KEYS:
+        assert torch.isfinite(whole[k]).all(), k
+    R = whole["R_samples"]
+    assert float((torch.matmul(R.transpose(-1, -2), R) - torch.eye(3, device=dev)).abs().max()) <= 1e-5
+    assert float(whole["unc"].min()) >= 0.0
+    # two "ranks" of 32 images reproduce the per-image outputs and the gathered metric sums
+    parts = [infer(net_gpu, smpl_gpu, x[r * 32:(r + 1) * 32], num_samples=N, seed=5, image_offset=r * 32) for r in range(2)]
+    for k in ("R_samples", "verts_mode", "unc"):
+        assert maxerr(torch.cat([p[k] for p in parts]), whole[k]) <= 1e-5, k
+    assert torch.equal(torch.cat([p["R_samples"] for p in parts]), whole["R_samples"]) or \
+        maxerr(torch.cat([p["R_samples"] for p in parts]), whole["R_samples"]) <= 1e-5
+    s_whole = sharding.batch_metric_sums(whole)
+    s_parts = sharding.batch_metric_sums(parts[0]) + sharding.batch_metric_sums(parts[1])
+    assert float(s_whole[0]) == 64.0 and maxerr(s_parts, s_whole) <= 1e-6 * float(s_whole.abs().max())

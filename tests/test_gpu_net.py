@@ -1,0 +1,103 @@
+"""GPU parity: ResNet-18 encoder (fp32 MFMA implicit GEMM) and the distribution head against the golden
+vectors of the imported reference and against the oracle.
+
+Stated tolerances: encoder features <= 1e-4 relative; head F, S, mode <= 1e-4 absolute given
+identical features and the host LAPACK SVD; U, V <= 1e-3 (they are sign-ambiguous and ill-conditioned where
+singular values are close; the sign choice is LAPACK's, the same as the reference's)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_cpu as O
+from hierarchicalprobabilistic3dhuman_amd import configs, _capi
+from hierarchicalprobabilistic3dhuman_amd.resnet import _ConvBN
+from conftest import maxerr
+
+pytestmark = pytest.mark.gpu
+
+
+def test_encoder_reproduces_reference_features(dev, net_gpu, golden, golden_input):
+    feats = net_gpu.image_encoder(golden_input.to(dev))
+    ref = golden["net_feats"]
+    assert feats.shape == (2, 512)
+    assert maxerr(feats, ref) <= 1e-4 * float(ref.abs().max())
+
+
+def test_net_reproduces_reference_outputs(dev, net_gpu, golden, golden_input):
+    pose_F, pose_U, pose_S, pose_V, mode, shape_dist, glob, cam = net_gpu(golden_input.to(dev))
+    assert maxerr(pose_F, golden["net_F"]) <= 1e-4
+    assert maxerr(pose_S, golden["net_S"]) <= 1e-4
+    assert maxerr(mode, golden["net_mode"]) <= 1e-4
+    assert maxerr(pose_U, golden["net_U"]) <= 1e-3 and maxerr(pose_V, golden["net_V"]) <= 1e-3
+    assert maxerr(shape_dist.loc, golden["net_shape_loc"]) <= 1e-4
+    assert maxerr(shape_dist.scale, golden["net_shape_scale"]) <= 1e-4
+    assert maxerr(glob, golden["net_glob"]) <= 1e-4 and maxerr(cam, golden["net_cam"]) <= 1e-4
+    assert isinstance(shape_dist, torch.distributions.Normal)
+
+
+@pytest.mark.parametrize("B", [1, 3, 17, 64])
+def test_head_from_features_matches_oracle(B, dev, net_gpu, net_cpu):
+    feats = torch.rand(B, 512, generator=torch.Generator().manual_seed(B)) * 2
+    ref = O.head_forward(net_cpu[1], feats, configs.SMPL_PARENTS)
+    out = net_gpu(None, input_feats=feats.to(dev))
+    assert maxerr(out[0], ref[0]) <= 1e-4 and maxerr(out[2], ref[2]) <= 1e-4 and maxerr(out[4], ref[4]) <= 1e-4
+    assert maxerr(out[5].loc, ref[5][0]) <= 1e-4 and maxerr(out[6], ref[6]) <= 1e-4 and maxerr(out[7], ref[7]) <= 1e-4
+
+
+@pytest.mark.parametrize("cfg", [
+    # B, H, Cin, Cout, k, stride, pad   -- one case per tile configuration / layer type of ResNet-18
+    (2, 64, 64, 64, 3, 1, 1), (2, 64, 64, 128, 3, 2, 1), (2, 64, 64, 128, 1, 2, 0), (64, 8, 512, 512, 3, 1, 1),
+    (3, 16, 256, 256, 3, 1, 1), (1, 8, 512, 512, 3, 1, 1), (1, 30, 20, 64, 7, 2, 3), (2, 9, 128, 256, 3, 2, 1)])
+def test_conv_bn_relu_kernel(cfg, dev):
+    B, H, Cin, Cout, k, s, p = cfg
+    torch.manual_seed(sum(cfg))
+    conv = torch.nn.Conv2d(Cin, Cout, k, s, p, bias=False)
+    bn = torch.nn.BatchNorm2d(Cout).eval()
+    bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_()
+    x = torch.randn(B, Cin, H, H)
+    Ho = (H + 2 * p - k) // s + 1
+    res = torch.randn(B, Cout, Ho, Ho)
+    with torch.no_grad():
+        want = F.relu(bn(conv(x)) + res)
+        want_nores = bn(conv(x))
+    cb = _ConvBN(conv.to(dev), bn.to(dev))
+    xh = x.to(dev).permute(0, 2, 3, 1).contiguous()
+    got = cb(xh, residual=res.to(dev).permute(0, 2, 3, 1).contiguous(), relu=True)
+    assert maxerr(got.permute(0, 3, 1, 2), want) <= 1e-4 * max(1.0, float(want.abs().max()))
+    got2 = cb(xh, relu=False)
+    assert maxerr(got2.permute(0, 3, 1, 2), want_nores) <= 1e-4 * max(1.0, float(want_nores.abs().max()))
+
+
+def test_pooling_and_layout_kernels(dev):
+    P = _capi.ptr
+    x = torch.randn(2, 18, 12, 10, generator=torch.Generator().manual_seed(0))
+    xh = torch.empty(2, 12, 10, 20, device=dev)
+    _capi.call("hps_nchw_to_nhwc", P(x.to(dev)), P(xh), 2, 18, 12, 10, 20, _capi.stream())
+    assert maxerr(xh[..., :18].permute(0, 3, 1, 2), x) == 0.0 and float(xh[..., 18:].abs().max()) == 0.0
+    y = torch.randn(2, 64, 13, 11)
+    yh = y.to(dev).permute(0, 2, 3, 1).contiguous()
+    out = torch.empty(2, 7, 6, 64, device=dev)
+    _capi.call("hps_maxpool3x3s2", P(yh), P(out), 2, 13, 11, 64, _capi.stream())
+    assert maxerr(out.permute(0, 3, 1, 2), F.max_pool2d(y, 3, 2, 1)) == 0.0
+    avg = torch.empty(2, 64, device=dev)
+    _capi.call("hps_global_avgpool", P(yh), P(avg), 2, 13 * 11, 64, _capi.stream())
+    assert maxerr(avg, y.mean(dim=(2, 3))) <= 1e-6
+
+
+def test_training_mode_is_refused(dev, net_gpu):
+    net_gpu.train()
+    try:
+        with pytest.raises(RuntimeError):
+            net_gpu(torch.zeros(1, 18, 256, 256, device=dev))
+    finally:
+        net_gpu.eval()
+
+
+def test_load_state_dict_invalidates_prepared_weights(dev, net_gpu, net_cpu, golden, golden_input):
+    import copy
+    net = copy.deepcopy(net_gpu)
+    sd = {k: v.clone() for k, v in net_cpu[1].items()}
+    sd["fc_cam.bias"] = sd["fc_cam.bias"] + 1.0
+    net.load_state_dict(sd)
+    out = net(None, input_feats=golden["net_feats"].to(dev))
+    assert maxerr(out[7], golden["net_cam"] + 1.0) <= 1e-4

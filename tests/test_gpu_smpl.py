@@ -1,0 +1,151 @@
+"""GPU parity: SMPL forward (pose prep / blend GEMM / LBS / joints / uncertainty kernels behind the C ABI)
+against the CPU oracle, the float64 twin, analytic known answers, and size-independent properties at the
+full BASELINE configs[1] size (6528 meshes).
+
+Stated fp32 tolerances: vertices and joints <= 2e-5 m given identical (R, beta)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+from oracle.smpl_np64 import smpl_forward64, rodrigues64
+from hierarchicalprobabilistic3dhuman_amd import configs, _capi
+from hierarchicalprobabilistic3dhuman_amd import sampling_utils as su
+from conftest import maxerr
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _pose(M, seed, scale=0.5):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(M, 10, generator=g), torch.randn(M, 24, 3, generator=g) * scale, torch.randn(M, 3, generator=g)
+
+
+@pytest.mark.parametrize("M", [1, 2, 37, 128, 129, 300])
+def test_rotmat_route_matches_oracle(M, dev, smpl_gpu, smpl_assets):
+    p = smpl_assets[2]
+    betas, aa, transl = _pose(M, M)
+    R = O.batch_rodrigues(aa.view(-1, 3)).view(M, 24, 3, 3)
+    ref = O.smpl_forward(p, betas=betas, body_pose=R[:, 1:], global_orient=R[:, :1], pose2rot=False, transl=transl,
+                         return_intermediates=True)
+    smpl_gpu.keep_intermediates = True
+    out = smpl_gpu(betas=betas.to(dev), body_pose=R[:, 1:].to(dev), global_orient=R[:, :1].to(dev), pose2rot=False,
+                   transl=transl.to(dev))
+    L = smpl_gpu._last
+    smpl_gpu.keep_intermediates = False
+    assert maxerr(L["v_posed"], ref["v_posed"]) <= TOL
+    assert maxerr(L["a"].view(M, 24, 3, 4), ref["A"][:, :, :3, :]) <= TOL
+    assert maxerr(L["j_posed"], ref["J_posed"]) <= TOL
+    assert maxerr(out.vertices, ref["vertices"]) <= TOL
+    assert maxerr(out.joints, ref["joints"]) <= TOL
+    assert out.joints.shape == (M, 90, 3) and out.vertices.shape == (M, 6890, 3)
+
+
+@pytest.mark.parametrize("M", [1, 5, 130])
+def test_axis_angle_route_matches_oracle_and_float64(M, dev, smpl_gpu, smpl_assets):
+    model, extra, p = smpl_assets
+    betas, aa, _ = _pose(M, 100 + M, scale=0.8)
+    ref = O.smpl_forward(p, betas=betas, body_pose=aa[:, 1:].reshape(M, 69), global_orient=aa[:, 0])
+    out = smpl_gpu(betas=betas.to(dev), body_pose=aa[:, 1:].reshape(M, 69).to(dev), global_orient=aa[:, 0].to(dev))
+    assert maxerr(out.vertices, ref["vertices"]) <= TOL and maxerr(out.joints, ref["joints"]) <= TOL
+    R64 = rodrigues64(aa.reshape(-1, 3).double().numpy()).reshape(M, 24, 3, 3)
+    v64, j64 = smpl_forward64(model, extra, configs.SMPLX_EXTRA_VERTEX_IDS, betas.double().numpy(), R64)
+    assert np.abs(out.vertices.cpu().numpy() - v64).max() <= TOL
+    assert np.abs(out.joints.cpu().numpy() - j64).max() <= TOL
+
+
+def test_default_arguments_and_beta_expansion(dev, smpl_gpu, smpl_assets):
+    p = smpl_assets[2]
+    b1 = torch.randn(1, 10, generator=torch.Generator().manual_seed(9))
+    # smpl(betas=...) with the zero module pose (predict/...:136)
+    assert maxerr(smpl_gpu(betas=b1.to(dev)).vertices, O.smpl_forward(p, betas=b1)["vertices"]) <= TOL
+    # zero pose, zero betas -> template
+    assert maxerr(smpl_gpu().vertices[0], p.v_template) <= 1e-6
+    # one row of betas expanded to the pose batch
+    _, aa, _ = _pose(3, 5)
+    ref = O.smpl_forward(p, betas=b1, body_pose=aa[:, 1:].reshape(3, 69), global_orient=aa[:, 0])
+    out = smpl_gpu(betas=b1.to(dev), body_pose=aa[:, 1:].reshape(3, 69).to(dev), global_orient=aa[:, 0].to(dev))
+    assert maxerr(out.vertices, ref["vertices"]) <= TOL
+    assert out.betas.shape[0] == 3
+
+
+def test_argument_errors(dev, smpl_gpu):
+    with pytest.raises(ValueError):
+        smpl_gpu(betas=torch.zeros(2, 10, device=dev), body_pose=torch.zeros(2, 23, 3, 3, device=dev),
+                 global_orient=torch.zeros(2, 3, device=dev), pose2rot=False)
+    with pytest.raises(ValueError):
+        smpl_gpu(betas=torch.zeros(2, 9, device=dev), body_pose=torch.zeros(2, 69, device=dev),
+                 global_orient=torch.zeros(2, 3, device=dev))
+
+
+def test_dense_skin_weights_use_wider_kernel(dev, smpl_assets):
+    """A model with more than 4 influences per vertex takes the K=8 / K=24 instantiations."""
+    from hierarchicalprobabilistic3dhuman_amd.smpl_official import SMPL
+    model, extra, _ = smpl_assets
+    rs = np.random.RandomState(1)
+    for nnz, K in ((7, 8), (24, 24)):
+        m2 = dict(model)
+        W = np.zeros((6890, 24))
+        for v in range(6890):
+            idx = rs.choice(24, nnz, replace=False)
+            w = rs.uniform(0.1, 1, nnz)
+            W[v, idx] = w / w.sum()
+        m2["weights"] = W
+        smpl = SMPL(m2).to(dev)
+        assert smpl._lbs_k == K
+        p2 = O.SMPLParams(m2, extra, configs.SMPLX_EXTRA_VERTEX_IDS)
+        betas, aa, _ = _pose(3, 77)
+        ref = O.smpl_forward(p2, betas=betas, body_pose=aa[:, 1:].reshape(3, 69), global_orient=aa[:, 0])
+        out = smpl(betas=betas.to(dev), body_pose=aa[:, 1:].reshape(3, 69).to(dev), global_orient=aa[:, 0].to(dev))
+        assert maxerr(out.vertices, ref["vertices"]) <= TOL
+
+
+def test_full_size_properties_6528_meshes(dev, smpl_gpu, smpl_assets):
+    """BASELINE configs[1] mesh count (64 x (100 + 2)); the oracle is too slow here, so check properties:
+    rigid global rotation, translation equivariance, batch-position independence, one-hot consistency."""
+    M = 6528
+    g = torch.Generator().manual_seed(42)
+    betas = torch.randn(M, 10, generator=g).to(dev)
+    aa = (torch.randn(M, 24, 3, generator=g) * 0.5).to(dev)
+    from hierarchicalprobabilistic3dhuman_amd.rigid_transform_utils import batch_rodrigues
+    R = batch_rodrigues(aa.view(-1, 3)).view(M, 24, 3, 3)
+    out = smpl_gpu(betas=betas, body_pose=R[:, 1:].contiguous(), global_orient=R[:, :1].contiguous(), pose2rot=False)
+    assert torch.isfinite(out.vertices).all() and torch.isfinite(out.joints).all()
+    # (a) a random subset recomputed in a small batch gives the same meshes (no cross-mesh coupling, tile edges)
+    idx = torch.tensor([0, 1, 127, 128, 129, 3000, 6400, 6527])
+    sub = smpl_gpu(betas=betas[idx], body_pose=R[idx, 1:].contiguous(), global_orient=R[idx, :1].contiguous(), pose2rot=False)
+    assert maxerr(sub.vertices, out.vertices[idx]) == 0.0 and maxerr(sub.joints, out.joints[idx]) == 0.0
+    # (b) those meshes against the oracle
+    ref = O.smpl_forward(smpl_assets[2], betas=betas[idx].cpu(), body_pose=R[idx, 1:].cpu(), global_orient=R[idx, :1].cpu(), pose2rot=False)
+    assert maxerr(sub.vertices, ref["vertices"]) <= TOL
+    # (c) pre-multiplying the global rotation by Q rotates the mesh rigidly about the root joint
+    Q = batch_rodrigues(torch.tensor([[0.3, -1.1, 0.4]], device=dev))[0]
+    out_q = smpl_gpu(betas=betas[:256], body_pose=R[:256, 1:].contiguous(),
+                     global_orient=torch.matmul(Q, R[:256, :1]).contiguous(), pose2rot=False)
+    J0 = out.joints[:256, :1]
+    want = torch.einsum("ij,bvj->bvi", Q, out.vertices[:256] - J0) + J0
+    assert maxerr(out_q.vertices, want) <= TOL
+    # (d) translation equivariance
+    t = torch.randn(256, 3, generator=g).to(dev)
+    out_t = smpl_gpu(betas=betas[:256], body_pose=R[:256, 1:].contiguous(), global_orient=R[:256, :1].contiguous(),
+                     pose2rot=False, transl=t)
+    assert maxerr(out_t.vertices, out.vertices[:256] + t[:, None]) <= 1e-6
+    assert maxerr(out_t.joints, out.joints[:256] + t[:, None]) <= 2e-6
+
+
+def test_vertex_uncertainty_kernel(dev):
+    g = torch.Generator().manual_seed(3)
+    v = torch.randn(3, 17, 6890, 3, generator=g)
+    got = su.vertex_uncertainty(v.to(dev))
+    want = torch.stack([O.vertex_uncertainty(v[i]) for i in range(3)])
+    assert maxerr(got, want) <= 1e-5
+    assert maxerr(su.vertex_uncertainty(v[:, :1].contiguous().to(dev)), torch.zeros(3, 6890)) == 0.0     # N = 1: zero spread
+
+
+def test_c_abi_rejects_unsupported_k(dev, smpl_gpu):
+    z = torch.zeros(16, device=dev)
+    zi = torch.zeros(16, device=dev, dtype=torch.int32)
+    with pytest.raises(_capi.HpsError):
+        _capi.call("hps_smpl_lbs", _capi.ptr(z), _capi.ptr(z), _capi.iptr(zi), _capi.ptr(z), 5, 24, None, _capi.ptr(z), 1, 1,
+                   _capi.stream())

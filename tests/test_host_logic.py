@@ -1,0 +1,78 @@
+"""CPU: host-side logic of the boundary -- kinematic levels, state-dict layout, derived SMPL constants,
+synthetic-model determinism, sharding arithmetic."""
+import hashlib
+
+import numpy as np
+import torch
+
+from hierarchicalprobabilistic3dhuman_amd import configs, smpl_data, sharding
+from hierarchicalprobabilistic3dhuman_amd.poseMF_shapeGaussian_net import immediate_parents_to_all_parents
+from hierarchicalprobabilistic3dhuman_amd.smpl_official import SMPL
+from oracle import ref_cpu as O
+
+
+def test_ancestor_lists_match_reference_probe():
+    anc = immediate_parents_to_all_parents(configs.SMPL_PARENTS)
+    assert len(anc) == 23
+    # values printed by the reference's immediate_parents_to_all_parents (models/poseMF_shapeGaussian_net.py:14-21)
+    assert anc[0] == [] and anc[3] == [0] and anc[6] == [3, 0] and anc[14] == [11, 8, 5, 2]
+    assert anc[22] == [20, 18, 16, 13, 8, 5, 2] and anc[21] == [19, 17, 15, 12, 8, 5, 2]
+    assert [anc[j] for j in range(23)] == O.all_ancestors(configs.SMPL_PARENTS)
+
+
+def test_levels_and_state_dict_layout(net_cpu):
+    net, sd = net_cpu
+    assert net.levels == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10, 11, 12, 13], [14, 15, 16], [17, 18], [19, 20], [21, 22]]
+    assert len(sd) == 224 and sum(p.numel() for p in net.parameters()) == 12616684
+    assert sd["fc_pose.22.0.weight"].shape == (128, 256 + 21 * 7) and sd["fc_pose.0.2.weight"].shape == (9, 128)
+    assert sd["init_glob"].tolist() == [[1.0, 0.0, 0.0, 1.0, 0.0, 0.0]]
+    assert sd["image_encoder.conv1.weight"].shape == (64, 18, 7, 7)
+
+
+def test_synthetic_smpl_is_deterministic_and_smpl_shaped():
+    m = smpl_data.synthetic_smpl_model(0)
+    assert m["v_template"].shape == (6890, 3) and m["shapedirs"].shape == (6890, 3, 10)
+    assert m["posedirs"].shape == (6890, 3, 207) and m["J_regressor"].shape == (24, 6890) and m["weights"].shape == (6890, 24)
+    assert ((m["weights"] != 0).sum(1) <= 4).all() and np.allclose(m["weights"].sum(1), 1) and np.allclose(m["J_regressor"].sum(1), 1)
+    h = hashlib.sha256(m["v_template"].tobytes() + m["weights"].tobytes() + m["posedirs"].tobytes()).hexdigest()
+    assert h == hashlib.sha256(smpl_data.synthetic_smpl_model(0)["v_template"].tobytes() + m["weights"].tobytes() + m["posedirs"].tobytes()).hexdigest()
+    assert smpl_data.parents_from_kintree(m["kintree_table"]).tolist() == configs.SMPL_PARENTS
+
+
+def test_extra_regressors_packaged_copy():
+    extra, coco, h36m = smpl_data.load_extra_joint_regressors(None)
+    assert extra.shape == (9, 6890) and coco.shape == (19, 6890) and h36m.shape == (17, 6890)
+    assert (extra != 0).sum() == 62 and (coco != 0).sum() == 86 and (h36m != 0).sum() == 107          # SURVEY.md probe
+
+
+def test_smpl_derived_constants(smpl_assets):
+    model, extra, p = smpl_assets
+    smpl = SMPL(model)
+    V = 6890
+    # compressed skin weights reproduce the dense matrix exactly
+    dense = torch.zeros(V, 24)
+    dense.scatter_add_(1, smpl._w_idx.long(), smpl._w_val)
+    assert torch.equal(dense, smpl.lbs_weights)
+    # blend matrix rows: shapedirs then posedirs, zero padded
+    assert smpl._bmat.shape == (224, 20736) and torch.equal(smpl._bmat[10:217, :3 * V], smpl.posedirs)
+    assert float(smpl._bmat[217:].abs().max()) == 0 and float(smpl._bmat[:, 3 * V:].abs().max()) == 0
+    # folded joint regression equals regressing the shaped template
+    betas = torch.randn(3, 10)
+    J = smpl._j_template + torch.einsum("jcl,bl->bjc", smpl._j_shapedirs, betas)
+    ref = O.smpl_forward(p, betas=betas, return_intermediates=True, body_pose=torch.zeros(3, 69), global_orient=torch.zeros(3, 3))
+    assert float((J - ref["J"]).abs().max()) <= 1e-6
+    # CSR joint rows: 21 picks + 9 + 19 + 17
+    assert smpl._n_joint_rows == 66 and int(smpl._csr_ptr[-1]) == 21 + 62 + 86 + 107
+    assert smpl._depth_i32.tolist() == [0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 6, 6, 7, 7, 8, 8]
+    assert smpl.parents.tolist() == configs.SMPL_PARENTS and len(smpl.state_dict()) == 12
+
+
+def test_shard_ranges_partition_the_batch():
+    for total in (0, 1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 4, 8):
+            r = [sharding.shard_range(total, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == total
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+    assert sharding.shard_range(512, 3, 8) == (192, 256)                      # BASELINE configs[2]: 64 images per GPU

@@ -1,0 +1,62 @@
+"""CPU: the oracle (oracle/ref_cpu.py) against the golden vectors the imported reference produced.
+This is what pins the oracle for encoder, head, sampler and rotation conversions."""
+import torch
+
+from oracle import ref_cpu as O
+from hierarchicalprobabilistic3dhuman_amd import configs
+from conftest import maxerr
+
+
+def test_encoder_matches_reference(golden, net_cpu, golden_input):
+    feats = O.resnet18_forward(net_cpu[1], golden_input)
+    assert maxerr(feats, golden["net_feats"]) <= 1e-6
+
+
+def test_head_matches_reference(golden, net_cpu):
+    out = O.head_forward(net_cpu[1], golden["net_feats"], configs.SMPL_PARENTS)
+    for got, key in zip(out[:5], ("net_F", "net_U", "net_S", "net_V", "net_mode")):
+        assert maxerr(got, golden[key]) <= 1e-6, key
+    assert maxerr(out[5][0], golden["net_shape_loc"]) <= 1e-6
+    assert maxerr(out[5][1], golden["net_shape_scale"]) <= 1e-6
+    assert maxerr(out[6], golden["net_glob"]) <= 1e-6
+    assert maxerr(out[7], golden["net_cam"]) <= 1e-6
+
+
+def test_sampler_replays_reference_stream(golden):
+    U, S, V = golden["net_U"], golden["net_S"], golden["net_V"]
+    for N in (1, 4, 100):
+        torch.manual_seed(0)
+        R = O.pose_matrix_fisher_sampling(U, S, V, N)
+        assert maxerr(R, golden["sampler_R_N%d" % N]) <= 1e-6, N
+
+
+def test_sampler_concentration_sweep(golden):
+    torch.manual_seed(1)
+    R = O.pose_matrix_fisher_sampling(golden["sweep_U"], golden["sweep_S"], golden["sweep_V"], 50)
+    assert maxerr(R, golden["sweep_R_N50"]) <= 1e-6
+
+
+def test_bingham_entry_point(golden):
+    A = golden["bingham_A"]
+    Om = 1 + 2 * A / 1.5
+    torch.manual_seed(2)
+    q = O.bingham_sampling(A, 16, Om, Om ** -0.5, O.m_star(1.5))
+    assert maxerr(q, golden["bingham_q_N16"]) <= 1e-6
+
+
+def test_rotation_conversions(golden):
+    assert maxerr(O.rot6d_to_rotmat(golden["rot6d_in"]), golden["rot6d_out"]) <= 1e-6
+    assert maxerr(O.quat_to_rotmat(golden["quat_in"]), golden["quat_out"]) <= 1e-6
+    assert maxerr(O.rotmat_to_rot6d(golden["quat_out"]), golden["rotmat_to_rot6d_out"]) <= 1e-6
+
+
+def test_sampler_first_moment_matches_normalising_constant_gradient(golden):
+    """E[R] = U_p diag(dlogc/ds) V_p^T; the gradient comes from the reference's LogMFNormConstant
+    (losses/matrix_fisher_loss.py:172-192), the samples from the oracle.  Seed-independent statistical KAT."""
+    U, S, V = golden["sweep_U"], golden["sweep_S"], golden["sweep_V"]
+    N = 3000
+    torch.manual_seed(123)
+    R = O.pose_matrix_fisher_sampling(U, S, V, N)[0]                  # (N,7,3,3)
+    D = torch.matmul(U[0].transpose(-1, -2), torch.matmul(R.mean(0), V[0]))
+    want = torch.diag_embed(golden["sweep_dlogc_dS"])
+    assert maxerr(D, want) <= 5.0 / N ** 0.5                          # ~5 sigma of the Monte-Carlo mean
