@@ -39,36 +39,43 @@ def test_bingham_entry_point_reproduces_reference(dev, golden):
 
 
 def test_discarded_rounds_follow_the_reference_stream(dev):
-    """N = 1 with 8 proposals fails ~1 % of the calls (SURVEY.md section 7 hard part 2): 1472 calls make the
-    discard-and-redraw path (utils/sampling_utils.py:68-69) certain to run; results must still match."""
+    """A round with fewer than N accepted proposals is discarded and redrawn (utils/sampling_utils.py:68-69),
+    which shifts every later call along the host random stream.  oversampling_ratio=2 with N=1 makes that
+    happen for ~10 % of the calls (including double discards); results must still match the sequential loop."""
     g = torch.Generator().manual_seed(5)
-    F = torch.randn(64, 23, 3, 3, generator=g) * 0.3 + torch.eye(3)
+    F = torch.randn(8, 23, 3, 3, generator=g) * 0.3 + torch.eye(3)
     U, S, Vh = torch.linalg.svd(F)
     V = Vh.transpose(-1, -2).contiguous()
     torch.manual_seed(9)
-    Rref, (_, _, disc) = O.pose_matrix_fisher_sampling(U, S, V, 1, return_noise=True)
-    assert int(disc.sum()) > 0, "test input no longer exercises a discarded round"
+    Rref, (_, _, disc) = O.pose_matrix_fisher_sampling(U, S, V, 1, oversampling_ratio=2, return_noise=True)
+    assert int(disc.sum()) >= 5 and int(disc.max()) >= 2, "test input no longer exercises discarded rounds"
     torch.manual_seed(9)
-    R = su.pose_matrix_fisher_sampling_torch(U.to(dev), S.to(dev), V.to(dev), 1, sample_on_cpu=True)
+    R = su.pose_matrix_fisher_sampling_torch(U.to(dev), S.to(dev), V.to(dev), 1, oversampling_ratio=2, sample_on_cpu=True)
     assert maxerr(R, Rref) <= TOL
     # the host generator must end in the same state as after the reference loop
     a = torch.rand(1)
     torch.manual_seed(9)
-    O.pose_matrix_fisher_sampling(U, S, V, 1)
+    O.pose_matrix_fisher_sampling(U, S, V, 1, oversampling_ratio=2)
     assert torch.equal(a, torch.rand(1))
+    # Philox route with the same starved proposal budget still returns N valid rotations per call
+    Rp = su.pose_matrix_fisher_sampling_torch(U.to(dev), S.to(dev), V.to(dev), 1, oversampling_ratio=2, seed=3)
+    assert float((torch.matmul(Rp.transpose(-1, -2), Rp) - torch.eye(3, device=dev)).abs().max()) <= 1e-5
 
 
 def test_philox_route_properties(dev, golden):
     U, S, V = (golden[k].to(dev) for k in ("sweep_U", "sweep_S", "sweep_V"))
-    N = 4000
+    N = 20000
     R = su.pose_matrix_fisher_sampling_torch(U, S, V, N, seed=2024)
     # proper rotations
     eye = torch.eye(3, device=dev)
     assert float((torch.matmul(R.transpose(-1, -2), R) - eye).abs().max()) <= 1e-5
     assert float((torch.det(R.cpu()) - 1).abs().max()) <= 1e-5
     # E[R] = U diag(dlogc/ds) V^T, gradient from the reference's LogMFNormConstant (golden)
+    # (row 5, S = (500,400,300), is left out: there the reference's 512-point trapezoid integral is itself off by
+    #  ~0.09 against a 20000-sample Monte-Carlo mean of the reference's own sampler; the other rows agree to 0.01)
     D = torch.matmul(U[0].transpose(-1, -2), torch.matmul(R[0].mean(0), V[0])).cpu()
-    assert maxerr(D, torch.diag_embed(golden["sweep_dlogc_dS"])) <= 5.0 / N ** 0.5
+    rows = [0, 1, 2, 3, 4, 6]
+    assert maxerr(D[rows], torch.diag_embed(golden["sweep_dlogc_dS"])[rows]) <= 0.025
     # same seed -> same samples; different seed -> different samples
     assert torch.equal(R, su.pose_matrix_fisher_sampling_torch(U, S, V, N, seed=2024))
     assert not torch.equal(R, su.pose_matrix_fisher_sampling_torch(U, S, V, N, seed=2025))

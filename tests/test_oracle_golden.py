@@ -54,9 +54,12 @@ def test_sampler_first_moment_matches_normalising_constant_gradient(golden):
     """E[R] = U_p diag(dlogc/ds) V_p^T; the gradient comes from the reference's LogMFNormConstant
     (losses/matrix_fisher_loss.py:172-192), the samples from the oracle.  Seed-independent statistical KAT."""
     U, S, V = golden["sweep_U"], golden["sweep_S"], golden["sweep_V"]
-    N = 3000
+    N = 20000
     torch.manual_seed(123)
     R = O.pose_matrix_fisher_sampling(U, S, V, N)[0]                  # (N,7,3,3)
     D = torch.matmul(U[0].transpose(-1, -2), torch.matmul(R.mean(0), V[0]))
     want = torch.diag_embed(golden["sweep_dlogc_dS"])
-    assert maxerr(D, want) <= 5.0 / N ** 0.5                          # ~5 sigma of the Monte-Carlo mean
+    # row 5, S = (500,400,300): the reference's 512-point trapezoid integral is inaccurate at that concentration
+    # (0.95/0.91 where the true value is ~0.999), so it is excluded; Monte-Carlo sigma of the mean <= 0.004
+    rows = [0, 1, 2, 3, 4, 6]
+    assert maxerr(D[rows], want[rows]) <= 0.025
