@@ -131,7 +131,7 @@ def main():
                                    "poseMF_shapeGaussian head (seed 0), Philox sampling" % (B, N),
                        "images_per_gpu": B, "global_batch": B * world, "num_samples": N,
                        "meshes_per_step_per_gpu": M, "parallelism": "images sharded over %d GPU(s)" % world},
-            "roofline": {"bound": "hbm", "kernel": "hps::lbs_kernel<4,4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "hps::lbs_kernel<4,8,1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
                          "avg_launch_ms": lbs_avg_ms, "launches": len(lbs_ms),
                          "algorithmic_bytes_per_launch": LBS_BYTES_PER_MESH * M},

@@ -23,6 +23,7 @@ _PROTOTYPES = {
     "hps_smpl_pose_prep": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
     "hps_smpl_blend": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "hps_smpl_lbs": [_P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
+    "hps_dev_lbs_variant": [_P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P],
     "hps_smpl_joints": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
     "hps_vertex_uncertainty": [_P, _P, _I, _I, _I, _P],
     "hps_mf_sample": [_P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _c.c_float, _P, _P, _P, _c.c_uint64,
@@ -31,8 +32,10 @@ _PROTOTYPES = {
     "hps_rot6d_to_rotmat": [_P, _P, _I, _P],
     "hps_batch_rodrigues": [_P, _P, _I, _P],
     "hps_linear": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "hps_head_joint_level": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _I, _I, _P],
-    "hps_head_svd_finish": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P],
+    "hps_head_joint_level": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _I, _I, _P],
+    "hps_host_svd3_packed": [_P, _P, _I, _I],
+    "hps_host_bind_lapack": [_c.c_char_p],
+    "hps_head_svd_finish": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "hps_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "hps_conv2d_bn_act": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "hps_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P],
@@ -63,6 +66,10 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the build is stale: fail loudly
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, _I)
+    # the head's host SVD uses the MKL sgesdd_ PyTorch itself links (same routine as the reference's torch.svd)
+    torch_cpu = os.path.join(os.path.dirname(torch.__file__), "lib", "libtorch_cpu.so")
+    if os.path.exists(torch_cpu):
+        lib.hps_host_bind_lapack(torch_cpu.encode())
     _lib = lib
     return lib
 

@@ -15,7 +15,7 @@ INCLUDE = os.path.join(REPO_ROOT, "include")
 LIB_PATH = os.path.join(PKG_DIR, "libhps.so")
 STAMP_PATH = os.path.join(PKG_DIR, "libhps.stamp")
 
-SOURCES = ["api.hip", "smpl.hip", "blend_gemm.hip", "mf_sample.hip", "head.hip", "conv.hip"]
+SOURCES = ["api.hip", "smpl.hip", "blend_gemm.hip", "mf_sample.hip", "head.hip", "conv.hip", "host_svd.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function"]
 
@@ -67,7 +67,7 @@ def build(force=False, verbose=True):
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl", "-lpthread"]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -8,18 +8,57 @@ namespace hps {
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x); }
 
-constexpr int TB = 16;  // batch rows per workgroup
+// These layers are tiny (<= 17 MFLOP per launch at B = 64) and sit on the critical path of the 8-level
+// kinematic chain, so the kernels are organised for latency, not throughput: the reduction dimension is
+// split over many lanes (KS slices), every lane keeps 8 independent weight loads in flight, and the
+// partial sums meet in LDS.
 
-// out[b, n] = act(x[b, :] . wt[:, n] + bias[n] + addend[n]);  256 threads = 4 K-slices x 64 columns
+constexpr int TB = 8;      // batch rows per workgroup
+constexpr int LCOLS = 16;  // output columns per workgroup of linear_kernel
+constexpr int LKS = 16;    // K slices of linear_kernel (LCOLS * LKS = 256 threads)
+
+// acc[r] += sum_{k in [k_lo, k_hi)} xs[k][r] * w[k * ldw]   with 8 weight loads in flight
+template <int ROWS>
+__device__ __forceinline__ void dot_slice(const float* __restrict__ w, size_t ldw, const float* xs, int k_lo, int k_hi,
+                                          float (&acc)[ROWS]) {
+    int k = k_lo;
+    for (; k + 8 <= k_hi; k += 8) {
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = w[(size_t)(k + u) * ldw];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4* xr = reinterpret_cast<const float4*>(xs + (k + u) * ROWS);
+#pragma unroll
+            for (int q = 0; q < ROWS / 4; ++q) {
+                const float4 xv = xr[q];
+                acc[q * 4 + 0] += xv.x * wv[u]; acc[q * 4 + 1] += xv.y * wv[u];
+                acc[q * 4 + 2] += xv.z * wv[u]; acc[q * 4 + 3] += xv.w * wv[u];
+            }
+        }
+    }
+    for (; k < k_hi; ++k) {
+        const float wv = w[(size_t)k * ldw];
+        const float4* xr = reinterpret_cast<const float4*>(xs + k * ROWS);
+#pragma unroll
+        for (int q = 0; q < ROWS / 4; ++q) {
+            const float4 xv = xr[q];
+            acc[q * 4 + 0] += xv.x * wv; acc[q * 4 + 1] += xv.y * wv;
+            acc[q * 4 + 2] += xv.z * wv; acc[q * 4 + 3] += xv.w * wv;
+        }
+    }
+}
+
+// out[b, n] = act(x[b, :] . wt[:, n] + bias[n] + addend[n]);  256 threads = LKS K-slices x LCOLS columns
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ wt,
                                                      const float* __restrict__ bias, const float* __restrict__ addend,
                                                      float* __restrict__ out, int ldo, int B, int K, int N, int act) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // xs[K][TB] then red[4][TB][64]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // xs[K][TB] then red[LKS][TB][LCOLS]
     float* xs = smem;
     float* red = smem + (size_t)((K * TB + 3) & ~3);
     const int b0 = blockIdx.y * TB;
-    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ks = threadIdx.x >> 6;
+    const int col = threadIdx.x % LCOLS, ks = threadIdx.x / LCOLS;
+    const int n = blockIdx.x * LCOLS + col;
 
     for (int i = threadIdx.x; i < K * TB; i += 256) {
         const int r = i / K, k = i % K;                      // coalesced along k
@@ -30,55 +69,48 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
     float acc[TB];
 #pragma unroll
     for (int r = 0; r < TB; ++r) acc[r] = 0.0f;
-    const int kchunk = ceil_div(K, 4);
-    const int k_lo = ks * kchunk, k_hi = min(K, k_lo + kchunk);
-    if (n < N) {
-        for (int k = k_lo; k < k_hi; ++k) {
-            const float wv = wt[(size_t)k * N + n];
-            const float4* xr = reinterpret_cast<const float4*>(xs + k * TB);
+    const int kchunk = ceil_div(K, LKS);
+    const int k_lo = min(K, ks * kchunk), k_hi = min(K, k_lo + kchunk);
+    if (n < N) dot_slice<TB>(wt + n, (size_t)N, xs, k_lo, k_hi, acc);
 #pragma unroll
-            for (int q = 0; q < TB / 4; ++q) {
-                const float4 xv = xr[q];
-                acc[q * 4 + 0] += xv.x * wv; acc[q * 4 + 1] += xv.y * wv;
-                acc[q * 4 + 2] += xv.z * wv; acc[q * 4 + 3] += xv.w * wv;
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < TB; ++r) red[(ks * TB + r) * 64 + (threadIdx.x & 63)] = acc[r];
+    for (int r = 0; r < TB; ++r) red[(ks * TB + r) * LCOLS + col] = acc[r];
     __syncthreads();
-    if (ks == 0 && n < N) {
-        const float add = bias[n] + (addend ? addend[n] : 0.0f);
-        for (int r = 0; r < TB && b0 + r < B; ++r) {
-            const int c = threadIdx.x & 63;
-            float v = red[(0 * TB + r) * 64 + c] + red[(1 * TB + r) * 64 + c] + red[(2 * TB + r) * 64 + c] +
-                      red[(3 * TB + r) * 64 + c] + add;
+    if (threadIdx.x < TB * LCOLS) {
+        const int r = threadIdx.x / LCOLS, c = threadIdx.x % LCOLS;
+        const int nn = blockIdx.x * LCOLS + c;
+        if (nn < N && b0 + r < B) {
+            float v = 0.0f;
+#pragma unroll
+            for (int q = 0; q < LKS; ++q) v += red[(q * TB + r) * LCOLS + c];
+            v += bias[nn] + (addend ? addend[nn] : 0.0f);
             if (act == HPS_ACT_ELU) v = elu1(v);
             else if (act == HPS_ACT_RELU) v = fmaxf(v, 0.0f);
-            out[(size_t)(b0 + r) * ldo + n] = v;
+            out[(size_t)(b0 + r) * ldo + nn] = v;
         }
     }
 }
 
-// One kinematic level: grid = (n_level joints, batch tiles).  hidden == 128 (EMBED_DIM / 2).
+// One kinematic level: grid = (n_level joints, batch tiles), 1024 threads = 8 K-slices x HID columns.
 template <int HID>
-__global__ __launch_bounds__(256) void joint_level_kernel(
+__global__ __launch_bounds__(1024) void joint_level_kernel(
     const float* __restrict__ embed, int embed_dim, const int32_t* __restrict__ joint_ids,
     const int32_t* __restrict__ anc_ptr, const int32_t* __restrict__ anc_idx, const float* const* __restrict__ w1t_ptrs,
     const float* const* __restrict__ b1_ptrs, const float* const* __restrict__ w2_ptrs,
     const float* const* __restrict__ b2_ptrs, const float* __restrict__ u_proper, const float* __restrict__ s_proper,
-    const float* __restrict__ mode, float delta_i_weight, float* __restrict__ pose_f, int B, int NJ) {
+    const float* __restrict__ mode, float delta_i_weight, float* __restrict__ pose_f, float* __restrict__ f_level,
+    int B, int NJ) {
+    constexpr int KS = 1024 / HID;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int joint = joint_ids[blockIdx.x];
     const int a_lo = anc_ptr[joint], P = anc_ptr[joint + 1] - a_lo;
     const int in_dim = embed_dim + 21 * P;
     float* xs = smem;                                        // [in_dim][TB]
     float* hs = smem + (size_t)((in_dim * TB + 3) & ~3);     // [HID][TB]
-    float* red = hs + HID * TB;                              // [TB][HID]  partial sums of K-slice 1
+    float* red = hs + HID * TB;                              // [KS][TB][HID] partial sums
     const int b0 = blockIdx.y * TB;
 
     // gather: cat[embed, U_proper[anc] (9P), S_proper[anc] (3P), mode[anc] (9P)]   (:126-132)
-    for (int i = threadIdx.x; i < in_dim * TB; i += 256) {
+    for (int i = threadIdx.x; i < in_dim * TB; i += 1024) {
         const int r = i / in_dim, k = i % in_dim;
         const int b = b0 + r;
         float v = 0.0f;
@@ -95,60 +127,66 @@ __global__ __launch_bounds__(256) void joint_level_kernel(
     }
     __syncthreads();
 
-    // hidden layer: 2 K-slices x HID columns
-    const float* w1t = w1t_ptrs[joint];
-    const int n = threadIdx.x % HID, ks = threadIdx.x / HID;     // HID == 128 -> ks in {0,1}
+    // hidden layer
+    const int n = threadIdx.x % HID, ks = threadIdx.x / HID;
     float acc[TB];
 #pragma unroll
     for (int r = 0; r < TB; ++r) acc[r] = 0.0f;
-    const int kh = (in_dim + 1) / 2;
-    const int k_lo = ks * kh, k_hi = min(in_dim, k_lo + kh);
-    for (int k = k_lo; k < k_hi; ++k) {
-        const float wv = w1t[(size_t)k * HID + n];
-        const float4* xr = reinterpret_cast<const float4*>(xs + k * TB);
+    const int kchunk = ceil_div(in_dim, KS);
+    const int k_lo = min(in_dim, ks * kchunk), k_hi = min(in_dim, k_lo + kchunk);
+    dot_slice<TB>(w1t_ptrs[joint] + n, (size_t)HID, xs, k_lo, k_hi, acc);
 #pragma unroll
-        for (int q = 0; q < TB / 4; ++q) {
-            const float4 xv = xr[q];
-            acc[q * 4 + 0] += xv.x * wv; acc[q * 4 + 1] += xv.y * wv;
-            acc[q * 4 + 2] += xv.z * wv; acc[q * 4 + 3] += xv.w * wv;
-        }
-    }
-    if (ks == 1) {
-#pragma unroll
-        for (int r = 0; r < TB; ++r) red[r * HID + n] = acc[r];
-    }
+    for (int r = 0; r < TB; ++r) red[(ks * TB + r) * HID + n] = acc[r];
     __syncthreads();
-    if (ks == 0) {
-        const float bv = b1_ptrs[joint][n];
+    if (threadIdx.x < HID * TB) {
+        const int r = threadIdx.x / HID, c = threadIdx.x % HID;
+        float v = b1_ptrs[joint][c];
 #pragma unroll
-        for (int r = 0; r < TB; ++r) hs[n * TB + r] = elu1(acc[r] + red[r * HID + n] + bv);
+        for (int q = 0; q < KS; ++q) v += red[(q * TB + r) * HID + c];
+        hs[c * TB + r] = elu1(v);
     }
     __syncthreads();
 
-    // output layer: 9 x TB dot products of length HID, + bias + delta_i_weight * I   (:134-135)
-    if (threadIdx.x < 9 * TB) {
-        const int e = threadIdx.x / TB, r = threadIdx.x % TB;
+    // output layer: 9 x TB dot products of length HID split over 8 lanes each, + bias + delta_i_weight * I (:134-135)
+    if (threadIdx.x < 9 * TB * 8) {
+        const int part = threadIdx.x & 7, o = threadIdx.x >> 3;
+        const int e = o / TB, r = o % TB;
         const float* w2 = w2_ptrs[joint] + (size_t)e * HID;
         float v = 0.0f;
-        for (int k = 0; k < HID; ++k) v += w2[k] * hs[k * TB + r];
-        v += b2_ptrs[joint][e];
-        if (e % 4 == 0) v += delta_i_weight;
-        if (b0 + r < B) pose_f[((size_t)(b0 + r) * NJ + joint) * 9 + e] = v;
+        for (int k = part; k < HID; k += 8) v += w2[k] * hs[k * TB + r];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        if (part == 0) {
+            v += b2_ptrs[joint][e];
+            if (e % 4 == 0) v += delta_i_weight;
+            if (b0 + r < B) {
+                pose_f[((size_t)(b0 + r) * NJ + joint) * 9 + e] = v;
+                if (f_level) f_level[((size_t)(b0 + r) * gridDim.x + blockIdx.x) * 9 + e] = v;
+            }
+        }
     }
 }
 
-// proper SVD + mode (:139-152): thread per (image, joint of the level)
-__global__ void svd_finish_kernel(const float* __restrict__ pose_u, const float* __restrict__ pose_s,
-                                  const float* __restrict__ pose_v, const int32_t* __restrict__ joint_ids, int n_level,
+// proper SVD + mode (:139-152): thread per (image, joint of the level); input packed [U | S | V] per matrix
+__global__ void svd_finish_kernel(const float* __restrict__ usv, const int32_t* __restrict__ joint_ids, int n_level,
+                                  float* __restrict__ pose_u, float* __restrict__ pose_s, float* __restrict__ pose_v,
                                   float* __restrict__ u_proper, float* __restrict__ s_proper, float* __restrict__ mode,
                                   int B, int NJ) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * n_level) return;
     const int b = i / n_level, joint = joint_ids[i % n_level];
     const size_t o = (size_t)b * NJ + joint;
-    float U[9], V[9];
+    const float* src = usv + (size_t)i * 21;
+    float U[9], V[9], S[3];
 #pragma unroll
-    for (int e = 0; e < 9; ++e) { U[e] = pose_u[o * 9 + e]; V[e] = pose_v[o * 9 + e]; }
+    for (int e = 0; e < 9; ++e) { U[e] = src[e]; V[e] = src[12 + e]; }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) S[e] = src[9 + e];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { pose_u[o * 9 + e] = U[e]; pose_v[o * 9 + e] = V[e]; }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) pose_s[o * 3 + e] = S[e];
     const float dU = det3(U), dV = det3(V);
     U[2] *= dU; U[5] *= dU; U[8] *= dU;
     V[2] *= dV; V[5] *= dV; V[8] *= dV;
@@ -156,9 +194,9 @@ __global__ void svd_finish_kernel(const float* __restrict__ pose_u, const float*
     mat3_mul_bt(U, V, Mo);
 #pragma unroll
     for (int e = 0; e < 9; ++e) { u_proper[o * 9 + e] = U[e]; mode[o * 9 + e] = Mo[e]; }
-    s_proper[o * 3 + 0] = pose_s[o * 3 + 0];
-    s_proper[o * 3 + 1] = pose_s[o * 3 + 1];
-    s_proper[o * 3 + 2] = pose_s[o * 3 + 2] * (dU * dV);
+    s_proper[o * 3 + 0] = S[0];
+    s_proper[o * 3 + 1] = S[1];
+    s_proper[o * 3 + 2] = S[2] * (dU * dV);
 }
 
 }  // namespace hps
@@ -170,9 +208,9 @@ extern "C" int hps_linear(const float* x, int ldx, const float* wt, const float*
     if (!x || !wt || !bias || !out) return bad_arg("hps_linear: null pointer");
     if (K <= 0 || N <= 0 || ldx < K || ldo < N) return bad_arg("hps_linear: dims");
     if (B <= 0) return HPS_OK;
-    size_t lds = ((size_t)((K * TB + 3) & ~3) + 4 * TB * 64) * sizeof(float);
-    if (lds > 160 * 1024) { set_error("hps_linear: K=%d too large for the LDS tile", K); return HPS_E_UNSUPPORTED; }
-    hipLaunchKernelGGL(linear_kernel, dim3(ceil_div(N, 64), ceil_div(B, TB)), dim3(256), lds, (hipStream_t)stream, x,
+    size_t lds = ((size_t)((K * TB + 3) & ~3) + LKS * TB * LCOLS) * sizeof(float);
+    if (lds > 64 * 1024) { set_error("hps_linear: K=%d too large for the LDS tile", K); return HPS_E_UNSUPPORTED; }
+    hipLaunchKernelGGL(linear_kernel, dim3(ceil_div(N, LCOLS), ceil_div(B, TB)), dim3(256), lds, (hipStream_t)stream, x,
                        ldx, wt, bias, addend, out, ldo, B, K, N, act);
     return check_launch("hps_linear");
 }
@@ -182,28 +220,28 @@ extern "C" int hps_head_joint_level(const float* embed, int embed_dim, int hidde
                                     const float* const* w1t_ptrs, const float* const* b1_ptrs,
                                     const float* const* w2_ptrs, const float* const* b2_ptrs, const float* u_proper,
                                     const float* s_proper, const float* mode, float delta_i_weight, float* pose_f,
-                                    int B, int num_body_joints, hps_stream_t stream) {
+                                    float* f_level, int B, int num_body_joints, hps_stream_t stream) {
     if (!embed || !joint_ids || !anc_ptr || !anc_idx || !w1t_ptrs || !b1_ptrs || !w2_ptrs || !b2_ptrs || !u_proper ||
         !s_proper || !mode || !pose_f)
         return bad_arg("hps_head_joint_level: null pointer");
     if (hidden != 128) { set_error("hps_head_joint_level: hidden=%d unsupported (128 = EMBED_DIM/2)", hidden); return HPS_E_UNSUPPORTED; }
     if (B <= 0 || n_level <= 0) return HPS_OK;
     const int max_in = embed_dim + 21 * num_body_joints;
-    size_t lds = ((size_t)((max_in * TB + 3) & ~3) + 2 * 128 * TB) * sizeof(float);
-    if (lds > 160 * 1024) { set_error("hps_head_joint_level: embed_dim=%d too large", embed_dim); return HPS_E_UNSUPPORTED; }
-    hipLaunchKernelGGL((joint_level_kernel<128>), dim3(n_level, ceil_div(B, TB)), dim3(256), lds, (hipStream_t)stream,
+    size_t lds = ((size_t)((max_in * TB + 3) & ~3) + 128 * TB + (1024 / 128) * TB * 128) * sizeof(float);
+    if (lds > 64 * 1024) { set_error("hps_head_joint_level: embed_dim=%d too large", embed_dim); return HPS_E_UNSUPPORTED; }
+    hipLaunchKernelGGL((joint_level_kernel<128>), dim3(n_level, ceil_div(B, TB)), dim3(1024), lds, (hipStream_t)stream,
                        embed, embed_dim, joint_ids, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper,
-                       s_proper, mode, delta_i_weight, pose_f, B, num_body_joints);
+                       s_proper, mode, delta_i_weight, pose_f, f_level, B, num_body_joints);
     return check_launch("hps_head_joint_level");
 }
 
-extern "C" int hps_head_svd_finish(const float* pose_u, const float* pose_s, const float* pose_v,
-                                   const int32_t* joint_ids, int n_level, float* u_proper, float* s_proper, float* mode,
-                                   int B, int num_body_joints, hps_stream_t stream) {
-    if (!pose_u || !pose_s || !pose_v || !joint_ids || !u_proper || !s_proper || !mode)
+extern "C" int hps_head_svd_finish(const float* usv_level, const int32_t* joint_ids, int n_level, float* pose_u,
+                                   float* pose_s, float* pose_v, float* u_proper, float* s_proper, float* mode, int B,
+                                   int num_body_joints, hps_stream_t stream) {
+    if (!usv_level || !pose_u || !pose_s || !pose_v || !joint_ids || !u_proper || !s_proper || !mode)
         return bad_arg("hps_head_svd_finish: null pointer");
     if (B <= 0 || n_level <= 0) return HPS_OK;
-    hipLaunchKernelGGL(svd_finish_kernel, dim3(ceil_div(B * n_level, 128)), dim3(128), 0, (hipStream_t)stream, pose_u,
-                       pose_s, pose_v, joint_ids, n_level, u_proper, s_proper, mode, B, num_body_joints);
+    hipLaunchKernelGGL(svd_finish_kernel, dim3(ceil_div(B * n_level, 128)), dim3(128), 0, (hipStream_t)stream, usv_level,
+                       joint_ids, n_level, pose_u, pose_s, pose_v, u_proper, s_proper, mode, B, num_body_joints);
     return check_launch("hps_head_svd_finish");
 }

@@ -122,38 +122,48 @@ __global__ __launch_bounds__(256) void pose_prep_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// LBS: one lane per vertex; the lane keeps its K (joint, weight) pairs in registers and walks the
-// meshes of its chunk.  A[m] (J x 12 floats) is staged through LDS, G meshes at a time, double
-// buffered so there is one barrier per group.  v_posed / verts move as lane-contiguous 12-byte
-// records (768 contiguous bytes per wave instruction).
+// LBS.  A workgroup owns VPT*256 consecutive vertices for its whole life (each lane keeps the K
+// (joint, weight) pairs of its VPT vertices in registers) and walks a contiguous chunk of meshes, G at a
+// time.  A[m] (J x 12 floats) is staged through LDS, double buffered: one barrier per G meshes.
+// v_posed / verts move as lane-contiguous 12-byte records (768 contiguous bytes per wave instruction).
+// The grid is sized to be resident in one round (no tail) and mapped so that the workgroups sharing a mesh
+// chunk -- the ones that read the same A -- run on the same XCD and hit its L2.
 // ---------------------------------------------------------------------------------------------
-template <int K, int G>
+template <int K, int G, int VPT>
 __global__ __launch_bounds__(256) void lbs_kernel(const f3* __restrict__ v_posed, const float* __restrict__ a,
                                                   const int32_t* __restrict__ w_idx, const float* __restrict__ w_val,
                                                   int J, const float* __restrict__ transl, f3* __restrict__ verts,
-                                                  int M, int V, int meshes_per_block) {
+                                                  int M, int V, int meshes_per_block, int n_vtiles) {
     extern __shared__ __attribute__((aligned(16))) float sA[];  // [2][G][J*12]
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    const bool live = v < V;
-    const int m_begin = blockIdx.y * meshes_per_block;
+    // block id -> (mesh chunk, vertex tile): ids congruent mod 8 (one XCD) share chunks
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int chunk = (local / n_vtiles) * 8 + xcd, vt = local % n_vtiles;
+    const int m_begin = chunk * meshes_per_block;
+    if (m_begin >= M) return;
     const int m_end = min(M, m_begin + meshes_per_block);
     const int a_stride = J * 12;
 
-    int idx[K];
-    float w[K];
+    int vtx[VPT];
+    bool live[VPT];
+    int idx[VPT][K];
+    float w[VPT][K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        idx[k] = live ? w_idx[(size_t)v * K + k] * 12 : 0;
-        w[k] = live ? w_val[(size_t)v * K + k] : 0.0f;
+    for (int q = 0; q < VPT; ++q) {
+        vtx[q] = vt * (256 * VPT) + q * 256 + threadIdx.x;
+        live[q] = vtx[q] < V;
+        if (!live[q]) vtx[q] = V - 1;          // clamp: loads stay in range, stores are predicated
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            idx[q][k] = w_idx[(size_t)vtx[q] * K + k] * 12;
+            w[q][k] = w_val[(size_t)vtx[q] * K + k];
+        }
     }
 
     auto stage = [&](int buf, int m0) {
-        const int n4 = (G * a_stride) >> 2;  // a_stride multiple of 4
-        const int avail = (min(M, m0 + G) - m0) * a_stride >> 2;
+        const int n4 = (min(m_end, m0 + G) - m0) * a_stride >> 2;  // a_stride is a multiple of 4
         const float4* src = reinterpret_cast<const float4*>(a + (size_t)m0 * a_stride);
         float4* dst = reinterpret_cast<float4*>(sA + buf * G * a_stride);
-        for (int i = threadIdx.x; i < n4; i += 256)
-            if (i < avail) dst[i] = src[i];
+        for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
     };
 
     int buf = 0;
@@ -161,35 +171,39 @@ __global__ __launch_bounds__(256) void lbs_kernel(const f3* __restrict__ v_posed
     for (int m0 = m_begin; m0 < m_end; m0 += G) {
         __syncthreads();
         if (m0 + G < m_end) stage(buf ^ 1, m0 + G);
-        f3 p[G];
+        f3 p[G][VPT];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const int m = m0 + g;
-            if (live && m < m_end) p[g] = v_posed[(size_t)m * V + v];
-            else p[g] = f3{0.f, 0.f, 0.f};
+            const int m = min(m0 + g, m_end - 1);   // clamp: the tail group re-reads the last mesh
+#pragma unroll
+            for (int q = 0; q < VPT; ++q) p[g][q] = v_posed[(size_t)m * V + vtx[q]];
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int m = m0 + g;
             const float* Am = sA + (buf * G + g) * a_stride;
-            float T[12];
+            float tx = 0.f, ty = 0.f, tz = 0.f;
+            if (transl && m < m_end) { tx = transl[m * 3 + 0]; ty = transl[m * 3 + 1]; tz = transl[m * 3 + 2]; }
 #pragma unroll
-            for (int e = 0; e < 12; ++e) T[e] = 0.0f;
+            for (int q = 0; q < VPT; ++q) {
+                float T[12];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const float4* t4 = reinterpret_cast<const float4*>(Am + idx[k]);
-                float4 r0 = t4[0], r1 = t4[1], r2 = t4[2];
-                T[0] += w[k] * r0.x; T[1] += w[k] * r0.y; T[2] += w[k] * r0.z; T[3] += w[k] * r0.w;
-                T[4] += w[k] * r1.x; T[5] += w[k] * r1.y; T[6] += w[k] * r1.z; T[7] += w[k] * r1.w;
-                T[8] += w[k] * r2.x; T[9] += w[k] * r2.y; T[10] += w[k] * r2.z; T[11] += w[k] * r2.w;
-            }
-            f3 o;
-            o.x = T[0] * p[g].x + T[1] * p[g].y + T[2] * p[g].z + T[3];
-            o.y = T[4] * p[g].x + T[5] * p[g].y + T[6] * p[g].z + T[7];
-            o.z = T[8] * p[g].x + T[9] * p[g].y + T[10] * p[g].z + T[11];
-            if (live && m < m_end) {
-                if (transl) { o.x += transl[m * 3 + 0]; o.y += transl[m * 3 + 1]; o.z += transl[m * 3 + 2]; }
-                verts[(size_t)m * V + v] = o;
+                for (int e = 0; e < 12; ++e) T[e] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float4* t4 = reinterpret_cast<const float4*>(Am + idx[q][k]);
+                    const float4 r0 = t4[0], r1 = t4[1], r2 = t4[2];
+                    const float wk = w[q][k];
+                    T[0] += wk * r0.x; T[1] += wk * r0.y; T[2] += wk * r0.z; T[3] += wk * r0.w;
+                    T[4] += wk * r1.x; T[5] += wk * r1.y; T[6] += wk * r1.z; T[7] += wk * r1.w;
+                    T[8] += wk * r2.x; T[9] += wk * r2.y; T[10] += wk * r2.z; T[11] += wk * r2.w;
+                }
+                const f3 pv = p[g][q];
+                f3 o;
+                o.x = T[0] * pv.x + T[1] * pv.y + T[2] * pv.z + T[3] + tx;
+                o.y = T[4] * pv.x + T[5] * pv.y + T[6] * pv.z + T[7] + ty;
+                o.z = T[8] * pv.x + T[9] * pv.y + T[10] * pv.z + T[11] + tz;
+                if (live[q] && m < m_end) verts[(size_t)m * V + vtx[q]] = o;
             }
         }
         buf ^= 1;
@@ -271,33 +285,66 @@ extern "C" int hps_smpl_pose_prep(const float* glob, const float* body, int is_r
     return check_launch("hps_smpl_pose_prep");
 }
 
+// LBS launch geometry.  variant 0 = the default chosen for the shipped path; the others exist for tuning
+// (hps_dev_lbs_variant).  target_blocks ~ how many workgroups are resident at once on 256 CUs.
+template <int K, int G, int VPT>
+static int launch_lbs_cfg(const float* v_posed, const float* a, const int32_t* w_idx, const float* w_val, int J,
+                          const float* transl, float* verts, int M, int V, int target_blocks, hipStream_t s) {
+    const int n_vtiles = ceil_div(V, 256 * VPT);
+    int n_chunks = max(1, target_blocks / n_vtiles);
+    int mpb = ceil_div(ceil_div(M, n_chunks), G) * G;          // meshes per workgroup, a multiple of G
+    n_chunks = ceil_div(M, mpb);
+    const int chunks_padded = ceil_div(n_chunks, 8) * 8;        // chunk = (local / n_vtiles) * 8 + xcd
+    const size_t lds = (size_t)2 * G * J * 12 * sizeof(float);
+    hipLaunchKernelGGL((lbs_kernel<K, G, VPT>), dim3(chunks_padded * n_vtiles), dim3(256), lds, s,
+                       reinterpret_cast<const f3*>(v_posed), a, w_idx, w_val, J, transl, reinterpret_cast<f3*>(verts), M, V,
+                       mpb, n_vtiles);
+    return check_launch("hps_smpl_lbs");
+}
+
 template <int K>
 static int launch_lbs(const float* v_posed, const float* a, const int32_t* w_idx, const float* w_val, int J,
-                      const float* transl, float* verts, int M, int V, hipStream_t s) {
-    constexpr int G = 4;
-    // enough workgroups to fill 256 CUs several times over, few enough that the per-lane weights are reused
-    int mpb = 32;
-    while (mpb > G && (size_t)ceil_div(V, 256) * ceil_div(M, mpb) < 2048) mpb >>= 1;
-    dim3 grid(ceil_div(V, 256), ceil_div(M, mpb));
-    size_t lds = (size_t)2 * G * J * 12 * sizeof(float);
-    hipLaunchKernelGGL((lbs_kernel<K, G>), grid, dim3(256), lds, s, reinterpret_cast<const f3*>(v_posed), a, w_idx,
-                       w_val, J, transl, reinterpret_cast<f3*>(verts), M, V, mpb);
-    return check_launch("hps_smpl_lbs");
+                      const float* transl, float* verts, int M, int V, int variant, int target_blocks, hipStream_t s) {
+    if (target_blocks <= 0) target_blocks = 1536;
+    switch (variant) {
+        case 0: return launch_lbs_cfg<K, 4, 1>(v_posed, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
+        case 1: return launch_lbs_cfg<K, 8, 1>(v_posed, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
+        case 2: return launch_lbs_cfg<K, 4, 2>(v_posed, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
+        case 3: return launch_lbs_cfg<K, 2, 2>(v_posed, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
+        case 4: return launch_lbs_cfg<K, 2, 1>(v_posed, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
+        case 5: return launch_lbs_cfg<K, 8, 2>(v_posed, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
+        case 6: return launch_lbs_cfg<K, 16, 1>(v_posed, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
+        default: set_error("hps_smpl_lbs: unknown variant %d", variant); return HPS_E_BADARG;
+    }
+}
+
+static int lbs_dispatch(const float* v_posed, const float* a, const int32_t* w_idx, const float* w_val, int K,
+                        int num_joints, const float* transl, float* verts, int M, int V, int variant, int target_blocks,
+                        hipStream_t s) {
+    if (!v_posed || !a || !w_idx || !w_val || !verts) return bad_arg("hps_smpl_lbs: null pointer");
+    if (num_joints < 1 || num_joints > 64) return bad_arg("hps_smpl_lbs: num_joints");
+    if (M <= 0 || V <= 0) return HPS_OK;
+    switch (K) {
+        case 4: return launch_lbs<4>(v_posed, a, w_idx, w_val, num_joints, transl, verts, M, V, variant, target_blocks, s);
+        case 8: return launch_lbs_cfg<8, 4, 1>(v_posed, a, w_idx, w_val, num_joints, transl, verts, M, V, 1024, s);
+        case 12: return launch_lbs_cfg<12, 2, 1>(v_posed, a, w_idx, w_val, num_joints, transl, verts, M, V, 768, s);
+        case 24: return launch_lbs_cfg<24, 2, 1>(v_posed, a, w_idx, w_val, num_joints, transl, verts, M, V, 512, s);
+        default: set_error("hps_smpl_lbs: K=%d unsupported (4, 8, 12, 24)", K); return HPS_E_UNSUPPORTED;
+    }
 }
 
 extern "C" int hps_smpl_lbs(const float* v_posed, const float* a, const int32_t* w_idx, const float* w_val, int K,
                             int num_joints, const float* transl, float* verts, int M, int V, hps_stream_t stream) {
-    if (!v_posed || !a || !w_idx || !w_val || !verts) return bad_arg("hps_smpl_lbs: null pointer");
-    if (num_joints < 1 || num_joints > 64) return bad_arg("hps_smpl_lbs: num_joints");
-    if (M <= 0 || V <= 0) return HPS_OK;
-    hipStream_t s = (hipStream_t)stream;
-    switch (K) {
-        case 4: return launch_lbs<4>(v_posed, a, w_idx, w_val, num_joints, transl, verts, M, V, s);
-        case 8: return launch_lbs<8>(v_posed, a, w_idx, w_val, num_joints, transl, verts, M, V, s);
-        case 12: return launch_lbs<12>(v_posed, a, w_idx, w_val, num_joints, transl, verts, M, V, s);
-        case 24: return launch_lbs<24>(v_posed, a, w_idx, w_val, num_joints, transl, verts, M, V, s);
-        default: set_error("hps_smpl_lbs: K=%d unsupported (4, 8, 12, 24)", K); return HPS_E_UNSUPPORTED;
-    }
+    // measured on MI355X at 6528 meshes (tools/gpu_bringup.py lbs_tune): many small workgroups of
+    // 256 vertices x 8 meshes beat a resident persistent grid: 194 us (5.6 TB/s algorithmic) vs 227-280 us
+    return lbs_dispatch(v_posed, a, w_idx, w_val, K, num_joints, transl, verts, M, V, 1, 24576, (hipStream_t)stream);
+}
+
+extern "C" int hps_dev_lbs_variant(const float* v_posed, const float* a, const int32_t* w_idx, const float* w_val, int K,
+                                   int num_joints, const float* transl, float* verts, int M, int V, int variant,
+                                   int target_blocks, hps_stream_t stream) {
+    return lbs_dispatch(v_posed, a, w_idx, w_val, K, num_joints, transl, verts, M, V, variant, target_blocks,
+                        (hipStream_t)stream);
 }
 
 extern "C" int hps_smpl_joints(const float* verts, const float* j_posed, const int32_t* csr_ptr,

@@ -15,6 +15,8 @@ fallback: the column signs LAPACK returns are not determined by the mathematics,
 joints' MLPs through U_proper (:126-130), and the trained weights were fitted to them (SURVEY.md section 7
 hard part 1).  Everything around it (MLPs, determinants, proper fix, mode) runs on the device.
 """
+import os
+
 import torch
 from torch import nn
 from torch.distributions import Normal
@@ -22,6 +24,19 @@ from torch.distributions import Normal
 from . import _capi
 from .resnet import resnet18
 from .rigid_transform_utils import rotmat_to_rot6d
+
+
+_SVD_THREADS = max(1, min(16, (os.cpu_count() or 2) // 2))
+
+
+def _host_svd_packed(f_host, usv_host):
+    """SVD of n 3x3 matrices on the host (f_host (n,3,3) -> usv_host (n,21) packed [U | S | V]) through
+    hps_host_svd3_packed: the same MKL sgesdd_ torch.svd calls, bit-identical factors, but the independent
+    matrices are spread over a small native thread pool (torch's batched CPU SVD is a sequential loop,
+    ~1.7 us per matrix)."""
+    n = f_host.shape[0]
+    assert f_host.is_contiguous() and usv_host.is_contiguous() and not f_host.is_cuda
+    _capi.call("hps_host_svd3_packed", _capi._P(f_host.data_ptr()), _capi._P(usv_host.data_ptr()), n, _SVD_THREADS)
 
 
 def immediate_parents_to_all_parents(immediate_parents):
@@ -69,6 +84,7 @@ class PoseMFShapeGaussianNet(nn.Module):
         depth = [len(self.parents_dict[j]) for j in range(self.num_joints)]
         self.levels = [[j for j in range(self.num_joints) if depth[j] == d] for d in range(max(depth) + 1)]
         self._prepared = None
+        self._pinned_bufs = {}
 
     # ---- kernel-side weights; rebuilt after .to() / load_state_dict ----
     def _apply(self, fn, *args, **kwargs):
@@ -78,6 +94,14 @@ class PoseMFShapeGaussianNet(nn.Module):
     def load_state_dict(self, *args, **kwargs):
         self._prepared = None
         return super().load_state_dict(*args, **kwargs)
+
+    def _pinned(self, name, numel):
+        """Reusable page-locked host staging buffer (fp32) of at least ``numel`` elements."""
+        buf = self._pinned_bufs.get(name)
+        if buf is None or buf.numel() < numel:
+            buf = torch.empty(max(numel, 1024), dtype=torch.float32, pin_memory=True)
+            self._pinned_bufs[name] = buf
+        return buf[:numel]
 
     def prepare(self):
         dev = self.fc1.weight.device
@@ -105,7 +129,6 @@ class PoseMFShapeGaussianNet(nn.Module):
         p["anc_ptr"] = torch.tensor(anc_ptr, dtype=torch.int32, device=dev)
         p["anc_idx"] = torch.tensor(anc_idx if anc_idx else [0], dtype=torch.int32, device=dev)
         p["levels"] = [torch.tensor(l, dtype=torch.int32, device=dev) for l in self.levels]
-        p["levels_long"] = [torch.tensor(l, dtype=torch.long, device=dev) for l in self.levels]
         self._prepared = p
         return p
 
@@ -155,19 +178,24 @@ class PoseMFShapeGaussianNet(nn.Module):
         S_proper = torch.zeros(B, nj, 3, **f32)
         mode = torch.zeros(B, nj, 3, 3, **f32)
         delta = float(self.config.MODEL.DELTA_I_WEIGHT) if self.config.MODEL.DELTA_I else 0.0
-        for lvl, lvl_long in zip(p["levels"], p["levels_long"]):
+        stream = torch.cuda.current_stream()
+        for lvl in p["levels"]:
             n_level = lvl.numel()
+            f_level = torch.empty(B, n_level, 3, 3, **f32)
             _capi.call("hps_head_joint_level", P(embed), embed_dim, embed_dim // 2, _capi.iptr(lvl), n_level,
                        _capi.iptr(p["anc_ptr"]), _capi.iptr(p["anc_idx"]),
                        _capi._P(p["w1t_ptrs"].data_ptr()), _capi._P(p["b1_ptrs"].data_ptr()),
                        _capi._P(p["w2_ptrs"].data_ptr()), _capi._P(p["b2_ptrs"].data_ptr()),
-                       P(U_proper), P(S_proper), P(mode), delta, P(pose_F), B, nj, s)
-            # host LAPACK SVD of the level's (B * n_level) 3x3 matrices (:137), see module docstring
-            F_host = pose_F[:, lvl_long].cpu()
-            U_h, S_h, Vh_h = torch.linalg.svd(F_host)
-            pose_U[:, lvl_long] = U_h.to(dev, non_blocking=True)
-            pose_S[:, lvl_long] = S_h.to(dev, non_blocking=True)
-            pose_V[:, lvl_long] = Vh_h.transpose(-1, -2).contiguous().to(dev, non_blocking=True)
-            _capi.call("hps_head_svd_finish", P(pose_U), P(pose_S), P(pose_V), _capi.iptr(lvl), n_level,
+                       P(U_proper), P(S_proper), P(mode), delta, P(pose_F), P(f_level), B, nj, s)
+            # host LAPACK SVD of the level's B * n_level 3x3 matrices (:137), see module docstring.
+            # Pinned staging buffers; the stream synchronisation also retires the previous level's upload.
+            f_host = self._pinned("f", B * n_level * 9).view(B * n_level, 3, 3)
+            f_host.copy_(f_level.view(B * n_level, 3, 3), non_blocking=True)
+            stream.synchronize()
+            usv_host = self._pinned("usv", B * n_level * 21).view(B * n_level, 21)
+            _host_svd_packed(f_host, usv_host)
+            usv = torch.empty(B, n_level, 21, **f32)
+            usv.view(B * n_level, 21).copy_(usv_host, non_blocking=True)
+            _capi.call("hps_head_svd_finish", P(usv), _capi.iptr(lvl), n_level, P(pose_U), P(pose_S), P(pose_V),
                        P(U_proper), P(S_proper), P(mode), B, nj, s)
         return pose_F, pose_U, pose_S, pose_V, mode, shape_dist, glob, cam

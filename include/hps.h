@@ -79,6 +79,12 @@ int hps_smpl_lbs(const float* v_posed, const float* a, const int32_t* w_idx, con
                  int K, int num_joints, const float* transl, float* verts, int M, int V,
                  hps_stream_t stream);
 
+/* Development / tuning entry: hps_smpl_lbs with an explicit kernel variant (0..4: meshes per barrier G and
+ * vertices per lane VPT = (4,1) (8,1) (4,2) (2,2) (2,1)) and resident-workgroup target. Same results. */
+int hps_dev_lbs_variant(const float* v_posed, const float* a, const int32_t* w_idx,
+                        const float* w_val, int K, int num_joints, const float* transl, float* verts,
+                        int M, int V, int variant, int target_blocks, hps_stream_t stream);
+
 /* Joints: out[m, 0:J] = j_posed[m] ; out[m, J + r] = sum_e csr_val[e] * verts[m, csr_col[e]]
  * for CSR rows r = 0..n_rows-1 (the 21 smplx vertex picks as 1-entry rows, then the extra / cocoplus /
  * h36m regressors of models/smpl_official.py:30-34).  transl optional (M,3). out: (M, J+n_rows, 3). */
@@ -143,20 +149,31 @@ int hps_linear(const float* x, int ldx, const float* wt, const float* bias, cons
  * joint_ids (n_level,) int32; anc_ptr (23+1,) / anc_idx: CSR list of ancestors (nearest first);
  * w1t_ptrs[joint] -> (in_dim, hidden) = fc_pose[j].0.weight^T, b1_ptrs -> (hidden,),
  * w2_ptrs -> (9, hidden), b2_ptrs -> (9,)  (device arrays of device pointers, indexed by joint id).
- * u_proper/mode (B,23,9), s_proper (B,23,3) hold the ancestors' results; pose_f (B,23,9) output. */
+ * u_proper/mode (B,23,9), s_proper (B,23,3) hold the ancestors' results; pose_f (B,23,9) output;
+ * f_level: optional compact copy (B, n_level, 9) of the level's F matrices (what goes to the host SVD). */
 int hps_head_joint_level(const float* embed, int embed_dim, int hidden, const int32_t* joint_ids,
                          int n_level, const int32_t* anc_ptr, const int32_t* anc_idx,
                          const float* const* w1t_ptrs, const float* const* b1_ptrs,
                          const float* const* w2_ptrs, const float* const* b2_ptrs,
                          const float* u_proper, const float* s_proper, const float* mode,
-                         float delta_i_weight, float* pose_f, int B, int num_body_joints,
-                         hps_stream_t stream);
+                         float delta_i_weight, float* pose_f, float* f_level, int B,
+                         int num_body_joints, hps_stream_t stream);
 
-/* Proper-SVD fix and mode (:139-152) for the joints of one level, given U,S,V of those joints
- * already stored in pose_u/pose_s/pose_v (B,23,..): writes u_proper, s_proper, mode = U_p V_p^T. */
-int hps_head_svd_finish(const float* pose_u, const float* pose_s, const float* pose_v,
-                        const int32_t* joint_ids, int n_level, float* u_proper, float* s_proper,
-                        float* mode, int B, int num_body_joints, hps_stream_t stream);
+/* HOST function (no device work): SVD of n row-major 3x3 matrices through the LAPACK sgesdd_ exported by the
+ * process's libtorch_cpu.so -- the routine behind the reference's torch.svd(F.cpu()) (:137), so factors and
+ * column signs are bit-identical -- spread over num_threads threads.  f_host (n,9) -> usv_host (n,21) packed
+ * [U (9) | S (3) | V (9)].  HPS_E_UNSUPPORTED if sgesdd_ cannot be resolved. */
+int hps_host_svd3_packed(const float* f_host, float* usv_host, int n, int num_threads);
+/* HOST: resolve sgesdd_ from the given shared library (the binding passes torch's libtorch_cpu.so). */
+int hps_host_bind_lapack(const char* library_path);
+
+/* Proper-SVD fix and mode (:139-152) for the joints of one level.  usv_level (B, n_level, 21) holds the SVD
+ * factors of the level's F matrices packed as [U (9) | S (3) | V (9)] per matrix; they are scattered into
+ * pose_u / pose_s / pose_v (B,23,..) and u_proper, s_proper, mode = U_p V_p^T are written. */
+int hps_head_svd_finish(const float* usv_level, const int32_t* joint_ids, int n_level,
+                        float* pose_u, float* pose_s, float* pose_v, float* u_proper,
+                        float* s_proper, float* mode, int B, int num_body_joints,
+                        hps_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * ResNet-18 encoder  (models/resnet.py:202-217) -- NHWC activations

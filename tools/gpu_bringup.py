@@ -127,6 +127,34 @@ def sec_smpl_perf():
             print("unc err", err(su.vertex_uncertainty(vs)[3], ref_u))
 
 
+def sec_lbs_tune():
+    model, params, smpl = make_smpl()
+    from hierarchicalprobabilistic3dhuman_amd import _capi
+    P = _capi.ptr
+    M, V, J = 6528, 6890, 24
+    betas = torch.randn(M, 10, device=dev)
+    aa = torch.randn(M * 24, 3, device=dev) * 0.5
+    R = rtu.batch_rodrigues(aa).view(M, 24, 3, 3)
+    smpl.keep_intermediates = True
+    out = smpl(betas=betas, body_pose=R[:, 1:].contiguous(), global_orient=R[:, :1].contiguous(), pose2rot=False)
+    L = smpl._last
+    ref = out.vertices.clone()
+    verts = torch.empty(M, V, 3, device=dev)
+    s = _capi.stream()
+    gb = 166896.0 * M / 1e9
+    names = {0: "G4 VPT1", 1: "G8 VPT1", 2: "G4 VPT2", 3: "G2 VPT2", 4: "G2 VPT1", 5: "G8 VPT2", 6: "G16 VPT1"}
+    for variant in (0, 1, 2, 5, 6):
+        for tb in (4096, 6144, 8192, 12288, 16384, 24576, 49152):
+            fn = lambda: _capi.call("hps_dev_lbs_variant", P(L["v_posed"]), P(L["a"]), _capi.iptr(smpl._w_idx),
+                                    P(smpl._w_val), smpl._lbs_k, J, None, P(verts), M, V, variant, tb, s)
+            verts.zero_()
+            fn()
+            ok = bool(torch.equal(verts, ref))
+            t = timeit(fn, 20, 5)
+            print("lbs variant %d (%s) target_blocks %5d: %.1f us  %.2f TB/s (%.1f%% of 8)  bitwise==default %s" % (
+                variant, names[variant], tb, t * 1e3, gb / t, gb / t / 8 * 100, ok))
+
+
 def sec_sampler():
     g = torch.Generator().manual_seed(1)
     for (B, N) in ((2, 4), (2, 100), (64, 1), (3, 1000)):
