@@ -119,6 +119,16 @@ def main():
     lbs_avg_ms = sum(lbs_ms) / max(1, len(lbs_ms))
     achieved = LBS_BYTES_PER_MESH * M / (lbs_avg_ms * 1e-3) / 1e9 if lbs_ms else None
 
+    # HBM traffic of the same kernel from the PMC counters: collected in separate rocprofv3 passes of this very
+    # command (tools/collect_profiles.sh), corrected as MI355X_MICROARCH.md prescribes, committed under profiles/
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "lbs_pmc_latest.json")
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        if pmc.get("meshes_per_launch", M) == M:
+            traffic = pmc.get("hbm_bytes_per_launch")
+
     if rank == 0:
         images = B * world * args.steps
         out = {
@@ -132,7 +142,8 @@ def main():
                        "images_per_gpu": B, "global_batch": B * world, "num_samples": N,
                        "meshes_per_step_per_gpu": M, "parallelism": "images sharded over %d GPU(s)" % world},
             "roofline": {"bound": "hbm", "kernel": "hps::lbs_kernel<4,8,1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_source": "profiles/lbs_pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
                          "avg_launch_ms": lbs_avg_ms, "launches": len(lbs_ms),
                          "algorithmic_bytes_per_launch": LBS_BYTES_PER_MESH * M},
             "metric_checksums": {"images": float(total[0]), "sum_unc": float(total[1]),
