@@ -148,6 +148,148 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v2 implicit GEMM for Cin % 32 == 0 (every 3x3 / 1x1 convolution of ResNet-18 after the stem).
+//   * a K-chunk of 32 lies inside ONE filter tap, so the tap decode and the channel offset are scalar
+//     (wave-uniform) and the per-lane address work is one multiply-add and a bounds test per row;
+//   * both LDS tiles are [row][36]: rows = output pixels (A) / output channels (B), k contiguous, 144-byte
+//     pitch.  Stores are ds_write_b128 (8 lanes fill one 128-byte row), fragment loads are ds_read_b128 and
+//     both are bank-conflict free at this pitch;
+//   * the MFMA k index is a free permutation as long as A and B agree: lane-half kl of 32x32x2 step t of
+//     8-wide group g takes actual k = 8g + 4kl + t, which is exactly what one 16-byte read delivers -- one
+//     LDS instruction feeds four MFMA steps instead of one;
+//   * filters are stored n-major (Cout, Kp) so a B row is 128 contiguous bytes like an A row.
+// Double-buffered LDS, next chunk prefetched into registers under the MFMAs, one barrier per chunk.
+// ---------------------------------------------------------------------------------------------
+constexpr int VBK = 32;
+constexpr int VPITCH = VBK + 4;
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_v2_kernel(
+    const float* __restrict__ x, const float* __restrict__ wn, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ residual, float* __restrict__ y, int H, int W,
+    int Cin, int Cout, int KW, int stride, int pad, int Ho, int Wo, int Mtot, int Kp, int relu, int tiles_m) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_LD = BM / 32, B_LD = BN / 32;        // float4 loads per thread per chunk
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                                   // [2][BM][VPITCH]
+    float* sB = smem + 2 * BM * VPITCH;                 // [2][BN][VPITCH]
+
+    const int tile_n = blockIdx.x / tiles_m, tile_m = blockIdx.x % tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    const int kl = lane >> 5, il = lane & 31;
+    const int lrow = tid >> 3, lq = (tid & 7) * 4;      // staging: row within a 32-row slab, float offset in the chunk
+
+    int a_hi0[A_LD], a_wi0[A_LD];
+    long a_base[A_LD];
+#pragma unroll
+    for (int r = 0; r < A_LD; ++r) {
+        const int m = m0 + lrow + 32 * r;
+        if (m < Mtot) {
+            const int b = m / (Ho * Wo), rem = m - b * (Ho * Wo);
+            const int ho = rem / Wo, wo = rem - ho * Wo;
+            a_hi0[r] = ho * stride - pad;
+            a_wi0[r] = wo * stride - pad;
+            a_base[r] = (long)b * H * W * Cin + lq;
+        } else {
+            a_hi0[r] = -(1 << 20); a_wi0[r] = 0; a_base[r] = 0;      // never in bounds
+        }
+    }
+    const float* b_src = wn + (size_t)(n0 + lrow) * Kp + lq;
+    const int chunks_per_tap = Cin / VBK;
+
+    // staging registers as scalars (float4 arrays written under a branch are not promoted out of scratch)
+    float ra[A_LD][4], rb[B_LD][4];
+    auto load_chunk = [&](int c) {
+        const int tap = c / chunks_per_tap;                      // wave-uniform
+        const int ci0 = (c - tap * chunks_per_tap) * VBK;
+        const int kh = tap / KW, kw = tap - kh * KW;
+#pragma unroll
+        for (int r = 0; r < A_LD; ++r) {
+            const int hi = a_hi0[r] + kh, wi = a_wi0[r] + kw;
+            const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+            const long off = ok ? a_base[r] + ((long)hi * W + wi) * Cin + ci0 : 0;     // clamped: always a valid address
+            const float4 v = *reinterpret_cast<const float4*>(x + off);
+            ra[r][0] = ok ? v.x : 0.f; ra[r][1] = ok ? v.y : 0.f; ra[r][2] = ok ? v.z : 0.f; ra[r][3] = ok ? v.w : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < B_LD; ++r) {
+            const float4 v = *reinterpret_cast<const float4*>(b_src + (size_t)(32 * r) * Kp + (size_t)c * VBK);
+            rb[r][0] = v.x; rb[r][1] = v.y; rb[r][2] = v.z; rb[r][3] = v.w;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float* da = sA + (size_t)buf * BM * VPITCH + lrow * VPITCH + lq;
+        float* db = sB + (size_t)buf * BN * VPITCH + lrow * VPITCH + lq;
+#pragma unroll
+        for (int r = 0; r < A_LD; ++r)
+            *reinterpret_cast<float4*>(da + 32 * r * VPITCH) = make_float4(ra[r][0], ra[r][1], ra[r][2], ra[r][3]);
+#pragma unroll
+        for (int r = 0; r < B_LD; ++r)
+            *reinterpret_cast<float4*>(db + 32 * r * VPITCH) = make_float4(rb[r][0], rb[r][1], rb[r][2], rb[r][3]);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    load_chunk(0);
+    const int nchunks = Kp / VBK;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        store_chunk(buf);
+        __syncthreads();
+        if (c + 1 < nchunks) load_chunk(c + 1);
+        const float* pa = sA + (size_t)buf * BM * VPITCH + (wm0 + il) * VPITCH + 4 * kl;
+        const float* pb = sB + (size_t)buf * BN * VPITCH + (wn0 + il) * VPITCH + 4 * kl;
+#pragma unroll
+        for (int g = 0; g < VBK / 8; ++g) {
+            float4 a4[TM], b4[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a4[i] = *reinterpret_cast<const float4*>(pa + i * 32 * VPITCH + 8 * g);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b4[j] = *reinterpret_cast<const float4*>(pb + j * 32 * VPITCH + 8 * g);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = n0 + wn0 + j * 32 + il;
+        const float sc = scale[co], sh = shift[co];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                if (m < Mtot) {
+                    float v = acc[i][j][r] * sc + sh;
+                    if (residual) v += residual[(size_t)m * Cout + co];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    y[(size_t)m * Cout + co] = v;
+                }
+            }
+        }
+    }
+}
+
 // (B,C,H,W) -> (B,H,W,Cp): lanes along w read each channel plane coalesced; every lane assembles its
 // pixel's Cp channels and stores them as float4s.
 template <int CP>
@@ -215,9 +357,52 @@ static int launch_conv(const float* x, const float* wk, const float* scale, cons
     return check_launch("hps_conv2d_bn_act");
 }
 
+template <int BM, int BN, int WM, int WN>
+static int launch_conv_v2(const float* x, const float* wn, const float* scale, const float* shift, const float* residual,
+                          float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int relu,
+                          hipStream_t s) {
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    const int Mtot = B * Ho * Wo, Kp = KH * KW * Cin;
+    const int tiles_m = ceil_div(Mtot, BM), tiles_n = Cout / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * VPITCH * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_v2_kernel<BM, BN, WM, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_v2_kernel<BM, BN, WM, WN>), dim3(tiles_m * tiles_n), dim3(256), lds, s, x, wn, scale,
+                       shift, residual, y, H, W, Cin, Cout, KW, stride, pad, Ho, Wo, Mtot, Kp, relu, tiles_m);
+    return check_launch("hps_conv2d_bn_act_v2");
+}
+
 }  // namespace hps
 
 using namespace hps;
+
+// variant: 0 = automatic, 1 = 128x128, 2 = 128x64, 3 = 64x64 tiles
+extern "C" int hps_conv2d_bn_act_v2(const float* x, const float* wn, const float* scale, const float* shift,
+                                    const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int KH,
+                                    int KW, int stride, int pad, int relu, int variant, hps_stream_t stream) {
+    if (!x || !wn || !scale || !shift || !y) return bad_arg("hps_conv2d_bn_act_v2: null pointer");
+    if (Cin % 32 != 0 || Cout % 64 != 0) return bad_arg("hps_conv2d_bn_act_v2: Cin % 32 == 0 and Cout % 64 == 0 required");
+    if (B <= 0) return HPS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    const long Mtot = (long)B * Ho * Wo;
+    if (variant == 0) {
+        // measured per ResNet-18 layer at B = 64 (tools/gpu_bringup.py conv_tune): the 64x64 tile (7 waves/SIMD)
+        // wins everywhere except where 128x128 tiles still give every CU two workgroups
+        variant = (Cout % 128 == 0 && (Mtot / 128) * (Cout / 128) >= 512) ? 1 : 3;
+    }
+    if (variant == 1 && Cout % 128 != 0) variant = 2;
+    switch (variant) {
+        case 1: return launch_conv_v2<128, 128, 64, 64>(x, wn, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
+        case 2: return launch_conv_v2<128, 64, 64, 32>(x, wn, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
+        case 3: return launch_conv_v2<64, 64, 32, 32>(x, wn, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
+        default: return bad_arg("hps_conv2d_bn_act_v2: variant");
+    }
+}
 
 extern "C" int hps_conv2d_bn_act(const float* x, const float* wk, const float* scale, const float* shift,
                                  const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int KH,

@@ -19,7 +19,7 @@ from .sampling_utils import pose_matrix_fisher_sampling_torch, vertex_uncertaint
 
 @torch.no_grad()
 def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mean_shape=True,
-          sample_on_cpu=False, seed=None, image_offset=0, input_feats=None):
+          sample_on_cpu=False, seed=None, image_offset=0, input_feats=None, _before_meshes=None):
     """predict/predict_poseMF_shapeGaussian_net.py:103-165 for a batch of B proxy representations.
 
     proxy_rep_input: (B,18,256,256) on the device.  Returns a dict of device tensors; every entry equals
@@ -38,6 +38,8 @@ def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mea
         glob_rotmats = batch_rodrigues(glob)
     else:
         glob_rotmats = rot6d_to_rotmat(glob)
+    if _before_meshes is not None:
+        _before_meshes()
     R = pose_matrix_fisher_sampling_torch(pose_U, pose_S, pose_V, N, b=1.5, oversampling_ratio=8,
                                           sample_on_cpu=sample_on_cpu, seed=seed, image_offset=image_offset)
     loc = shape_dist.loc
@@ -63,6 +65,56 @@ def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mea
                 glob_rotmats=glob_rotmats, verts_mode=out.vertices[:B], joints_mode=out.joints[:B],
                 verts_tpose=out.vertices[B:2 * B], R_samples=R, verts_samples=verts_s, joints_samples=joints_s,
                 unc=unc)
+
+
+class InferencePipeline:
+    """Two-stage software pipeline over successive batches on two HIP streams.
+
+    The head of batch i is host-paced (eight kinematic levels, each with a host LAPACK SVD round trip), which
+    leaves the GPU idle for ~1 ms per batch; the encoder of batch i+1 does not depend on it.  ``submit`` enqueues
+    the encoder on a side stream, ``finish`` runs head -> sampling -> SMPL -> uncertainty on the caller's stream
+    after waiting for the encoder's event, so the next batch's convolutions fill the head's gaps:
+
+        pipe = InferencePipeline(net, smpl, num_samples=100)
+        t = pipe.submit(x0)
+        for x_next in batches[1:]:
+            t_next = pipe.submit(x_next)
+            result = pipe.finish(t, after=t_next)     # same dict as infer()
+            t = t_next
+        result = pipe.finish(t)
+
+    ``after=`` makes the bandwidth-bound mesh phase (sampling, blend GEMM, LBS, joints, uncertainty) of this batch
+    start only when the next batch's encoder has drained: the two would otherwise time-share CUs and HBM with no
+    gain in throughput (the GPU is busy either way) while every kernel runs slower than its roofline.  Only the
+    host-paced head overlaps the encoder.  Results are identical to ``infer`` (same kernels, same order per batch)."""
+
+    def __init__(self, pose_shape_model, smpl_model, num_samples=50, use_mean_shape=True, sample_on_cpu=False):
+        self.net, self.smpl = pose_shape_model, smpl_model
+        self.num_samples, self.use_mean_shape, self.sample_on_cpu = num_samples, use_mean_shape, sample_on_cpu
+        self.enc_stream = torch.cuda.Stream()
+
+    @torch.no_grad()
+    def submit(self, proxy_rep_input):
+        _capi.require_device(proxy_rep_input, "proxy_rep_input")
+        main = torch.cuda.current_stream()
+        self.enc_stream.wait_stream(main)            # the input may have been produced on the caller's stream
+        with torch.cuda.stream(self.enc_stream):
+            feats = self.net.image_encoder(proxy_rep_input)
+            done = torch.cuda.Event()
+            done.record(self.enc_stream)
+        proxy_rep_input.record_stream(self.enc_stream)
+        return feats, done
+
+    @torch.no_grad()
+    def finish(self, ticket, seed=None, image_offset=0, after=None):
+        feats, done = ticket
+        main = torch.cuda.current_stream()
+        main.wait_event(done)
+        feats.record_stream(main)
+        hook = (lambda: main.wait_event(after[1])) if after is not None else None
+        return infer(self.net, self.smpl, None, num_samples=self.num_samples, use_mean_shape=self.use_mean_shape,
+                     sample_on_cpu=self.sample_on_cpu, seed=seed, image_offset=image_offset, input_feats=feats,
+                     _before_meshes=hook)
 
 
 def predict_poseMF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_model, hrnet_model, hrnet_cfg,

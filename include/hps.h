@@ -193,6 +193,14 @@ int hps_conv2d_bn_act(const float* x, const float* wk, const float* scale, const
                       const float* residual, float* y, int B, int H, int W, int Cin, int Cout,
                       int KH, int KW, int stride, int pad, int relu, hps_stream_t stream);
 
+/* Same convolution for Cin % 32 == 0 (all of ResNet-18 after the stem), faster kernel: K-chunks of 32 inside one
+ * filter tap, 128-bit LDS fragment traffic.  wn: filter stored n-major (Cout, KH*KW*Cin) = weight.permute(0,2,3,1).
+ * variant: 0 automatic tile choice, 1 = 128x128, 2 = 128x64, 3 = 64x64 workgroup tiles (tuning). */
+int hps_conv2d_bn_act_v2(const float* x, const float* wn, const float* scale, const float* shift,
+                         const float* residual, float* y, int B, int H, int W, int Cin, int Cout,
+                         int KH, int KW, int stride, int pad, int relu, int variant,
+                         hps_stream_t stream);
+
 /* nn.MaxPool2d(3, stride 2, pad 1) on NHWC (models/resnet.py:152, :207). */
 int hps_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, hps_stream_t stream);
 

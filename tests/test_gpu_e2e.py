@@ -70,3 +70,21 @@ def test_full_size_config_properties(dev, net_gpu, smpl_gpu):
     s_whole = sharding.batch_metric_sums(whole)
     s_parts = sharding.batch_metric_sums(parts[0]) + sharding.batch_metric_sums(parts[1])
     assert float(s_whole[0]) == 64.0 and maxerr(s_parts, s_whole) <= 1e-6 * float(s_whole.abs().max())
+
+
+def test_pipelined_steps_equal_sequential_infer(dev, net_gpu, smpl_gpu, golden_input):
+    """InferencePipeline (encoder of the next batch on a side stream) returns exactly what infer() returns."""
+    from hierarchicalprobabilistic3dhuman_amd.predict_poseMF_shapeGaussian_net import InferencePipeline
+    xs = [golden_input.to(dev), golden_input.flip(0).contiguous().to(dev), (golden_input * 0.5).to(dev)]
+    want = [infer(net_gpu, smpl_gpu, x, num_samples=5, seed=40 + i) for i, x in enumerate(xs)]
+    pipe = InferencePipeline(net_gpu, smpl_gpu, num_samples=5)
+    got = []
+    t = pipe.submit(xs[0])
+    for i in range(len(xs)):
+        nxt = pipe.submit(xs[i + 1]) if i + 1 < len(xs) else None
+        got.append(pipe.finish(t, seed=40 + i, after=nxt))
+        t = nxt
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        for k in ("pose_F", "R_samples", "verts_samples", "unc", "verts_mode"):
+            assert torch.equal(w[k], g[k]), k

@@ -289,6 +289,37 @@ def sec_encoder_perf():
         cur = o2
 
 
+def sec_conv_tune():
+    """Every distinct convolution of ResNet-18 at B=64 under the v1 kernel and the three v2 tile shapes."""
+    from hierarchicalprobabilistic3dhuman_amd.resnet import _ConvBN
+    shapes = [  # H, Cin, Cout, k, stride, pad
+        (64, 64, 64, 3, 1, 1), (64, 64, 128, 3, 2, 1), (64, 64, 128, 1, 2, 0), (32, 128, 128, 3, 1, 1),
+        (32, 128, 256, 3, 2, 1), (32, 128, 256, 1, 2, 0), (16, 256, 256, 3, 1, 1), (16, 256, 512, 3, 2, 1),
+        (16, 256, 512, 1, 2, 0), (8, 512, 512, 3, 1, 1)]
+    B = 64
+    for (H, Cin, Cout, k, st, pd) in shapes:
+        conv = torch.nn.Conv2d(Cin, Cout, k, st, pd, bias=False).to(dev)
+        bn = torch.nn.BatchNorm2d(Cout).eval().to(dev)
+        cb = _ConvBN(conv, bn)
+        x = torch.randn(B, H, H, Cin, device=dev)
+        Ho = (H + 2 * pd - k) // st + 1
+        res = torch.randn(B, Ho, Ho, Cout, device=dev)
+        fl = 2.0 * B * Ho * Ho * Cout * k * k * Cin / 1e9
+        line = "conv H%d %d->%d k%d s%d (%.1f GFLOP):" % (H, Cin, Cout, k, st, fl)
+        ref = None
+        for v in (-1, 1, 2, 3):
+            if v == 1 and Cout % 128:
+                continue
+            cb.variant = v
+            y = cb(x, residual=res)
+            if ref is None:
+                ref = y
+            e = float((y - ref).abs().max())
+            t = timeit(lambda: cb(x, residual=res), 10, 3)
+            line += "  %s %.0f us (%.0f TF, d=%.1e)" % ("v1" if v < 0 else "v2/%d" % v, t * 1e3, fl / t, e)
+        print(line)
+
+
 def sec_e2e():
     model, params, smpl = make_smpl()
     net, sd = make_net()
