@@ -10,6 +10,53 @@ namespace hps {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Epilogue shared by the MFMA convolution kernels: eval-mode BatchNorm (scale, shift), residual add, ReLU.
+// C layout of a 32x32 tile: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+// Full tiles take the branch-free path: all residual loads of a 32x32 tile are issued before the first use.
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], const float* __restrict__ scale,
+                                              const float* __restrict__ shift, const float* __restrict__ residual,
+                                              float* __restrict__ y, int mbase, int nbase, int il, int kl, int Cout,
+                                              int Mtot, int relu, bool full_tile) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = nbase + j * 32 + il;
+        const float sc = scale[co], sh = shift[co];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mrow = mbase + i * 32 + 4 * kl;
+            if (full_tile) {
+                float res[16];
+                if (residual) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        res[r] = residual[(size_t)(mrow + (r & 3) + 8 * (r >> 2)) * Cout + co];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) res[r] = 0.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] * sc + sh + res[r];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    y[(size_t)(mrow + (r & 3) + 8 * (r >> 2)) * Cout + co] = v;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mrow + (r & 3) + 8 * (r >> 2);
+                    if (m < Mtot) {
+                        float v = acc[i][j][r] * sc + sh;
+                        if (residual) v += residual[(size_t)m * Cout + co];
+                        if (relu) v = fmaxf(v, 0.0f);
+                        y[(size_t)m * Cout + co] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 constexpr int CBK = 16;        // K-chunk
 constexpr int LDA = CBK + 1;   // odd pitch: the 32 pixel rows a half-wave reads hit 32 distinct banks
 
@@ -127,25 +174,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
         }
     }
 
-    // ---- epilogue: BN (scale, shift), residual, ReLU; C layout col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int co = n0 + wn0 + j * 32 + il;
-        const float sc = scale[co], sh = shift[co];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
-                if (m < Mtot) {
-                    float v = acc[i][j][r] * sc + sh;
-                    if (residual) v += residual[(size_t)m * Cout + co];
-                    if (relu) v = fmaxf(v, 0.0f);
-                    y[(size_t)m * Cout + co] = v;
-                }
-            }
-        }
-    }
+    conv_epilogue<TM, TN>(acc, scale, shift, residual, y, m0 + wm0, n0 + wn0, il, kl, Cout, Mtot, relu, m0 + BM <= Mtot);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -270,24 +299,142 @@ __global__ __launch_bounds__(256) void conv_igemm_v2_kernel(
         }
     }
 
+    conv_epilogue<TM, TN>(acc, scale, shift, residual, y, m0 + wm0, n0 + wn0, il, kl, Cout, Mtot, relu, m0 + BM <= Mtot);
+}
+
+// ---------------------------------------------------------------------------------------------
+// v3: v2's tiling with LDS filled directly from global memory (global_load_lds_dwordx4, 1 KiB per wave
+// instruction = 8 tile rows of 128 bytes) -- no staging registers, no ds_write pass, no per-element zero
+// select.  An LDS-DMA destination is lane-linear, so the tile rows are unpadded (128-byte pitch) and the bank
+// conflicts of the 128-bit fragment reads are removed by an XOR swizzle applied on the SOURCE side: lane
+// (row, q) fetches 16-byte quad q ^ f(row) of its row, the reader of quad G of row r looks in slot G ^ f(r),
+// f(r) = (r >> 1) & 7 (conflict-free for ds_read_b128's 16-lane groups: checked in DESIGN.md).
+// Out-of-image taps read from a small zero buffer.  Two LDS buffers: the DMA of chunk c+1 flies under the
+// MFMAs of chunk c; one barrier per chunk.
+// ---------------------------------------------------------------------------------------------
+// One LDS-DMA instruction issued from inline asm: hipcc does not count it, so it does not drain it with a
+// vmcnt(0) in front of the next ds_read (which is what the builtin form does and what would serialise the DMA of
+// chunk c+1 with the MFMAs of chunk c).  The kernel waits for it explicitly (s_waitcnt vmcnt(0) + barrier) before
+// the buffer is read.  lds_addr: wave-uniform LDS byte address; lane l lands at lds_addr + 16 l.  M0 is saved and
+// restored because the compiler owns it (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void lds_dma16(const float* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int ABLATE = 0>   // ABLATE (tuning only): 1 = no DMA after chunk 0, 2 = no MFMA
+__global__ __launch_bounds__(256) void conv_igemm_v3_kernel(
+    const float* __restrict__ x, const float* __restrict__ wn, const float* __restrict__ zeros,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ residual,
+    float* __restrict__ y, int H, int W, int Cin, int Cout, int KW, int stride, int pad, int Ho, int Wo, int Mtot,
+    int Kp, int relu, int tiles_m) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_LD = BM / 32, B_LD = BN / 32;        // DMA instructions per wave per chunk
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                                   // [2][BM][32]
+    float* sB = smem + 2 * BM * VBK;                    // [2][BN][32]
+
+    const int tile_n = blockIdx.x / tiles_m, tile_m = blockIdx.x % tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    const int kl = lane >> 5, il = lane & 31;
+    // DMA role of this lane: tile row (r * 32 + wave * 8 + lane / 8), slot lane % 8, source quad slot ^ f(row)
+    const int drow = wave * 8 + (lane >> 3);
+    const int dquad = ((lane & 7) ^ ((drow >> 1) & 7)) * 4;      // float offset of the source quad (f(row + 32 r) = f(row))
+
+    int a_hi0[A_LD], a_wi0[A_LD];
+    long a_base[A_LD];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int co = n0 + wn0 + j * 32 + il;
-        const float sc = scale[co], sh = shift[co];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
-                if (m < Mtot) {
-                    float v = acc[i][j][r] * sc + sh;
-                    if (residual) v += residual[(size_t)m * Cout + co];
-                    if (relu) v = fmaxf(v, 0.0f);
-                    y[(size_t)m * Cout + co] = v;
-                }
-            }
+    for (int r = 0; r < A_LD; ++r) {
+        const int m = m0 + drow + 32 * r;
+        if (m < Mtot) {
+            const int b = m / (Ho * Wo), rem = m - b * (Ho * Wo);
+            const int ho = rem / Wo, wo = rem - ho * Wo;
+            a_hi0[r] = ho * stride - pad;
+            a_wi0[r] = wo * stride - pad;
+            a_base[r] = (long)b * H * W * Cin + dquad;
+        } else {
+            a_hi0[r] = -(1 << 20); a_wi0[r] = 0; a_base[r] = 0;
         }
     }
+    const float* b_src = wn + (size_t)(n0 + drow) * Kp + dquad;
+    const int chunks_per_tap = Cin / VBK;
+
+    auto dma_chunk = [&](int c, int buf) {
+        const int tap = c / chunks_per_tap;                      // wave-uniform
+        const int ci0 = (c - tap * chunks_per_tap) * VBK;
+        const int kh = tap / KW, kw = tap - kh * KW;
+        // wave-uniform LDS byte addresses; lanes land at +16 B each
+        const unsigned la = __builtin_amdgcn_readfirstlane(
+            (unsigned)(size_t)(lptr_t)(sA + (size_t)buf * BM * VBK + wave * 8 * VBK));
+        const unsigned lb = __builtin_amdgcn_readfirstlane(
+            (unsigned)(size_t)(lptr_t)(sB + (size_t)buf * BN * VBK + wave * 8 * VBK));
+#pragma unroll
+        for (int r = 0; r < A_LD; ++r) {
+            const int hi = a_hi0[r] + kh, wi = a_wi0[r] + kw;
+            const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+            const float* src = ok ? x + a_base[r] + ((long)hi * W + wi) * Cin + ci0 : zeros;
+            lds_dma16(src, la + r * 32 * VBK * 4);
+        }
+#pragma unroll
+        for (int r = 0; r < B_LD; ++r)
+            lds_dma16(b_src + (size_t)(32 * r) * Kp + (size_t)c * VBK, lb + r * 32 * VBK * 4);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int fsw = (il >> 1) & 7;                       // f(row) of the fragment rows this lane reads
+    dma_chunk(0, 0);
+    const int nchunks = Kp / VBK;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA of chunk c has landed
+        __syncthreads();                                     // ... everyone's has, and buf^1 is no longer being read
+        if (c + 1 < nchunks && ABLATE != 1) dma_chunk(c + 1, buf ^ 1);
+        const float* pa = sA + (size_t)buf * BM * VBK + (wm0 + il) * VBK;
+        const float* pb = sB + (size_t)buf * BN * VBK + (wn0 + il) * VBK;
+#pragma unroll
+        for (int g = 0; g < VBK / 8; ++g) {
+            const int slot = ((2 * g + kl) ^ fsw) * 4;
+            float4 a4[TM], b4[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a4[i] = *reinterpret_cast<const float4*>(pa + i * 32 * VBK + slot);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b4[j] = *reinterpret_cast<const float4*>(pb + j * 32 * VBK + slot);
+            if (ABLATE == 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(a4[i].x), "v"(a4[i].y), "v"(a4[i].z), "v"(a4[i].w));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(b4[j].x), "v"(b4[j].y), "v"(b4[j].z), "v"(b4[j].w));
+                continue;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    conv_epilogue<TM, TN>(acc, scale, shift, residual, y, m0 + wm0, n0 + wn0, il, kl, Cout, Mtot, relu, m0 + BM <= Mtot);
 }
 
 // (B,C,H,W) -> (B,H,W,Cp): lanes along w read each channel plane coalesced; every lane assembles its
@@ -376,9 +523,51 @@ static int launch_conv_v2(const float* x, const float* wn, const float* scale, c
     return check_launch("hps_conv2d_bn_act_v2");
 }
 
+template <int BM, int BN, int WM, int WN, int ABLATE = 0>
+static int launch_conv_v3(const float* x, const float* wn, const float* zeros, const float* scale, const float* shift,
+                          const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                          int stride, int pad, int relu, hipStream_t s) {
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    const int Mtot = B * Ho * Wo, Kp = KH * KW * Cin;
+    const int tiles_m = ceil_div(Mtot, BM), tiles_n = Cout / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * VBK * sizeof(float);
+    hipLaunchKernelGGL((conv_igemm_v3_kernel<BM, BN, WM, WN, ABLATE>), dim3(tiles_m * tiles_n), dim3(256), lds, s, x, wn, zeros,
+                       scale, shift, residual, y, H, W, Cin, Cout, KW, stride, pad, Ho, Wo, Mtot, Kp, relu, tiles_m);
+    return check_launch("hps_conv2d_bn_act_v3");
+}
+
 }  // namespace hps
 
 using namespace hps;
+
+// variant: 1 = 128x128, 2 = 128x64, 3 = 64x64 tiles; zeros: >= 64 bytes of zeros on the device
+extern "C" int hps_conv2d_bn_act_v3(const float* x, const float* wn, const float* zeros, const float* scale,
+                                    const float* shift, const float* residual, float* y, int B, int H, int W, int Cin,
+                                    int Cout, int KH, int KW, int stride, int pad, int relu, int variant,
+                                    hps_stream_t stream) {
+    if (!x || !wn || !zeros || !scale || !shift || !y) return bad_arg("hps_conv2d_bn_act_v3: null pointer");
+    if (Cin % 32 != 0 || Cout % 64 != 0) return bad_arg("hps_conv2d_bn_act_v3: Cin % 32 == 0 and Cout % 64 == 0 required");
+    if (B <= 0) return HPS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (variant == 0) {
+        // measured per ResNet-18 layer at B = 64 (tools/gpu_bringup.py conv_tune): 128x128 tiles where they still give
+        // every CU two workgroups, otherwise the 64x64 tile (8 waves/SIMD)
+        const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+        const long Mtot = (long)B * Ho * Wo;
+        variant = (Cout % 128 == 0 && (Mtot / 128) * (Cout / 128) >= 512) ? 1 : 3;
+    }
+    if (variant % 10 == 1 && Cout % 128 != 0) variant = 2;
+    switch (variant) {
+        case 1: return launch_conv_v3<128, 128, 64, 64>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
+        case 2: return launch_conv_v3<128, 64, 64, 32>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
+        case 3: return launch_conv_v3<64, 64, 32, 32>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
+        case 21: return launch_conv_v3<128, 128, 64, 64, 1>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
+        case 31: return launch_conv_v3<128, 128, 64, 64, 2>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
+        case 23: return launch_conv_v3<64, 64, 32, 32, 1>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
+        case 33: return launch_conv_v3<64, 64, 32, 32, 2>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
+        default: return bad_arg("hps_conv2d_bn_act_v3: variant");
+    }
+}
 
 // variant: 0 = automatic, 1 = 128x128, 2 = 128x64, 3 = 64x64 tiles
 extern "C" int hps_conv2d_bn_act_v2(const float* x, const float* wn, const float* scale, const float* shift,

@@ -35,7 +35,9 @@ class _ConvBN:
         self.stride, self.pad = conv.stride[0], conv.padding[0]
         # n-major filter (Cout, KH*KW*Cin) for the v2 kernel (Cin % 32 == 0: every conv after the stem)
         self.wn = wk.reshape(k_real, cout).t().contiguous() if cin_p % 32 == 0 else None
-        self.variant = 0
+        self.kernel = "v3"        # "v3" direct global->LDS (default), "v2" register-staged, "v1" generic (any Cin % 4 == 0)
+        self.variant = 0          # tile choice of the v2 / v3 kernels (0 = automatic)
+        self.zeros = torch.zeros(64, device=w.device, dtype=torch.float32)
 
     def __call__(self, x, residual=None, relu=True):
         B, H, W, C = x.shape
@@ -44,7 +46,12 @@ class _ConvBN:
         Wo = (W + 2 * self.pad - self.kw) // self.stride + 1
         y = torch.empty(B, Ho, Wo, self.cout, device=x.device, dtype=torch.float32)
         P = _capi.ptr
-        if self.wn is not None and self.variant >= 0:
+        if self.wn is not None and self.kernel == "v3":
+            _capi.call("hps_conv2d_bn_act_v3", P(x), P(self.wn), P(self.zeros), P(self.scale), P(self.shift),
+                       P(residual) if residual is not None else None, P(y), B, H, W, C, self.cout, self.kh, self.kw,
+                       self.stride, self.pad, 1 if relu else 0, self.variant, _capi.stream())
+            return y
+        if self.wn is not None and self.kernel == "v2":
             _capi.call("hps_conv2d_bn_act_v2", P(x), P(self.wn), P(self.scale), P(self.shift),
                        P(residual) if residual is not None else None, P(y), B, H, W, C, self.cout, self.kh, self.kw,
                        self.stride, self.pad, 1 if relu else 0, self.variant, _capi.stream())

@@ -66,6 +66,12 @@ def test_conv_bn_relu_kernel(cfg, dev):
     assert maxerr(got.permute(0, 3, 1, 2), want) <= 1e-4 * max(1.0, float(want.abs().max()))
     got2 = cb(xh, relu=False)
     assert maxerr(got2.permute(0, 3, 1, 2), want_nores) <= 1e-4 * max(1.0, float(want_nores.abs().max()))
+    # every kernel generation / tile shape that supports this layer gives the same answer
+    kernels = [("v1", 0)] + ([(kern, v) for kern in ("v2", "v3") for v in (1, 2, 3)] if Cin % 32 == 0 else [])
+    for kern, v in kernels:
+        cb.kernel, cb.variant = kern, v
+        alt = cb(xh, residual=res.to(dev).permute(0, 2, 3, 1).contiguous(), relu=True)
+        assert maxerr(alt, got) <= 1e-4 * max(1.0, float(want.abs().max())), (kern, v)
 
 
 def test_pooling_and_layout_kernels(dev):

@@ -301,22 +301,43 @@ def sec_conv_tune():
         conv = torch.nn.Conv2d(Cin, Cout, k, st, pd, bias=False).to(dev)
         bn = torch.nn.BatchNorm2d(Cout).eval().to(dev)
         cb = _ConvBN(conv, bn)
-        x = torch.randn(B, H, H, Cin, device=dev)
+        x = torch.relu(torch.randn(B, H, H, Cin, device=dev))     # post-ReLU statistics like the real activations
         Ho = (H + 2 * pd - k) // st + 1
         res = torch.randn(B, Ho, Ho, Cout, device=dev)
         fl = 2.0 * B * Ho * Ho * Cout * k * k * Cin / 1e9
         line = "conv H%d %d->%d k%d s%d (%.1f GFLOP):" % (H, Cin, Cout, k, st, fl)
         ref = None
-        for v in (-1, 1, 2, 3):
-            if v == 1 and Cout % 128:
+        for v in (-1, 1, 2, 3, 11, 12, 13):
+            if v % 10 == 1 and Cout % 128:
                 continue
-            cb.variant = v
+            cb.kernel, cb.variant = ("v1", 0) if v < 0 else (("v2", v) if v < 10 else ("v3", v - 10))
             y = cb(x, residual=res)
             if ref is None:
                 ref = y
             e = float((y - ref).abs().max())
             t = timeit(lambda: cb(x, residual=res), 10, 3)
-            line += "  %s %.0f us (%.0f TF, d=%.1e)" % ("v1" if v < 0 else "v2/%d" % v, t * 1e3, fl / t, e)
+            line += "  %s %.0f us (%.0f TF, d=%.1e)" % ("v1" if v < 0 else ("v2/%d" % v if v < 10 else "v3/%d" % (v - 10)), t * 1e3, fl / t, e)
+        print(line)
+
+
+def sec_conv_ablate():
+    """v3 kernel with the DMA (variant 2x) or the MFMAs (variant 3x) removed: where does the time go?"""
+    from hierarchicalprobabilistic3dhuman_amd.resnet import _ConvBN
+    B = 64
+    for (H, Cin, Cout, k, st, pd) in [(32, 128, 128, 3, 1, 1), (64, 64, 64, 3, 1, 1), (8, 512, 512, 3, 1, 1)]:
+        conv = torch.nn.Conv2d(Cin, Cout, k, st, pd, bias=False).to(dev)
+        bn = torch.nn.BatchNorm2d(Cout).eval().to(dev)
+        cb = _ConvBN(conv, bn)
+        x = torch.relu(torch.randn(B, H, H, Cin, device=dev))
+        Ho = (H + 2 * pd - k) // st + 1
+        fl = 2.0 * B * Ho * Ho * Cout * k * k * Cin / 1e9
+        line = "ablate H%d %d->%d:" % (H, Cin, Cout)
+        for v in (1, 21, 31, 3, 23, 33):
+            if v % 10 == 1 and Cout % 128:
+                continue
+            cb.kernel, cb.variant = "v3", v
+            t = timeit(lambda: cb(x), 10, 3)
+            line += "  v3/%d %.0f us (%.0f TF-equiv)" % (v, t * 1e3, fl / t)
         print(line)
 
 
