@@ -102,8 +102,10 @@ def main():
             ticket = nxt
         return res
 
+    distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+
     def barrier():
-        if world > 1:
+        if distributed:
             torch.distributed.barrier()
 
     if not args.no_pipeline:
@@ -131,7 +133,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if distributed:
         torch.distributed.all_reduce(dt_t, op=torch.distributed.ReduceOp.MAX)
     dt = float(dt_t.item())
 
@@ -177,7 +179,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(net_state, configs.SMPL_PARENTS, N, args.cpu_images)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         torch.distributed.destroy_process_group()
 
 

@@ -531,6 +531,12 @@ static int launch_conv_v3(const float* x, const float* wn, const float* zeros, c
     const int Mtot = B * Ho * Wo, Kp = KH * KW * Cin;
     const int tiles_m = ceil_div(Mtot, BM), tiles_n = Cout / BN;
     const size_t lds = (size_t)2 * (BM + BN) * VBK * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_v3_kernel<BM, BN, WM, WN, ABLATE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
     hipLaunchKernelGGL((conv_igemm_v3_kernel<BM, BN, WM, WN, ABLATE>), dim3(tiles_m * tiles_n), dim3(256), lds, s, x, wn, zeros,
                        scale, shift, residual, y, H, W, Cin, Cout, KW, stride, pad, Ho, Wo, Mtot, Kp, relu, tiles_m);
     return check_launch("hps_conv2d_bn_act_v3");
@@ -550,17 +556,21 @@ extern "C" int hps_conv2d_bn_act_v3(const float* x, const float* wn, const float
     if (B <= 0) return HPS_OK;
     hipStream_t s = (hipStream_t)stream;
     if (variant == 0) {
-        // measured per ResNet-18 layer at B = 64 (tools/gpu_bringup.py conv_tune): 128x128 tiles where they still give
-        // every CU two workgroups, otherwise the 64x64 tile (8 waves/SIMD)
+        // measured per ResNet-18 layer at B = 64 (tools/gpu_bringup.py conv_tune): the L2->LDS path per CU is the
+        // limiter, so take the largest tile that still gives every CU a workgroup: 128x128 (>= 256 workgroups),
+        // 256x64 for 64-channel outputs, else 64x64 (8 waves/SIMD)
         const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
         const long Mtot = (long)B * Ho * Wo;
-        variant = (Cout % 128 == 0 && (Mtot / 128) * (Cout / 128) >= 512) ? 1 : 3;
+        if (Cout % 128 == 0 && (Mtot / 128) * (Cout / 128) >= 256) variant = 1;
+        else if (Cout == 64 && Mtot / 256 >= 512) variant = 4;
+        else variant = 3;
     }
     if (variant % 10 == 1 && Cout % 128 != 0) variant = 2;
     switch (variant) {
         case 1: return launch_conv_v3<128, 128, 64, 64>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
         case 2: return launch_conv_v3<128, 64, 64, 32>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
         case 3: return launch_conv_v3<64, 64, 32, 32>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
+        case 4: return launch_conv_v3<256, 64, 64, 64>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
         case 21: return launch_conv_v3<128, 128, 64, 64, 1>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
         case 31: return launch_conv_v3<128, 128, 64, 64, 2>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
         case 23: return launch_conv_v3<64, 64, 32, 32, 1>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);

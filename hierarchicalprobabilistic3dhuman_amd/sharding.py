@@ -15,11 +15,14 @@ import torch.distributed as dist
 
 def init_distributed(backend=None):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them).
-    Returns (rank, world_size, local_rank).  A single process without those variables is world size 1."""
+    Returns (rank, world_size, local_rank).  A single process without those variables is world size 1 and no
+    process group is created; under torch.distributed.run a group is created even for one rank, so the same
+    collectives run for every N."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ        # torch.distributed.run / torchrun
+    if (world > 1 or launched) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -42,7 +45,7 @@ def gather_metric_sums(local_sums):
     the total being the rank-ordered sum -- bit-identical on every rank and to a single-process run that adds
     the same per-shard sums in the same order."""
     local_sums = local_sums.reshape(-1)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         per_rank = local_sums[None].clone()
     else:
         bufs = [torch.empty_like(local_sums) for _ in range(dist.get_world_size())]
