@@ -10,6 +10,8 @@ behaviour) over libhps.so, a C-ABI library of hand-written gfx950 HIP kernels (i
     utils/sampling_utils.py                  ->   sampling_utils.*
     utils/rigid_transform_utils.py           ->   rigid_transform_utils.*
     predict/predict_poseMF_shapeGaussian_net ->   predict_poseMF_shapeGaussian_net.*
+    models/canny_edge_detector.py            ->   canny_edge_detector.CannyEdgeDetector
+    utils/label_conversions.py (heat-maps)   ->   label_conversions.*
 """
 from .configs import get_cfg_defaults, SMPL_PARENTS  # noqa: F401
 

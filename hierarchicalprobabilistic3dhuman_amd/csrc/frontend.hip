@@ -1,0 +1,159 @@
+// Proxy-representation front end: Canny edge detection
+// (models/canny_edge_detector.py:104-166) and 2D-joint Gaussian heat-maps
+// (utils/label_conversions.py:105-124), i.e. what turns an RGB crop + 17 keypoints into the 18-channel network
+// input (predict/predict_poseMF_shapeGaussian_net.py:88-100).  Pure stencil / element-wise work: HBM bound.
+#include "hps_common.h"
+
+namespace hps {
+
+constexpr int CT = 32;                 // output tile edge
+constexpr int G = 5, GH = G / 2;       // Gaussian taps (DATA.EDGE_GAUSSIAN_SIZE = 5)
+constexpr int MAGD = CT + 2;           // gradient magnitude is needed on a 1-pixel halo (non-max suppression)
+constexpr int BLD = MAGD + 2;          // blurred image on a further 1-pixel halo (Sobel)
+constexpr int HROWS = BLD + 2 * GH;    // rows of the horizontal pass feeding the vertical pass
+constexpr int IND = BLD + 2 * GH;      // input tile edge (40)
+
+// One workgroup = one 32x32 tile of one image.  Every stage reproduces the zero padding of the reference's
+// chain of nn.Conv2d calls: each convolution sees zeros outside the IMAGE, not outside the tile.
+__global__ __launch_bounds__(256) void canny_kernel(const float* __restrict__ img, float g0, float g1, float g2,
+                                                    float g3, float g4, float* __restrict__ blurred,
+                                                    float* __restrict__ grad_mag, float* __restrict__ grad_ori,
+                                                    float* __restrict__ thr_mag, float* __restrict__ thin,
+                                                    float* __restrict__ thr_thin, int C, int H, int W,
+                                                    float threshold, int nms) {
+    __shared__ float sIn[IND][IND + 1];
+    __shared__ float sH[HROWS][BLD + 1];
+    __shared__ float sBl[BLD][BLD + 1];
+    __shared__ float sGx[MAGD][MAGD + 1];
+    __shared__ float sGy[MAGD][MAGD + 1];
+    const float gk[G] = {g0, g1, g2, g3, g4};
+    const int b = blockIdx.z, y0 = blockIdx.y * CT, x0 = blockIdx.x * CT;
+    const int tid = threadIdx.x;
+    const size_t plane = (size_t)H * W;
+
+    for (int i = tid; i < MAGD * MAGD; i += 256) { sGx[i / MAGD][i % MAGD] = 0.f; sGy[i / MAGD][i % MAGD] = 0.f; }
+
+    for (int c = 0; c < C; ++c) {
+        const float* src = img + ((size_t)b * C + c) * plane;
+        __syncthreads();
+        // input tile with halo GH + 2 (rows/cols y0 - 4 .. y0 + 35), zero outside the image
+        for (int i = tid; i < IND * IND; i += 256) {
+            const int r = i / IND, q = i % IND;
+            const int y = y0 - (GH + 2) + r, x = x0 - (GH + 2) + q;
+            sIn[r][q] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(size_t)y * W + x] : 0.f;
+        }
+        __syncthreads();
+        // horizontal Gaussian (:118): columns x0 - 2 .. x0 + 33
+        for (int i = tid; i < HROWS * BLD; i += 256) {
+            const int r = i / BLD, q = i % BLD;
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < G; ++t) acc += gk[t] * sIn[r][q + t];
+            const int x = x0 - 2 + q;
+            sH[r][q] = (x >= 0 && x < W) ? acc : 0.f;      // the horizontal pass only exists inside the image
+        }
+        __syncthreads();
+        // vertical Gaussian: rows y0 - 2 .. y0 + 33; zero outside the image (that is what the Sobel convs pad with)
+        for (int i = tid; i < BLD * BLD; i += 256) {
+            const int p = i / BLD, q = i % BLD;
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < G; ++t) acc += gk[t] * sH[p + t][q];
+            const int y = y0 - 2 + p, x = x0 - 2 + q;
+            const bool inside = y >= 0 && y < H && x >= 0 && x < W;
+            sBl[p][q] = inside ? acc : 0.f;
+            if (inside && p >= 2 && p < 2 + CT && q >= 2 && q < 2 + CT)
+                blurred[((size_t)b * C + c) * plane + (size_t)y * W + x] = acc;                       // :119
+        }
+        __syncthreads();
+        // Sobel (:122-123) on rows/cols -1 .. 32 of the tile, accumulated over channels
+        for (int i = tid; i < MAGD * MAGD; i += 256) {
+            const int p = i / MAGD, q = i % MAGD;              // blurred index of the centre: (p + 1, q + 1)
+            const float a00 = sBl[p][q], a01 = sBl[p][q + 1], a02 = sBl[p][q + 2];
+            const float a10 = sBl[p + 1][q], a12 = sBl[p + 1][q + 2];
+            const float a20 = sBl[p + 2][q], a21 = sBl[p + 2][q + 1], a22 = sBl[p + 2][q + 2];
+            // cross-correlation with [[1,0,-1],[2,0,-2],[1,0,-1]] and its transpose
+            sGx[p][q] += (a00 - a02) + 2.f * (a10 - a12) + (a20 - a22);
+            sGy[p][q] += (a00 - a20) + 2.f * (a01 - a21) + (a02 - a22);
+        }
+    }
+    __syncthreads();
+    // gradient magnitude (:126-127) on the halo region, zero outside the image (padding of the directional filters)
+    float* sMag = &sIn[0][0];                                   // reuse: [MAGD][MAGD + 1]
+    for (int i = tid; i < MAGD * MAGD; i += 256) {
+        const int p = i / MAGD, q = i % MAGD;
+        const int y = y0 - 1 + p, x = x0 - 1 + q;
+        const float gx = sGx[p][q] / (float)C, gy = sGy[p][q] / (float)C;
+        sGx[p][q] = gx; sGy[p][q] = gy;
+        sMag[p * (MAGD + 1) + q] = (y >= 0 && y < H && x >= 0 && x < W) ? sqrtf(gx * gx + gy * gy) : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < CT * CT; i += 256) {
+        const int p = i / CT + 1, q = i % CT + 1;
+        const int y = y0 + p - 1, x = x0 + q - 1;
+        if (y >= H || x >= W) continue;
+        const size_t o = (size_t)b * plane + (size_t)y * W + x;
+        const float m = sMag[p * (MAGD + 1) + q];
+        float ori = atan2f(sGy[p][q], sGx[p][q]) * (180.0f / 3.14159265358979323846f) + 180.0f;    // :128
+        ori = rintf(ori / 45.0f) * 45.0f;                                                       // :129 (half to even)
+        grad_mag[o] = m;
+        grad_ori[o] = ori;
+        thr_mag[o] = (m < threshold) ? 0.f : m;                                                 // :132-133
+        if (!nms) continue;
+        // directional differences centre - neighbour, order 0,45,...,315 degrees (:56-102)
+        auto M = [&](int dy, int dx) { return sMag[(p + dy) * (MAGD + 1) + q + dx]; };
+        const float d[8] = {m - M(0, 1), m - M(1, 1), m - M(1, 0), m - M(1, -1),
+                            m - M(0, -1), m - M(-1, -1), m - M(-1, 0), m - M(-1, 1)};
+        const int idx = (int)fmodf(ori / 45.0f, 8.0f);                                           // :144
+        const int pos = idx & 3;                                                                // pos_i or pos_i + 4
+        const bool is_max = fminf(d[pos], d[pos + 4]) > 0.0f;                                    // :154
+        const float t = is_max ? m : 0.f;                                                       // :158-159
+        thin[o] = t;
+        thr_thin[o] = (t < threshold) ? 0.f : t;                                                // :160-161
+    }
+}
+
+// proxy representation (predict/...:93-100): channel 0 = edge map, channels 1..K = visibility * Gaussian blob
+__global__ __launch_bounds__(256) void proxy_rep_kernel(const float* __restrict__ edge, const float* __restrict__ joints2d,
+                                                        const float* __restrict__ visib, float* __restrict__ out, int K,
+                                                        int H, int W, float std) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x >= W) return;
+    const size_t plane = (size_t)H * W;
+    float* o = out + (size_t)b * (K + 1) * plane + (size_t)y * W + x;
+    o[0] = edge[(size_t)b * plane + (size_t)y * W + x];
+    for (int k = 0; k < K; ++k) {
+        const float u = joints2d[((size_t)b * K + k) * 2 + 0], v = joints2d[((size_t)b * K + k) * 2 + 1];
+        const float a = ((float)y - v) / std, c = ((float)x - u) / std;
+        const float h = expf(-(a * a) / 2.0f - (c * c) / 2.0f);                       // label_conversions.py:123
+        o[(size_t)(k + 1) * plane] = visib ? h * visib[(size_t)b * K + k] : h;
+    }
+}
+
+}  // namespace hps
+
+using namespace hps;
+
+extern "C" int hps_canny_edges(const float* img, const float* gauss_taps_host, int gauss_size, float* blurred,
+                               float* grad_mag, float* grad_ori, float* thr_mag, float* thin, float* thr_thin, int B,
+                               int C, int H, int W, float threshold, int nms, hps_stream_t stream) {
+    if (!img || !gauss_taps_host || !blurred || !grad_mag || !grad_ori || !thr_mag) return bad_arg("hps_canny_edges: null pointer");
+    if (nms && (!thin || !thr_thin)) return bad_arg("hps_canny_edges: thin / thr_thin needed with nms");
+    if (gauss_size != G) { set_error("hps_canny_edges: gaussian size %d unsupported (5)", gauss_size); return HPS_E_UNSUPPORTED; }
+    if (B <= 0) return HPS_OK;
+    dim3 grid(ceil_div(W, CT), ceil_div(H, CT), B);
+    hipLaunchKernelGGL(canny_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gauss_taps_host[0], gauss_taps_host[1],
+                       gauss_taps_host[2], gauss_taps_host[3], gauss_taps_host[4], blurred, grad_mag, grad_ori, thr_mag,
+                       thin, thr_thin, C, H, W, threshold, nms);
+    return check_launch("hps_canny_edges");
+}
+
+extern "C" int hps_proxy_rep(const float* edge, const float* joints2d, const float* visib, float* out, int B, int K, int H,
+                             int W, float std, hps_stream_t stream) {
+    if (!edge || !joints2d || !out) return bad_arg("hps_proxy_rep: null pointer");
+    if (B <= 0) return HPS_OK;
+    hipLaunchKernelGGL(proxy_rep_kernel, dim3(ceil_div(W, 256), H, B), dim3(256), 0, (hipStream_t)stream, edge, joints2d,
+                       visib, out, K, H, W, std);
+    return check_launch("hps_proxy_rep");
+}

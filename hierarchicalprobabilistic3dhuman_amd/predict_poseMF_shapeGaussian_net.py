@@ -15,6 +15,7 @@ import torch
 from . import _capi
 from .rigid_transform_utils import rot6d_to_rotmat, batch_rodrigues
 from .sampling_utils import pose_matrix_fisher_sampling_torch, vertex_uncertainty
+from .label_conversions import make_proxy_representation
 
 
 @torch.no_grad()
@@ -65,6 +66,15 @@ def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mea
                 glob_rotmats=glob_rotmats, verts_mode=out.vertices[:B], joints_mode=out.joints[:B],
                 verts_tpose=out.vertices[B:2 * B], R_samples=R, verts_samples=verts_s, joints_samples=joints_s,
                 unc=unc)
+
+
+def proxy_representation(rgb, joints2D, joints2D_visib, edge_detect_model, pose_shape_cfg):
+    """predict/predict_poseMF_shapeGaussian_net.py:88-100: RGB crop (B,3,D,D), 2D joints (B,17,2) in crop pixels and
+    their visibility (B,17) -> the (B,18,D,D) network input.  ``edge_detect_model`` is a CannyEdgeDetector."""
+    edges = edge_detect_model(rgb)
+    edge = edges["thresholded_thin_edges"] if pose_shape_cfg.DATA.EDGE_NMS else edges["thresholded_grad_magnitude"]
+    return make_proxy_representation(edge, joints2D, joints2D_visib, pose_shape_cfg.DATA.PROXY_REP_SIZE,
+                                     pose_shape_cfg.DATA.HEATMAP_GAUSSIAN_STD)
 
 
 class InferencePipeline:

@@ -215,6 +215,24 @@ int hps_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, hps_s
 /* AdaptiveAvgPool2d((1,1)) + flatten on NHWC (models/resnet.py:214-215): (B,H,W,C) -> (B,C). */
 int hps_global_avgpool(const float* x, float* y, int B, int HW, int C, hps_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Proxy-representation front end  
+ * ---------------------------------------------------------------------------------------- */
+
+/* models/canny_edge_detector.py:104-166: per-channel separable Gaussian blur (zero padded), Sobel gradients averaged
+ * over channels, magnitude, orientation binned to 45 degrees, threshold, and (nms != 0) non-max suppression.
+ * img (B,C,H,W); gauss_taps_host: HOST array of gauss_size (= 5) normalised taps; outputs blurred (B,C,H,W) and
+ * grad_mag, grad_ori, thr_mag, thin, thr_thin (B,1,H,W) -- the entries of the reference's output dict. */
+int hps_canny_edges(const float* img, const float* gauss_taps_host, int gauss_size, float* blurred,
+                    float* grad_mag, float* grad_ori, float* thr_mag, float* thin, float* thr_thin,
+                    int B, int C, int H, int W, float threshold, int nms, hps_stream_t stream);
+
+/* predict/predict_poseMF_shapeGaussian_net.py:93-100 with utils/label_conversions.py:105-124: out (B,K+1,H,W),
+ * channel 0 = edge (B,1,H,W), channel 1+k = visib[b,k] * exp(-((row - v)/std)^2/2 - ((col - u)/std)^2/2) for
+ * joints2d (B,K,2) = (u, v); visib (B,K) float 0/1 or NULL. */
+int hps_proxy_rep(const float* edge, const float* joints2d, const float* visib, float* out, int B,
+                  int K, int H, int W, float std, hps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

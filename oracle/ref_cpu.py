@@ -354,6 +354,79 @@ def vertex_uncertainty(verts_samples):
 
 
 # ----------------------------------------------------------------------------------------------
+# Proxy-representation front end -- models/canny_edge_detector.py, utils/label_conversions.py
+# ----------------------------------------------------------------------------------------------
+
+def gaussian_taps(size=5, std=1.0):
+    """models/canny_edge_detector.py:23-24: scipy.signal.windows.gaussian(size, std), normalised to sum 1 (float64
+    then cast to fp32 exactly like the reference's torch.from_numpy(...).float())."""
+    n = np.arange(size, dtype=np.float64) - (size - 1) / 2.0
+    g = np.exp(-0.5 * (n / std) ** 2)
+    return torch.from_numpy(g / g.sum()).float()
+
+
+def canny_edge_detector(img, non_max_suppression=True, gaussian_filter_std=1.0, gaussian_filter_size=5, threshold=0.2):
+    """models/canny_edge_detector.py:104-166 for img (B,C,H,W); returns the same dict of tensors."""
+    B, C = img.shape[:2]
+    g = gaussian_taps(gaussian_filter_size, gaussian_filter_std)
+    pad = gaussian_filter_size // 2
+    wh, wv = g.view(1, 1, 1, -1), g.view(1, 1, -1, 1)
+    sob = torch.tensor([[1., 0., -1.], [2., 0., -2.], [1., 0., -1.]])
+    blurred_img = torch.zeros_like(img)
+    grad_x = torch.zeros(B, 1, *img.shape[2:])
+    grad_y = torch.zeros(B, 1, *img.shape[2:])
+    for c in range(C):                                                                 # :113-123
+        blurred = F.conv2d(F.conv2d(img[:, [c]], wh, padding=(0, pad)), wv, padding=(pad, 0))
+        blurred_img[:, [c]] = blurred
+        grad_x += F.conv2d(blurred, sob.view(1, 1, 3, 3), padding=1)
+        grad_y += F.conv2d(blurred, sob.t().contiguous().view(1, 1, 3, 3), padding=1)
+    grad_x, grad_y = grad_x / C, grad_y / C                                            # :126
+    mag = (grad_x ** 2 + grad_y ** 2) ** 0.5
+    ori = torch.atan2(grad_y, grad_x) * (180.0 / np.pi) + 180.0                        # :128
+    ori = torch.round(ori / 45.0) * 45.0
+    thr_mag = mag.clone()
+    thr_mag[mag < threshold] = 0.0
+    out = dict(blurred_img=blurred_img, grad_magnitude=mag, grad_orientation=ori, thresholded_grad_magnitude=thr_mag)
+    if non_max_suppression:                                                            # :142-164
+        offs = [(0, 1), (1, 1), (1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1)]     # neighbour of filter_0 .. filter_315
+        filt = torch.zeros(8, 1, 3, 3)
+        for k, (dy, dx) in enumerate(offs):
+            filt[k, 0, 1, 1] = 1.0
+            filt[k, 0, 1 + dy, 1 + dx] = -1.0
+        directional = F.conv2d(mag, filt, padding=1)
+        positive_idx = (ori / 45) % 8
+        thin = mag.clone()
+        for pos_i in range(4):
+            neg_i = pos_i + 4
+            oriented = ((positive_idx == pos_i) * 1 + (positive_idx == neg_i) * 1)
+            is_max = (torch.stack([directional[:, pos_i], directional[:, neg_i]]).min(dim=0)[0] > 0.0).unsqueeze(1)
+            thin[(is_max == 0) * 1 * oriented > 0] = 0.0
+        thr_thin = thin.clone()
+        thr_thin[thin < threshold] = 0.0
+        out.update(thin_edges=thin, thresholded_thin_edges=thr_thin)
+    return out
+
+
+def joints2d_to_gaussian_heatmaps(joints2D, img_wh, std=4):
+    """utils/label_conversions.py:105-124: (B,N,2) (u = column, v = row) -> (B,N,img_wh,img_wh)."""
+    ii, jj = torch.meshgrid(torch.arange(img_wh), torch.arange(img_wh), indexing="ij")
+    ii, jj = ii[None, None].float(), jj[None, None].float()
+    u = joints2D[:, :, 0, None, None]
+    v = joints2D[:, :, 1, None, None]
+    return torch.exp(-(((ii - v) / std) ** 2) / 2 - (((jj - u) / std) ** 2) / 2)
+
+
+def proxy_representation(rgb, joints2D, joints2D_visib, edge_nms=True, edge_threshold=0.0, edge_std=1.0, edge_size=5,
+                         img_wh=256, heatmap_std=4.0):
+    """predict/predict_poseMF_shapeGaussian_net.py:88-100: RGB crop (B,3,D,D), joints (B,17,2), visibility (B,17)
+    -> proxy representation (B,18,D,D)."""
+    edges = canny_edge_detector(rgb, edge_nms, edge_std, edge_size, edge_threshold)
+    edge = edges["thresholded_thin_edges"] if edge_nms else edges["thresholded_grad_magnitude"]
+    heat = joints2d_to_gaussian_heatmaps(joints2D, img_wh, heatmap_std) * joints2D_visib[:, :, None, None]
+    return torch.cat([edge, heat], dim=1).float()
+
+
+# ----------------------------------------------------------------------------------------------
 # The batched per-image path (predict/predict_poseMF_shapeGaussian_net.py:103-165, looped over B)
 # ----------------------------------------------------------------------------------------------
 

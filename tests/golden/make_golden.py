@@ -83,6 +83,21 @@ def main():
     quat = torch.randn(7, 4, generator=g)
     out.update(rot6d_in=x6, rot6d_out=ref_rtu.rot6d_to_rotmat(x6), quat_in=quat, quat_out=ref_rtu.quat_to_rotmat(quat),
                rotmat_to_rot6d_out=ref_rtu.rotmat_to_rot6d(ref_rtu.quat_to_rotmat(quat)))
+    # ---- proxy-representation front end: Canny + heat-maps on a seeded 2x3x64x64 crop ----
+    from models.canny_edge_detector import CannyEdgeDetector
+    from utils.label_conversions import convert_2Djoints_to_gaussian_heatmaps_torch
+    g = torch.Generator().manual_seed(11)
+    rgb = torch.nn.functional.interpolate(torch.rand(2, 3, 24, 24, generator=g), size=(64, 64), mode="bilinear",
+                                          align_corners=False) + 0.05 * torch.rand(2, 3, 64, 64, generator=g)
+    j2d = torch.rand(2, 17, 2, generator=g) * 64
+    with torch.no_grad():
+        for tag, (nms, thr) in (("nms0", (True, 0.0)), ("nms2", (True, 0.2)), ("plain", (False, 0.1))):
+            res = CannyEdgeDetector(non_max_suppression=nms, gaussian_filter_std=1.0, gaussian_filter_size=5, threshold=thr)(rgb)
+            for k, v in res.items():
+                if tag == "nms0" or k in ("thresholded_thin_edges", "thresholded_grad_magnitude"):
+                    out["canny_%s_%s" % (tag, k)] = v
+    out["canny_rgb"], out["heat_joints"] = rgb, j2d
+    out["heat_out"] = convert_2Djoints_to_gaussian_heatmaps_torch(j2d, 64, 4.0)
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"),
                         **{k: v.detach().numpy() for k, v in out.items()})
     print("wrote", os.path.join(HERE, "reference_vectors.npz"), {k: tuple(v.shape) for k, v in out.items()})
