@@ -59,10 +59,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--num-samples", type=int, default=100)
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after another on one stream")
+    ap.add_argument("--trace-steps", action="store_true", help="print host-side per-step times to stderr (debugging)")
     ap.add_argument("--cpu-images", type=int, default=16, help="images in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -91,6 +92,8 @@ def main():
     # submitted and finished inside the timed region.
     pipe = InferencePipeline(net, smpl, num_samples=N, use_mean_shape=True)
 
+    step_marks = []
+
     def run_steps(first, count, on_result=None):
         ticket = pipe.submit(x)
         res = None
@@ -100,6 +103,8 @@ def main():
             if on_result is not None:
                 on_result(res)
             ticket = nxt
+            if args.trace_steps:
+                step_marks.append(time.perf_counter())
         return res
 
     distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
@@ -108,11 +113,16 @@ def main():
         if distributed:
             torch.distributed.barrier()
 
+    # warm-up runs everything the timed region runs (including the metric accumulation and the collective), so
+    # no kernel is loaded for the first time inside the timed region
+    warm_sums = torch.zeros(4, dtype=torch.float64, device=dev)
     if not args.no_pipeline:
-        run_steps(0, args.warmup)
+        run_steps(0, args.warmup, lambda r: warm_sums.add_(sharding.batch_metric_sums(r)))
     else:
         for i in range(args.warmup):
-            infer(net, smpl, x, num_samples=N, use_mean_shape=True, seed=1234 + i, image_offset=lo)
+            warm_sums.add_(sharding.batch_metric_sums(
+                infer(net, smpl, x, num_samples=N, use_mean_shape=True, seed=1234 + i, image_offset=lo)))
+    sharding.gather_metric_sums(warm_sums)
     torch.cuda.synchronize()
     smpl.lbs_events = []
     sums = torch.zeros(4, dtype=torch.float64, device=dev)
@@ -154,6 +164,10 @@ def main():
         if pmc.get("meshes_per_launch", M) == M:
             traffic = pmc.get("hbm_bytes_per_launch")
 
+    if args.trace_steps and rank == 0:
+        marks = step_marks[-args.steps:]
+        print("host ms between step completions:", ["%.2f" % ((b - a) * 1e3) for a, b in zip(marks[:-1], marks[1:])],
+              file=sys.stderr)
     if rank == 0:
         images = B * world * args.steps
         out = {
