@@ -233,6 +233,19 @@ int hps_canny_edges(const float* img, const float* gauss_taps_host, int gauss_si
 int hps_proxy_rep(const float* edge, const float* joints2d, const float* visib, float* out, int B,
                   int K, int H, int W, float std, hps_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Evaluation metrics  
+ * ---------------------------------------------------------------------------------------- */
+
+/* Per point-set L2 error sums (metrics/eval_metrics_tracker.py:89-269).  pred (S,P,3); prediction s is compared with
+ * target set s / group of target (ceil(S/group),P,3).  mode 0: raw; 1: after scale_and_translation_transform_batch
+ * (utils/eval_utils.py:70-89); 2: after the Procrustes similarity transform (utils/eval_utils.py:11-59).
+ * err_sum (S,) double = sum_i || transform(pred_i) - target_i ||.  Workspaces: stats_ws (S,17) double, xf_ws (S,12)
+ * float (receives the applied 3x4 transforms).  transformed: optional (S,P,3) transformed predictions. */
+int hps_pointset_errors(const float* pred, const float* target, int S, int group, int P, int mode,
+                        double* stats_ws, float* xf_ws, double* err_sum, float* transformed,
+                        hps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -427,6 +427,64 @@ def proxy_representation(rgb, joints2D, joints2D_visib, edge_nms=True, edge_thre
 
 
 # ----------------------------------------------------------------------------------------------
+# Evaluation metrics -- utils/eval_utils.py, metrics/eval_metrics_tracker.py (numpy, like the reference)
+# ----------------------------------------------------------------------------------------------
+
+def compute_similarity_transform(S1, S2):
+    """utils/eval_utils.py:11-59 for (N,3) inputs (the transposed=True route)."""
+    S1, S2 = S1.T, S2.T
+    mu1, mu2 = S1.mean(axis=1, keepdims=True), S2.mean(axis=1, keepdims=True)
+    X1, X2 = S1 - mu1, S2 - mu2
+    var1 = np.sum(X1 ** 2)
+    K = X1.dot(X2.T)
+    U, s, Vh = np.linalg.svd(K)
+    V = Vh.T
+    Z = np.eye(U.shape[0])
+    Z[-1, -1] *= np.sign(np.linalg.det(U.dot(V.T)))
+    R = V.dot(Z.dot(U.T))
+    scale = np.trace(R.dot(K)) / var1
+    t = mu2 - scale * (R.dot(mu1))
+    return (scale * R.dot(S1) + t).T
+
+
+def procrustes_analysis_batch(S1, S2):
+    """utils/eval_utils.py:62-67."""
+    return np.stack([compute_similarity_transform(S1[i], S2[i]) for i in range(S1.shape[0])])
+
+
+def scale_and_translation_transform_batch(P, T):
+    """utils/eval_utils.py:70-89."""
+    P_mean = np.mean(P, axis=1, keepdims=True)
+    P_trans = P - P_mean
+    P_scale = np.sqrt(np.sum(P_trans ** 2, axis=(1, 2), keepdims=True) / P.shape[1])
+    T_mean = np.mean(T, axis=1, keepdims=True)
+    T_scale = np.sqrt(np.sum((T - T_mean) ** 2, axis=(1, 2), keepdims=True) / T.shape[1])
+    return P_trans / P_scale * T_scale + T_mean
+
+
+def metric_sums(pred, target, metrics):
+    """Sums that metrics/eval_metrics_tracker.py:89-269 accumulates for one update_per_batch call (numpy arrays):
+    3D metrics and their *_samples_min forms.  Returns {metric: sum of per-point errors}."""
+    align = {"": lambda p, t: p, "-SC": scale_and_translation_transform_batch, "-PA": procrustes_analysis_batch}
+    keys = {"PVE": "verts", "MPJPE": "joints3D", "PVE-T": "reposed_verts"}
+    out = {}
+    for m in metrics:
+        smin = m.endswith("_samples_min")
+        base = m[:-len("_samples_min")] if smin else m
+        sfx = "-SC" if base.endswith("-SC") else ("-PA" if base.endswith("-PA") else "")
+        key = keys[base[:len(base) - len(sfx)]]
+        if smin:
+            p = pred[key + "_samples"]
+            t = np.tile(target[key], (p.shape[0], 1, 1))
+            e = np.linalg.norm(align[sfx](p, t) - t, axis=-1)
+            out[m] = float(np.sum(e[np.argmin(np.mean(e, axis=-1))]))
+        else:
+            e = np.linalg.norm(align[sfx](pred[key], target[key]) - target[key], axis=-1)
+            out[m] = float(np.sum(e))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
 # The batched per-image path (predict/predict_poseMF_shapeGaussian_net.py:103-165, looped over B)
 # ----------------------------------------------------------------------------------------------
 

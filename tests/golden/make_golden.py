@@ -98,6 +98,21 @@ def main():
                     out["canny_%s_%s" % (tag, k)] = v
     out["canny_rgb"], out["heat_joints"] = rgb, j2d
     out["heat_out"] = convert_2Djoints_to_gaussian_heatmaps_torch(j2d, 64, 4.0)
+    # ---- evaluation metrics: the reference tracker on a seeded synthetic scenario ----
+    from metrics.eval_metrics_tracker import EvalMetricsTracker
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from metric_scenario import METRICS, make_frames
+    tracker = EvalMetricsTracker(METRICS)
+    tracker.initialise_metric_sums()
+    tracker.initialise_per_frame_metric_lists()
+    for pred, target in make_frames():
+        tracker.update_per_batch(pred, target, 1)
+    tracker.compute_final_metrics()                      # prints only (metrics/eval_metrics_tracker.py:332-362)
+    per = lambda m: 6890 if "PVE" in m else 14
+    out["metrics_final"] = torch.tensor([tracker.metric_sums[m] / (tracker.total_samples * per(m)) for m in METRICS],
+                                        dtype=torch.float64)
+    out["metrics_sums"] = torch.tensor([tracker.metric_sums[m] for m in METRICS], dtype=torch.float64)
+    out["metrics_pve_pa_per_frame"] = torch.tensor(np.concatenate(tracker.per_frame_metrics["PVE-PA"]), dtype=torch.float64)
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"),
                         **{k: v.detach().numpy() for k, v in out.items()})
     print("wrote", os.path.join(HERE, "reference_vectors.npz"), {k: tuple(v.shape) for k, v in out.items()})
