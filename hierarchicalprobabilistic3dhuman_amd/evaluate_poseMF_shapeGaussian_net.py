@@ -1,0 +1,125 @@
+"""Dataset evaluation harness with the signature of the reference's
+evaluate/evaluate_poseMF_shapeGaussian_net.py:19-33, for the 3D metrics (BASELINE configs[3]: 3DPW with gendered SMPL).
+
+Per batch: Canny + heat-maps -> net -> SMPL(mode) -> SMPL(T-pose, mean shape) -> [N pose samples, N shape samples,
+SMPL(samples), SMPL(T-pose samples)] -> metrics on the device.  Differences from the reference, none of which change
+the numbers beyond fp32 rounding: any batch size (the reference's DataLoader uses 1); targets are posed from rotation
+matrices directly instead of going through cv2.Rodrigues' log map and back (:84-92); metric sums stay on the device
+and are reduced across ranks once at the end.  The silhouette / 2D-joint metrics need the pytorch3d renderer and the
+detector outputs and are out of scope.
+
+The 3DPW frames and the licensed SMPL_{MALE,FEMALE}.pkl files are external assets; any ``eval_dataset`` yielding the
+item dict of data/pw3d_eval_dataset.py:72-77 works (tests use a synthetic one).
+"""
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from . import _capi
+from .eval_metrics_tracker import EvalMetricsTracker
+from .label_conversions import ALL_JOINTS_TO_H36M_MAP, H36M_TO_J14
+from .rigid_transform_utils import batch_rodrigues, rot6d_to_rotmat
+from .sampling_utils import pose_matrix_fisher_sampling_torch
+
+
+def _h36mlsp(joints):
+    return joints[:, ALL_JOINTS_TO_H36M_MAP, :][:, H36M_TO_J14, :]
+
+
+def evaluate_pose_MF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_model, smpl_model_male, smpl_model_female,
+                                       edge_detect_model, device, eval_dataset, metrics, save_path, num_workers=4,
+                                       pin_memory=True, save_per_frame_metrics=True, num_samples_for_metrics=10,
+                                       sample_on_cpu=False, batch_size=1, reduce_across_ranks=True):
+    loader = DataLoader(eval_dataset, batch_size=batch_size, shuffle=False, drop_last=False, num_workers=num_workers,
+                        pin_memory=pin_memory)
+    tracker = EvalMetricsTracker(metrics, save_path=save_path, save_per_frame_metrics=save_per_frame_metrics)
+    tracker.initialise_metric_sums()
+    tracker.initialise_per_frame_metric_lists()
+    want_samples = any("samples" in m for m in metrics)
+    N = num_samples_for_metrics
+    flip = torch.diag(torch.tensor([1.0, -1.0, -1.0], device=device))          # rotation by pi about x (:86-91)
+    fnames, poses, shapes, cams = [], [], [], []
+    pose_shape_model.eval()
+    for batch in loader:
+        with torch.no_grad():
+            image = batch["image"].to(device)
+            heatmaps = batch["heatmaps"].to(device)
+            edges = edge_detect_model(image)                                                          # :69-71
+            edge = edges["thresholded_thin_edges"] if pose_shape_cfg.DATA.EDGE_NMS else edges["thresholded_grad_magnitude"]
+            proxy = torch.cat([edge, heatmaps], dim=1)
+            B = proxy.shape[0]
+
+            # ------------------ targets (:74-105) ------------------
+            target_pose = batch["pose"].to(device).float()
+            target_shape = batch["shape"].to(device).float()
+            genders = list(batch["gender"])
+            R = batch_rodrigues(target_pose.reshape(-1, 3)).view(B, 24, 3, 3)
+            R[:, 0] = torch.matmul(flip, R[:, 0])                                 # 'pre' multiplication
+            target_vertices = torch.empty(B, smpl_model.num_verts, 3, device=device)
+            target_reposed = torch.empty_like(target_vertices)
+            target_joints = torch.empty(B, 14, 3, device=device)
+            for g, model in (("m", smpl_model_male), ("f", smpl_model_female)):
+                idx = [i for i, x in enumerate(genders) if x == g]
+                if not idx:
+                    continue
+                ii = torch.tensor(idx, device=device)
+                out = model(body_pose=R[ii, 1:].contiguous(), global_orient=R[ii, :1].contiguous(), betas=target_shape[ii],
+                            pose2rot=False)
+                rest = model(betas=target_shape[ii], body_pose=torch.zeros(len(idx), 69, device=device),
+                             global_orient=torch.zeros(len(idx), 3, device=device))
+                target_vertices[ii], target_reposed[ii], target_joints[ii] = out.vertices, rest.vertices, _h36mlsp(out.joints)
+            if any(x not in ("m", "f") for x in genders):
+                raise ValueError("gender must be 'm' or 'f' (data/pw3d_eval_dataset.py:66)")
+
+            # ------------------ predictions (:108-132) ------------------
+            pose_F, pose_U, pose_S, pose_V, mode, shape_dist, glob, cam = pose_shape_model(proxy)
+            glob_R = batch_rodrigues(glob) if glob.shape[-1] == 3 else rot6d_to_rotmat(glob)
+            out_mode = smpl_model(body_pose=mode, global_orient=glob_R.unsqueeze(1), betas=shape_dist.loc, pose2rot=False)
+            zeros69, zeros3 = torch.zeros(B, 69, device=device), torch.zeros(B, 3, device=device)
+            out_rest = smpl_model(betas=shape_dist.loc, body_pose=zeros69, global_orient=zeros3)
+            pred = {"verts": out_mode.vertices, "reposed_verts": out_rest.vertices, "joints3D": _h36mlsp(out_mode.joints)}
+            target = {"verts": target_vertices, "reposed_verts": target_reposed, "joints3D": target_joints}
+            base_metrics = [m for m in metrics if "samples" not in m]
+            sample_metrics = [m for m in metrics if "samples" in m]
+            tracker.metrics_to_track = base_metrics
+            tracker.update_per_batch(pred, target, B)
+
+            if want_samples:                                                                              # :157-179
+                R_s = pose_matrix_fisher_sampling_torch(pose_U, pose_S, pose_V, N, b=1.5, oversampling_ratio=8,
+                                                        sample_on_cpu=sample_on_cpu)                    # (B,N,23,3,3)
+                if sample_on_cpu:      # the reference's CPU route: shape noise from the global CPU generator too
+                    cpu_dist = torch.distributions.Normal(shape_dist.loc.cpu(), shape_dist.scale.cpu())
+                    shape_s = cpu_dist.rsample([N]).to(device).transpose(0, 1)
+                else:
+                    shape_s = shape_dist.rsample([N]).transpose(0, 1)                                    # (B,N,nb)
+                out_s = smpl_model(body_pose=R_s.reshape(B * N, 23, 3, 3),
+                                   global_orient=glob_R[:, None, None].expand(B, N, 1, 3, 3).reshape(B * N, 1, 3, 3),
+                                   betas=shape_s.reshape(B * N, -1), pose2rot=False)
+                verts_s = out_s.vertices.view(B, N, -1, 3).clone()
+                joints_s = _h36mlsp(out_s.joints).view(B, N, 14, 3).clone()
+                verts_s[:, 0], joints_s[:, 0] = out_mode.vertices, pred["joints3D"]                      # :172-174
+                rest_s = smpl_model(betas=shape_s.reshape(B * N, -1), body_pose=torch.zeros(B * N, 69, device=device),
+                                    global_orient=torch.zeros(B * N, 3, device=device)).vertices.view(B, N, -1, 3).clone()
+                rest_s[:, 0] = out_rest.vertices                                                          # :179
+                tracker.metrics_to_track = sample_metrics
+                for i in range(B):     # the samples_min metrics are per frame (metrics/eval_metrics_tracker.py:181)
+                    tracker.update_per_batch({"verts_samples": verts_s[i], "reposed_verts_samples": rest_s[i],
+                                              "joints3D_samples": joints_s[i]},
+                                             {k: v[i:i + 1] for k, v in target.items()}, 1)
+                tracker.total_samples -= B                                       # already counted by the base update
+            tracker.metrics_to_track = list(metrics)
+            if save_per_frame_metrics:
+                fnames.extend(list(batch["fname"]))
+                poses.append(torch.cat([glob_R[:, None], mode], dim=1).cpu().numpy())
+                shapes.append(shape_dist.loc.cpu().numpy())
+                cams.append(cam.cpu().numpy())
+    if reduce_across_ranks:
+        tracker.reduce_across_ranks()
+    final = tracker.compute_final_metrics()
+    if save_per_frame_metrics and save_path is not None:
+        import os
+        np.save(os.path.join(save_path, "fname_per_frame.npy"), np.array(fnames))
+        np.save(os.path.join(save_path, "pose_per_frame.npy"), np.concatenate(poses, axis=0))
+        np.save(os.path.join(save_path, "shape_per_frame.npy"), np.concatenate(shapes, axis=0))
+        np.save(os.path.join(save_path, "cam_per_frame.npy"), np.concatenate(cams, axis=0))
+    return final

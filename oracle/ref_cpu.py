@@ -484,6 +484,64 @@ def metric_sums(pred, target, metrics):
     return out
 
 
+def rotmat_to_axis_angle64(R):
+    """SO(3) log map in float64 (what cv2.Rodrigues does for the target flip, utils/rigid_transform_utils.py:48-56)."""
+    R = np.asarray(R, np.float64)
+    c = np.clip((np.trace(R) - 1.0) / 2.0, -1.0, 1.0)
+    theta = np.arccos(c)
+    if theta < 1e-12:
+        return np.zeros(3)
+    w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / (2.0 * np.sin(theta))
+    return w * theta
+
+
+def evaluate_frames(sd, smpl_neutral, smpl_by_gender, smpl_parents, frames, metrics, num_samples, edge_nms=True,
+                    edge_threshold=0.0):
+    """evaluate/evaluate_poseMF_shapeGaussian_net.py:64-234 for the 3D metrics, one frame at a time like the reference's
+    batch-1 DataLoader; ``frames`` yields dicts with image (1,3,D,D), heatmaps (1,17,D,D), pose (1,72), shape (1,10),
+    gender.  Returns the final metrics dict (metrics/eval_metrics_tracker.py:332-362)."""
+    h36m_j14 = [73 + i for i in [6, 5, 4, 1, 2, 3, 16, 15, 14, 11, 12, 13, 8, 10]]       # label_conversions.py:18-20
+    sums = {m: 0.0 for m in metrics}
+    total = 0
+    flip = np.diag([1.0, -1.0, -1.0])
+    # the reference iterates a torch DataLoader (:35-40, :64): creating its iterator draws the workers' base seed from
+    # the global CPU generator (one int64 random_()), which shifts every later sample of the run
+    torch.empty((), dtype=torch.int64).random_()
+    for fr in frames:
+        edges = canny_edge_detector(fr["image"], edge_nms, 1.0, 5, edge_threshold)
+        edge = edges["thresholded_thin_edges"] if edge_nms else edges["thresholded_grad_magnitude"]
+        proxy = torch.cat([edge, fr["heatmaps"]], dim=1)
+        pose, shape = fr["pose"].clone(), fr["shape"]
+        Rg = batch_rodrigues(pose[:, :3])[0].double().numpy()
+        pose[:, :3] = torch.from_numpy(rotmat_to_axis_angle64(flip @ Rg)).float()                  # :84-92
+        tp = smpl_by_gender[fr["gender"]]
+        t_out = smpl_forward(tp, betas=shape, body_pose=pose[:, 3:], global_orient=pose[:, :3])
+        t_rest = smpl_forward(tp, betas=shape)
+        pose_F, U, S, V, mode, (loc, scale), glob, cam = net_forward(sd, proxy, smpl_parents)
+        glob_R = rot6d_to_rotmat(glob)
+        o_mode = smpl_forward(smpl_neutral, body_pose=mode, global_orient=glob_R.unsqueeze(1), betas=loc, pose2rot=False)
+        o_rest = smpl_forward(smpl_neutral, betas=loc)
+        pred = {"verts": o_mode["vertices"].numpy(), "reposed_verts": o_rest["vertices"].numpy(),
+                "joints3D": o_mode["joints"][:, h36m_j14].numpy()}
+        target = {"verts": t_out["vertices"].numpy(), "reposed_verts": t_rest["vertices"].numpy(),
+                  "joints3D": t_out["joints"][:, h36m_j14].numpy()}
+        if any("samples" in m for m in metrics):
+            N = num_samples
+            R_s = pose_matrix_fisher_sampling(U, S, V, N)                                            # :159-165
+            shape_s = torch.distributions.Normal(loc, scale).rsample([N]).transpose(0, 1)            # :166
+            o_s = smpl_forward(smpl_neutral, body_pose=R_s[0], global_orient=glob_R.unsqueeze(1).expand(N, -1, -1, -1),
+                               betas=shape_s[0], pose2rot=False)
+            vs, js = o_s["vertices"].clone(), o_s["joints"][:, h36m_j14].clone()
+            vs[0], js[0] = o_mode["vertices"][0], o_mode["joints"][0, h36m_j14]                       # :172-174
+            rs = smpl_forward(smpl_neutral, betas=shape_s[0], body_pose=torch.zeros(N, 69), global_orient=torch.zeros(N, 3))["vertices"].clone()
+            rs[0] = o_rest["vertices"][0]
+            pred.update(verts_samples=vs.numpy(), reposed_verts_samples=rs.numpy(), joints3D_samples=js.numpy())
+        for k, v in metric_sums(pred, target, metrics).items():
+            sums[k] += v
+        total += 1
+    return {m: sums[m] / (total * (6890 if "PVE" in m else 14)) for m in metrics}
+
+
 # ----------------------------------------------------------------------------------------------
 # The batched per-image path (predict/predict_poseMF_shapeGaussian_net.py:103-165, looped over B)
 # ----------------------------------------------------------------------------------------------
