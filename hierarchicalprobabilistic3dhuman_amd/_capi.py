@@ -43,6 +43,8 @@ _PROTOTYPES = {
     "hps_canny_edges": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _I, _P],
     "hps_proxy_rep": [_P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _P],
     "hps_pointset_errors": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "hps_heatmaps_to_joints2d": [_P, _P, _P, _I, _I, _I, _c.c_float, _P],
+    "hps_sample_joints2d_error": [_P, _P, _I, _P, _P, _P, _c.c_float, _P, _I, _I, _P],
     "hps_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P],
     "hps_global_avgpool": [_P, _P, _I, _I, _I, _P],
 }

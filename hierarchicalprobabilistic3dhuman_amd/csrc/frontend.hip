@@ -131,9 +131,80 @@ __global__ __launch_bounds__(256) void proxy_rep_kernel(const float* __restrict_
     }
 }
 
+// utils/label_conversions.py:127-155: arg-max of every (b,k) heat-map -> (x, y) pixel coordinates and a visibility flag
+// (max > eps); invisible joints get (-1,-1).  One workgroup per heat-map; ties resolve to the first (lowest) index
+// like torch.max.
+__global__ __launch_bounds__(256) void heatmap_argmax_kernel(const float* __restrict__ heat, float* __restrict__ joints2d,
+                                                             float* __restrict__ visib, int HW, int W, float eps) {
+    const float* h = heat + (size_t)blockIdx.x * HW;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float v = h[i];
+        if (v > best) { best = v; bi = i; }                  // strided scan: each lane keeps its first maximum
+    }
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            const float ov = sv[threadIdx.x + off];
+            const int oi = si[threadIdx.x + off];
+            if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const bool vis = sv[0] > eps;
+        joints2d[blockIdx.x * 2 + 0] = vis ? (float)(si[0] % W) : -1.0f;
+        joints2d[blockIdx.x * 2 + 1] = vis ? floorf((float)si[0] / (float)W) : -1.0f;
+        visib[blockIdx.x] = vis ? 1.0f : 0.0f;
+    }
+}
+
+// utils/sampling_utils.py:210-229: per sample, the largest image-plane distance between its projected COCO joints
+// (flipped 180 degrees about x, weak-perspective projection utils/cam_utils.py:9-16, de-normalised
+// utils/joints2d_utils.py:5-10) and the visible input joints.
+__global__ void sample_j2d_error_kernel(const float* __restrict__ joints, const int32_t* __restrict__ coco_map, int n_joints_all,
+                                        const float* __restrict__ in_j2d, const float* __restrict__ in_vis,
+                                        const float* __restrict__ cam, float img_wh, float* __restrict__ err, int N, int K) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const float sc = cam[0], tx = cam[1], ty = cam[2];
+    float worst = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+        if (in_vis[k] == 0.0f) continue;
+        const float* j = joints + ((size_t)s * n_joints_all + coco_map[k]) * 3;
+        const float u = (sc * (j[0] + tx) + 1.0f) * (img_wh / 2.0f);
+        const float v = (sc * (-j[1] + ty) + 1.0f) * (img_wh / 2.0f);
+        const float du = u - in_j2d[k * 2], dv = v - in_j2d[k * 2 + 1];
+        worst = fmaxf(worst, sqrtf(du * du + dv * dv));
+    }
+    err[s] = worst;
+}
+
 }  // namespace hps
 
 using namespace hps;
+
+extern "C" int hps_heatmaps_to_joints2d(const float* heatmaps, float* joints2d, float* visib, int BK, int H, int W, float eps,
+                                        hps_stream_t stream) {
+    if (!heatmaps || !joints2d || !visib) return bad_arg("hps_heatmaps_to_joints2d: null pointer");
+    if (BK <= 0) return HPS_OK;
+    hipLaunchKernelGGL(heatmap_argmax_kernel, dim3(BK), dim3(256), 0, (hipStream_t)stream, heatmaps, joints2d, visib, H * W, W, eps);
+    return check_launch("hps_heatmaps_to_joints2d");
+}
+
+extern "C" int hps_sample_joints2d_error(const float* joints, const int32_t* coco_map, int n_joints_all, const float* in_j2d,
+                                         const float* in_vis, const float* cam, float img_wh, float* err, int N, int K,
+                                         hps_stream_t stream) {
+    if (!joints || !coco_map || !in_j2d || !in_vis || !cam || !err) return bad_arg("hps_sample_joints2d_error: null pointer");
+    if (N <= 0) return HPS_OK;
+    hipLaunchKernelGGL(sample_j2d_error_kernel, dim3(ceil_div(N, 64)), dim3(64), 0, (hipStream_t)stream, joints, coco_map,
+                       n_joints_all, in_j2d, in_vis, cam, img_wh, err, N, K);
+    return check_launch("hps_sample_joints2d_error");
+}
 
 extern "C" int hps_canny_edges(const float* img, const float* gauss_taps_host, int gauss_size, float* blurred,
                                float* grad_mag, float* grad_ori, float* thr_mag, float* thin, float* thr_thin, int B,

@@ -34,3 +34,15 @@ def make_proxy_representation(edge, joints2D, joints2D_visib, img_wh, std=4.0):
     _capi.call("hps_proxy_rep", P(e), P(j), P(vis) if vis is not None else None, P(out), B, N, img_wh, img_wh,
                float(std), _capi.stream())
     return out
+
+
+def convert_heatmaps_to_2Djoints_coordinates_torch(joints2D_heatmaps, eps=1e-6):
+    """utils/label_conversions.py:127-155: (N,K,H,W) heat-maps -> joints2D (N,K,2) = arg-max (x, y), joints2D_vis (N,K) bool
+    (max > eps); invisible joints are (-1,-1)."""
+    _capi.require_device(joints2D_heatmaps, "joints2D_heatmaps")
+    h = _capi.f32c(joints2D_heatmaps)
+    N, K, H, W = h.shape
+    j = torch.empty(N, K, 2, device=h.device, dtype=torch.float32)
+    v = torch.empty(N, K, device=h.device, dtype=torch.float32)
+    _capi.call("hps_heatmaps_to_joints2d", _capi.ptr(h), _capi.ptr(j), _capi.ptr(v), N * K, H, W, float(eps), _capi.stream())
+    return j, v > 0.5

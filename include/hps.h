@@ -233,6 +233,18 @@ int hps_canny_edges(const float* img, const float* gauss_taps_host, int gauss_si
 int hps_proxy_rep(const float* edge, const float* joints2d, const float* visib, float* out, int B,
                   int K, int H, int W, float std, hps_stream_t stream);
 
+/* utils/label_conversions.py:127-155: heatmaps (BK, H, W) -> joints2d (BK,2) = (x, y) of the maximum (first index on
+ * ties), visib (BK,) = 1.0 if max > eps else 0.0 (then joints2d = -1). */
+int hps_heatmaps_to_joints2d(const float* heatmaps, float* joints2d, float* visib, int BK, int H, int W,
+                             float eps, hps_stream_t stream);
+
+/* utils/sampling_utils.py:210-229: err[s] = max over visible input joints k of the pixel distance
+ * between in_j2d[k] and the weak-perspective projection of joints[s, coco_map[k]] flipped 180 degrees about x.
+ * joints (N, n_joints_all, 3); in_j2d (K,2); in_vis (K,); cam (3,) = (scale, tx, ty). */
+int hps_sample_joints2d_error(const float* joints, const int32_t* coco_map, int n_joints_all,
+                              const float* in_j2d, const float* in_vis, const float* cam, float img_wh,
+                              float* err, int N, int K, hps_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Evaluation metrics  
  * ---------------------------------------------------------------------------------------- */

@@ -484,6 +484,29 @@ def metric_sums(pred, target, metrics):
     return out
 
 
+def heatmaps_to_joints2d(heat, eps=1e-6):
+    """utils/label_conversions.py:127-155."""
+    N, K, H, W = heat.shape
+    mx, idx = torch.max(heat.reshape(N, K, -1), dim=-1)
+    j = torch.zeros(N, K, 2)
+    j[:, :, 0] = idx % W
+    j[:, :, 1] = torch.floor(idx / float(W))
+    vis = mx > eps
+    j[torch.logical_not(vis)] = -1
+    return j, vis
+
+
+def joints2d_error_sorted(verts_samples, joints_samples, heat, cam_wp, coco_map):
+    """utils/sampling_utils.py:195-233 with the pytorch3d flip written as diag(1,-1,-1); returns (sorted verts, order)."""
+    jc = joints_samples[:, coco_map, :] * torch.tensor([1.0, -1.0, -1.0])
+    proj = cam_wp[:, None, [0]] * (jc[:, :, :2] + cam_wp[:, None, 1:])                 # utils/cam_utils.py:9-16
+    proj = (proj + 1) * (heat.shape[-1] / 2.0)                                       # utils/joints2d_utils.py:5-10
+    in_j, in_vis = heatmaps_to_joints2d(heat)
+    l2 = torch.norm(proj[:, in_vis[0], :] - in_j[:, in_vis[0], :], dim=-1)
+    order = torch.sort(l2.max(dim=-1)[0], descending=False)[1]
+    return verts_samples[order], order
+
+
 def rotmat_to_axis_angle64(R):
     """SO(3) log map in float64 (what cv2.Rodrigues does for the target flip, utils/rigid_transform_utils.py:48-56)."""
     R = np.asarray(R, np.float64)

@@ -98,6 +98,14 @@ def main():
                     out["canny_%s_%s" % (tag, k)] = v
     out["canny_rgb"], out["heat_joints"] = rgb, j2d
     out["heat_out"] = convert_2Djoints_to_gaussian_heatmaps_torch(j2d, 64, 4.0)
+    # ---- heat-map arg-max (utils/label_conversions.py:127-155) on the case tests/test_frontend.py builds ----
+    from utils.label_conversions import convert_heatmaps_to_2Djoints_coordinates_torch
+    g4 = torch.Generator().manual_seed(4)
+    jj = torch.rand(1, 17, 2, generator=g4) * 200 + 20
+    hh = convert_2Djoints_to_gaussian_heatmaps_torch(jj.round(), 256, 4.0)
+    hh[:, [7, 9]] = 0.0
+    hh[:, 3, 10, 10] = hh[:, 3].max()
+    out["argmax_joints"] = convert_heatmaps_to_2Djoints_coordinates_torch(hh)[0]
     # ---- evaluation metrics: the reference tracker on a seeded synthetic scenario ----
     from metrics.eval_metrics_tracker import EvalMetricsTracker
     sys.path.insert(0, os.path.join(ROOT, "tests"))

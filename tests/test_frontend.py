@@ -94,3 +94,29 @@ def test_heatmaps_and_proxy_representation(dev, golden):
     assert proxy.shape == (2, 18, 64, 64)
     assert maxerr(proxy[:, 1:], want[:, 1:]) <= 2e-6
     assert _fraction_differing(proxy[:, :1], want[:, :1], 2e-6) <= 1e-3
+
+
+@pytest.mark.gpu
+def test_heatmap_argmax_and_sample_ranking(dev, golden):
+    """utils/label_conversions.py:127-155 and utils/sampling_utils.py:195-233."""
+    from hierarchicalprobabilistic3dhuman_amd.label_conversions import (convert_heatmaps_to_2Djoints_coordinates_torch,
+                                                                        ALL_JOINTS_TO_COCO_MAP)
+    from hierarchicalprobabilistic3dhuman_amd.sampling_utils import joints2D_error_sorted_verts_sampling
+    from utils_reference_check import reference_argmax_golden
+    g = torch.Generator().manual_seed(4)
+    j2d = torch.rand(1, 17, 2, generator=g) * 200 + 20
+    heat = O.joints2d_to_gaussian_heatmaps(j2d.round(), 256, 4.0)
+    heat[:, [7, 9]] = 0.0                                                     # two undetected joints
+    heat[:, 3, 10, 10] = heat[:, 3].max()                                     # a tie: the first index must win
+    j_ref, v_ref = O.heatmaps_to_joints2d(heat)
+    j, v = convert_heatmaps_to_2Djoints_coordinates_torch(heat.to(dev))
+    assert torch.equal(j.cpu(), j_ref) and torch.equal(v.cpu(), v_ref)
+    reference_argmax_golden(golden, j_ref)
+    # ranking
+    N = 12
+    joints = torch.randn(N, 90, 3, generator=g) * 0.4
+    verts = torch.randn(N, 6890, 3, generator=g)
+    cam = torch.tensor([[0.9, 0.05, -0.1]])
+    want, order = O.joints2d_error_sorted(verts, joints, heat, cam, ALL_JOINTS_TO_COCO_MAP)
+    got = joints2D_error_sorted_verts_sampling(verts.to(dev), joints.to(dev), heat.to(dev), cam.to(dev))
+    assert torch.equal(got.cpu(), want)
