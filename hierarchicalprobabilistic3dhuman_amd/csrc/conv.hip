@@ -556,7 +556,7 @@ extern "C" int hps_conv2d_bn_act_v3(const float* x, const float* wn, const float
     if (B <= 0) return HPS_OK;
     hipStream_t s = (hipStream_t)stream;
     if (variant == 0) {
-        // measured per ResNet-18 layer at B = 64 (tools/gpu_bringup.py conv_tune): the L2->LDS path per CU is the
+        // measured per ResNet-18 layer at B = 64 (tests/dev/gpu_bringup.py conv_tune): the L2->LDS path per CU is the
         // limiter, so take the largest tile that still gives every CU a workgroup: 128x128 (>= 256 workgroups),
         // 256x64 for 64-channel outputs, else 64x64 (8 waves/SIMD)
         const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
@@ -590,7 +590,7 @@ extern "C" int hps_conv2d_bn_act_v2(const float* x, const float* wn, const float
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     const long Mtot = (long)B * Ho * Wo;
     if (variant == 0) {
-        // measured per ResNet-18 layer at B = 64 (tools/gpu_bringup.py conv_tune): the 64x64 tile (7 waves/SIMD)
+        // measured per ResNet-18 layer at B = 64 (tests/dev/gpu_bringup.py conv_tune): the 64x64 tile (7 waves/SIMD)
         // wins everywhere except where 128x128 tiles still give every CU two workgroups
         variant = (Cout % 128 == 0 && (Mtot / 128) * (Cout / 128) >= 512) ? 1 : 3;
     }

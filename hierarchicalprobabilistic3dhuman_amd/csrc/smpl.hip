@@ -335,7 +335,7 @@ static int lbs_dispatch(const float* v_posed, const float* a, const int32_t* w_i
 
 extern "C" int hps_smpl_lbs(const float* v_posed, const float* a, const int32_t* w_idx, const float* w_val, int K,
                             int num_joints, const float* transl, float* verts, int M, int V, hps_stream_t stream) {
-    // measured on MI355X at 6528 meshes (tools/gpu_bringup.py lbs_tune): many small workgroups of
+    // measured on MI355X at 6528 meshes (tests/dev/gpu_bringup.py lbs_tune): many small workgroups of
     // 256 vertices x 8 meshes beat a resident persistent grid: 194 us (5.6 TB/s algorithmic) vs 227-280 us
     return lbs_dispatch(v_posed, a, w_idx, w_val, K, num_joints, transl, verts, M, V, 1, 24576, (hipStream_t)stream);
 }

@@ -1,6 +1,6 @@
-"""Developer bring-up / micro-benchmark script for a GPU box (not part of the product or the test-suite).
+"""Developer bring-up / micro-benchmark script for a GPU box (test infrastructure: it imports the oracle; not part of the product, not collected by pytest).
 
-    python tools/gpu_bringup.py <section> [...]      sections: rot smpl smpl_perf sampler head encoder encoder_perf e2e
+    python tests/dev/gpu_bringup.py <section> [...]      sections: rot smpl smpl_perf sampler head encoder encoder_perf e2e
 Each section compares the HIP path with the CPU oracle and prints max-abs errors and timings.
 """
 import os
@@ -10,7 +10,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from hierarchicalprobabilistic3dhuman_amd import configs, smpl_data  # noqa: E402
