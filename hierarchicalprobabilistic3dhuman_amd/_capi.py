@@ -21,9 +21,9 @@ _PROTOTYPES = {
     "hps_version": [],
     "hps_last_error": [],
     "hps_smpl_pose_prep": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
-    "hps_smpl_blend": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "hps_smpl_lbs": [_P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
-    "hps_dev_lbs_variant": [_P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P],
+    "hps_smpl_blend": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "hps_smpl_lbs": [_P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
+    "hps_dev_lbs_variant": [_P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P],
     "hps_smpl_joints": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
     "hps_vertex_uncertainty": [_P, _P, _I, _I, _I, _P],
     "hps_mf_sample": [_P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _c.c_float, _P, _P, _P, _c.c_uint64,

@@ -20,7 +20,7 @@ constexpr int BM = 128, BN = 128, BK = 16;
 __global__ __launch_bounds__(256) void blend_gemm_kernel(const float* __restrict__ xt, const float* __restrict__ bmat,
                                                          const float* __restrict__ v_template,
                                                          float* __restrict__ out, int M, int N, int kp, int mp,
-                                                         int np, int tiles_m) {
+                                                         int np, int tiles_m, int ld_out) {
     __shared__ __attribute__((aligned(16))) float sA[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float sB[2][BK][BN];
 
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void blend_gemm_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
-                if (m < M) out[(size_t)m * N + n] = vt + acc[tm][tn][r];
+                if (m < M) out[(size_t)m * ld_out + n] = vt + acc[tm][tn][r];
             }
         }
     }
@@ -108,13 +108,14 @@ __global__ __launch_bounds__(256) void blend_gemm_kernel(const float* __restrict
 using namespace hps;
 
 extern "C" int hps_smpl_blend(const float* xt, const float* bmat, const float* v_template, float* v_posed, int M,
-                              int N, int kp, int mp, int np, hps_stream_t stream) {
+                              int N, int kp, int mp, int np, int ld_out, hps_stream_t stream) {
     if (!xt || !bmat || !v_template || !v_posed) return bad_arg("hps_smpl_blend: null pointer");
     if (kp <= 0 || kp % BK != 0) return bad_arg("hps_smpl_blend: kp must be a positive multiple of 16");
     if (mp % BM != 0 || mp < M || np % BN != 0 || np < N) return bad_arg("hps_smpl_blend: mp/np must be multiples of 128 covering M/N");
+    if (ld_out < N) return bad_arg("hps_smpl_blend: ld_out < N");
     if (M <= 0 || N <= 0) return HPS_OK;
     const int tiles_m = ceil_div(M, BM), tiles_n = ceil_div(N, BN);
     hipLaunchKernelGGL(blend_gemm_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, (hipStream_t)stream, xt, bmat,
-                       v_template, v_posed, M, N, kp, mp, np, tiles_m);
+                       v_template, v_posed, M, N, kp, mp, np, tiles_m, ld_out);
     return check_launch("hps_smpl_blend");
 }

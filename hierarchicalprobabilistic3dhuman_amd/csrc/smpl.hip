@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void pose_prep_kernel(
 // chunk -- the ones that read the same A -- run on the same XCD and hit its L2.
 // ---------------------------------------------------------------------------------------------
 template <int K, int G, int VPT>
-__global__ __launch_bounds__(256) void lbs_kernel(const f3* __restrict__ v_posed, const float* __restrict__ a,
+__global__ __launch_bounds__(256) void lbs_kernel(const float* __restrict__ v_posed_f, int ld_vposed,
+                                                  const float* __restrict__ a,
                                                   const int32_t* __restrict__ w_idx, const float* __restrict__ w_val,
                                                   int J, const float* __restrict__ transl, f3* __restrict__ verts,
                                                   int M, int V, int meshes_per_block, int n_vtiles) {
@@ -176,7 +177,8 @@ __global__ __launch_bounds__(256) void lbs_kernel(const f3* __restrict__ v_posed
         for (int g = 0; g < G; ++g) {
             const int m = min(m0 + g, m_end - 1);   // clamp: the tail group re-reads the last mesh
 #pragma unroll
-            for (int q = 0; q < VPT; ++q) p[g][q] = v_posed[(size_t)m * V + vtx[q]];
+            for (int q = 0; q < VPT; ++q)
+                p[g][q] = reinterpret_cast<const f3*>(v_posed_f + (size_t)m * ld_vposed)[vtx[q]];     // row pitch ld_vposed floats
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -288,7 +290,7 @@ extern "C" int hps_smpl_pose_prep(const float* glob, const float* body, int is_r
 // LBS launch geometry.  variant 0 = the default chosen for the shipped path; the others exist for tuning
 // (hps_dev_lbs_variant).  target_blocks ~ how many workgroups are resident at once on 256 CUs.
 template <int K, int G, int VPT>
-static int launch_lbs_cfg(const float* v_posed, const float* a, const int32_t* w_idx, const float* w_val, int J,
+static int launch_lbs_cfg(const float* v_posed, int ldv, const float* a, const int32_t* w_idx, const float* w_val, int J,
                           const float* transl, float* verts, int M, int V, int target_blocks, hipStream_t s) {
     const int n_vtiles = ceil_div(V, 256 * VPT);
     int n_chunks = max(1, target_blocks / n_vtiles);
@@ -296,54 +298,54 @@ static int launch_lbs_cfg(const float* v_posed, const float* a, const int32_t* w
     n_chunks = ceil_div(M, mpb);
     const int chunks_padded = ceil_div(n_chunks, 8) * 8;        // chunk = (local / n_vtiles) * 8 + xcd
     const size_t lds = (size_t)2 * G * J * 12 * sizeof(float);
-    hipLaunchKernelGGL((lbs_kernel<K, G, VPT>), dim3(chunks_padded * n_vtiles), dim3(256), lds, s,
-                       reinterpret_cast<const f3*>(v_posed), a, w_idx, w_val, J, transl, reinterpret_cast<f3*>(verts), M, V,
-                       mpb, n_vtiles);
+    hipLaunchKernelGGL((lbs_kernel<K, G, VPT>), dim3(chunks_padded * n_vtiles), dim3(256), lds, s, v_posed, ldv, a, w_idx,
+                       w_val, J, transl, reinterpret_cast<f3*>(verts), M, V, mpb, n_vtiles);
     return check_launch("hps_smpl_lbs");
 }
 
 template <int K>
-static int launch_lbs(const float* v_posed, const float* a, const int32_t* w_idx, const float* w_val, int J,
+static int launch_lbs(const float* v_posed, int ldv, const float* a, const int32_t* w_idx, const float* w_val, int J,
                       const float* transl, float* verts, int M, int V, int variant, int target_blocks, hipStream_t s) {
     if (target_blocks <= 0) target_blocks = 1536;
     switch (variant) {
-        case 0: return launch_lbs_cfg<K, 4, 1>(v_posed, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
-        case 1: return launch_lbs_cfg<K, 8, 1>(v_posed, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
-        case 2: return launch_lbs_cfg<K, 4, 2>(v_posed, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
-        case 3: return launch_lbs_cfg<K, 2, 2>(v_posed, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
-        case 4: return launch_lbs_cfg<K, 2, 1>(v_posed, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
-        case 5: return launch_lbs_cfg<K, 8, 2>(v_posed, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
-        case 6: return launch_lbs_cfg<K, 16, 1>(v_posed, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
+        case 0: return launch_lbs_cfg<K, 4, 1>(v_posed, ldv, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
+        case 1: return launch_lbs_cfg<K, 8, 1>(v_posed, ldv, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
+        case 2: return launch_lbs_cfg<K, 4, 2>(v_posed, ldv, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
+        case 3: return launch_lbs_cfg<K, 2, 2>(v_posed, ldv, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
+        case 4: return launch_lbs_cfg<K, 2, 1>(v_posed, ldv, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
+        case 5: return launch_lbs_cfg<K, 8, 2>(v_posed, ldv, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
+        case 6: return launch_lbs_cfg<K, 16, 1>(v_posed, ldv, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
         default: set_error("hps_smpl_lbs: unknown variant %d", variant); return HPS_E_BADARG;
     }
 }
 
-static int lbs_dispatch(const float* v_posed, const float* a, const int32_t* w_idx, const float* w_val, int K,
+static int lbs_dispatch(const float* v_posed, int ldv, const float* a, const int32_t* w_idx, const float* w_val, int K,
                         int num_joints, const float* transl, float* verts, int M, int V, int variant, int target_blocks,
                         hipStream_t s) {
     if (!v_posed || !a || !w_idx || !w_val || !verts) return bad_arg("hps_smpl_lbs: null pointer");
     if (num_joints < 1 || num_joints > 64) return bad_arg("hps_smpl_lbs: num_joints");
+    if (ldv < 3 * V) return bad_arg("hps_smpl_lbs: ld_vposed < 3 V");
     if (M <= 0 || V <= 0) return HPS_OK;
     switch (K) {
-        case 4: return launch_lbs<4>(v_posed, a, w_idx, w_val, num_joints, transl, verts, M, V, variant, target_blocks, s);
-        case 8: return launch_lbs_cfg<8, 4, 1>(v_posed, a, w_idx, w_val, num_joints, transl, verts, M, V, 1024, s);
-        case 12: return launch_lbs_cfg<12, 2, 1>(v_posed, a, w_idx, w_val, num_joints, transl, verts, M, V, 768, s);
-        case 24: return launch_lbs_cfg<24, 2, 1>(v_posed, a, w_idx, w_val, num_joints, transl, verts, M, V, 512, s);
+        case 4: return launch_lbs<4>(v_posed, ldv, a, w_idx, w_val, num_joints, transl, verts, M, V, variant, target_blocks, s);
+        case 8: return launch_lbs_cfg<8, 4, 1>(v_posed, ldv, a, w_idx, w_val, num_joints, transl, verts, M, V, 1024, s);
+        case 12: return launch_lbs_cfg<12, 2, 1>(v_posed, ldv, a, w_idx, w_val, num_joints, transl, verts, M, V, 768, s);
+        case 24: return launch_lbs_cfg<24, 2, 1>(v_posed, ldv, a, w_idx, w_val, num_joints, transl, verts, M, V, 512, s);
         default: set_error("hps_smpl_lbs: K=%d unsupported (4, 8, 12, 24)", K); return HPS_E_UNSUPPORTED;
     }
 }
 
-extern "C" int hps_smpl_lbs(const float* v_posed, const float* a, const int32_t* w_idx, const float* w_val, int K,
-                            int num_joints, const float* transl, float* verts, int M, int V, hps_stream_t stream) {
+extern "C" int hps_smpl_lbs(const float* v_posed, int ld_vposed, const float* a, const int32_t* w_idx, const float* w_val,
+                            int K, int num_joints, const float* transl, float* verts, int M, int V, hps_stream_t stream) {
     // measured on MI355X at 6528 meshes (tests/dev/gpu_bringup.py lbs_tune): many small workgroups of
     // 256 vertices x 8 meshes beat a resident persistent grid: 194 us (5.6 TB/s algorithmic) vs 227-280 us
-    return lbs_dispatch(v_posed, a, w_idx, w_val, K, num_joints, transl, verts, M, V, 1, 24576, (hipStream_t)stream);
+    return lbs_dispatch(v_posed, ld_vposed, a, w_idx, w_val, K, num_joints, transl, verts, M, V, 1, 24576, (hipStream_t)stream);
 }
 
-extern "C" int hps_dev_lbs_variant(const float* v_posed, const float* a, const int32_t* w_idx, const float* w_val, int K,
-                                   int num_joints, const float* transl, float* verts, int M, int V, int variant,
-                                   int target_blocks, hps_stream_t stream) {
-    return lbs_dispatch(v_posed, a, w_idx, w_val, K, num_joints, transl, verts, M, V, variant, target_blocks,
+extern "C" int hps_dev_lbs_variant(const float* v_posed, int ld_vposed, const float* a, const int32_t* w_idx,
+                                   const float* w_val, int K, int num_joints, const float* transl, float* verts, int M,
+                                   int V, int variant, int target_blocks, hps_stream_t stream) {
+    return lbs_dispatch(v_posed, ld_vposed, a, w_idx, w_val, K, num_joints, transl, verts, M, V, variant, target_blocks,
                         (hipStream_t)stream);
 }
 

@@ -51,6 +51,7 @@ class SMPL(nn.Module):
         self.dtype = dtype
         self.keep_intermediates = False
         self.lbs_events = None
+        self.pad_v_posed = True
 
         f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
         v_template = np.asarray(model["v_template"], np.float64)
@@ -161,7 +162,8 @@ class SMPL(nn.Module):
         xt = torch.empty(self._kp, mp, **f32)
         a = torch.empty(M, J, 12, **f32)
         j_posed = torch.empty(M, J, 3, **f32)
-        v_posed = torch.empty(M, V, 3, **f32)
+        ldv = self._np if self.pad_v_posed else N          # row pitch of v_posed in floats (128-byte aligned rows)
+        v_posed = torch.empty(M, ldv, **f32)
         verts = torch.empty(M, V, 3, **f32)
         joints = torch.empty(M, J + self._n_joint_rows, 3, **f32)
         s = _capi.stream()
@@ -170,12 +172,12 @@ class SMPL(nn.Module):
                    P(self._j_shapedirs), _capi.iptr(self._parents_i32), _capi.iptr(self._depth_i32), J, P(xt),
                    self._kp, mp, P(a), P(j_posed), None, M, s)
         _capi.call("hps_smpl_blend", P(xt), P(self._bmat), P(self._v_template_flat), P(v_posed), M, N, self._kp,
-                   mp, self._np, s)
+                   mp, self._np, ldv, s)
         ev = None
         if self.lbs_events is not None:      # bench.py: HIP events around the LBS launch, on its own stream
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        _capi.call("hps_smpl_lbs", P(v_posed), P(a), _capi.iptr(self._w_idx), P(self._w_val), self._lbs_k, J,
+        _capi.call("hps_smpl_lbs", P(v_posed), ldv, P(a), _capi.iptr(self._w_idx), P(self._w_val), self._lbs_k, J,
                    P(tr) if tr is not None else None, P(verts), M, V, s)
         if ev is not None:
             ev[1].record()
@@ -184,6 +186,6 @@ class SMPL(nn.Module):
                    P(self._csr_val), self._n_joint_rows, J, P(tr) if tr is not None else None, P(joints), M, V, s)
         full_pose = torch.cat([g, b], dim=1) if return_full_pose else None
         if self.keep_intermediates:                                         # tests / profiling only
-            self._last = dict(xt=xt, a=a, j_posed=j_posed, v_posed=v_posed)
+            self._last = dict(xt=xt, a=a, j_posed=j_posed, v_posed=v_posed[:, :N].reshape(M, V, 3), v_posed_raw=v_posed, ldv=ldv)
         return SMPLOutput(vertices=verts if return_verts else None, joints=joints, full_pose=full_pose,
                           betas=betas, global_orient=global_orient, body_pose=body_pose)

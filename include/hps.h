@@ -66,22 +66,24 @@ int hps_smpl_pose_prep(const float* glob, const float* body, int is_rotmat, cons
  *   v_posed[m, n] = v_template[n] + sum_k xt[k, m] * bmat[k, n]      (n = 3*vertex + coord)
  * bmat: (kp, np) = [shapedirs ; posedirs ; 0] with np = N rounded up to 128 (zero padded),
  * xt: (kp, mp) from hps_smpl_pose_prep, mp = M rounded up to 128, kp a multiple of 16.
+ * v_posed rows have pitch ld_out floats (>= N; a multiple of 32 keeps every 128-byte store segment line-aligned).
  * Replaces lbs steps (1) and (3): blend_shapes einsum + pose_feature @ posedirs. */
 int hps_smpl_blend(const float* xt, const float* bmat, const float* v_template, float* v_posed,
-                   int M, int N, int kp, int mp, int np, hps_stream_t stream);
+                   int M, int N, int kp, int mp, int np, int ld_out, hps_stream_t stream);
 
 /* Linear blend skinning, lbs step (5):  verts[m,v] = (sum_k w[v,k] * A[m, idx[v,k]]) . [v_posed[m,v]; 1]
  * Skinning weights in compressed form: w_idx/w_val (V, K) -- the K largest-support entries of each
  * row of lbs_weights, padded with (0, 0.0f); exact for any model with <= K non-zeros per row.
+ * v_posed rows have pitch ld_vposed floats (>= 3 V); verts is contiguous (M,V,3) like the reference's output.
  * transl: optional (M,3) added to the result (smplx SMPL.forward step (7)), may be NULL.
  * Algorithmic HBM bytes per mesh: 12 V (v_posed) + 48 J.. (A) + 12 V (verts); SURVEY section 8(d). */
-int hps_smpl_lbs(const float* v_posed, const float* a, const int32_t* w_idx, const float* w_val,
-                 int K, int num_joints, const float* transl, float* verts, int M, int V,
-                 hps_stream_t stream);
+int hps_smpl_lbs(const float* v_posed, int ld_vposed, const float* a, const int32_t* w_idx,
+                 const float* w_val, int K, int num_joints, const float* transl, float* verts, int M,
+                 int V, hps_stream_t stream);
 
 /* Development / tuning entry: hps_smpl_lbs with an explicit kernel variant (0..4: meshes per barrier G and
  * vertices per lane VPT = (4,1) (8,1) (4,2) (2,2) (2,1)) and resident-workgroup target. Same results. */
-int hps_dev_lbs_variant(const float* v_posed, const float* a, const int32_t* w_idx,
+int hps_dev_lbs_variant(const float* v_posed, int ld_vposed, const float* a, const int32_t* w_idx,
                         const float* w_val, int K, int num_joints, const float* transl, float* verts,
                         int M, int V, int variant, int target_blocks, hps_stream_t stream);
 

@@ -109,8 +109,8 @@ def sec_smpl_perf():
                                            P(smpl._j_shapedirs), _capi.iptr(smpl._parents_i32), _capi.iptr(smpl._depth_i32),
                                            J, P(L["xt"]), smpl._kp, L["xt"].shape[1], P(L["a"]), P(L["j_posed"]), None, M, s))
         t_blend = timeit(lambda: _capi.call("hps_smpl_blend", P(L["xt"]), P(smpl._bmat), P(smpl._v_template_flat),
-                                            P(L["v_posed"]), M, 3 * V, smpl._kp, L["xt"].shape[1], smpl._np, s))
-        t_lbs = timeit(lambda: _capi.call("hps_smpl_lbs", P(L["v_posed"]), P(L["a"]), _capi.iptr(smpl._w_idx),
+                                            P(L["v_posed_raw"]), M, 3 * V, smpl._kp, L["xt"].shape[1], smpl._np, L["ldv"], s))
+        t_lbs = timeit(lambda: _capi.call("hps_smpl_lbs", P(L["v_posed_raw"]), L["ldv"], P(L["a"]), _capi.iptr(smpl._w_idx),
                                           P(smpl._w_val), smpl._lbs_k, J, None, P(verts), M, V, s), 20, 5)
         t_j = timeit(lambda: _capi.call("hps_smpl_joints", P(verts), P(L["j_posed"]), _capi.iptr(smpl._csr_ptr),
                                         _capi.iptr(smpl._csr_col), P(smpl._csr_val), smpl._n_joint_rows, J, None,
@@ -145,7 +145,7 @@ def sec_lbs_tune():
     names = {0: "G4 VPT1", 1: "G8 VPT1", 2: "G4 VPT2", 3: "G2 VPT2", 4: "G2 VPT1", 5: "G8 VPT2", 6: "G16 VPT1"}
     for variant in (0, 1, 2, 5, 6):
         for tb in (4096, 6144, 8192, 12288, 16384, 24576, 49152):
-            fn = lambda: _capi.call("hps_dev_lbs_variant", P(L["v_posed"]), P(L["a"]), _capi.iptr(smpl._w_idx),
+            fn = lambda: _capi.call("hps_dev_lbs_variant", P(L["v_posed_raw"]), L["ldv"], P(L["a"]), _capi.iptr(smpl._w_idx),
                                     P(smpl._w_val), smpl._lbs_k, J, None, P(verts), M, V, variant, tb, s)
             verts.zero_()
             fn()

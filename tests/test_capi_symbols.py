@@ -37,9 +37,9 @@ def test_version_and_error_string():
 def test_argument_validation_needs_no_gpu():
     """Bad arguments are rejected on the host before any launch."""
     lib = _capi.load()
-    rc = lib.hps_smpl_lbs(None, None, None, None, 4, 24, None, None, 1, 6890, None)
+    rc = lib.hps_smpl_lbs(None, 20670, None, None, None, 4, 24, None, None, 1, 6890, None)
     assert rc == -1 and b"null pointer" in lib.hps_last_error()
-    rc = lib.hps_smpl_blend(None, None, None, None, 1, 1, 16, 128, 128, None)
+    rc = lib.hps_smpl_blend(None, None, None, None, 1, 1, 16, 128, 128, 128, None)
     assert rc == -1
 
 

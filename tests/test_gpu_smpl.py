@@ -151,5 +151,5 @@ def test_c_abi_rejects_unsupported_k(dev, smpl_gpu):
     z = torch.zeros(16, device=dev)
     zi = torch.zeros(16, device=dev, dtype=torch.int32)
     with pytest.raises(_capi.HpsError):
-        _capi.call("hps_smpl_lbs", _capi.ptr(z), _capi.ptr(z), _capi.iptr(zi), _capi.ptr(z), 5, 24, None, _capi.ptr(z), 1, 1,
+        _capi.call("hps_smpl_lbs", _capi.ptr(z), 3, _capi.ptr(z), _capi.iptr(zi), _capi.ptr(z), 5, 24, None, _capi.ptr(z), 1, 1,
                    _capi.stream())
