@@ -39,7 +39,7 @@ _PROTOTYPES = {
     "hps_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "hps_conv2d_bn_act": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "hps_conv2d_bn_act_v2": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "hps_conv2d_bn_act_v3": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "hps_conv2d_bn_act_v3": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "hps_canny_edges": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _I, _P],
     "hps_proxy_rep": [_P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _P],
     "hps_pointset_errors": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],

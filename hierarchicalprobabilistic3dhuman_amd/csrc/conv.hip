@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(
     const float* __restrict__ x, const float* __restrict__ wn, const float* __restrict__ zeros,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ residual,
     float* __restrict__ y, int H, int W, int Cin, int Cout, int KW, int stride, int pad, int Ho, int Wo, int Mtot,
-    int Kp, int relu, int tiles_m) {
+    int Kp, int relu, int tiles_m, int ksplit, float* __restrict__ partial) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int A_LD = BM / 32, B_LD = BN / 32;        // DMA instructions per wave per chunk
@@ -398,13 +398,17 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int fsw = (il >> 1) & 7;                       // f(row) of the fragment rows this lane reads
-    dma_chunk(0, 0);
-    const int nchunks = Kp / VBK;
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
+    // split-K: blockIdx.y owns the chunk range [c_begin, c_end) and writes raw partial sums (reduced, in slice
+    // order, by splitk_epilogue_kernel -- deterministic, no atomics)
+    const int chunks_total = Kp / VBK;
+    const int per_split = chunks_total / ksplit;
+    const int c_begin = blockIdx.y * per_split, c_end = c_begin + per_split;
+    dma_chunk(c_begin, 0);
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA of chunk c has landed
         __syncthreads();                                     // ... everyone's has, and buf^1 is no longer being read
-        if (c + 1 < nchunks && ABLATE != 1) dma_chunk(c + 1, buf ^ 1);
+        if (c + 1 < c_end && ABLATE != 1) dma_chunk(c + 1, buf ^ 1);
         const float* pa = sA + (size_t)buf * BM * VBK + (wm0 + il) * VBK;
         const float* pb = sB + (size_t)buf * BN * VBK + (wn0 + il) * VBK;
 #pragma unroll
@@ -434,7 +438,45 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(
         }
     }
 
+    if (ksplit > 1) {
+        float* dst = partial + (size_t)blockIdx.y * Mtot * Cout;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int co = n0 + wn0 + j * 32 + il;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                    if (m < Mtot) dst[(size_t)m * Cout + co] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     conv_epilogue<TM, TN>(acc, scale, shift, residual, y, m0 + wm0, n0 + wn0, il, kl, Cout, Mtot, relu, m0 + BM <= Mtot);
+}
+
+// second pass of a split-K convolution: y = act(scale * (sum of the slices, in slice order) + shift + residual)
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ partial, int ksplit,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              const float* __restrict__ residual, float* __restrict__ y,
+                                                              long total4, int Cout, int relu) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    float4 acc = reinterpret_cast<const float4*>(partial)[i];
+    for (int k = 1; k < ksplit; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(partial)[(size_t)k * total4 + i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const int co = (int)((i * 4) % Cout);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + co), sh = *reinterpret_cast<const float4*>(shift + co);
+    float4 o = make_float4(acc.x * sc.x + sh.x, acc.y * sc.y + sh.y, acc.z * sc.z + sh.z, acc.w * sc.w + sh.w);
+    if (residual) {
+        const float4 r = reinterpret_cast<const float4*>(residual)[i];
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    reinterpret_cast<float4*>(y)[i] = o;
 }
 
 // (B,C,H,W) -> (B,H,W,Cp): lanes along w read each channel plane coalesced; every lane assembles its
@@ -526,10 +568,11 @@ static int launch_conv_v2(const float* x, const float* wn, const float* scale, c
 template <int BM, int BN, int WM, int WN, int ABLATE = 0>
 static int launch_conv_v3(const float* x, const float* wn, const float* zeros, const float* scale, const float* shift,
                           const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
-                          int stride, int pad, int relu, hipStream_t s) {
+                          int stride, int pad, int relu, hipStream_t s, int ksplit = 1, float* partial = nullptr) {
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     const int Mtot = B * Ho * Wo, Kp = KH * KW * Cin;
     const int tiles_m = ceil_div(Mtot, BM), tiles_n = Cout / BN;
+    if (ksplit < 1 || (Kp / VBK) % ksplit != 0 || (ksplit > 1 && !partial)) return bad_arg("hps_conv2d_bn_act_v3: ksplit");
     const size_t lds = (size_t)2 * (BM + BN) * VBK * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
@@ -537,8 +580,14 @@ static int launch_conv_v3(const float* x, const float* wn, const float* zeros, c
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_v3_kernel<BM, BN, WM, WN, ABLATE>), dim3(tiles_m * tiles_n), dim3(256), lds, s, x, wn, zeros,
-                       scale, shift, residual, y, H, W, Cin, Cout, KW, stride, pad, Ho, Wo, Mtot, Kp, relu, tiles_m);
+    hipLaunchKernelGGL((conv_igemm_v3_kernel<BM, BN, WM, WN, ABLATE>), dim3(tiles_m * tiles_n, ksplit), dim3(256), lds, s, x,
+                       wn, zeros, scale, shift, residual, y, H, W, Cin, Cout, KW, stride, pad, Ho, Wo, Mtot, Kp, relu, tiles_m,
+                       ksplit, partial);
+    if (ksplit > 1) {
+        const long total4 = (long)Mtot * Cout / 4;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, partial, ksplit,
+                           scale, shift, residual, y, total4, Cout, relu);
+    }
     return check_launch("hps_conv2d_bn_act_v3");
 }
 
@@ -549,9 +598,12 @@ using namespace hps;
 // variant: 1 = 128x128, 2 = 128x64, 3 = 64x64 tiles; zeros: >= 64 bytes of zeros on the device
 extern "C" int hps_conv2d_bn_act_v3(const float* x, const float* wn, const float* zeros, const float* scale,
                                     const float* shift, const float* residual, float* y, int B, int H, int W, int Cin,
-                                    int Cout, int KH, int KW, int stride, int pad, int relu, int variant,
-                                    hps_stream_t stream) {
+                                    int Cout, int KH, int KW, int stride, int pad, int relu, int variant, int ksplit,
+                                    float* splitk_ws, hps_stream_t stream) {
     if (!x || !wn || !zeros || !scale || !shift || !y) return bad_arg("hps_conv2d_bn_act_v3: null pointer");
+    if (ksplit > 1)     // split-K runs on the 128x128 tile
+        return launch_conv_v3<128, 128, 64, 64>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride,
+                                                pad, relu, (hipStream_t)stream, ksplit, splitk_ws);
     if (Cin % 32 != 0 || Cout % 64 != 0) return bad_arg("hps_conv2d_bn_act_v3: Cin % 32 == 0 and Cout % 64 == 0 required");
     if (B <= 0) return HPS_OK;
     hipStream_t s = (hipStream_t)stream;

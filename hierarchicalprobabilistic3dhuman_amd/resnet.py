@@ -37,7 +37,19 @@ class _ConvBN:
         self.wn = wk.reshape(k_real, cout).t().contiguous() if cin_p % 32 == 0 else None
         self.kernel = "v3"        # "v3" direct global->LDS (default), "v2" register-staged, "v1" generic (any Cin % 4 == 0)
         self.variant = 0          # tile choice of the v2 / v3 kernels (0 = automatic)
+        self.ksplit = 0           # split-K slices of the v3 kernel (0 = automatic, 1 = off)
         self.zeros = torch.zeros(64, device=w.device, dtype=torch.float32)
+
+    def _auto_ksplit(self, pixels_per_image):
+        """Split K (4 slices) for the late layers whose 128x128 output tiles cannot fill 256 CUs at the benchmark batch
+        (8x8 outputs: layer4).  The rule depends on the layer only, never on the batch size: the summation order of a
+        pixel must not change with B, otherwise per-image results (and, through accept decisions that sit on rounding
+        ties, whole sample streams) would depend on how images are batched or sharded over GPUs."""
+        chunks = self.kh * self.kw * self.cin_p // 32
+        if self.variant == 0 and self.cout % 128 == 0 and self.kh * self.kw > 1 and pixels_per_image <= 64 \
+                and chunks % 4 == 0 and chunks // 4 >= 18:
+            return 4
+        return 1
 
     def __call__(self, x, residual=None, relu=True):
         B, H, W, C = x.shape
@@ -47,9 +59,12 @@ class _ConvBN:
         y = torch.empty(B, Ho, Wo, self.cout, device=x.device, dtype=torch.float32)
         P = _capi.ptr
         if self.wn is not None and self.kernel == "v3":
+            ksplit = self.ksplit if self.ksplit > 0 else self._auto_ksplit(Ho * Wo)
+            ws = torch.empty(ksplit, B * Ho * Wo, self.cout, device=x.device, dtype=torch.float32) if ksplit > 1 else None
             _capi.call("hps_conv2d_bn_act_v3", P(x), P(self.wn), P(self.zeros), P(self.scale), P(self.shift),
                        P(residual) if residual is not None else None, P(y), B, H, W, C, self.cout, self.kh, self.kw,
-                       self.stride, self.pad, 1 if relu else 0, self.variant, _capi.stream())
+                       self.stride, self.pad, 1 if relu else 0, self.variant if ksplit <= 1 else 1, ksplit,
+                       P(ws) if ws is not None else None, _capi.stream())
             return y
         if self.wn is not None and self.kernel == "v2":
             _capi.call("hps_conv2d_bn_act_v2", P(x), P(self.wn), P(self.scale), P(self.shift),

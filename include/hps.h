@@ -205,11 +205,14 @@ int hps_conv2d_bn_act_v2(const float* x, const float* wn, const float* scale, co
 
 /* As hps_conv2d_bn_act_v2 but the LDS tiles are filled by direct global->LDS DMA (global_load_lds_dwordx4) with a
  * source-side XOR swizzle.  zeros: device buffer of >= 64 zero bytes (source of out-of-image taps).
- * variant: 0 automatic, 1 = 128x128, 2 = 128x64, 3 = 64x64 workgroup tiles (2x / 3x: tuning ablations). */
+ * variant: 0 automatic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x64 workgroup tiles (2x / 3x: tuning ablations).
+ * ksplit > 1 (Cout % 128 == 0, KH*KW*Cin/32 divisible by ksplit): split-K over ksplit slices on 128x128 tiles for
+ * layers with too few output tiles to fill 256 CUs; splitk_ws: (ksplit, B*Ho*Wo, Cout) floats of workspace; the slices
+ * are summed in slice order by a second kernel that also applies BN / residual / ReLU (deterministic, no atomics). */
 int hps_conv2d_bn_act_v3(const float* x, const float* wn, const float* zeros, const float* scale,
                          const float* shift, const float* residual, float* y, int B, int H, int W,
                          int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, int variant,
-                         hps_stream_t stream);
+                         int ksplit, float* splitk_ws, hps_stream_t stream);
 
 /* nn.MaxPool2d(3, stride 2, pad 1) on NHWC (models/resnet.py:152, :207). */
 int hps_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, hps_stream_t stream);

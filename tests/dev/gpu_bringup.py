@@ -307,18 +307,24 @@ def sec_conv_tune():
         fl = 2.0 * B * Ho * Ho * Cout * k * k * Cin / 1e9
         line = "conv H%d %d->%d k%d s%d (%.1f GFLOP):" % (H, Cin, Cout, k, st, fl)
         ref = None
-        for v in (-1, 3, 11, 12, 13, 14):
+        for v in (11, 13, 14, 102, 104):
             if v % 10 == 1 and Cout % 128:
                 continue
             if x.numel() >= 2 ** 31:
                 continue
-            cb.kernel, cb.variant = ("v1", 0) if v < 0 else (("v2", v) if v < 10 else ("v3", v - 10))
+            if v >= 100:
+                if Cout % 128 or (k * k * Cin // 32) % (v - 100) or (B * Ho * Ho) % 128:
+                    continue
+                cb.kernel, cb.variant, cb.ksplit = "v3", 0, v - 100
+            else:
+                cb.ksplit = 1
+                cb.kernel, cb.variant = ("v1", 0) if v < 0 else (("v2", v) if v < 10 else ("v3", v - 10))
             y = cb(x, residual=res)
             if ref is None:
                 ref = y
             e = float((y - ref).abs().max())
             t = timeit(lambda: cb(x, residual=res), 10, 3)
-            line += "  %s %.0f us (%.0f TF, d=%.1e)" % ("v1" if v < 0 else ("v2/%d" % v if v < 10 else "v3/%d" % (v - 10)), t * 1e3, fl / t, e)
+            line += "  %s %.0f us (%.0f TF, d=%.1e)" % ("v1" if v < 0 else ("v2/%d" % v if v < 10 else ("v3/%d" % (v - 10) if v < 100 else "splitK%d" % (v - 100))), t * 1e3, fl / t, e)
         print(line)
 
 

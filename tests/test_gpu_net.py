@@ -72,6 +72,15 @@ def test_conv_bn_relu_kernel(cfg, dev):
         cb.kernel, cb.variant = kern, v
         alt = cb(xh, residual=res.to(dev).permute(0, 2, 3, 1).contiguous(), relu=True)
         assert maxerr(alt, got) <= 1e-4 * max(1.0, float(want.abs().max())), (kern, v)
+    # split-K (two-pass, deterministic) where the shape allows it
+    if Cin % 32 == 0 and Cout % 128 == 0:
+        chunks = k * k * Cin // 32
+        for ks in (2, 4):
+            if chunks % ks == 0:
+                cb.kernel, cb.variant, cb.ksplit = "v3", 0, ks
+                alt = cb(xh, residual=res.to(dev).permute(0, 2, 3, 1).contiguous(), relu=True)
+                assert maxerr(alt, got) <= 1e-4 * max(1.0, float(want.abs().max())), ("split-K", ks)
+                assert torch.equal(alt, cb(xh, residual=res.to(dev).permute(0, 2, 3, 1).contiguous(), relu=True))
 
 
 def test_pooling_and_layout_kernels(dev):
