@@ -20,7 +20,7 @@ from .label_conversions import make_proxy_representation
 
 @torch.no_grad()
 def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mean_shape=True,
-          sample_on_cpu=False, seed=None, image_offset=0, input_feats=None, _before_meshes=None):
+          sample_on_cpu=False, seed=None, image_offset=0, input_feats=None, _before_meshes=None, _after_smpl=None):
     """predict/predict_poseMF_shapeGaussian_net.py:103-165 for a batch of B proxy representations.
 
     proxy_rep_input: (B,18,256,256) on the device.  Returns a dict of device tensors; every entry equals
@@ -57,6 +57,8 @@ def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mea
                           glob_rotmats[:, None].expand(B, N, 3, 3).reshape(B * N, 3, 3)], dim=0).unsqueeze(1)
     betas_all = torch.cat([loc, loc, betas_s.reshape(B * N, -1)], dim=0)
     out = smpl_model(body_pose=body, global_orient=glob_all, betas=betas_all, pose2rot=False)
+    if _after_smpl is not None:
+        _after_smpl()
     V = out.vertices.shape[1]
     verts_s = out.vertices[2 * B:].view(B, N, V, 3)
     joints_s = out.joints[2 * B:].view(B, N, -1, 3)
@@ -93,21 +95,33 @@ class InferencePipeline:
             t = t_next
         result = pipe.finish(t)
 
-    ``after=`` makes the bandwidth-bound mesh phase (sampling, blend GEMM, LBS, joints, uncertainty) of this batch
-    start only when the next batch's encoder has drained: the two would otherwise time-share CUs and HBM with no
-    gain in throughput (the GPU is busy either way) while every kernel runs slower than its roofline.  Only the
-    host-paced head overlaps the encoder.  Results are identical to ``infer`` (same kernels, same order per batch)."""
+    ``after=`` makes the mesh phase (sampling, blend GEMM, LBS) of this batch start only when the next batch's encoder
+    has drained: the two would otherwise time-share CUs and HBM with little gain in throughput (the GPU is busy either
+    way) while every kernel runs slower than its roofline.  The host-paced head overlaps the encoder, and so does the
+    HBM-bound tail after the SMPL kernels (per-vertex uncertainty, result slicing): the following ``submit`` only waits
+    for the SMPL kernels, so that tail runs beside the MFMA-bound convolutions of the batch after next.
+    Results are identical to ``infer`` (same kernels, same order per batch)."""
 
     def __init__(self, pose_shape_model, smpl_model, num_samples=50, use_mean_shape=True, sample_on_cpu=False):
         self.net, self.smpl = pose_shape_model, smpl_model
         self.num_samples, self.use_mean_shape, self.sample_on_cpu = num_samples, use_mean_shape, sample_on_cpu
         self.enc_stream = torch.cuda.Stream()
+        self._smpl_done = None
 
     @torch.no_grad()
-    def submit(self, proxy_rep_input):
+    def submit(self, proxy_rep_input, input_ready=None):
+        """Enqueue the encoder of one batch on the side stream.  ``input_ready``: optional event after which the input
+        tensor is complete; by default the first submit waits for everything already queued on the caller's stream and
+        later ones for the SMPL kernels of the previously finished batch (inputs produced on the caller's stream after
+        that point need ``input_ready``)."""
         _capi.require_device(proxy_rep_input, "proxy_rep_input")
         main = torch.cuda.current_stream()
-        self.enc_stream.wait_stream(main)            # the input may have been produced on the caller's stream
+        if input_ready is not None:
+            self.enc_stream.wait_event(input_ready)
+        if self._smpl_done is None:
+            self.enc_stream.wait_stream(main)
+        else:
+            self.enc_stream.wait_event(self._smpl_done)
         with torch.cuda.stream(self.enc_stream):
             feats = self.net.image_encoder(proxy_rep_input)
             done = torch.cuda.Event()
@@ -122,9 +136,14 @@ class InferencePipeline:
         main.wait_event(done)
         feats.record_stream(main)
         hook = (lambda: main.wait_event(after[1])) if after is not None else None
+
+        def smpl_done():
+            self._smpl_done = torch.cuda.Event()
+            self._smpl_done.record(main)
+
         return infer(self.net, self.smpl, None, num_samples=self.num_samples, use_mean_shape=self.use_mean_shape,
                      sample_on_cpu=self.sample_on_cpu, seed=seed, image_offset=image_offset, input_feats=feats,
-                     _before_meshes=hook)
+                     _before_meshes=hook, _after_smpl=smpl_done)
 
 
 def predict_poseMF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_model, hrnet_model, hrnet_cfg,

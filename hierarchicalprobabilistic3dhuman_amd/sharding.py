@@ -61,6 +61,11 @@ def batch_metric_sums(result):
     """Accumulator of one ``infer`` result: [image count, sum of per-vertex uncertainty, sum |mode vertices|,
     sum |sample joints|] in float64 -- the checksum-of-checksums the scaling tests compare across world sizes."""
     B = result["unc"].shape[0]
-    vals = [float(B), result["unc"].double().sum(), result["verts_mode"].double().abs().sum(),
-            result["joints_samples"].double().abs().sum()]
-    return torch.stack([torch.as_tensor(v, dtype=torch.float64, device=result["unc"].device) for v in vals])
+    dev = result["unc"].device
+    l1 = lambda t: torch.linalg.vector_norm(t, ord=1, dtype=torch.float64)        # sum |x| accumulated in float64, one kernel
+    out = torch.empty(4, dtype=torch.float64, device=dev)
+    out[0] = float(B)
+    out[1] = result["unc"].sum(dtype=torch.float64)
+    out[2] = l1(result["verts_mode"])
+    out[3] = l1(result["joints_samples"])
+    return out
