@@ -267,6 +267,59 @@ __global__ __launch_bounds__(256) void uncertainty_kernel(const f3* __restrict__
     unc[(size_t)b * V + v] = acc / N;
 }
 
+// Single-pass form: one workgroup = one image x 128 vertices, 1024 lanes = 8 sample groups x 128 vertices.  The
+// image's N x 128 vertex positions are read from HBM once into LDS (N * 1536 bytes: N <= 100 fits the 160 KiB of a
+// CU), the mean and the mean distance are then formed from LDS -- half the HBM traffic of the two-sweep kernel.
+constexpr int UV = 128, UG = 8;
+
+__global__ __launch_bounds__(1024) void uncertainty_lds_kernel(const f3* __restrict__ verts, float* __restrict__ unc,
+                                                               int N, int V) {
+    extern __shared__ __attribute__((aligned(16))) float sU[];   // [N][3][UV] samples, then [UG/2][3][UV] reduction slots
+    float* sRed = sU + (size_t)N * 3 * UV;
+    const int v = threadIdx.x & (UV - 1), g = threadIdx.x >> 7;
+    const int vg = blockIdx.x * UV + v, b = blockIdx.y;
+    const bool live = vg < V;
+    const f3* base = verts + (size_t)b * N * V + (live ? vg : V - 1);
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int s = g; s < N; s += UG) {
+        const f3 p = base[(size_t)s * V];
+        sU[(s * 3 + 0) * UV + v] = p.x; sU[(s * 3 + 1) * UV + v] = p.y; sU[(s * 3 + 2) * UV + v] = p.z;
+        sx += p.x; sy += p.y; sz += p.z;
+    }
+    // two-step reduction over the 8 sample groups through a 4-slot buffer (keeps N = 100 within 160 KiB)
+    constexpr int H = UG / 2;
+    if (g >= H) { sRed[((g - H) * 3 + 0) * UV + v] = sx; sRed[((g - H) * 3 + 1) * UV + v] = sy; sRed[((g - H) * 3 + 2) * UV + v] = sz; }
+    __syncthreads();
+    if (g < H) {
+        sx += sRed[(g * 3 + 0) * UV + v]; sy += sRed[(g * 3 + 1) * UV + v]; sz += sRed[(g * 3 + 2) * UV + v];
+    }
+    __syncthreads();
+    if (g < H) { sRed[(g * 3 + 0) * UV + v] = sx; sRed[(g * 3 + 1) * UV + v] = sy; sRed[(g * 3 + 2) * UV + v] = sz; }
+    __syncthreads();
+    float mx = 0.f, my = 0.f, mz = 0.f;
+#pragma unroll
+    for (int q = 0; q < H; ++q) { mx += sRed[(q * 3 + 0) * UV + v]; my += sRed[(q * 3 + 1) * UV + v]; mz += sRed[(q * 3 + 2) * UV + v]; }
+    mx /= N; my /= N; mz /= N;
+    __syncthreads();                                    // everyone has read the partial sums before they are reused
+    float acc = 0.f;
+    for (int s = g; s < N; s += UG) {
+        const float dx = sU[(s * 3 + 0) * UV + v] - mx, dy = sU[(s * 3 + 1) * UV + v] - my, dz = sU[(s * 3 + 2) * UV + v] - mz;
+        acc += sqrtf(dx * dx + dy * dy + dz * dz);
+    }
+    if (g >= H) sRed[(g - H) * UV + v] = acc;
+    __syncthreads();
+    if (g < H) acc += sRed[g * UV + v];
+    __syncthreads();
+    if (g < H) sRed[g * UV + v] = acc;
+    __syncthreads();
+    if (g == 0 && live) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < UG / 2; ++q) t += sRed[q * UV + v];
+        unc[(size_t)b * V + vg] = t / N;
+    }
+}
+
 }  // namespace hps
 
 using namespace hps;
@@ -362,6 +415,18 @@ extern "C" int hps_smpl_joints(const float* verts, const float* j_posed, const i
 extern "C" int hps_vertex_uncertainty(const float* verts, float* unc, int B, int N, int V, hps_stream_t stream) {
     if (!verts || !unc) return bad_arg("hps_vertex_uncertainty: null pointer");
     if (B <= 0 || N <= 0 || V <= 0) return HPS_OK;
+    const size_t lds = ((size_t)N * 3 * UV + (size_t)(UG / 2) * 3 * UV) * sizeof(float);
+    if (N >= 8 && lds <= 160 * 1024) {       // the image's samples of 128 vertices fit in LDS: read HBM once
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&uncertainty_lds_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(uncertainty_lds_kernel, dim3(ceil_div(V, UV), B), dim3(1024), lds, (hipStream_t)stream,
+                           reinterpret_cast<const f3*>(verts), unc, N, V);
+        return check_launch("hps_vertex_uncertainty");
+    }
     hipLaunchKernelGGL(uncertainty_kernel, dim3(ceil_div(V, 256), B), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const f3*>(verts), unc, N, V);
     return check_launch("hps_vertex_uncertainty");

@@ -145,6 +145,11 @@ def test_vertex_uncertainty_kernel(dev):
     want = torch.stack([O.vertex_uncertainty(v[i]) for i in range(3)])
     assert maxerr(got, want) <= 1e-5
     assert maxerr(su.vertex_uncertainty(v[:, :1].contiguous().to(dev)), torch.zeros(3, 6890)) == 0.0     # N = 1: zero spread
+    # N = 100 takes the single-pass LDS kernel, N = 120 the two-sweep one; both against the oracle
+    for n in (8, 100, 102, 120):
+        vv = torch.randn(2, n, 6890, 3, generator=g)
+        want_n = torch.stack([O.vertex_uncertainty(vv[i]) for i in range(2)])
+        assert maxerr(su.vertex_uncertainty(vv.to(dev)), want_n) <= 1e-5, n
 
 
 def test_c_abi_rejects_unsupported_k(dev, smpl_gpu):
