@@ -368,7 +368,8 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(
     const float* b_src = wn + (size_t)(n0 + drow) * Kp + dquad;
     const int chunks_per_tap = Cin / VBK;
 
-    auto dma_chunk = [&](int c, int buf) {
+    // pieces [p0, p1) of chunk c's A_LD + B_LD one-KiB DMA pieces (A rows first, then filter rows)
+    auto dma_pieces = [&](int c, int buf, int p0, int p1) {
         const int tap = c / chunks_per_tap;                      // wave-uniform
         const int ci0 = (c - tap * chunks_per_tap) * VBK;
         const int kh = tap / KW, kw = tap - kh * KW;
@@ -379,15 +380,24 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(
             (unsigned)(size_t)(lptr_t)(sB + (size_t)buf * BN * VBK + wave * 8 * VBK));
 #pragma unroll
         for (int r = 0; r < A_LD; ++r) {
+            if (r < p0 || r >= p1) continue;
+            if (ABLATE == 4) {   // experiment: no tap decode / bounds test (wrong results, same traffic volume)
+                lds_dma16(x + a_base[r] + (long)(c % 8) * VBK, la + r * 32 * VBK * 4);
+                continue;
+            }
             const int hi = a_hi0[r] + kh, wi = a_wi0[r] + kw;
             const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
             const float* src = ok ? x + a_base[r] + ((long)hi * W + wi) * Cin + ci0 : zeros;
             lds_dma16(src, la + r * 32 * VBK * 4);
         }
 #pragma unroll
-        for (int r = 0; r < B_LD; ++r)
+        for (int r = 0; r < B_LD; ++r) {
+            if (A_LD + r < p0 || A_LD + r >= p1) continue;
             lds_dma16(b_src + (size_t)(32 * r) * Kp + (size_t)c * VBK, lb + r * 32 * VBK * 4);
+        }
     };
+    auto dma_chunk = [&](int c, int buf) { dma_pieces(c, buf, 0, A_LD + B_LD); };
+    constexpr int NPIECE = A_LD + B_LD, PPG = (NPIECE + VBK / 8 - 1) / (VBK / 8);   // pieces per MFMA group when spread
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(
         const int buf = (c - c_begin) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA of chunk c has landed
         __syncthreads();                                     // ... everyone's has, and buf^1 is no longer being read
-        if (c + 1 < c_end && ABLATE != 1) dma_chunk(c + 1, buf ^ 1);
+        if (c + 1 < c_end && ABLATE != 1 && ABLATE != 3) dma_chunk(c + 1, buf ^ 1);
         const float* pa = sA + (size_t)buf * BM * VBK + (wm0 + il) * VBK;
         const float* pb = sB + (size_t)buf * BN * VBK + (wn0 + il) * VBK;
 #pragma unroll
@@ -419,6 +429,8 @@ __global__ __launch_bounds__(256) void conv_igemm_v3_kernel(
             for (int i = 0; i < TM; ++i) a4[i] = *reinterpret_cast<const float4*>(pa + i * 32 * VBK + slot);
 #pragma unroll
             for (int j = 0; j < TN; ++j) b4[j] = *reinterpret_cast<const float4*>(pb + j * 32 * VBK + slot);
+            // ABLATE 3 (experiment): the next chunk's DMA pieces spread over the MFMA groups instead of all up front
+            if (ABLATE == 3 && c + 1 < c_end) dma_pieces(c + 1, buf ^ 1, g * PPG, (g + 1) * PPG < NPIECE ? (g + 1) * PPG : NPIECE);
             if (ABLATE == 2) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(a4[i].x), "v"(a4[i].y), "v"(a4[i].z), "v"(a4[i].w));
@@ -623,6 +635,10 @@ extern "C" int hps_conv2d_bn_act_v3(const float* x, const float* wn, const float
         case 2: return launch_conv_v3<128, 64, 64, 32>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
         case 3: return launch_conv_v3<64, 64, 32, 32>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
         case 4: return launch_conv_v3<256, 64, 64, 64>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
+        case 41: return launch_conv_v3<128, 128, 64, 64, 3>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
+        case 43: return launch_conv_v3<64, 64, 32, 32, 3>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
+        case 44: return launch_conv_v3<256, 64, 64, 64, 3>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
+        case 51: return launch_conv_v3<128, 128, 64, 64, 4>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
         case 21: return launch_conv_v3<128, 128, 64, 64, 1>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
         case 31: return launch_conv_v3<128, 128, 64, 64, 2>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);
         case 23: return launch_conv_v3<64, 64, 32, 32, 1>(x, wn, zeros, scale, shift, residual, y, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, s);

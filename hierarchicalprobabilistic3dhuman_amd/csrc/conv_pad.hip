@@ -1,0 +1,436 @@
+// ResNet-18 encoder, halo-padded NHWC generation (models/resnet.py:202-217).
+//
+// What the PMC counters said about the LDS-DMA kernel in conv.hip (128x128 tile, 128->128 3x3 layer): the MFMA pipe
+// is busy 73 % of the cycles with the fill and 85 % without it, the clock is the same, and the extra time equals the
+// extra *instruction issue* time (SQ_ACTIVE_INST_ANY +750 cycles per K-chunk per wave) -- the two workgroups of a CU
+// run in lock step, so the per-chunk address arithmetic of one (tap decode, bounds tests, zero-source select, 64-bit
+// lane addresses, the branches hipcc makes of them: ~190 instructions) is not hidden behind the MFMAs of the other.
+// This generation removes that arithmetic instead of trying to hide it:
+//   * activations live in HBM with a zero halo, (B, H + 2P, W + 2P, C): every filter tap of every output pixel is
+//     in bounds, so there is no bounds test and no zero source;
+//   * the source address of a DMA piece is  SGPR base (tensor + tap offset, advanced by scalar code per chunk)
+//     + a per-lane 32-bit byte offset that never changes inside the kernel  (global_load_lds_dwordx4 v, s[..]);
+//   * per chunk and wave that leaves the pieces themselves, three scalar adds and the barrier.
+// The stem (7x7 / 2, 18 channels) runs on the same kernel in "row mode": in NHWC one filter row of a window is
+// KW * C = 126 contiguous floats, so it is treated as one tap of 128 "channels" (the two extra floats meet zero
+// filter entries): K = 7 * 128 = 896 instead of 7 * 7 * 20 = 980, no channel padding of the image.
+#include "hps_common.h"
+
+namespace hps {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int PBK = 32;   // K-chunk (floats); one 128-byte LDS row per tile row
+
+// n / d for n < 2^32 with magic = floor(2^32 / d) (0xffffffff for d = 1): the estimate is at most one short
+__device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned d, unsigned magic) {
+    unsigned q = __umulhi(n, magic);
+    if (n - q * d >= d) ++q;
+    return q;
+}
+static unsigned div_magic(unsigned d) { return d <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / d); }
+
+// one 1-KiB LDS-DMA piece: lane l fetches 16 bytes at sbase + voff and they land at lds_addr + 16 l.
+// Issued from inline asm so that hipcc does not drain it in front of the next ds_read (conv.hip lds_dma16).
+__device__ __forceinline__ void lds_dma16_sv(unsigned voff, const float* sbase, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
+
+struct PadGeom {
+    int img_pitch, row_pitch, pix_pitch;   // input strides in floats (padded frame)
+    int cin_k;                             // contiguous floats per tap, multiple of 32
+    int kw;                                // taps per filter row
+    int stride, off;                       // output (0,0) / tap (0,0) reads padded input (off, off)
+    int Ho, Wo, Mtot, Kp, Cout;
+    int opad;                              // halo of the output (and residual) frame
+    int relu, tiles_m, ksplit;
+    unsigned magic_howo, magic_wo;
+};
+
+// offset (floats) of output pixel m, channel 0, in the output frame
+__device__ __forceinline__ unsigned out_pixel_offset(unsigned m, const PadGeom& g) {
+    const unsigned howo = (unsigned)(g.Ho * g.Wo);
+    const unsigned b = fastdiv(m, howo, g.magic_howo), rem = m - b * howo;
+    const unsigned ho = fastdiv(rem, (unsigned)g.Wo, g.magic_wo), wo = rem - ho * g.Wo;
+    return ((b * (g.Ho + 2 * g.opad) + ho + g.opad) * (g.Wo + 2 * g.opad) + wo + g.opad) * (unsigned)g.Cout;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__ x, const float* __restrict__ wn,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ residual, float* __restrict__ y,
+                                                       float* __restrict__ partial, const PadGeom g) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_LD = BM / 32, B_LD = BN / 32;        // DMA pieces per wave per chunk
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                                   // [2][BM][32]
+    float* sB = smem + 2 * BM * PBK;                    // [2][BN][32]
+
+    const int tile_n = blockIdx.x / g.tiles_m, tile_m = blockIdx.x % g.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    const int kl = lane >> 5, il = lane & 31;
+    // DMA role of this lane: tile row (32 r + 8 wave + lane / 8), LDS slot lane % 8 <- source quad slot ^ f(row),
+    // f(row) = (row >> 1) & 7 (conv.hip: conflict-free ds_read_b128)
+    const int drow = wave * 8 + (lane >> 3);
+    const int dquad = ((lane & 7) ^ ((drow >> 1) & 7)) * 4;
+
+    unsigned a_off[A_LD], b_off[B_LD];                  // per-lane byte offsets, constant for the whole kernel
+    {
+        const unsigned howo = (unsigned)(g.Ho * g.Wo);
+#pragma unroll
+        for (int r = 0; r < A_LD; ++r) {
+            const unsigned m = (unsigned)(m0 + drow + 32 * r);
+            unsigned o = 0;                              // tile overhang rows read pixel 0 (results discarded)
+            if (m < (unsigned)g.Mtot) {
+                const unsigned b = fastdiv(m, howo, g.magic_howo), rem = m - b * howo;
+                const unsigned ho = fastdiv(rem, (unsigned)g.Wo, g.magic_wo), wo = rem - ho * g.Wo;
+                o = b * g.img_pitch + (ho * g.stride + g.off) * g.row_pitch + (wo * g.stride + g.off) * g.pix_pitch;
+            }
+            a_off[r] = (o + dquad) * 4u;
+        }
+#pragma unroll
+        for (int r = 0; r < B_LD; ++r) b_off[r] = ((unsigned)(n0 + drow + 32 * r) * g.Kp + dquad) * 4u;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // split-K: blockIdx.y owns the chunk range [c_begin, c_end) and writes raw partial sums (summed in slice order by
+    // splitk_pad_epilogue_kernel: deterministic, no atomics)
+    const int chunks_total = g.Kp / PBK;
+    const int per_split = chunks_total / g.ksplit;
+    const int c_begin = blockIdx.y * per_split, c_end = c_begin + per_split;
+    // scalar walk over (kh, kw, ci0): the A base pointer advances by 32 floats per chunk and jumps at tap / row ends
+    const int cpt = g.cin_k / PBK;
+    int ci = c_begin % cpt, tap = c_begin / cpt;
+    int kw = tap % g.kw, kh = tap / g.kw;
+    const float* a_src = x + (size_t)kh * g.row_pitch + (size_t)kw * g.pix_pitch + (size_t)ci * PBK;
+    const float* b_src = wn + (size_t)c_begin * PBK;
+    const int tap_jump = g.pix_pitch - g.cin_k + PBK;                    // from the last chunk of a tap to the next tap
+    const int row_jump = g.row_pitch - (g.kw - 1) * g.pix_pitch - g.cin_k + PBK;   // ... to the next filter row
+
+    const unsigned lds_a = (unsigned)(size_t)(lptr_t)(sA + wave * 8 * PBK);
+    const unsigned lds_b = (unsigned)(size_t)(lptr_t)(sB + wave * 8 * PBK);
+    auto dma_chunk = [&](int buf) {
+        const unsigned la = __builtin_amdgcn_readfirstlane(lds_a + buf * BM * PBK * 4);
+        const unsigned lb = __builtin_amdgcn_readfirstlane(lds_b + buf * BN * PBK * 4);
+#pragma unroll
+        for (int r = 0; r < A_LD; ++r) lds_dma16_sv(a_off[r], a_src, la + r * 32 * PBK * 4);
+#pragma unroll
+        for (int r = 0; r < B_LD; ++r) lds_dma16_sv(b_off[r], b_src, lb + r * 32 * PBK * 4);
+        // advance to the next chunk
+        b_src += PBK;
+        if (++ci < cpt) a_src += PBK;
+        else {
+            ci = 0;
+            if (++kw < g.kw) a_src += tap_jump;
+            else { kw = 0; a_src += row_jump; }
+        }
+    };
+
+    const int fsw = (il >> 1) & 7;                       // f(row) of the fragment rows this lane reads
+    dma_chunk(0);
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of chunk c have landed
+        __syncthreads();                                     // ... everyone's have, and buf^1 is no longer being read
+        if (c + 1 < c_end) dma_chunk(buf ^ 1);
+        const float* pa = sA + (size_t)buf * BM * PBK + (wm0 + il) * PBK;
+        const float* pb = sB + (size_t)buf * BN * PBK + (wn0 + il) * PBK;
+#pragma unroll
+        for (int gq = 0; gq < PBK / 8; ++gq) {
+            const int slot = ((2 * gq + kl) ^ fsw) * 4;
+            float4 a4[TM], b4[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a4[i] = *reinterpret_cast<const float4*>(pa + i * 32 * PBK + slot);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b4[j] = *reinterpret_cast<const float4*>(pb + j * 32 * PBK + slot);
+            // k order inside the group is x, y, z, w for every accumulator (same summation order as conv.hip)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    // C layout of a 32x32 tile: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    if (g.ksplit > 1) {
+        float* dst = partial + (size_t)blockIdx.y * g.Mtot * g.Cout;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int co = n0 + wn0 + j * 32 + il;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                    if (m < g.Mtot) dst[(size_t)m * g.Cout + co] = acc[i][j][r];
+                }
+        }
+        return;
+    }
+
+    // BatchNorm (scale, shift), residual, ReLU.  Rows are located in the output frame once per group of four
+    // consecutive pixels when Wo % 4 == 0 (they share an image row), otherwise per pixel; all 16 residual loads of a
+    // 32x32 tile are issued before the first use.
+    const bool quad_rows = (g.Wo & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        unsigned po[16];
+        bool live[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int mq = m0 + wm0 + i * 32 + 8 * q + 4 * kl;
+            if (quad_rows) {
+                const bool ok = mq < g.Mtot;
+                const unsigned p = ok ? out_pixel_offset((unsigned)mq, g) : 0u;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { po[4 * q + t] = p + t * g.Cout; live[4 * q + t] = ok; }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    live[4 * q + t] = mq + t < g.Mtot;
+                    po[4 * q + t] = live[4 * q + t] ? out_pixel_offset((unsigned)(mq + t), g) : 0u;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int co = n0 + wn0 + j * 32 + il;
+            const float sc = scale[co], sh = shift[co];
+            float res[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) res[r] = (residual && live[r]) ? residual[(size_t)po[r] + co] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r] * sc + sh + res[r];
+                if (g.relu) v = fmaxf(v, 0.0f);
+                if (live[r]) y[(size_t)po[r] + co] = v;
+            }
+        }
+    }
+}
+
+// second pass of a split-K convolution: y = act(scale * (sum of the slices, in slice order) + shift + residual),
+// y / residual in the padded output frame
+__global__ __launch_bounds__(256) void splitk_pad_epilogue_kernel(const float* __restrict__ partial,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift,
+                                                                  const float* __restrict__ residual,
+                                                                  float* __restrict__ y, long total4, const PadGeom g) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    float4 acc = reinterpret_cast<const float4*>(partial)[i];
+    for (int k = 1; k < g.ksplit; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(partial)[(size_t)k * total4 + i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const unsigned e = (unsigned)(i * 4);
+    const unsigned m = e / (unsigned)g.Cout, co = e - m * g.Cout;
+    const size_t o = (size_t)out_pixel_offset(m, g) + co;
+    const float4 sc = *reinterpret_cast<const float4*>(scale + co), sh = *reinterpret_cast<const float4*>(shift + co);
+    float4 v = make_float4(acc.x * sc.x + sh.x, acc.y * sc.y + sh.y, acc.z * sc.z + sh.z, acc.w * sc.w + sh.w);
+    if (residual) {
+        const float4 r = *reinterpret_cast<const float4*>(residual + o);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4*>(y + o) = v;
+}
+
+// (B,C,H,W) -> (B, H + 2P, W + 2P, C) interior (the halo is zeroed once by the owner of the buffer): lanes along w
+// read each channel plane coalesced, every lane assembles its pixel's C channels and stores them as float2s
+template <int C>
+__global__ __launch_bounds__(256) void nchw_to_padded_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  int H, int W, int P, long total) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;   // pixel index over B*H*W
+    if (p >= total) return;
+    const long hw = (long)H * W;
+    const long b = p / hw, r = p - b * hw;
+    const int h = (int)(r / W), w = (int)(r - (long)h * W);
+    float v[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = x[(b * C + c) * hw + r];
+    float2* d = reinterpret_cast<float2*>(y + ((b * (H + 2 * P) + h + P) * (long)(W + 2 * P) + w + P) * C);
+#pragma unroll
+    for (int q = 0; q < C / 2; ++q) d[q] = make_float2(v[2 * q], v[2 * q + 1]);
+}
+
+// MaxPool2d(3, 2, 1) on NHWC, thread per (output pixel, 4 channels); output written into a frame with halo opad
+__global__ __launch_bounds__(256) void maxpool_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
+                                                          int C, int Ho, int Wo, int opad, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = C / 4;
+    const int cq = (int)(i % c4);
+    long p = i / c4;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho);
+    const long b = p / Ho;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hi = ho * 2 - 1 + kh;
+        if (hi < 0 || hi >= H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int wi = wo * 2 - 1 + kw;
+            if (wi < 0 || wi >= W) continue;
+            const float4 v = *reinterpret_cast<const float4*>(x + ((b * H + hi) * W + wi) * C + cq * 4);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    *reinterpret_cast<float4*>(y + ((b * (Ho + 2 * opad) + ho + opad) * (long)(Wo + 2 * opad) + wo + opad) * C + cq * 4) = m;
+}
+
+// global average pool over the interior of a padded frame: thread per (b, c), coalesced over c, pixels in row-major order
+__global__ __launch_bounds__(256) void avgpool_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
+                                                          int C, int P, int total) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int b = i / C, c = i % C;
+    const int Wp = W + 2 * P;
+    const float* s = x + ((size_t)b * (H + 2 * P) + P) * Wp * C + (size_t)P * C + c;
+    float acc = 0.0f;
+    for (int h = 0; h < H; ++h)
+        for (int w = 0; w < W; ++w) acc += s[((size_t)h * Wp + w) * C];
+    y[i] = acc / (float)(H * W);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_conv_pad(const float* x, const float* wn, const float* scale, const float* shift, const float* residual,
+                           float* y, float* partial, PadGeom g, hipStream_t s) {
+    g.tiles_m = ceil_div(g.Mtot, BM);
+    const int tiles_n = g.Cout / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * PBK * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pad_kernel<BM, BN, WM, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_pad_kernel<BM, BN, WM, WN>), dim3(g.tiles_m * tiles_n, g.ksplit), dim3(256), lds, s, x, wn, scale,
+                       shift, residual, y, partial, g);
+    if (g.ksplit > 1) {
+        const long total4 = (long)g.Mtot * g.Cout / 4;
+        hipLaunchKernelGGL(splitk_pad_epilogue_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, partial, scale,
+                           shift, residual, y, total4, g);
+    }
+    return check_launch("hps_conv2d_bn_act_pad");
+}
+
+}  // namespace hps
+
+using namespace hps;
+
+extern "C" int hps_conv2d_bn_act_pad(const float* x, const float* wn, const float* scale, const float* shift,
+                                     const float* residual, float* y, int B, int H, int W, int ipad, int Cin, int Cout,
+                                     int KH, int KW, int stride, int pad, int opad, int relu, int row_mode, int variant,
+                                     int ksplit, float* splitk_ws, hps_stream_t stream) {
+    if (!x || !wn || !scale || !shift || !y) return bad_arg("hps_conv2d_bn_act_pad: null pointer");
+    if (ipad < pad || opad < 0) return bad_arg("hps_conv2d_bn_act_pad: the input halo must cover the convolution padding");
+    if (Cout % 64 != 0) return bad_arg("hps_conv2d_bn_act_pad: Cout % 64 == 0 required");
+    if (B <= 0) return HPS_OK;
+    PadGeom g;
+    const int Hp = H + 2 * ipad, Wp = W + 2 * ipad;
+    g.pix_pitch = Cin;
+    g.row_pitch = Wp * Cin;
+    g.img_pitch = Hp * g.row_pitch;
+    g.stride = stride;
+    g.off = ipad - pad;
+    g.Ho = (H + 2 * pad - KH) / stride + 1;
+    g.Wo = (W + 2 * pad - KW) / stride + 1;
+    g.Mtot = B * g.Ho * g.Wo;
+    g.Cout = Cout;
+    g.opad = opad;
+    g.relu = relu;
+    g.ksplit = ksplit < 1 ? 1 : ksplit;
+    if (row_mode) {
+        // a filter row = KW * Cin contiguous floats, rounded up to the chunk; the DMA needs 16-byte aligned windows
+        g.cin_k = ceil_div(KW * Cin, PBK) * PBK;
+        g.kw = 1;
+        if ((stride * Cin) % 4 != 0 || g.row_pitch % 4 != 0 || (g.off * Cin) % 4 != 0)
+            return bad_arg("hps_conv2d_bn_act_pad: row mode needs 16-byte aligned window starts");
+        if (((g.Wo - 1) * stride + g.off) * Cin + g.cin_k > g.row_pitch)
+            return bad_arg("hps_conv2d_bn_act_pad: row mode window overruns the padded row");
+    } else {
+        if (Cin % PBK != 0) return bad_arg("hps_conv2d_bn_act_pad: Cin % 32 == 0 required (or row mode)");
+        g.cin_k = Cin;
+        g.kw = KW;
+    }
+    g.Kp = KH * g.kw * g.cin_k;
+    if ((size_t)B * g.img_pitch * 4 >= 0xffffffffull || (size_t)Cout * g.Kp * 4 >= 0xffffffffull)
+        return bad_arg("hps_conv2d_bn_act_pad: tensor exceeds the 32-bit lane offsets");
+    if ((g.Kp / PBK) % g.ksplit != 0 || (g.ksplit > 1 && !splitk_ws)) return bad_arg("hps_conv2d_bn_act_pad: ksplit");
+    g.magic_howo = div_magic((unsigned)(g.Ho * g.Wo));
+    g.magic_wo = div_magic((unsigned)g.Wo);
+    hipStream_t s = (hipStream_t)stream;
+    if (g.ksplit > 1) variant = Cout % 128 == 0 ? 1 : 2;     // split-K runs on the 128-row tiles
+    if (variant == 0) {
+        // same rule as hps_conv2d_bn_act_v3 (measured per layer): largest tile that still gives every CU a workgroup
+        if (Cout % 128 == 0 && ((long)g.Mtot / 128) * (Cout / 128) >= 256) variant = 1;
+        else if (Cout == 64 && g.Mtot / 256 >= 512) variant = 4;
+        else variant = 3;
+    }
+    if (variant == 1 && Cout % 128 != 0) variant = 2;
+    switch (variant) {
+        case 1: return launch_conv_pad<128, 128, 64, 64>(x, wn, scale, shift, residual, y, splitk_ws, g, s);
+        case 2: return launch_conv_pad<128, 64, 64, 32>(x, wn, scale, shift, residual, y, splitk_ws, g, s);
+        case 3: return launch_conv_pad<64, 64, 32, 32>(x, wn, scale, shift, residual, y, splitk_ws, g, s);
+        case 4: return launch_conv_pad<256, 64, 64, 64>(x, wn, scale, shift, residual, y, splitk_ws, g, s);
+        default: return bad_arg("hps_conv2d_bn_act_pad: variant");
+    }
+}
+
+extern "C" int hps_nchw_to_padded_nhwc(const float* x, float* y, int B, int C, int H, int W, int P, hps_stream_t stream) {
+    if (!x || !y) return bad_arg("hps_nchw_to_padded_nhwc: null pointer");
+    const long total = (long)B * H * W;
+    if (total <= 0) return HPS_OK;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 18) hipLaunchKernelGGL(nchw_to_padded_nhwc_kernel<18>, dim3(blocks), dim3(256), 0, s, x, y, H, W, P, total);
+    else if (C == 4) hipLaunchKernelGGL(nchw_to_padded_nhwc_kernel<4>, dim3(blocks), dim3(256), 0, s, x, y, H, W, P, total);
+    else if (C == 64) hipLaunchKernelGGL(nchw_to_padded_nhwc_kernel<64>, dim3(blocks), dim3(256), 0, s, x, y, H, W, P, total);
+    else return bad_arg("hps_nchw_to_padded_nhwc: C must be 4, 18 or 64");
+    return check_launch("hps_nchw_to_padded_nhwc");
+}
+
+extern "C" int hps_maxpool3x3s2_pad(const float* x, float* y, int B, int H, int W, int C, int opad, hps_stream_t stream) {
+    if (!x || !y) return bad_arg("hps_maxpool3x3s2_pad: null pointer");
+    if (C % 4 != 0) return bad_arg("hps_maxpool3x3s2_pad: C % 4 == 0 required");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long total = (long)B * Ho * Wo * (C / 4);
+    if (total <= 0) return HPS_OK;
+    hipLaunchKernelGGL(maxpool_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, H, W,
+                       C, Ho, Wo, opad, total);
+    return check_launch("hps_maxpool3x3s2_pad");
+}
+
+extern "C" int hps_global_avgpool_pad(const float* x, float* y, int B, int H, int W, int C, int P, hps_stream_t stream) {
+    if (!x || !y) return bad_arg("hps_global_avgpool_pad: null pointer");
+    const int total = B * C;
+    if (total <= 0) return HPS_OK;
+    hipLaunchKernelGGL(avgpool_pad_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, P,
+                       total);
+    return check_launch("hps_global_avgpool_pad");
+}

@@ -35,6 +35,15 @@ class _ConvBN:
         self.stride, self.pad = conv.stride[0], conv.padding[0]
         # n-major filter (Cout, KH*KW*Cin) for the v2 kernel (Cin % 32 == 0: every conv after the stem)
         self.wn = wk.reshape(k_real, cout).t().contiguous() if cin_p % 32 == 0 else None
+        # row-mode filter (Cout, KH * ceil32(KW*Cin)) for the halo-padded kernel when Cin % 32 != 0 (the stem): one
+        # filter row of a window is KW*Cin contiguous NHWC floats, treated as one tap; the tail of each row is zero
+        self.cin = cin
+        self.wrow = None
+        if cin % 32 != 0:
+            ck = (kw * cin + 31) // 32 * 32
+            wr = torch.zeros(cout, kh, ck, device=w.device, dtype=torch.float32)
+            wr[:, :, :kw * cin] = w.permute(0, 2, 3, 1).reshape(cout, kh, kw * cin)
+            self.wrow = wr.reshape(cout, kh * ck).contiguous()
         self.kernel = "v3"        # "v3" direct global->LDS (default), "v2" register-staged, "v1" generic (any Cin % 4 == 0)
         self.variant = 0          # tile choice of the v2 / v3 kernels (0 = automatic)
         self.ksplit = 0           # split-K slices of the v3 kernel (0 = automatic, 1 = off)
@@ -50,6 +59,29 @@ class _ConvBN:
                 and chunks % 4 == 0 and chunks // 4 >= 18:
             return 4
         return 1
+
+    def padded(self, xp, ipad, out, opad, residual=None, relu=True, ws=None):
+        """Halo-padded generation (csrc/conv_pad.hip): xp (B, H+2*ipad, W+2*ipad, Cin) with a zero halo; writes the interior
+        of ``out`` (B, Ho+2*opad, Wo+2*opad, Cout) -- the caller owns the halo (zeroed once); ``residual`` has out's frame."""
+        B, Hp, Wp, C = xp.shape
+        H, W = Hp - 2 * ipad, Wp - 2 * ipad
+        row_mode = self.wn is None
+        assert C == (self.cin if row_mode else self.cin_p)
+        Ho = (H + 2 * self.pad - self.kh) // self.stride + 1
+        Wo = (W + 2 * self.pad - self.kw) // self.stride + 1
+        assert tuple(out.shape) == (B, Ho + 2 * opad, Wo + 2 * opad, self.cout)
+        ksplit = 1 if row_mode else (self.ksplit if self.ksplit > 0 else self._auto_ksplit(Ho * Wo))
+        if ksplit > 1 and ws is None:
+            ws = torch.empty(ksplit, B * Ho * Wo, self.cout, device=xp.device, dtype=torch.float32)
+        P = _capi.ptr
+        _capi.call("hps_conv2d_bn_act_pad", P(xp), P(self.wrow if row_mode else self.wn), P(self.scale), P(self.shift),
+                   P(residual) if residual is not None else None, P(out), B, H, W, ipad, C, self.cout, self.kh, self.kw,
+                   self.stride, self.pad, opad, 1 if relu else 0, 1 if row_mode else 0, self.variant if ksplit <= 1 else 0,
+                   ksplit, P(ws) if ksplit > 1 else None, _capi.stream())
+        return out
+
+    def out_hw(self, H, W):
+        return (H + 2 * self.pad - self.kh) // self.stride + 1, (W + 2 * self.pad - self.kw) // self.stride + 1
 
     def __call__(self, x, residual=None, relu=True):
         B, H, W, C = x.shape
@@ -115,6 +147,8 @@ class ResNet(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
         self._prepared = None
+        self.layout = "padded"    # "padded": halo-padded NHWC + scalar-base LDS-DMA kernel; "plain": the conv.hip kernels
+        self._frames = {}
 
     def _make_layer(self, planes, blocks, stride=1):
         downsample = None
@@ -130,6 +164,7 @@ class ResNet(nn.Module):
     # ---- weight preparation (BN folding, k-major filters); redone after .to() / load_state_dict ----
     def _apply(self, fn, *args, **kwargs):
         self._prepared = None
+        self._frames = {}
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
@@ -147,6 +182,56 @@ class ResNet(nn.Module):
         self._prepared = prep
         return prep
 
+    # ---- halo-padded activation frames: owned by the module, zeroed once, only interiors are ever written ----
+    def _frame_set(self, prep, B, C, H, W, device):
+        key = (B, C, H, W, str(device), _capi.stream().value)
+        fs = self._frames.get(key)
+        if fs is not None:
+            return fs
+        if len(self._frames) >= 6:                       # a handful of batch shapes / streams at most
+            self._frames.pop(next(iter(self._frames)))
+        z = lambda *shape: torch.zeros(*shape, device=device, dtype=torch.float32)
+        stem = prep["stem"]
+        fs = {"in": z(B, H + 6, W + 6, C)}
+        h, w = stem.out_hw(H, W)
+        fs["stem"] = torch.empty(B, h, w, stem.cout, device=device, dtype=torch.float32)
+        h, w = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        fs["pool"] = z(B, h + 2, w + 2, stem.cout)
+        fs["blocks"] = []
+        for c1, c2, down in prep["blocks"]:
+            h, w = c1.out_hw(h, w)
+            ent = {"c1": z(B, h + 2, w + 2, c1.cout), "c2": z(B, h + 2, w + 2, c2.cout),
+                   "down": z(B, h + 2, w + 2, down.cout) if down is not None else None}
+            ks = max(c._auto_ksplit(h * w) if c.ksplit == 0 else c.ksplit for c in (c1, c2))
+            ent["ws"] = torch.empty(ks, B * h * w, c1.cout, device=device, dtype=torch.float32) if ks > 1 else None
+            fs["blocks"].append(ent)
+        fs["hw"] = (h, w)
+        self._frames[key] = fs
+        return fs
+
+    def _padded_ok(self, C, H, W):
+        # row-mode stem (csrc/conv_pad.hip): 16-byte aligned window starts and rows
+        return self.layout == "padded" and (2 * C) % 4 == 0 and ((W + 6) * C) % 4 == 0 and C in (4, 18, 64)
+
+    def _forward_padded(self, prep, x):
+        B, C, H, W = x.shape
+        s = _capi.stream()
+        P = _capi.ptr
+        fs = self._frame_set(prep, B, C, H, W, x.device)
+        _capi.call("hps_nchw_to_padded_nhwc", P(x), P(fs["in"]), B, C, H, W, 3, s)
+        stem = prep["stem"]
+        y = stem.padded(fs["in"], 3, fs["stem"], 0, relu=True)             # conv1 + bn1 + relu
+        _capi.call("hps_maxpool3x3s2_pad", P(y), P(fs["pool"]), B, y.shape[1], y.shape[2], y.shape[3], 1, s)
+        y = fs["pool"]
+        for (c1, c2, down), ent in zip(prep["blocks"], fs["blocks"]):      # BasicBlock.forward :62-78
+            identity = down.padded(y, 1, ent["down"], 1, relu=False) if down is not None else y
+            out = c1.padded(y, 1, ent["c1"], 1, relu=True, ws=ent["ws"])
+            y = c2.padded(out, 1, ent["c2"], 1, residual=identity, relu=True, ws=ent["ws"])
+        h, w = fs["hw"]
+        feats = torch.empty(B, y.shape[3], device=x.device, dtype=torch.float32)
+        _capi.call("hps_global_avgpool_pad", P(y), P(feats), B, h, w, y.shape[3], 1, s)
+        return feats
+
     def forward(self, x):
         """models/resnet.py:202-217: (B,C,H,W) NCHW fp32 -> (B,512)."""
         _capi.require_device(x, "encoder input")
@@ -155,6 +240,8 @@ class ResNet(nn.Module):
         prep = self._prepared or self.prepare()
         x = _capi.f32c(x)
         B, C, H, W = x.shape
+        if self._padded_ok(C, H, W):
+            return self._forward_padded(prep, x)
         s = _capi.stream()
         P = _capi.ptr
         cp = self._cin_pad

@@ -214,6 +214,29 @@ int hps_conv2d_bn_act_v3(const float* x, const float* wn, const float* zeros, co
                          int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, int variant,
                          int ksplit, float* splitk_ws, hps_stream_t stream);
 
+/* Halo-padded generation of the convolution (csrc/conv_pad.hip), same arithmetic and summation order as
+ * hps_conv2d_bn_act_v3.  x is (B, H + 2 ipad, W + 2 ipad, Cin) NHWC with a ZERO halo of ipad >= pad pixels, so every
+ * filter tap is in bounds; y (and residual) are frames (B, Ho + 2 opad, Wo + 2 opad, Cout) of which only the interior
+ * is written (the owner zeroes the halo once).  wn: n-major filter (Cout, KH*KW*Cin), Cin % 32 == 0; or, row_mode != 0
+ * (the 18-channel 7x7 stem, models/resnet.py:150, :203): (Cout, KH * ceil32(KW*Cin)), one filter row = KW*Cin contiguous
+ * NHWC floats taken as a single tap, zero filled tail.  variant / ksplit / splitk_ws as for _v3
+ * (splitk_ws (ksplit, B*Ho*Wo, Cout)).  Lane offsets are 32-bit: tensors < 4 GiB. */
+int hps_conv2d_bn_act_pad(const float* x, const float* wn, const float* scale, const float* shift,
+                          const float* residual, float* y, int B, int H, int W, int ipad, int Cin, int Cout,
+                          int KH, int KW, int stride, int pad, int opad, int relu, int row_mode, int variant,
+                          int ksplit, float* splitk_ws, hps_stream_t stream);
+
+/* (B,C,H,W) -> interior of the (B, H + 2P, W + 2P, C) NHWC frame; C in {4, 18, 64}
+ * (predict/predict_poseMF_shapeGaussian_net.py:103 hands the net an NCHW proxy representation). */
+int hps_nchw_to_padded_nhwc(const float* x, float* y, int B, int C, int H, int W, int P, hps_stream_t stream);
+
+/* nn.MaxPool2d(3, 2, 1) (models/resnet.py:152, :207): x (B,H,W,C) plain NHWC -> interior of the
+ * (B, Ho + 2 opad, Wo + 2 opad, C) frame. */
+int hps_maxpool3x3s2_pad(const float* x, float* y, int B, int H, int W, int C, int opad, hps_stream_t stream);
+
+/* AdaptiveAvgPool2d((1,1)) + flatten (models/resnet.py:214-215) over the interior of a (B, H + 2P, W + 2P, C) frame. */
+int hps_global_avgpool_pad(const float* x, float* y, int B, int H, int W, int C, int P, hps_stream_t stream);
+
 /* nn.MaxPool2d(3, stride 2, pad 1) on NHWC (models/resnet.py:152, :207). */
 int hps_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, hps_stream_t stream);
 

@@ -289,6 +289,46 @@ def sec_encoder_perf():
         cur = o2
 
 
+def sec_encoder_pad():
+    """Halo-padded generation (csrc/conv_pad.hip): whole encoder against the plain layout, then per layer."""
+    net, sd = make_net()
+    enc = net.image_encoder
+    x = torch.rand(64, 18, 256, 256, device=dev)
+    enc.layout = "plain"
+    f0 = enc(x)
+    t0 = timeit(lambda: enc(x), 5, 2)
+    enc.layout = "padded"
+    f1 = enc(x)
+    t1 = timeit(lambda: enc(x), 5, 2)
+    print("encoder B=64: plain %.3f ms, padded %.3f ms (%.1f TFLOP/s on 6.279 GFLOP/img); feats diff %.2e (max |f| %.2e)" % (
+        t0, t1, 64 * 6.279 / t1, err(f0, f1), float(f0.abs().max())))
+    prep = enc._prepared
+    fs = enc._frame_set(prep, 64, 18, 256, 256, x.device)
+    from hierarchicalprobabilistic3dhuman_amd import _capi
+    P = _capi.ptr
+    t = timeit(lambda: _capi.call("hps_nchw_to_padded_nhwc", P(x), P(fs["in"]), 64, 18, 256, 256, 3, _capi.stream()))
+    print("  nchw->padded nhwc %.3f ms" % t)
+    stem = prep["stem"]
+    for v in (0, 1, 2, 3, 4):
+        stem.variant = v
+        t = timeit(lambda: stem.padded(fs["in"], 3, fs["stem"], 0), 5, 2)
+        print("  stem row-mode variant %d: %.3f ms (%.1f TF real, %.1f TF issued)" % (v, t, 64 * 2 * 0.925 / t, 64 * 2 * 0.925 * 896 / 882 / t))
+    stem.variant = 0
+    t = timeit(lambda: _capi.call("hps_maxpool3x3s2_pad", P(fs["stem"]), P(fs["pool"]), 64, 128, 128, 64, 1, _capi.stream()))
+    print("  maxpool %.3f ms" % t)
+    cur = fs["pool"]
+    for bi, ((c1, c2, down), ent) in enumerate(zip(prep["blocks"], fs["blocks"])):
+        t1 = timeit(lambda: c1.padded(cur, 1, ent["c1"], 1, ws=ent["ws"]), 5, 2)
+        idn = down.padded(cur, 1, ent["down"], 1, relu=False) if down is not None else cur
+        td = timeit(lambda: down.padded(cur, 1, ent["down"], 1, relu=False), 5, 2) if down is not None else 0.0
+        t2 = timeit(lambda: c2.padded(ent["c1"], 1, ent["c2"], 1, residual=idn, ws=ent["ws"]), 5, 2)
+        Ho = ent["c1"].shape[1] - 2
+        fl1 = 2.0 * 64 * Ho * Ho * c1.cout * c1.kh * c1.kw * c1.cin_p / 1e9
+        fl2 = 2.0 * 64 * Ho * Ho * c2.cout * c2.kh * c2.kw * c2.cin_p / 1e9
+        print("  block %d: conv1 %.3f ms (%.1f TF) conv2 %.3f ms (%.1f TF) down %.3f ms" % (bi, t1, fl1 / t1, t2, fl2 / t2, td))
+        cur = ent["c2"]
+
+
 def sec_conv_tune():
     """Every distinct convolution of ResNet-18 at B=64 under the v1 kernel and the three v2 tile shapes."""
     from hierarchicalprobabilistic3dhuman_amd.resnet import _ConvBN
@@ -340,12 +380,17 @@ def sec_conv_ablate():
         Ho = (H + 2 * pd - k) // st + 1
         fl = 2.0 * B * Ho * Ho * Cout * k * k * Cin / 1e9
         line = "ablate H%d %d->%d:" % (H, Cin, Cout)
-        for v in (1, 21, 31, 3, 23, 33):
+        cb.kernel, cb.variant = "v3", 3
+        ref = cb(x)
+        for v in (1, 21, 31, 41, 51, 3, 23, 33, 43, 4, 44):
             if v % 10 == 1 and Cout % 128:
                 continue
+            if v % 10 == 4 and Cout != 64:
+                continue
             cb.kernel, cb.variant = "v3", v
+            d = float((cb(x) - ref).abs().max()) if v in (1, 3, 4, 41, 43, 44) else -1.0
             t = timeit(lambda: cb(x), 10, 3)
-            line += "  v3/%d %.0f us (%.0f TF-equiv)" % (v, t * 1e3, fl / t)
+            line += "  v3/%d %.0f us (%.0f TF-equiv, d=%.0e)" % (v, t * 1e3, fl / t, d)
         print(line)
 
 

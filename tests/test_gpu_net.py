@@ -83,6 +83,106 @@ def test_conv_bn_relu_kernel(cfg, dev):
                 assert torch.equal(alt, cb(xh, residual=res.to(dev).permute(0, 2, 3, 1).contiguous(), relu=True))
 
 
+def _frame(t_nhwc, pad):
+    """(B,H,W,C) -> zero-haloed (B,H+2p,W+2p,C) frame."""
+    return F.pad(t_nhwc, (0, 0, pad, pad, pad, pad)).contiguous()
+
+
+@pytest.mark.parametrize("cfg", [
+    # B, H, Cin, Cout, k, stride, pad, ipad -- every layer type of ResNet-18, ragged tiles, Wo % 4 != 0, split-K, the row-mode stem
+    (2, 64, 64, 64, 3, 1, 1, 1), (2, 64, 64, 128, 3, 2, 1, 1), (2, 64, 64, 128, 1, 2, 0, 1), (64, 8, 512, 512, 3, 1, 1, 1),
+    (3, 16, 256, 256, 3, 1, 1, 1), (1, 8, 512, 512, 3, 1, 1, 1), (2, 9, 128, 256, 3, 2, 1, 1), (3, 14, 64, 64, 3, 1, 1, 2),
+    (2, 30, 18, 64, 7, 2, 3, 3), (1, 256, 18, 64, 7, 2, 3, 3), (2, 12, 4, 64, 7, 2, 3, 3)])
+def test_padded_conv_kernel(cfg, dev):
+    """csrc/conv_pad.hip against torch's convolution and, bit for bit, against the conv.hip kernel it replaces
+    (same K order and summation order; the row-mode stem has its own K order and is held to the tolerance only)."""
+    B, H, Cin, Cout, k, s, p, ipad = cfg
+    torch.manual_seed(sum(cfg))
+    conv = torch.nn.Conv2d(Cin, Cout, k, s, p, bias=False)
+    bn = torch.nn.BatchNorm2d(Cout).eval()
+    bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_()
+    x = torch.randn(B, Cin, H, H)
+    Ho = (H + 2 * p - k) // s + 1
+    res = torch.randn(B, Cout, Ho, Ho)
+    with torch.no_grad():
+        want = F.relu(bn(conv(x)) + res)
+        want_nores = bn(conv(x))
+    tol = 1e-4 * max(1.0, float(want.abs().max()))
+    cb = _ConvBN(conv.to(dev), bn.to(dev))
+    xh = x.to(dev).permute(0, 2, 3, 1).contiguous()
+    resh = res.to(dev).permute(0, 2, 3, 1).contiguous()
+    xp = _frame(xh, ipad)
+    for opad in (0, 1):
+        out = torch.full((B, Ho + 2 * opad, Ho + 2 * opad, Cout), 7.0, device=dev)
+        cb.padded(xp, ipad, out, opad, residual=_frame(resh, opad), relu=True)
+        inner = out[:, opad:opad + Ho, opad:opad + Ho]
+        assert maxerr(inner.permute(0, 3, 1, 2), want) <= tol
+        if opad:        # the halo is never written
+            assert float((out[:, 0] - 7).abs().max()) == 0 and float((out[:, :, -1] - 7).abs().max()) == 0
+        out2 = torch.zeros_like(out)
+        cb.padded(xp, ipad, out2, opad, relu=False)
+        assert maxerr(out2[:, opad:opad + Ho, opad:opad + Ho].permute(0, 3, 1, 2), want_nores) <= tol
+    if Cin % 32 == 0:
+        for v in (0, 1, 2, 3, 4):
+            if v == 4 and Cout != 64:
+                continue
+            cb.variant = v
+            plain = cb(xh, residual=resh, relu=True)        # same tile / split-K rule on both sides
+            out = torch.zeros(B, Ho + 2, Ho + 2, Cout, device=dev)
+            cb.padded(xp, ipad, out, 1, residual=_frame(resh, 1), relu=True)
+            assert torch.equal(out[:, 1:-1, 1:-1], plain), v
+        cb.variant = 0
+        if Cout % 128 == 0:
+            chunks = k * k * Cin // 32
+            for ks in (2, 4):
+                if chunks % ks == 0:
+                    cb.ksplit = ks
+                    plain_k = cb(xh, residual=resh, relu=True)
+                    out = torch.zeros(B, Ho + 2, Ho + 2, Cout, device=dev)
+                    cb.padded(xp, ipad, out, 1, residual=_frame(resh, 1), relu=True)
+                    assert torch.equal(out[:, 1:-1, 1:-1], plain_k), ("split-K", ks)
+
+
+def test_padded_and_plain_encoders_agree(dev, net_gpu, golden, golden_input):
+    enc = net_gpu.image_encoder
+    x = golden_input.to(dev)
+    try:
+        enc.layout = "plain"
+        plain = enc(x)
+    finally:
+        enc.layout = "padded"
+    padded = enc(x)
+    again = enc(x)
+    assert torch.equal(padded, again)                       # frames are reused: nothing stale leaks between calls
+    ref = golden["net_feats"]
+    assert maxerr(plain, ref) <= 1e-4 * float(ref.abs().max()) and maxerr(padded, ref) <= 1e-4 * float(ref.abs().max())
+    assert maxerr(padded, plain) <= 2e-5 * float(ref.abs().max())
+    # a different batch in between does not disturb the cached frames
+    other = enc(torch.rand(3, 18, 256, 256, device=dev))
+    assert torch.isfinite(other).all() and torch.equal(enc(x), padded)
+
+
+def test_padded_pooling_and_layout_kernels(dev):
+    P = _capi.ptr
+    x = torch.randn(2, 18, 12, 10, generator=torch.Generator().manual_seed(0))
+    xp = torch.zeros(2, 18, 16, 18, device=dev)
+    _capi.call("hps_nchw_to_padded_nhwc", P(x.to(dev)), P(xp), 2, 18, 12, 10, 3, _capi.stream())
+    assert maxerr(xp[:, 3:-3, 3:-3].permute(0, 3, 1, 2), x) == 0.0
+    xp[:, 3:-3, 3:-3] = 0
+    assert float(xp.abs().max()) == 0.0
+    y = torch.randn(2, 64, 13, 11)
+    yh = y.to(dev).permute(0, 2, 3, 1).contiguous()
+    out = torch.zeros(2, 9, 8, 64, device=dev)
+    _capi.call("hps_maxpool3x3s2_pad", P(yh), P(out), 2, 13, 11, 64, 1, _capi.stream())
+    assert maxerr(out[:, 1:-1, 1:-1].permute(0, 3, 1, 2), F.max_pool2d(y, 3, 2, 1)) == 0.0
+    assert float(out[:, 0].abs().max()) == 0.0 and float(out[:, :, 0].abs().max()) == 0.0
+    avg = torch.empty(2, 64, device=dev)
+    _capi.call("hps_global_avgpool_pad", P(_frame(yh, 1)), P(avg), 2, 13, 11, 64, 1, _capi.stream())
+    plain = torch.empty(2, 64, device=dev)
+    _capi.call("hps_global_avgpool", P(yh), P(plain), 2, 13 * 11, 64, _capi.stream())
+    assert torch.equal(avg, plain) and maxerr(avg, y.mean(dim=(2, 3))) <= 1e-6
+
+
 def test_pooling_and_layout_kernels(dev):
     P = _capi.ptr
     x = torch.randn(2, 18, 12, 10, generator=torch.Generator().manual_seed(0))
