@@ -49,7 +49,9 @@ struct PadGeom {
     int opad;                              // halo of the output (and residual) frame
     int relu, tiles_m, ksplit;
     unsigned magic_howo, magic_wo;
+    int ablate;                            // tuning only (hps_dev_conv_pad_ablate): 1 = no epilogue
 };
+static int g_pad_ablate = 0;
 
 // offset (floats) of output pixel m, channel 0, in the output frame
 __device__ __forceinline__ unsigned out_pixel_offset(unsigned m, const PadGeom& g) {
@@ -165,68 +167,84 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[j].x, a4[i].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[j].y, a4[i].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[j].z, a4[i].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[j].w, a4[i].w, acc[i][j], 0, 0, 0);
                 }
         }
     }
 
-    // C layout of a 32x32 tile: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    // The filter fragment is the MFMA's row operand and the pixel fragment its column operand (products commute, the
+    // k order is unchanged), so a lane ends up with ONE pixel (column = lane & 31) and, per register quad q, four
+    // consecutive output channels: row = (r & 3) + 8 q + 4 (lane >> 5)  ->  128-bit accesses along Cout.
     if (g.ksplit > 1) {
         float* dst = partial + (size_t)blockIdx.y * g.Mtot * g.Cout;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int co = n0 + wn0 + j * 32 + il;
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm0 + i * 32 + il;
+            if (m >= g.Mtot) continue;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
-                    if (m < g.Mtot) dst[(size_t)m * g.Cout + co] = acc[i][j][r];
-                }
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(dst + (size_t)m * g.Cout + n0 + wn0 + j * 32 + 8 * q + 4 * kl) =
+                        make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
         }
         return;
     }
 
-    // BatchNorm (scale, shift), residual, ReLU.  Rows are located in the output frame once per group of four
-    // consecutive pixels when Wo % 4 == 0 (they share an image row), otherwise per pixel; all 16 residual loads of a
-    // 32x32 tile are issued before the first use.
-    const bool quad_rows = (g.Wo & 3) == 0;
+    if (g.ablate == 1) {        // tuning: keep the accumulators alive, write (almost) nothing
+        float t = 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 12345.678f) y[0] = t;
+        return;
+    }
+
+    // Epilogue: BatchNorm (scale, shift), residual, ReLU, stored as whole pixel rows.  Each wave transposes its 32-pixel
+    // sub-tiles through a private LDS patch [32][WN + 4] (the +4 keeps both the 128-bit writes -- 16 lanes = 16 pixels,
+    // bank step 4 -- and the row reads conflict free), then WN/4 consecutive lanes own one pixel's WN channels: residual
+    // loads and output stores are 16 bytes per lane, WN*4 contiguous bytes per pixel (64 stores -> 16 per wave).
+    constexpr int EP = WN + 4;                 // patch pitch (floats)
+    constexpr int LPP = WN / 4;                // lanes per pixel
+    constexpr int PPI = 64 / LPP;              // pixels per wave instruction
+    static_assert(4 * 32 * EP <= 2 * (BM + BN) * PBK, "the epilogue patches fit in the K-loop buffers");
+    __syncthreads();                           // every wave is done with the K-loop buffers
+    float* patch = smem + wave * 32 * EP;
+    const int c4 = (lane % LPP) * 4;
+    const int co = n0 + wn0 + c4;
+    const float4 sc = *reinterpret_cast<const float4*>(scale + co), sh = *reinterpret_cast<const float4*>(shift + co);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        unsigned po[16];
-        bool live[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int mq = m0 + wm0 + i * 32 + 8 * q + 4 * kl;
-            if (quad_rows) {
-                const bool ok = mq < g.Mtot;
-                const unsigned p = ok ? out_pixel_offset((unsigned)mq, g) : 0u;
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) { po[4 * q + t] = p + t * g.Cout; live[4 * q + t] = ok; }
-            } else {
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(patch + il * EP + j * 32 + 8 * q + 4 * kl) =
+                    make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        // wave-private patch: no barrier, the LDS queue is in order per wave
+        unsigned po[32 / PPI];
+        bool live[32 / PPI];
+        float4 res[32 / PPI];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    live[4 * q + t] = mq + t < g.Mtot;
-                    po[4 * q + t] = live[4 * q + t] ? out_pixel_offset((unsigned)(mq + t), g) : 0u;
-                }
-            }
+        for (int u = 0; u < 32 / PPI; ++u) {
+            const int m = m0 + wm0 + i * 32 + u * PPI + lane / LPP;
+            live[u] = m < g.Mtot;
+            po[u] = live[u] ? out_pixel_offset((unsigned)m, g) + (unsigned)co : 0u;
+            res[u] = (residual && live[u]) ? *reinterpret_cast<const float4*>(residual + po[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int co = n0 + wn0 + j * 32 + il;
-            const float sc = scale[co], sh = shift[co];
-            float res[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) res[r] = (residual && live[r]) ? residual[(size_t)po[r] + co] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[i][j][r] * sc + sh + res[r];
-                if (g.relu) v = fmaxf(v, 0.0f);
-                if (live[r]) y[(size_t)po[r] + co] = v;
-            }
+        for (int u = 0; u < 32 / PPI; ++u) {
+            const float4 a = *reinterpret_cast<const float4*>(patch + (u * PPI + lane / LPP) * EP + c4);
+            float4 v = make_float4(a.x * sc.x + sh.x + res[u].x, a.y * sc.y + sh.y + res[u].y, a.z * sc.z + sh.z + res[u].z,
+                                   a.w * sc.w + sh.w + res[u].w);
+            if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (live[u]) *reinterpret_cast<float4*>(y + po[u]) = v;
         }
     }
 }
@@ -384,6 +402,7 @@ extern "C" int hps_conv2d_bn_act_pad(const float* x, const float* wn, const floa
     if ((g.Kp / PBK) % g.ksplit != 0 || (g.ksplit > 1 && !splitk_ws)) return bad_arg("hps_conv2d_bn_act_pad: ksplit");
     g.magic_howo = div_magic((unsigned)(g.Ho * g.Wo));
     g.magic_wo = div_magic((unsigned)g.Wo);
+    g.ablate = g_pad_ablate;
     hipStream_t s = (hipStream_t)stream;
     if (g.ksplit > 1) variant = Cout % 128 == 0 ? 1 : 2;     // split-K runs on the 128-row tiles
     if (variant == 0) {
@@ -400,6 +419,11 @@ extern "C" int hps_conv2d_bn_act_pad(const float* x, const float* wn, const floa
         case 4: return launch_conv_pad<256, 64, 64, 64>(x, wn, scale, shift, residual, y, splitk_ws, g, s);
         default: return bad_arg("hps_conv2d_bn_act_pad: variant");
     }
+}
+
+extern "C" int hps_dev_conv_pad_ablate(int mode) {
+    g_pad_ablate = mode;
+    return HPS_OK;
 }
 
 extern "C" int hps_nchw_to_padded_nhwc(const float* x, float* y, int B, int C, int H, int W, int P, hps_stream_t stream) {

@@ -226,6 +226,9 @@ int hps_conv2d_bn_act_pad(const float* x, const float* wn, const float* scale, c
                           int KH, int KW, int stride, int pad, int opad, int relu, int row_mode, int variant,
                           int ksplit, float* splitk_ws, hps_stream_t stream);
 
+/* Tuning hook (tests/dev only): 1 = hps_conv2d_bn_act_pad skips its epilogue (results are garbage), 0 = normal. */
+int hps_dev_conv_pad_ablate(int mode);
+
 /* (B,C,H,W) -> interior of the (B, H + 2P, W + 2P, C) NHWC frame; C in {4, 18, 64}
  * (predict/predict_poseMF_shapeGaussian_net.py:103 hands the net an NCHW proxy representation). */
 int hps_nchw_to_padded_nhwc(const float* x, float* y, int B, int C, int H, int W, int P, hps_stream_t stream);

@@ -329,6 +329,36 @@ def sec_encoder_pad():
         cur = ent["c2"]
 
 
+def sec_pad_ablate():
+    """conv_pad kernel per layer shape: full vs no-epilogue, per tile variant."""
+    from hierarchicalprobabilistic3dhuman_amd.resnet import _ConvBN
+    from hierarchicalprobabilistic3dhuman_amd import _capi
+    import torch.nn.functional as F
+    B = 64
+    for (H, Cin, Cout, k, st, pd) in [(64, 64, 64, 3, 1, 1), (64, 64, 128, 3, 2, 1), (32, 128, 128, 3, 1, 1), (16, 256, 256, 3, 1, 1),
+                                      (8, 512, 512, 3, 1, 1)]:
+        conv = torch.nn.Conv2d(Cin, Cout, k, st, pd, bias=False).to(dev)
+        bn = torch.nn.BatchNorm2d(Cout).eval().to(dev)
+        cb = _ConvBN(conv, bn)
+        xp = F.pad(torch.relu(torch.randn(B, H, H, Cin, device=dev)), (0, 0, 1, 1, 1, 1)).contiguous()
+        Ho = (H + 2 * pd - k) // st + 1
+        out = torch.zeros(B, Ho + 2, Ho + 2, Cout, device=dev)
+        res = torch.randn(B, Ho + 2, Ho + 2, Cout, device=dev)
+        fl = 2.0 * B * Ho * Ho * Cout * k * k * Cin / 1e9
+        line = "pad H%d %d->%d s%d:" % (H, Cin, Cout, st)
+        for v in (1, 2, 3, 4):
+            if (v == 1 and Cout % 128) or (v == 4 and Cout != 64):
+                continue
+            cb.variant = v
+            ts = []
+            for ab in (0, 1):
+                _capi.call("hps_dev_conv_pad_ablate", ab)
+                ts.append(timeit(lambda: cb.padded(xp, 1, out, 1, residual=res), 10, 3))
+            _capi.call("hps_dev_conv_pad_ablate", 0)
+            line += "  v%d %.0f us (%.0f TF) no-epi %.0f us" % (v, ts[0] * 1e3, fl / ts[0], ts[1] * 1e3)
+        print(line)
+
+
 def sec_conv_tune():
     """Every distinct convolution of ResNet-18 at B=64 under the v1 kernel and the three v2 tile shapes."""
     from hierarchicalprobabilistic3dhuman_amd.resnet import _ConvBN
