@@ -276,22 +276,30 @@ __global__ __launch_bounds__(256) void splitk_pad_epilogue_kernel(const float* _
     *reinterpret_cast<float4*>(y + o) = v;
 }
 
-// (B,C,H,W) -> (B, H + 2P, W + 2P, C) interior (the halo is zeroed once by the owner of the buffer): lanes along w
-// read each channel plane coalesced, every lane assembles its pixel's C channels and stores them as float2s
+// (B,C,H,W) -> (B, H + 2P, W + 2P, C) interior (the halo is zeroed once by the owner of the buffer).  A workgroup moves
+// one run of up to 256 pixels of an image row: lanes along w read each channel plane coalesced into LDS [pixel][C], then
+// the run's 256*C contiguous output floats leave as lane-contiguous 8-byte stores (pixel records are 8-byte aligned
+// for even C; 512 contiguous bytes per wave instruction instead of 64 scattered records).
 template <int C>
 __global__ __launch_bounds__(256) void nchw_to_padded_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                                  int H, int W, int P, long total) {
-    const long p = (long)blockIdx.x * 256 + threadIdx.x;   // pixel index over B*H*W
-    if (p >= total) return;
+                                                                  int H, int W, int P, int runs_per_row) {
+    __shared__ float sp[256 * C];
+    const int t = threadIdx.x;
+    const int run = blockIdx.x % runs_per_row;
+    const long row = blockIdx.x / runs_per_row;              // b * H + h
+    const long b = row / H;
+    const int h = (int)(row - b * H);
+    const int w0 = run * 256, n = min(256, W - w0);
     const long hw = (long)H * W;
-    const long b = p / hw, r = p - b * hw;
-    const int h = (int)(r / W), w = (int)(r - (long)h * W);
-    float v[C];
+    if (t < n) {
+        const float* src = x + (b * C) * hw + (long)h * W + w0 + t;
 #pragma unroll
-    for (int c = 0; c < C; ++c) v[c] = x[(b * C + c) * hw + r];
-    float2* d = reinterpret_cast<float2*>(y + ((b * (H + 2 * P) + h + P) * (long)(W + 2 * P) + w + P) * C);
-#pragma unroll
-    for (int q = 0; q < C / 2; ++q) d[q] = make_float2(v[2 * q], v[2 * q + 1]);
+        for (int c = 0; c < C; ++c) sp[t * C + c] = src[c * hw];
+    }
+    __syncthreads();
+    float2* dst = reinterpret_cast<float2*>(y + ((b * (H + 2 * P) + h + P) * (long)(W + 2 * P) + w0 + P) * C);
+    const float2* s2 = reinterpret_cast<const float2*>(sp);
+    for (int i = t; i < n * C / 2; i += 256) dst[i] = s2[i];
 }
 
 // MaxPool2d(3, 2, 1) on NHWC, thread per (output pixel, 4 channels); output written into a frame with halo opad
@@ -428,13 +436,14 @@ extern "C" int hps_dev_conv_pad_ablate(int mode) {
 
 extern "C" int hps_nchw_to_padded_nhwc(const float* x, float* y, int B, int C, int H, int W, int P, hps_stream_t stream) {
     if (!x || !y) return bad_arg("hps_nchw_to_padded_nhwc: null pointer");
-    const long total = (long)B * H * W;
-    if (total <= 0) return HPS_OK;
-    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (B <= 0 || H <= 0 || W <= 0) return HPS_OK;
+    const int runs = ceil_div(W, 256);
+    const long blocks = (long)B * H * runs;
+    if (blocks > 0x7fffffffL) return bad_arg("hps_nchw_to_padded_nhwc: too many rows");
     hipStream_t s = (hipStream_t)stream;
-    if (C == 18) hipLaunchKernelGGL(nchw_to_padded_nhwc_kernel<18>, dim3(blocks), dim3(256), 0, s, x, y, H, W, P, total);
-    else if (C == 4) hipLaunchKernelGGL(nchw_to_padded_nhwc_kernel<4>, dim3(blocks), dim3(256), 0, s, x, y, H, W, P, total);
-    else if (C == 64) hipLaunchKernelGGL(nchw_to_padded_nhwc_kernel<64>, dim3(blocks), dim3(256), 0, s, x, y, H, W, P, total);
+    if (C == 18) hipLaunchKernelGGL(nchw_to_padded_nhwc_kernel<18>, dim3((unsigned)blocks), dim3(256), 0, s, x, y, H, W, P, runs);
+    else if (C == 4) hipLaunchKernelGGL(nchw_to_padded_nhwc_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, x, y, H, W, P, runs);
+    else if (C == 64) hipLaunchKernelGGL(nchw_to_padded_nhwc_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, s, x, y, H, W, P, runs);
     else return bad_arg("hps_nchw_to_padded_nhwc: C must be 4, 18 or 64");
     return check_launch("hps_nchw_to_padded_nhwc");
 }

@@ -127,6 +127,41 @@ def sec_smpl_perf():
             print("unc err", err(su.vertex_uncertainty(vs)[3], ref_u))
 
 
+def sec_blend_conv():
+    """The blend GEMM run by the halo-padded convolution kernel as a 1x1 'convolution' (row-major operands)."""
+    model, params, smpl = make_smpl()
+    from hierarchicalprobabilistic3dhuman_amd import _capi
+    P = _capi.ptr
+    M = 6528
+    betas = torch.randn(M, 10, device=dev)
+    aa = torch.randn(M * 24, 3, device=dev) * 0.5
+    R = rtu.batch_rodrigues(aa).view(M, 24, 3, 3)
+    smpl.keep_intermediates = True
+    smpl(betas=betas, body_pose=R[:, 1:].contiguous(), global_orient=R[:, :1].contiguous(), pose2rot=False)
+    L = smpl._last
+    s = _capi.stream()
+    V = 6890
+    t_blend = timeit(lambda: _capi.call("hps_smpl_blend", P(L["xt"]), P(smpl._bmat), P(smpl._v_template_flat),
+                                        P(L["v_posed_raw"]), M, 3 * V, smpl._kp, L["xt"].shape[1], smpl._np, L["ldv"], s))
+    ref = L["v_posed_raw"][:, :3 * V].clone()
+    x_rm = L["xt"][:, :M].t().contiguous()                    # (M, kp)
+    w_rm = smpl._bmat.t().contiguous()                        # (np, kp)
+    npad = w_rm.shape[0]
+    ones = torch.ones(npad, device=dev)
+    shift = torch.zeros(npad, device=dev)
+    shift[:3 * V] = smpl._v_template_flat
+    out = torch.empty(M, npad, device=dev)
+    for v, ab in ((1, 0), (2, 0), (3, 0)):
+        fn = lambda: _capi.call("hps_conv2d_bn_act_pad", P(x_rm), P(w_rm), P(ones), P(shift), None, P(out), M, 1, 1, 0, smpl._kp, npad,
+                                1, 1, 1, 0, 0, 0, 0, v, 1, None, s)
+        _capi.call("hps_dev_conv_pad_ablate", ab)
+        fn()
+        t = timeit(fn)
+        _capi.call("hps_dev_conv_pad_ablate", 0)
+        print("blend: GEMM kernel %.3f ms (%.1f TF) | conv_pad variant %d dephase %d: %.3f ms (%.1f TF)  max diff %.2e" % (
+            t_blend, 2.0 * M * 217 * 20670 / t_blend / 1e9, v, ab, t, 2.0 * M * 217 * 20670 / t / 1e9, err(out[:, :3 * V], ref)))
+
+
 def sec_lbs_tune():
     model, params, smpl = make_smpl()
     from hierarchicalprobabilistic3dhuman_amd import _capi
