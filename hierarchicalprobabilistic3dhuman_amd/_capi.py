@@ -47,6 +47,9 @@ _PROTOTYPES = {
     "hps_sample_joints2d_error": [_P, _P, _I, _P, _P, _P, _c.c_float, _P, _I, _I, _P],
     "hps_conv2d_bn_act_pad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "hps_dev_conv_pad_ablate": [_I],
+    "hps_encoder_run": [_P, _I, _P],
+    "hps_head_pose_levels": [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _P, _P, _P,
+                             _P, _P, _I, _I, _I, _P],
     "hps_nchw_to_padded_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "hps_maxpool3x3s2_pad": [_P, _P, _I, _I, _I, _I, _I, _P],
     "hps_global_avgpool_pad": [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -58,6 +61,16 @@ _RESTYPES = {"hps_last_error": _c.c_char_p}
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
 
 _lib = None
+
+
+class EncOp(_c.Structure):
+    """include/hps.h: hps_enc_op."""
+    _fields_ = [("kind", _I), ("x", _P), ("w", _P), ("scale", _P), ("shift", _P), ("residual", _P), ("y", _P),
+                ("splitk_ws", _P)] + [(n, _I) for n in ("B", "H", "W", "ipad", "Cin", "Cout", "KH", "KW", "stride", "pad", "opad",
+                                                       "relu", "row_mode", "variant", "ksplit")]
+
+
+ENC_RELAYOUT, ENC_CONV, ENC_MAXPOOL, ENC_AVGPOOL = 0, 1, 2, 3
 
 
 class HpsError(RuntimeError):

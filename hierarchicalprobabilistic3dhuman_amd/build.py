@@ -15,7 +15,7 @@ INCLUDE = os.path.join(REPO_ROOT, "include")
 LIB_PATH = os.path.join(PKG_DIR, "libhps.so")
 STAMP_PATH = os.path.join(PKG_DIR, "libhps.stamp")
 
-SOURCES = ["api.hip", "smpl.hip", "blend_gemm.hip", "mf_sample.hip", "head.hip", "conv.hip", "conv_pad.hip", "host_svd.hip", "frontend.hip", "metrics.hip"]
+SOURCES = ["api.hip", "smpl.hip", "blend_gemm.hip", "mf_sample.hip", "head.hip", "conv.hip", "conv_pad.hip", "composite.hip", "host_svd.hip", "frontend.hip", "metrics.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function"]
 

@@ -85,6 +85,7 @@ class PoseMFShapeGaussianNet(nn.Module):
         self.levels = [[j for j in range(self.num_joints) if depth[j] == d] for d in range(max(depth) + 1)]
         self._prepared = None
         self._pinned_bufs = {}
+        self.composite_head = True     # joint loop through hps_head_pose_levels (one call) instead of per-level Python
 
     # ---- kernel-side weights; rebuilt after .to() / load_state_dict ----
     def _apply(self, fn, *args, **kwargs):
@@ -129,6 +130,8 @@ class PoseMFShapeGaussianNet(nn.Module):
         p["anc_ptr"] = torch.tensor(anc_ptr, dtype=torch.int32, device=dev)
         p["anc_idx"] = torch.tensor(anc_idx if anc_idx else [0], dtype=torch.int32, device=dev)
         p["levels"] = [torch.tensor(l, dtype=torch.int32, device=dev) for l in self.levels]
+        p["level_joints"] = torch.tensor([j for l in self.levels for j in l], dtype=torch.int32, device=dev)
+        p["level_sizes_host"] = torch.tensor([len(l) for l in self.levels], dtype=torch.int32)
         self._prepared = p
         return p
 
@@ -179,6 +182,21 @@ class PoseMFShapeGaussianNet(nn.Module):
         mode = torch.zeros(B, nj, 3, 3, **f32)
         delta = float(self.config.MODEL.DELTA_I_WEIGHT) if self.config.MODEL.DELTA_I else 0.0
         stream = torch.cuda.current_stream()
+        if self.composite_head:
+            # the whole joint loop in one call across the C ABI (csrc/composite.hip: same launches, same order)
+            sizes = p["level_sizes_host"]
+            max_n = int(sizes.max())
+            f_dev = torch.empty(B * max_n * 9, **f32)
+            usv_dev = torch.empty(B * max_n * 21, **f32)
+            f_host = self._pinned("f", B * max_n * 9)
+            usv_host = self._pinned("usv", B * max_n * 21)
+            VP = _capi._P
+            _capi.call("hps_head_pose_levels", P(embed), embed_dim, embed_dim // 2, _capi.iptr(p["level_joints"]),
+                       VP(sizes.data_ptr()), len(p["levels"]), _capi.iptr(p["anc_ptr"]), _capi.iptr(p["anc_idx"]),
+                       VP(p["w1t_ptrs"].data_ptr()), VP(p["b1_ptrs"].data_ptr()), VP(p["w2_ptrs"].data_ptr()),
+                       VP(p["b2_ptrs"].data_ptr()), P(U_proper), P(S_proper), P(mode), delta, P(pose_F), P(pose_U), P(pose_S),
+                       P(pose_V), P(f_dev), P(usv_dev), VP(f_host.data_ptr()), VP(usv_host.data_ptr()), B, nj, _SVD_THREADS, s)
+            return pose_F, pose_U, pose_S, pose_V, mode, shape_dist, glob, cam
         for lvl in p["levels"]:
             n_level = lvl.numel()
             f_level = torch.empty(B, n_level, 3, 3, **f32)

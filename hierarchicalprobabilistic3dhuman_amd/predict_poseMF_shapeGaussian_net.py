@@ -39,8 +39,6 @@ def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mea
         glob_rotmats = batch_rodrigues(glob)
     else:
         glob_rotmats = rot6d_to_rotmat(glob)
-    if _before_meshes is not None:
-        _before_meshes()
     R = pose_matrix_fisher_sampling_torch(pose_U, pose_S, pose_V, N, b=1.5, oversampling_ratio=8,
                                           sample_on_cpu=sample_on_cpu, seed=seed, image_offset=image_offset)
     loc = shape_dist.loc
@@ -56,6 +54,8 @@ def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mea
     glob_all = torch.cat([glob_rotmats, eye.expand(B, 3, 3),
                           glob_rotmats[:, None].expand(B, N, 3, 3).reshape(B * N, 3, 3)], dim=0).unsqueeze(1)
     betas_all = torch.cat([loc, loc, betas_s.reshape(B * N, -1)], dim=0)
+    if _before_meshes is not None:          # InferencePipeline: the heavy mesh kernels wait here; sampling and the input
+        _before_meshes()                    # assembly above are small and may run beside the next batch's encoder
     out = smpl_model(body_pose=body, global_orient=glob_all, betas=betas_all, pose2rot=False)
     if _after_smpl is not None:
         _after_smpl()

@@ -80,6 +80,22 @@ class _ConvBN:
                    ksplit, P(ws) if ksplit > 1 else None, _capi.stream())
         return out
 
+    def enc_op(self, xp, ipad, out, opad, residual=None, relu=True, ws=None):
+        """The hps_enc_op of ``padded(...)`` for hps_encoder_run (same arguments, nothing is launched)."""
+        B, Hp, Wp, C = xp.shape
+        H, W = Hp - 2 * ipad, Wp - 2 * ipad
+        row_mode = self.wn is None
+        Ho, Wo = self.out_hw(H, W)
+        assert tuple(out.shape) == (B, Ho + 2 * opad, Wo + 2 * opad, self.cout) and C == (self.cin if row_mode else self.cin_p)
+        ksplit = 1 if row_mode else (self.ksplit if self.ksplit > 0 else self._auto_ksplit(Ho * Wo))
+        assert ksplit == 1 or ws is not None
+        dp = lambda t: t.data_ptr() if t is not None else None
+        return _capi.EncOp(kind=_capi.ENC_CONV, x=dp(xp), w=dp(self.wrow if row_mode else self.wn), scale=dp(self.scale),
+                           shift=dp(self.shift), residual=dp(residual), y=dp(out), splitk_ws=dp(ws) if ksplit > 1 else None,
+                           B=B, H=H, W=W, ipad=ipad, Cin=C, Cout=self.cout, KH=self.kh, KW=self.kw, stride=self.stride,
+                           pad=self.pad, opad=opad, relu=1 if relu else 0, row_mode=1 if row_mode else 0,
+                           variant=self.variant if ksplit <= 1 else 0, ksplit=ksplit)
+
     def out_hw(self, H, W):
         return (H + 2 * self.pad - self.kh) // self.stride + 1, (W + 2 * self.pad - self.kw) // self.stride + 1
 
@@ -148,6 +164,7 @@ class ResNet(nn.Module):
                 nn.init.constant_(m.bias, 0)
         self._prepared = None
         self.layout = "padded"    # "padded": halo-padded NHWC + scalar-base LDS-DMA kernel; "plain": the conv.hip kernels
+        self.composite = True     # padded layout: issue the launch list through hps_encoder_run (one call) instead of one by one
         self._frames = {}
 
     def _make_layer(self, planes, blocks, stride=1):
@@ -180,6 +197,7 @@ class ResNet(nn.Module):
                 down = _ConvBN(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
                 prep["blocks"].append((_ConvBN(blk.conv1, blk.bn1), _ConvBN(blk.conv2, blk.bn2), down))
         self._prepared = prep
+        self._frames = {}          # launch lists hold pointers to the previous filters
         return prep
 
     # ---- halo-padded activation frames: owned by the module, zeroed once, only interiors are ever written ----
@@ -206,8 +224,30 @@ class ResNet(nn.Module):
             ent["ws"] = torch.empty(ks, B * h * w, c1.cout, device=device, dtype=torch.float32) if ks > 1 else None
             fs["blocks"].append(ent)
         fs["hw"] = (h, w)
+        # the launch list of hps_encoder_run: every pointer but the input image and the feature output is fixed
+        ops = [_capi.EncOp(kind=_capi.ENC_RELAYOUT, x=None, y=fs["in"].data_ptr(), B=B, Cin=C, H=H, W=W, opad=3),
+               stem.enc_op(fs["in"], 3, fs["stem"], 0, relu=True),
+               _capi.EncOp(kind=_capi.ENC_MAXPOOL, x=fs["stem"].data_ptr(), y=fs["pool"].data_ptr(), B=B, H=fs["stem"].shape[1],
+                           W=fs["stem"].shape[2], Cin=stem.cout, opad=1)]
+        y = fs["pool"]
+        for (c1, c2, down), ent in zip(prep["blocks"], fs["blocks"]):      # BasicBlock.forward :62-78
+            identity = y
+            if down is not None:
+                ops.append(down.enc_op(y, 1, ent["down"], 1, relu=False))
+                identity = ent["down"]
+            ops.append(c1.enc_op(y, 1, ent["c1"], 1, relu=True, ws=ent["ws"]))
+            ops.append(c2.enc_op(ent["c1"], 1, ent["c2"], 1, residual=identity, relu=True, ws=ent["ws"]))
+            y = ent["c2"]
+        ops.append(_capi.EncOp(kind=_capi.ENC_AVGPOOL, x=y.data_ptr(), y=None, B=B, H=h, W=w, Cin=y.shape[3], ipad=1))
+        fs["ops"] = (_capi.EncOp * len(ops))(*ops)
+        fs["variants"] = self._variant_state(prep)
         self._frames[key] = fs
         return fs
+
+    @staticmethod
+    def _variant_state(prep):
+        convs = [prep["stem"]] + [c for blk in prep["blocks"] for c in blk if c is not None]
+        return tuple((c.variant, c.ksplit) for c in convs)
 
     def _padded_ok(self, C, H, W):
         # row-mode stem (csrc/conv_pad.hip): 16-byte aligned window starts and rows
@@ -218,6 +258,14 @@ class ResNet(nn.Module):
         s = _capi.stream()
         P = _capi.ptr
         fs = self._frame_set(prep, B, C, H, W, x.device)
+        if self.composite and fs["variants"] == self._variant_state(prep):
+            # one call across the C ABI for the whole encoder (csrc/composite.hip)
+            feats = torch.empty(B, fs["blocks"][-1]["c2"].shape[3], device=x.device, dtype=torch.float32)
+            ops = fs["ops"]
+            ops[0].x = x.data_ptr()
+            ops[len(ops) - 1].y = feats.data_ptr()
+            _capi.call("hps_encoder_run", ops, len(ops), s)
+            return feats
         _capi.call("hps_nchw_to_padded_nhwc", P(x), P(fs["in"]), B, C, H, W, 3, s)
         stem = prep["stem"]
         y = stem.padded(fs["in"], 3, fs["stem"], 0, relu=True)             # conv1 + bn1 + relu

@@ -57,15 +57,17 @@ def gather_metric_sums(local_sums):
     return per_rank, total
 
 
+_COUNTS = {}
+
+
 def batch_metric_sums(result):
     """Accumulator of one ``infer`` result: [image count, sum of per-vertex uncertainty, sum |mode vertices|,
     sum |sample joints|] in float64 -- the checksum-of-checksums the scaling tests compare across world sizes."""
     B = result["unc"].shape[0]
     dev = result["unc"].device
     l1 = lambda t: torch.linalg.vector_norm(t, ord=1, dtype=torch.float64)        # sum |x| accumulated in float64, one kernel
-    out = torch.empty(4, dtype=torch.float64, device=dev)
-    out[0] = float(B)
-    out[1] = result["unc"].sum(dtype=torch.float64)
-    out[2] = l1(result["verts_mode"])
-    out[3] = l1(result["joints_samples"])
-    return out
+    count = _COUNTS.get((B, dev))
+    if count is None:
+        count = _COUNTS[(B, dev)] = torch.tensor(float(B), dtype=torch.float64, device=dev)
+    # five launches (three reductions, the stack) -- this runs inside bench.py's timed step
+    return torch.stack([count, result["unc"].sum(dtype=torch.float64), l1(result["verts_mode"]), l1(result["joints_samples"])])

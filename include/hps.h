@@ -226,6 +226,43 @@ int hps_conv2d_bn_act_pad(const float* x, const float* wn, const float* scale, c
                           int KH, int KW, int stride, int pad, int opad, int relu, int row_mode, int variant,
                           int ksplit, float* splitk_ws, hps_stream_t stream);
 
+/* One launch of the encoder's operation list (hps_encoder_run).  kind: HPS_ENC_RELAYOUT = hps_nchw_to_padded_nhwc
+ * (x, y, B, Cin = C, H, W, opad = P), HPS_ENC_CONV = hps_conv2d_bn_act_pad (all fields), HPS_ENC_MAXPOOL =
+ * hps_maxpool3x3s2_pad (x, y, B, H, W, Cin = C, opad), HPS_ENC_AVGPOOL = hps_global_avgpool_pad (x, y, B, H, W,
+ * Cin = C, ipad = P). */
+enum { HPS_ENC_RELAYOUT = 0, HPS_ENC_CONV = 1, HPS_ENC_MAXPOOL = 2, HPS_ENC_AVGPOOL = 3 };
+typedef struct hps_enc_op {
+    int kind;
+    const float* x;
+    const float* w;
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    float* y;
+    float* splitk_ws;
+    int B, H, W, ipad, Cin, Cout, KH, KW, stride, pad, opad, relu, row_mode, variant, ksplit;
+} hps_enc_op;
+
+/* models/resnet.py:202-217 in one call: issues ops[0..n_ops) in order on `stream` (same launches as the individual
+ * entry points; exists because issuing ~27 launches through a scripting-language FFI costs more host time than the
+ * GPU needs to run them). */
+int hps_encoder_run(const hps_enc_op* ops, int n_ops, hps_stream_t stream);
+
+/* models/poseMF_shapeGaussian_net.py:121-160 in one call: for each kinematic level  hps_head_joint_level -> D2H of
+ * the level's F matrices -> stream synchronise -> hps_host_svd3_packed (:137, host LAPACK) -> H2D ->
+ * hps_head_svd_finish.  level_joints: DEVICE int32 array, the levels' joint ids concatenated; level_sizes_host: HOST
+ * array of n_levels sizes; f_level_dev (B*max_level*9) / usv_level_dev (B*max_level*21): device scratch;
+ * f_host_pinned / usv_host_pinned: page-locked host staging of the same sizes.  Blocks the calling thread (it waits
+ * for each level's matrices); other streams keep running. */
+int hps_head_pose_levels(const float* embed, int embed_dim, int hidden, const int32_t* level_joints,
+                         const int32_t* level_sizes_host, int n_levels, const int32_t* anc_ptr,
+                         const int32_t* anc_idx, const float* const* w1t_ptrs, const float* const* b1_ptrs,
+                         const float* const* w2_ptrs, const float* const* b2_ptrs, float* u_proper,
+                         float* s_proper, float* mode, float delta_i_weight, float* pose_f, float* pose_u,
+                         float* pose_s, float* pose_v, float* f_level_dev, float* usv_level_dev,
+                         float* f_host_pinned, float* usv_host_pinned, int B, int num_body_joints,
+                         int svd_threads, hps_stream_t stream);
+
 /* Tuning hook (tests/dev only): 1 = hps_conv2d_bn_act_pad skips its epilogue (results are garbage), 0 = normal. */
 int hps_dev_conv_pad_ablate(int mode);
 
