@@ -20,7 +20,8 @@ from .label_conversions import make_proxy_representation
 
 @torch.no_grad()
 def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mean_shape=True,
-          sample_on_cpu=False, seed=None, image_offset=0, input_feats=None, _before_meshes=None, _after_smpl=None):
+          sample_on_cpu=False, seed=None, image_offset=0, input_feats=None, _before_meshes=None, _after_smpl=None,
+          _run_net=None):
     """predict/predict_poseMF_shapeGaussian_net.py:103-165 for a batch of B proxy representations.
 
     proxy_rep_input: (B,18,256,256) on the device.  Returns a dict of device tensors; every entry equals
@@ -30,8 +31,8 @@ def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mea
       verts_tpose (B,6890,3), R_samples (B,N,23,3,3), verts_samples (B,N,6890,3),
       joints_samples (B,N,90,3), unc (B,6890).
     """
-    pose_F, pose_U, pose_S, pose_V, mode, shape_dist, glob, cam = pose_shape_model(proxy_rep_input,
-                                                                                   input_feats=input_feats)
+    run_net = _run_net if _run_net is not None else pose_shape_model
+    pose_F, pose_U, pose_S, pose_V, mode, shape_dist, glob, cam = run_net(proxy_rep_input, input_feats=input_feats)
     B, nj = pose_F.shape[:2]
     N = num_samples
     dev = pose_F.device
@@ -106,6 +107,10 @@ class InferencePipeline:
         self.net, self.smpl = pose_shape_model, smpl_model
         self.num_samples, self.use_mean_shape, self.sample_on_cpu = num_samples, use_mean_shape, sample_on_cpu
         self.enc_stream = torch.cuda.Stream()
+        # The head is a chain of ~30 small dependent kernels and copies; next to a convolution that keeps every CU's
+        # LDS full, each of them would otherwise queue behind the convolution's pending workgroups (measured: 240 us
+        # per kinematic level instead of ~130).  A high-priority stream lets its few workgroups take the next free slots.
+        self.head_stream = torch.cuda.Stream(priority=-1)
         self._smpl_done = None
 
     @torch.no_grad()
@@ -136,6 +141,19 @@ class InferencePipeline:
         main.wait_event(done)
         feats.record_stream(main)
         hook = (lambda: main.wait_event(after[1])) if after is not None else None
+        hs = self.head_stream
+
+        def run_net(_, input_feats=None):
+            # head on the high-priority stream: depends on the encoder only, not on what is still queued on `main`
+            hs.wait_event(done)
+            input_feats.record_stream(hs)
+            with torch.cuda.stream(hs):
+                outs = self.net(None, input_feats=input_feats)
+            main.wait_stream(hs)
+            for t in outs:
+                for u in ((t.loc, t.scale) if isinstance(t, torch.distributions.Normal) else (t,)):
+                    u.record_stream(main)
+            return outs
 
         def smpl_done():
             self._smpl_done = torch.cuda.Event()
@@ -143,7 +161,7 @@ class InferencePipeline:
 
         return infer(self.net, self.smpl, None, num_samples=self.num_samples, use_mean_shape=self.use_mean_shape,
                      sample_on_cpu=self.sample_on_cpu, seed=seed, image_offset=image_offset, input_feats=feats,
-                     _before_meshes=hook, _after_smpl=smpl_done)
+                     _before_meshes=hook, _after_smpl=smpl_done, _run_net=run_net)
 
 
 def predict_poseMF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_model, hrnet_model, hrnet_cfg,

@@ -125,6 +125,16 @@ class _ConvBN:
         return y
 
 
+class _FrameCache(dict):
+    """Per-(batch shape, stream) activation frames and launch lists; device-bound scratch, never copied or pickled."""
+
+    def __deepcopy__(self, memo):
+        return _FrameCache()
+
+    def __reduce__(self):
+        return (_FrameCache, ())
+
+
 class BasicBlock(nn.Module):
     """models/resnet.py:40-78 (parameter container; executed by ResNet._run_block)."""
     expansion = 1
@@ -165,7 +175,7 @@ class ResNet(nn.Module):
         self._prepared = None
         self.layout = "padded"    # "padded": halo-padded NHWC + scalar-base LDS-DMA kernel; "plain": the conv.hip kernels
         self.composite = True     # padded layout: issue the launch list through hps_encoder_run (one call) instead of one by one
-        self._frames = {}
+        self._frames = _FrameCache()
 
     def _make_layer(self, planes, blocks, stride=1):
         downsample = None
@@ -181,7 +191,7 @@ class ResNet(nn.Module):
     # ---- weight preparation (BN folding, k-major filters); redone after .to() / load_state_dict ----
     def _apply(self, fn, *args, **kwargs):
         self._prepared = None
-        self._frames = {}
+        self._frames = _FrameCache()
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
@@ -197,7 +207,7 @@ class ResNet(nn.Module):
                 down = _ConvBN(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
                 prep["blocks"].append((_ConvBN(blk.conv1, blk.bn1), _ConvBN(blk.conv2, blk.bn2), down))
         self._prepared = prep
-        self._frames = {}          # launch lists hold pointers to the previous filters
+        self._frames = _FrameCache()          # launch lists hold pointers to the previous filters
         return prep
 
     # ---- halo-padded activation frames: owned by the module, zeroed once, only interiors are ever written ----
