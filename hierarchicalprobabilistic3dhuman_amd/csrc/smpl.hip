@@ -270,13 +270,17 @@ __global__ __launch_bounds__(256) void uncertainty_kernel(const f3* __restrict__
 // Single-pass form: one workgroup = one image x 128 vertices, 1024 lanes = 8 sample groups x 128 vertices.  The
 // image's N x 128 vertex positions are read from HBM once into LDS (N * 1536 bytes: N <= 100 fits the 160 KiB of a
 // CU), the mean and the mean distance are then formed from LDS -- half the HBM traffic of the two-sweep kernel.
-constexpr int UV = 128, UG = 8;
+// UV = 64 halves the footprint (N = 100: 80 KiB): a second workgroup -- e.g. of the next batch's convolution, beside
+// which this kernel runs in the pipelined loop -- can share the CU.
+constexpr int UG = 8;
+static int g_unc_mode = 0;        // hps_dev_unc_mode: 0 = automatic, 1 = two-sweep, 2 = LDS with 128 vertices, 3 = LDS with 64
 
-__global__ __launch_bounds__(1024) void uncertainty_lds_kernel(const f3* __restrict__ verts, float* __restrict__ unc,
-                                                               int N, int V) {
+template <int UV>
+__global__ __launch_bounds__(UV * UG) void uncertainty_lds_kernel(const f3* __restrict__ verts, float* __restrict__ unc,
+                                                                  int N, int V) {
     extern __shared__ __attribute__((aligned(16))) float sU[];   // [N][3][UV] samples, then [UG/2][3][UV] reduction slots
     float* sRed = sU + (size_t)N * 3 * UV;
-    const int v = threadIdx.x & (UV - 1), g = threadIdx.x >> 7;
+    const int v = threadIdx.x & (UV - 1), g = threadIdx.x / UV;
     const int vg = blockIdx.x * UV + v, b = blockIdx.y;
     const bool live = vg < V;
     const f3* base = verts + (size_t)b * N * V + (live ? vg : V - 1);
@@ -412,18 +416,39 @@ extern "C" int hps_smpl_joints(const float* verts, const float* j_posed, const i
     return check_launch("hps_smpl_joints");
 }
 
+extern "C" int hps_dev_unc_mode(int mode) {
+    g_unc_mode = mode;
+    return HPS_OK;
+}
+
 extern "C" int hps_vertex_uncertainty(const float* verts, float* unc, int B, int N, int V, hps_stream_t stream) {
     if (!verts || !unc) return bad_arg("hps_vertex_uncertainty: null pointer");
     if (B <= 0 || N <= 0 || V <= 0) return HPS_OK;
-    const size_t lds = ((size_t)N * 3 * UV + (size_t)(UG / 2) * 3 * UV) * sizeof(float);
-    if (N >= 8 && lds <= 160 * 1024) {       // the image's samples of 128 vertices fit in LDS: read HBM once
+    auto lds_bytes = [&](int uv) { return ((size_t)N * 3 * uv + (size_t)(UG / 2) * 3 * uv) * sizeof(float); };
+    int uv = 0;
+    if (g_unc_mode == 0) uv = (N >= 8 && lds_bytes(128) <= 160 * 1024) ? 128 : 0;
+    else if (g_unc_mode == 2) uv = 128;
+    else if (g_unc_mode == 3) uv = 64;
+    if (uv && (N < 8 || lds_bytes(uv) > 160 * 1024)) uv = 0;
+    if (uv == 128) {       // the image's samples of 128 vertices fit in LDS: read HBM once
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&uncertainty_lds_kernel),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&uncertainty_lds_kernel<128>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL(uncertainty_lds_kernel, dim3(ceil_div(V, UV), B), dim3(1024), lds, (hipStream_t)stream,
+        hipLaunchKernelGGL(uncertainty_lds_kernel<128>, dim3(ceil_div(V, 128), B), dim3(1024), lds_bytes(128), (hipStream_t)stream,
+                           reinterpret_cast<const f3*>(verts), unc, N, V);
+        return check_launch("hps_vertex_uncertainty");
+    }
+    if (uv == 64) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&uncertainty_lds_kernel<64>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(uncertainty_lds_kernel<64>, dim3(ceil_div(V, 64), B), dim3(512), lds_bytes(64), (hipStream_t)stream,
                            reinterpret_cast<const f3*>(verts), unc, N, V);
         return check_launch("hps_vertex_uncertainty");
     }

@@ -111,7 +111,6 @@ class InferencePipeline:
         # LDS full, each of them would otherwise queue behind the convolution's pending workgroups (measured: 240 us
         # per kinematic level instead of ~130).  A high-priority stream lets its few workgroups take the next free slots.
         self.head_stream = torch.cuda.Stream(priority=-1)
-        self.prep_stream = torch.cuda.Stream()
         self._smpl_done = None
 
     @torch.no_grad()
@@ -122,20 +121,6 @@ class InferencePipeline:
         that point need ``input_ready``)."""
         _capi.require_device(proxy_rep_input, "proxy_rep_input")
         main = torch.cuda.current_stream()
-        enc = self.net.image_encoder
-        # input relayout (HBM-bound) right away on its own stream: it runs beside whatever MFMA-bound work is in flight
-        # instead of at the head of this batch's encoder
-        staged = None
-        if hasattr(enc, "stage_input"):
-            if input_ready is not None:
-                self.prep_stream.wait_event(input_ready)
-            if self._smpl_done is None:
-                self.prep_stream.wait_stream(main)
-            with torch.cuda.stream(self.prep_stream):
-                staged = enc.stage_input(proxy_rep_input, owner=id(self))
-                if staged is not None:
-                    self.enc_stream.wait_stream(self.prep_stream)
-            proxy_rep_input.record_stream(self.prep_stream)
         if input_ready is not None:
             self.enc_stream.wait_event(input_ready)
         if self._smpl_done is None:
@@ -143,7 +128,7 @@ class InferencePipeline:
         else:
             self.enc_stream.wait_event(self._smpl_done)
         with torch.cuda.stream(self.enc_stream):
-            feats = enc(proxy_rep_input, staged=staged) if staged is not None else enc(proxy_rep_input)
+            feats = self.net.image_encoder(proxy_rep_input)
             done = torch.cuda.Event()
             done.record(self.enc_stream)
         proxy_rep_input.record_stream(self.enc_stream)

@@ -7,8 +7,6 @@ the reference); their own forward is never used.  Inference only: BatchNorm uses
 (the reference runs the encoder under ``model.eval()``, predict/...:55) and is fused, together with the
 residual add and ReLU, into the convolution epilogue.
 """
-import ctypes as _c
-
 import torch
 from torch import nn
 
@@ -213,8 +211,8 @@ class ResNet(nn.Module):
         return prep
 
     # ---- halo-padded activation frames: owned by the module, zeroed once, only interiors are ever written ----
-    def _frame_set(self, prep, B, C, H, W, device, owner=None):
-        key = (B, C, H, W, str(device), _capi.stream().value if owner is None else owner)
+    def _frame_set(self, prep, B, C, H, W, device):
+        key = (B, C, H, W, str(device), _capi.stream().value)
         fs = self._frames.get(key)
         if fs is not None:
             return fs
@@ -222,7 +220,7 @@ class ResNet(nn.Module):
             self._frames.pop(next(iter(self._frames)))
         z = lambda *shape: torch.zeros(*shape, device=device, dtype=torch.float32)
         stem = prep["stem"]
-        fs = {"in": z(B, H + 6, W + 6, C), "in2": None, "staged": 0}
+        fs = {"in": z(B, H + 6, W + 6, C)}
         h, w = stem.out_hw(H, W)
         fs["stem"] = torch.empty(B, h, w, stem.cout, device=device, dtype=torch.float32)
         h, w = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
@@ -265,45 +263,19 @@ class ResNet(nn.Module):
         # row-mode stem (csrc/conv_pad.hip): 16-byte aligned window starts and rows
         return self.layout == "padded" and (2 * C) % 4 == 0 and ((W + 6) * C) % 4 == 0 and C in (4, 18, 64)
 
-    def stage_input(self, x, owner):
-        """First operation of the encoder on its own: (B,C,H,W) -> one of two haloed NHWC input frames, on the current
-        stream.  ``forward(x, staged=token)`` then starts at the stem.  The relayout is HBM-bound and the convolutions are
-        MFMA-bound, so a pipeline (InferencePipeline.submit) issues it early, beside the previous batch's convolutions;
-        two frames alternate so that it never overwrites the input a running stem still reads.  Returns None when the
-        padded layout does not apply."""
-        _capi.require_device(x, "encoder input")
-        prep = self._prepared or self.prepare()
-        x = _capi.f32c(x)
-        B, C, H, W = x.shape
-        if not self._padded_ok(C, H, W):
-            return None
-        fs = self._frame_set(prep, B, C, H, W, x.device, owner)
-        if fs["in2"] is None:
-            fs["in2"] = torch.zeros_like(fs["in"])
-        fs["staged"] ^= 1
-        frame = fs["in2"] if fs["staged"] else fs["in"]
-        _capi.call("hps_nchw_to_padded_nhwc", _capi.ptr(x), _capi.ptr(frame), B, C, H, W, 3, _capi.stream())
-        return (owner, frame)
-
-    def _forward_padded(self, prep, x, staged=None):
+    def _forward_padded(self, prep, x):
         B, C, H, W = x.shape
         s = _capi.stream()
         P = _capi.ptr
-        fs = self._frame_set(prep, B, C, H, W, x.device, None if staged is None else staged[0])
+        fs = self._frame_set(prep, B, C, H, W, x.device)
         if self.composite and fs["variants"] == self._variant_state(prep):
             # one call across the C ABI for the whole encoder (csrc/composite.hip)
             feats = torch.empty(B, fs["blocks"][-1]["c2"].shape[3], device=x.device, dtype=torch.float32)
             ops = fs["ops"]
             ops[0].x = x.data_ptr()
-            ops[1].x = (fs["in"] if staged is None else staged[1]).data_ptr()
             ops[len(ops) - 1].y = feats.data_ptr()
-            if staged is None:
-                _capi.call("hps_encoder_run", ops, len(ops), s)
-            else:           # the relayout (ops[0]) has been issued by stage_input
-                _capi.call("hps_encoder_run", _c.byref(ops, _c.sizeof(_capi.EncOp)), len(ops) - 1, s)
+            _capi.call("hps_encoder_run", ops, len(ops), s)
             return feats
-        if staged is not None:
-            raise _capi.HpsError("a staged input needs the composite launch list (tile variants were changed after staging)")
         _capi.call("hps_nchw_to_padded_nhwc", P(x), P(fs["in"]), B, C, H, W, 3, s)
         stem = prep["stem"]
         y = stem.padded(fs["in"], 3, fs["stem"], 0, relu=True)             # conv1 + bn1 + relu
@@ -318,8 +290,8 @@ class ResNet(nn.Module):
         _capi.call("hps_global_avgpool_pad", P(y), P(feats), B, h, w, y.shape[3], 1, s)
         return feats
 
-    def forward(self, x, staged=None):
-        """models/resnet.py:202-217: (B,C,H,W) NCHW fp32 -> (B,512).  ``staged``: token of ``stage_input(x, owner)``."""
+    def forward(self, x):
+        """models/resnet.py:202-217: (B,C,H,W) NCHW fp32 -> (B,512)."""
         _capi.require_device(x, "encoder input")
         if self.training:
             raise RuntimeError("the MI355X encoder path is inference-only (eval-mode BatchNorm); call .eval()")
@@ -327,7 +299,7 @@ class ResNet(nn.Module):
         x = _capi.f32c(x)
         B, C, H, W = x.shape
         if self._padded_ok(C, H, W):
-            return self._forward_padded(prep, x, staged)
+            return self._forward_padded(prep, x)
         s = _capi.stream()
         P = _capi.ptr
         cp = self._cin_pad

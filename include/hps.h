@@ -263,6 +263,10 @@ int hps_head_pose_levels(const float* embed, int embed_dim, int hidden, const in
                          float* f_host_pinned, float* usv_host_pinned, int B, int num_body_joints,
                          int svd_threads, hps_stream_t stream);
 
+/* Tuning hook (tests/dev only): kernel choice of hps_vertex_uncertainty: 0 = automatic, 1 = two-sweep, 2 = single pass
+ * with 128 vertices per workgroup in LDS, 3 = with 64. */
+int hps_dev_unc_mode(int mode);
+
 /* Tuning hook (tests/dev only): 1 = hps_conv2d_bn_act_pad skips its epilogue (results are garbage), 0 = normal. */
 int hps_dev_conv_pad_ablate(int mode);
 
