@@ -21,13 +21,15 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from hierarchicalprobabilistic3dhuman_amd import configs, smpl_data, sharding  # noqa: E402
+from hierarchicalprobabilistic3dhuman_amd import configs, smpl_data, sharding, sampling_utils  # noqa: E402
 from hierarchicalprobabilistic3dhuman_amd.poseMF_shapeGaussian_net import PoseMFShapeGaussianNet  # noqa: E402
 from hierarchicalprobabilistic3dhuman_amd.predict_poseMF_shapeGaussian_net import infer, InferencePipeline  # noqa: E402
 from hierarchicalprobabilistic3dhuman_amd.smpl_official import SMPL  # noqa: E402
 
 LBS_BYTES_PER_MESH = 166896          # 82,680 (v_posed) + 1,536 (A) + 82,680 (verts)
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8 TB/s
+ENCODER_GFLOP_PER_IMAGE = 6.279      # 3.139 GMAC per 18x256x256 image
+MFMA_FP32_PEAK_TF = 157.3            # MI355X_MICROARCH.md: dense fp32 matrix peak
 
 
 def synthetic_inputs(lo, hi):
@@ -44,15 +46,32 @@ def cpu_baseline(net_state, parents, num_samples, n_images):
     model = smpl_data.synthetic_smpl_model(0)
     params = O.SMPLParams(model, smpl_data.load_extra_joint_regressors(None), configs.SMPLX_EXTRA_VERTEX_IDS)
     x = synthetic_inputs(0, n_images)
+    default_threads = torch.get_num_threads()
+    cores = max(1, min(default_threads, sharding.effective_cpus()))     # do not oversubscribe a cgroup CPU quota
+    torch.set_num_threads(cores)
     with torch.no_grad():
         torch.manual_seed(0)
         O.infer(net_state, params, parents, x[:1], num_samples)          # warm (thread pools, allocator)
+        stages = {}
         t0 = time.perf_counter()
-        O.infer(net_state, params, parents, x, num_samples)
+        O.infer(net_state, params, parents, x, num_samples, timings=stages)
         dt = time.perf_counter() - t0
-    return {"value": n_images / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+        # the same port on ONE host thread, on a smaller sample
+        n1 = min(2, n_images)
+        torch.set_num_threads(1)
+        try:
+            t1 = time.perf_counter()
+            O.infer(net_state, params, parents, x[:n1], num_samples)
+            dt1 = time.perf_counter() - t1
+        finally:
+            torch.set_num_threads(default_threads)
+    return {"value": n_images / dt, "unit": "images/s", "cores": cores, "kind": "port",
             "sample": "%d images, num_samples=%d, oracle/ref_cpu.infer timed once after a 1-image warm-up (%.2f s)"
-                      % (n_images, num_samples, dt)}
+                      % (n_images, num_samples, dt),
+            "host": "%d usable hardware threads (affinity / cgroup quota) of %d reported" % (sharding.effective_cpus(), os.cpu_count() or 0),
+            "stage_seconds": {k: round(v, 4) for k, v in stages.items()},
+            "single_thread": {"value": n1 / dt1, "unit": "images/s", "cores": 1,
+                              "sample": "%d images, num_samples=%d (%.2f s)" % (n1, num_samples, dt1)}}
 
 
 def main():
@@ -125,6 +144,8 @@ def main():
     sharding.gather_metric_sums(warm_sums)
     torch.cuda.synchronize()
     smpl.lbs_events = []
+    pipe.enc_events = []
+    sampling_utils.launch_events = []
     sums = torch.zeros(4, dtype=torch.float64, device=dev)
     barrier()
     torch.cuda.synchronize()
@@ -153,6 +174,21 @@ def main():
     smpl.lbs_events = None
     lbs_avg_ms = sum(lbs_ms) / max(1, len(lbs_ms))
     achieved = LBS_BYTES_PER_MESH * M / (lbs_avg_ms * 1e-3) / 1e9 if lbs_ms else None
+    # secondary figures of SURVEY section 8(d), same method (HIP events on the launch stream, timed region only); the
+    # encoder shares the GPU with the previous batch's head and uncertainty kernels while it runs
+    enc_ms = [e0.elapsed_time(e1) for (e0, e1) in (pipe.enc_events or [])]
+    smp_ms = [e0.elapsed_time(e1) for (e0, e1) in (sampling_utils.launch_events or [])]
+    pipe.enc_events, sampling_utils.launch_events = None, None
+    secondary = {}
+    if enc_ms:
+        t = sum(enc_ms) / len(enc_ms)
+        tf = ENCODER_GFLOP_PER_IMAGE * B / t
+        secondary["encoder"] = {"avg_ms": t, "tflops": tf, "peak": MFMA_FP32_PEAK_TF, "frac": tf / MFMA_FP32_PEAK_TF,
+                                "unit": "TFLOP/s fp32 MFMA (6.279 GFLOP/image algorithmic, relayout/pools included in the time)"}
+    if smp_ms:
+        t = sum(smp_ms) / len(smp_ms)
+        secondary["sampler"] = {"avg_ms": t, "proposals_per_s": B * 23 * 8 * N / (t * 1e-3),
+                                "unit": "matrix-Fisher proposals/s (8N per image and joint, Philox)"}
 
     # HBM traffic of the same kernel from the PMC counters: collected in separate rocprofv3 passes of this very
     # command (tools/collect_profiles.sh), corrected as MI355X_MICROARCH.md prescribes, committed under profiles/
@@ -180,12 +216,13 @@ def main():
                                    "poseMF_shapeGaussian head (seed 0), Philox sampling" % (B, N),
                        "images_per_gpu": B, "global_batch": B * world, "num_samples": N,
                        "meshes_per_step_per_gpu": M, "parallelism": "images sharded over %d GPU(s)" % world,
-                       "step_pipelining": "none" if args.no_pipeline else "encoder of step i+1 overlaps the host-paced head of step i (2 HIP streams); mesh kernels run alone"},
+                       "step_pipelining": "none" if args.no_pipeline else "encoder of step i+1 (own stream) overlaps the host-paced head of step i (high-priority stream); blend GEMM / LBS / joints of a batch run alone"},
             "roofline": {"bound": "hbm", "kernel": "hps::lbs_kernel<4,8,1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_source": "profiles/lbs_pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
                          "avg_launch_ms": lbs_avg_ms, "launches": len(lbs_ms),
                          "algorithmic_bytes_per_launch": LBS_BYTES_PER_MESH * M},
+            "secondary": secondary,
             "metric_checksums": {"images": float(total[0]), "sum_unc": float(total[1]),
                                  "sum_abs_verts_mode": float(total[2]), "sum_abs_joints_samples": float(total[3])},
         }

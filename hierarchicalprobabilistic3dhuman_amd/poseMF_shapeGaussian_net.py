@@ -24,10 +24,11 @@ from torch.distributions import Normal
 from . import _capi
 from .resnet import resnet18
 from .rigid_transform_utils import rotmat_to_rot6d
+from .sharding import effective_cpus
 
 
-# host SVD pool size: half the hardware threads, shared between the ranks torchrun started on this node
-_SVD_THREADS = max(1, min(16, (os.cpu_count() or 2) // (2 * max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
+# host SVD pool size: half the usable hardware threads (cgroup quota aware), shared between the ranks torchrun started on this node
+_SVD_THREADS = max(2, min(16, effective_cpus() // (2 * max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
 
 
 def _host_svd_packed(f_host, usv_host):

@@ -112,6 +112,7 @@ class InferencePipeline:
         # per kinematic level instead of ~130).  A high-priority stream lets its few workgroups take the next free slots.
         self.head_stream = torch.cuda.Stream(priority=-1)
         self._smpl_done = None
+        self.enc_events = None
 
     @torch.no_grad()
     def submit(self, proxy_rep_input, input_ready=None):
@@ -128,7 +129,14 @@ class InferencePipeline:
         else:
             self.enc_stream.wait_event(self._smpl_done)
         with torch.cuda.stream(self.enc_stream):
+            ev = None
+            if self.enc_events is not None:      # bench.py: HIP events around the encoder, on its own stream
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record(self.enc_stream)
             feats = self.net.image_encoder(proxy_rep_input)
+            if ev is not None:
+                ev[1].record(self.enc_stream)
+                self.enc_events.append(ev)
             done = torch.cuda.Event()
             done.record(self.enc_stream)
         proxy_rep_input.record_stream(self.enc_stream)

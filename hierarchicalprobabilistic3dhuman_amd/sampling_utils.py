@@ -19,6 +19,7 @@ import torch
 from . import _capi
 
 _MAX_ROUNDS = 64
+launch_events = None        # bench.py: list collecting (start, end) HIP events around every hps_mf_sample launch
 
 
 def _m_star(b):
@@ -35,12 +36,19 @@ def _launch(pose_U, pose_S, pose_V, num_samples, n_prop, b, eps=None, w=None, dr
     quat = torch.empty(B, num_samples, nj, 4, device=dev, dtype=torch.float32) if want_quat else None
     accepted = torch.empty(C, device=dev, dtype=torch.int32)
     P = _capi.ptr
+    ev = None
+    if launch_events is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     _capi.call("hps_mf_sample", P(pose_U), P(pose_S), P(pose_V), P(bingham_a) if bingham_a is not None else None,
                C, nj, num_samples, n_prop, float(b), _m_star(b),
                P(eps) if eps is not None else None, P(w) if w is not None else None,
                _capi.iptr(draw_idx) if draw_idx is not None else None,
                int(seed) & 0xFFFFFFFFFFFFFFFF, int(call_offset), _MAX_ROUNDS,
                P(R), P(quat) if quat is not None else None, _capi.iptr(accepted), _capi.stream())
+    if ev is not None:
+        ev[1].record()
+        launch_events.append(ev)
     return R, quat, accepted
 
 

@@ -60,6 +60,29 @@ def gather_metric_sums(local_sums):
 _COUNTS = {}
 
 
+def effective_cpus():
+    """Hardware threads this process may actually use: the affinity mask capped by the cgroup CPU quota (a container
+    can report 256 CPUs and be throttled to 16 -- oversubscribing a quota makes CPU work slower, not faster)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            with open(path) as f:
+                text = f.read().strip()
+            if parse is not None:
+                quota, period = parse(text)
+            else:
+                quota = text
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = f.read().strip()
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
+
+
 def batch_metric_sums(result):
     """Accumulator of one ``infer`` result: [image count, sum of per-vertex uncertainty, sum |mode vertices|,
     sum |sample joints|] in float64 -- the checksum-of-checksums the scaling tests compare across world sizes."""

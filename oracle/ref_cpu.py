@@ -570,20 +570,33 @@ def evaluate_frames(sd, smpl_neutral, smpl_by_gender, smpl_parents, frames, metr
 # ----------------------------------------------------------------------------------------------
 
 def infer(sd, smpl_params, smpl_parents, proxy_rep_input, num_samples, use_mean_shape=True, feats=None,
-          return_noise=False):
+          return_noise=False, timings=None):
     """What predict/predict_poseMF_shapeGaussian_net.py:103-165 computes, for a batch of B images,
     identical to looping the reference's B=1 calls (same RNG draw order: image outer, joint inner).
     """
+    import time as _time
+    _t = [_time.perf_counter()]
+
+    def _mark(stage):           # bench.py's cpu_baseline leg: seconds per stage (``timings`` dict), otherwise a no-op
+        if timings is not None:
+            now = _time.perf_counter()
+            timings[stage] = timings.get(stage, 0.0) + now - _t[0]
+            _t[0] = now
+
     if feats is None:
         feats = resnet18_forward(sd, proxy_rep_input)
+    _mark("encoder")
     pose_F, pose_U, pose_S, pose_V, mode, (loc, scale), glob, cam = head_forward(sd, feats, smpl_parents)
+    _mark("head+svd")
     B = feats.shape[0]
     glob_R = rot6d_to_rotmat(glob)                                                 # predict:107-110
     out_mode = smpl_forward(smpl_params, body_pose=mode, global_orient=glob_R.unsqueeze(1), betas=loc,
                             pose2rot=False)                                        # predict:112-115
     out_tpose = smpl_forward(smpl_params, betas=loc, global_orient=torch.zeros(B, 3),
                              body_pose=torch.zeros(B, 69))                         # predict:136 per image
+    _mark("smpl")
     R = pose_matrix_fisher_sampling(pose_U, pose_S, pose_V, num_samples, return_noise=return_noise)
+    _mark("sampler")
     noise = None
     if return_noise:
         R, noise = R
@@ -595,9 +608,11 @@ def infer(sd, smpl_params, smpl_parents, proxy_rep_input, num_samples, use_mean_
     out_s = smpl_forward(smpl_params, body_pose=R.reshape(B * num_samples, 23, 3, 3),
                          global_orient=glob_R[:, None, None].expand(B, num_samples, 1, 3, 3).reshape(-1, 1, 3, 3),
                          betas=betas_s.reshape(B * num_samples, -1), pose2rot=False)  # sampling_utils:182-185
+    _mark("smpl")
     V = out_s['vertices'].shape[1]
     verts_s = out_s['vertices'].view(B, num_samples, V, 3)
     unc = torch.stack([vertex_uncertainty(verts_s[i]) for i in range(B)])
+    _mark("uncertainty")
     res = dict(pose_F=pose_F, pose_U=pose_U, pose_S=pose_S, pose_V=pose_V, pose_rotmats_mode=mode,
                shape_loc=loc, shape_scale=scale, glob=glob, cam=cam, glob_rotmats=glob_R, feats=feats,
                verts_mode=out_mode['vertices'], joints_mode=out_mode['joints'],

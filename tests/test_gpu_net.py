@@ -162,6 +162,25 @@ def test_padded_and_plain_encoders_agree(dev, net_gpu, golden, golden_input):
     assert torch.isfinite(other).all() and torch.equal(enc(x), padded)
 
 
+def test_composite_calls_issue_the_same_work(dev, net_gpu, golden_input):
+    """hps_encoder_run / hps_head_pose_levels against the one-launch-per-call Python loops: bit-identical outputs."""
+    x = torch.cat([golden_input, torch.rand(3, 18, 256, 256, generator=torch.Generator().manual_seed(5))]).to(dev)
+    enc = net_gpu.image_encoder
+    want = net_gpu(x)
+    try:
+        enc.composite = False
+        net_gpu.composite_head = False
+        got = net_gpu(x)
+    finally:
+        enc.composite = True
+        net_gpu.composite_head = True
+    for a, b in zip(want, got):
+        if isinstance(a, torch.distributions.Normal):
+            assert torch.equal(a.loc, b.loc) and torch.equal(a.scale, b.scale)
+        else:
+            assert torch.equal(a, b)
+
+
 def test_padded_pooling_and_layout_kernels(dev):
     P = _capi.ptr
     x = torch.randn(2, 18, 12, 10, generator=torch.Generator().manual_seed(0))
