@@ -77,7 +77,7 @@ def cpu_baseline(net_state, parents, num_samples, n_images):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--num-samples", type=int, default=100)
