@@ -175,13 +175,15 @@ class PoseMFShapeGaussianNet(nn.Module):
         cam = cat_buf[:, nf + nsh + ng:].clone()
 
         # hierarchical pose prediction (:121-160), one kinematic level at a time
-        pose_F = torch.zeros(B, nj, 3, 3, **f32)
-        pose_U = torch.zeros(B, nj, 3, 3, **f32)
-        pose_S = torch.zeros(B, nj, 3, **f32)
-        pose_V = torch.zeros(B, nj, 3, 3, **f32)
-        U_proper = torch.zeros(B, nj, 3, 3, **f32)
-        S_proper = torch.zeros(B, nj, 3, **f32)
-        mode = torch.zeros(B, nj, 3, 3, **f32)
+        # every joint is in exactly one level and ancestors come from earlier levels: all entries are written before
+        # they are read, no zero fill needed (seven launches less on the head's stream)
+        pose_F = torch.empty(B, nj, 3, 3, **f32)
+        pose_U = torch.empty(B, nj, 3, 3, **f32)
+        pose_S = torch.empty(B, nj, 3, **f32)
+        pose_V = torch.empty(B, nj, 3, 3, **f32)
+        U_proper = torch.empty(B, nj, 3, 3, **f32)
+        S_proper = torch.empty(B, nj, 3, **f32)
+        mode = torch.empty(B, nj, 3, 3, **f32)
         delta = float(self.config.MODEL.DELTA_I_WEIGHT) if self.config.MODEL.DELTA_I else 0.0
         stream = torch.cuda.current_stream()
         if self.composite_head:
