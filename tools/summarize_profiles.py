@@ -28,6 +28,11 @@ lbs = [r for n, r in stats.items() if "lbs_kernel" in n]
 if lbs:
     out["rocprof_avg_launch_ns"] = float(lbs[0]["AverageNs"])
     out["rocprof_calls"] = int(lbs[0]["Calls"])
+try:      # the workload the counters belong to (bench.py only quotes `traffic` for the same launch size)
+    line = json.load(open(os.path.join(src, "bench_under_rocprof.json")))
+    out["meshes_per_launch"] = line["config"]["meshes_per_step_per_gpu"]
+except (OSError, ValueError, KeyError):
+    out["meshes_per_launch"] = 6528
 json.dump(out, open(os.path.join(dst, tag + "_lbs_pmc.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(dst, "lbs_pmc_latest.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
