@@ -394,6 +394,32 @@ def sec_pad_ablate():
         print(line)
 
 
+def sec_pad_splitk():
+    """conv_pad kernel: split-K factors per ResNet-18 layer shape at B=64 (tile variant automatic)."""
+    from hierarchicalprobabilistic3dhuman_amd.resnet import _ConvBN
+    import torch.nn.functional as F
+    B = 64
+    for (H, Cin, Cout, k, st, pd) in [(64, 64, 128, 3, 2, 1), (32, 128, 128, 3, 1, 1), (32, 128, 256, 3, 2, 1), (16, 256, 256, 3, 1, 1),
+                                      (16, 256, 512, 3, 2, 1), (8, 512, 512, 3, 1, 1)]:
+        conv = torch.nn.Conv2d(Cin, Cout, k, st, pd, bias=False).to(dev)
+        bn = torch.nn.BatchNorm2d(Cout).eval().to(dev)
+        cb = _ConvBN(conv, bn)
+        xp = F.pad(torch.relu(torch.randn(B, H, H, Cin, device=dev)), (0, 0, 1, 1, 1, 1)).contiguous()
+        Ho = (H + 2 * pd - k) // st + 1
+        out = torch.zeros(B, Ho + 2, Ho + 2, Cout, device=dev)
+        res = torch.randn(B, Ho + 2, Ho + 2, Cout, device=dev)
+        fl = 2.0 * B * Ho * Ho * Cout * k * k * Cin / 1e9
+        line = "pad H%d %d->%d s%d (%d px/img):" % (H, Cin, Cout, st, Ho * Ho)
+        for ks in (1, 2, 3, 4, 6):
+            if (k * k * Cin // 32) % ks:
+                continue
+            cb.ksplit = ks
+            ws = torch.empty(ks, B * Ho * Ho, Cout, device=dev) if ks > 1 else None
+            t = timeit(lambda: cb.padded(xp, 1, out, 1, residual=res, ws=ws), 10, 3)
+            line += "  K/%d %.0f us (%.0f TF)" % (ks, t * 1e3, fl / t)
+        print(line)
+
+
 def sec_conv_tune():
     """Every distinct convolution of ResNet-18 at B=64 under the v1 kernel and the three v2 tile shapes."""
     from hierarchicalprobabilistic3dhuman_amd.resnet import _ConvBN
