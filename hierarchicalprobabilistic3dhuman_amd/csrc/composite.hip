@@ -11,6 +11,9 @@
 
 using namespace hps;
 
+// ABI guard for bindings that mirror hps_enc_op by hand (ctypes.Structure, cgo, ...)
+extern "C" int hps_sizeof_enc_op(void) { return (int)sizeof(hps_enc_op); }
+
 // models/resnet.py:202-217 as a list of operations on caller-owned buffers (padded frames, weights)
 extern "C" int hps_encoder_run(const hps_enc_op* ops, int n_ops, hps_stream_t stream) {
     if (!ops && n_ops > 0) return bad_arg("hps_encoder_run: null op list");

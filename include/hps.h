@@ -243,6 +243,9 @@ typedef struct hps_enc_op {
     int B, H, W, ipad, Cin, Cout, KH, KW, stride, pad, opad, relu, row_mode, variant, ksplit;
 } hps_enc_op;
 
+/* sizeof(hps_enc_op) as compiled into the library: lets a hand-written mirror of the struct check itself. */
+int hps_sizeof_enc_op(void);
+
 /* models/resnet.py:202-217 in one call: issues ops[0..n_ops) in order on `stream` (same launches as the individual
  * entry points; exists because issuing ~27 launches through a scripting-language FFI costs more host time than the
  * GPU needs to run them). */

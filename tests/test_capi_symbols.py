@@ -43,6 +43,26 @@ def test_argument_validation_needs_no_gpu():
     assert rc == -1
 
 
+def test_struct_mirror_and_composite_argument_checks():
+    """The ctypes mirror of hps_enc_op has the layout the library was compiled with; the composites validate on the host."""
+    lib = _capi.load()
+    assert lib.hps_sizeof_enc_op() == ctypes.sizeof(_capi.EncOp)
+    assert lib.hps_encoder_run(None, 0, None) == 0                     # empty list: nothing to do
+    ops = (_capi.EncOp * 1)(_capi.EncOp(kind=99))
+    assert lib.hps_encoder_run(ops, 1, None) == -1 and b"unknown op kind" in lib.hps_last_error()
+    ops = (_capi.EncOp * 1)(_capi.EncOp(kind=_capi.ENC_CONV))          # null tensors are caught before any launch
+    assert lib.hps_encoder_run(ops, 1, None) == -1 and b"null pointer" in lib.hps_last_error()
+    rc = lib.hps_conv2d_bn_act_pad(ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), None,
+                                   ctypes.c_void_p(16), 1, 8, 8, 0, 64, 64, 3, 3, 1, 1, 1, 1, 0, 0, 1, None, None)
+    assert rc == -1 and b"halo" in lib.hps_last_error()                # input halo smaller than the padding
+
+
+def test_effective_cpus_is_sane():
+    from hierarchicalprobabilistic3dhuman_amd import sharding
+    n = sharding.effective_cpus()
+    assert isinstance(n, int) and 1 <= n <= (os.cpu_count() or 1)
+
+
 def test_product_refuses_cpu_tensors(smpl_assets, net_cpu):
     from hierarchicalprobabilistic3dhuman_amd.smpl_official import SMPL
     from hierarchicalprobabilistic3dhuman_amd import rigid_transform_utils as rtu, sampling_utils as su
