@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void uncertainty_kernel(const f3* __restrict__
 // UV = 64 halves the footprint (N = 100: 80 KiB): a second workgroup -- e.g. of the next batch's convolution, beside
 // which this kernel runs in the pipelined loop -- can share the CU.
 constexpr int UG = 8;
-static int g_unc_mode = 0;        // hps_dev_unc_mode: 0 = automatic, 1 = two-sweep, 2 = LDS with 128 vertices, 3 = LDS with 64
+static int g_unc_mode = 0;        // hps_dev_unc_mode: 0 = automatic, 1 = two-sweep, 2 = LDS with 128 vertices, 3 = LDS with 64, 4 = registers
 
 template <int UV>
 __global__ __launch_bounds__(UV * UG) void uncertainty_lds_kernel(const f3* __restrict__ verts, float* __restrict__ unc,
@@ -322,6 +322,71 @@ __global__ __launch_bounds__(UV * UG) void uncertainty_lds_kernel(const f3* __re
         for (int q = 0; q < UG / 2; ++q) t += sRed[q * UV + v];
         unc[(size_t)b * V + vg] = t / N;
     }
+}
+
+// Register-resident single pass: a workgroup is 64 vertices x 8 sample groups (one wave per group); lane (v, g) keeps
+// its samples s = g, g + 8, ... (SPT of them, 3 floats each) in registers, so the samples are read from HBM once, the
+// only LDS is the 3 KB reduction buffer, and many workgroups share a CU (the LDS-resident form allows one).
+// Same sample-to-group assignment, same summation order and reduction tree as uncertainty_lds_kernel: identical bits.
+template <int SPT>
+__global__ __launch_bounds__(512) void uncertainty_reg_kernel(const f3* __restrict__ verts, float* __restrict__ unc,
+                                                              int N, int V) {
+    constexpr int RV = 64, H = UG / 2;
+    __shared__ float sRed[H * 3 * RV];
+    const int v = threadIdx.x & (RV - 1), g = threadIdx.x / RV;
+    const int vg = blockIdx.x * RV + v, b = blockIdx.y;
+    const bool live = vg < V;
+    const f3* base = verts + (size_t)b * N * V + (live ? vg : V - 1);
+    f3 p[SPT];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) {
+        const int s = g + UG * i;
+        if (s < N) {
+            p[i] = base[(size_t)s * V];
+            sx += p[i].x; sy += p[i].y; sz += p[i].z;
+        }
+    }
+    if (g >= H) { sRed[((g - H) * 3 + 0) * RV + v] = sx; sRed[((g - H) * 3 + 1) * RV + v] = sy; sRed[((g - H) * 3 + 2) * RV + v] = sz; }
+    __syncthreads();
+    if (g < H) {
+        sx += sRed[(g * 3 + 0) * RV + v]; sy += sRed[(g * 3 + 1) * RV + v]; sz += sRed[(g * 3 + 2) * RV + v];
+    }
+    __syncthreads();
+    if (g < H) { sRed[(g * 3 + 0) * RV + v] = sx; sRed[(g * 3 + 1) * RV + v] = sy; sRed[(g * 3 + 2) * RV + v] = sz; }
+    __syncthreads();
+    float mx = 0.f, my = 0.f, mz = 0.f;
+#pragma unroll
+    for (int q = 0; q < H; ++q) { mx += sRed[(q * 3 + 0) * RV + v]; my += sRed[(q * 3 + 1) * RV + v]; mz += sRed[(q * 3 + 2) * RV + v]; }
+    mx /= N; my /= N; mz /= N;
+    __syncthreads();                                    // everyone has read the partial sums before they are reused
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) {
+        if (g + UG * i < N) {
+            const float dx = p[i].x - mx, dy = p[i].y - my, dz = p[i].z - mz;
+            acc += sqrtf(dx * dx + dy * dy + dz * dz);
+        }
+    }
+    if (g >= H) sRed[(g - H) * RV + v] = acc;
+    __syncthreads();
+    if (g < H) acc += sRed[g * RV + v];
+    __syncthreads();
+    if (g < H) sRed[g * RV + v] = acc;
+    __syncthreads();
+    if (g == 0 && live) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < H; ++q) t += sRed[q * RV + v];
+        unc[(size_t)b * V + vg] = t / N;
+    }
+}
+
+template <int SPT>
+static int launch_unc_reg(const float* verts, float* unc, int B, int N, int V, hipStream_t s) {
+    hipLaunchKernelGGL(uncertainty_reg_kernel<SPT>, dim3(ceil_div(V, 64), B), dim3(512), 0, s, reinterpret_cast<const f3*>(verts),
+                       unc, N, V);
+    return check_launch("hps_vertex_uncertainty");
 }
 
 }  // namespace hps
@@ -425,6 +490,16 @@ extern "C" int hps_vertex_uncertainty(const float* verts, float* unc, int B, int
     if (!verts || !unc) return bad_arg("hps_vertex_uncertainty: null pointer");
     if (B <= 0 || N <= 0 || V <= 0) return HPS_OK;
     auto lds_bytes = [&](int uv) { return ((size_t)N * 3 * uv + (size_t)(UG / 2) * 3 * uv) * sizeof(float); };
+    // N <= 128 samples: register-resident single pass (mode 4 forces it, modes 1-3 select the older kernels)
+    if ((g_unc_mode == 0 || g_unc_mode == 4) && N >= 8 && N <= 16 * UG) {
+        const int spt = ceil_div(N, UG);
+        hipStream_t st = (hipStream_t)stream;
+        if (spt <= 2) return launch_unc_reg<2>(verts, unc, B, N, V, st);
+        if (spt <= 4) return launch_unc_reg<4>(verts, unc, B, N, V, st);
+        if (spt <= 8) return launch_unc_reg<8>(verts, unc, B, N, V, st);
+        if (spt <= 13) return launch_unc_reg<13>(verts, unc, B, N, V, st);
+        return launch_unc_reg<16>(verts, unc, B, N, V, st);
+    }
     int uv = 0;
     if (g_unc_mode == 0) uv = (N >= 8 && lds_bytes(128) <= 160 * 1024) ? 128 : 0;
     else if (g_unc_mode == 2) uv = 128;

@@ -162,6 +162,25 @@ def sec_blend_conv():
             t_blend, 2.0 * M * 217 * 20670 / t_blend / 1e9, v, ab, t, 2.0 * M * 217 * 20670 / t / 1e9, err(out[:, :3 * V], ref)))
 
 
+def sec_unc_modes():
+    """hps_vertex_uncertainty kernel generations on the bench shape and a few others: time and bit equality."""
+    from hierarchicalprobabilistic3dhuman_amd import _capi
+    for (B, N) in ((64, 100), (64, 8), (16, 128), (3, 37)):
+        v = torch.randn(B, N, 6890, 3, device=dev)
+        outs = {}
+        line = "unc B=%d N=%d:" % (B, N)
+        for mode, name in ((1, "two-sweep"), (2, "lds128"), (3, "lds64"), (4, "registers"), (0, "auto")):
+            _capi.call("hps_dev_unc_mode", mode)
+            outs[name] = su.vertex_uncertainty(v)
+            t = timeit(lambda: su.vertex_uncertainty(v), 10, 3)
+            line += "  %s %.1f us (%.2f TB/s)" % (name, t * 1e3, v.numel() * 4 / t / 1e9)
+        _capi.call("hps_dev_unc_mode", 0)
+        print(line)
+        print("    registers == lds128: %s, == lds64: %s, auto == registers: %s, max |two-sweep - registers| %.2e" % (
+            bool(torch.equal(outs["registers"], outs["lds128"])), bool(torch.equal(outs["registers"], outs["lds64"])),
+            bool(torch.equal(outs["auto"], outs["registers"])), float((outs["two-sweep"] - outs["registers"]).abs().max())))
+
+
 def sec_lbs_tune():
     model, params, smpl = make_smpl()
     from hierarchicalprobabilistic3dhuman_amd import _capi

@@ -145,11 +145,20 @@ def test_vertex_uncertainty_kernel(dev):
     want = torch.stack([O.vertex_uncertainty(v[i]) for i in range(3)])
     assert maxerr(got, want) <= 1e-5
     assert maxerr(su.vertex_uncertainty(v[:, :1].contiguous().to(dev)), torch.zeros(3, 6890)) == 0.0     # N = 1: zero spread
-    # N = 100 takes the single-pass LDS kernel, N = 120 the two-sweep one; both against the oracle
-    for n in (8, 100, 102, 120):
+    # N <= 128 takes the register-resident single pass (2, 4, 8, 13 or 16 samples per lane), larger N the two-sweep kernel;
+    # the LDS-resident forms it replaced give the same bits (same summation order)
+    for n in (8, 9, 31, 64, 100, 102, 120, 128, 130):
         vv = torch.randn(2, n, 6890, 3, generator=g)
         want_n = torch.stack([O.vertex_uncertainty(vv[i]) for i in range(2)])
-        assert maxerr(su.vertex_uncertainty(vv.to(dev)), want_n) <= 1e-5, n
+        got_n = su.vertex_uncertainty(vv.to(dev))
+        assert maxerr(got_n, want_n) <= 1e-5, n
+        if n <= 100:
+            try:
+                for mode in (2, 3):
+                    _capi.call("hps_dev_unc_mode", mode)
+                    assert torch.equal(su.vertex_uncertainty(vv.to(dev)), got_n), (n, mode)
+            finally:
+                _capi.call("hps_dev_unc_mode", 0)
 
 
 def test_c_abi_rejects_unsupported_k(dev, smpl_gpu):
