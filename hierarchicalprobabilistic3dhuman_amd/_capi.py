@@ -48,6 +48,7 @@ _PROTOTYPES = {
     "hps_conv2d_bn_act_pad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "hps_dev_conv_pad_ablate": [_I],
     "hps_dev_unc_mode": [_I],
+    "hps_dev_blend_mode": [_I],
     "hps_sizeof_enc_op": [],
     "hps_encoder_run": [_P, _I, _P],
     "hps_head_pose_levels": [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _P, _P, _P,

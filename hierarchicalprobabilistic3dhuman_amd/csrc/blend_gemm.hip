@@ -103,9 +103,126 @@ __global__ __launch_bounds__(256) void blend_gemm_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stationary-A form.  With K = 224 a 128 x 128 tile is only 7-14 K-chunks long, so the tile prologue (first operand
+// fetch) and epilogue are ~20 % of blend_gemm_kernel.  Here a workgroup owns one 128-mesh slice of xt for its whole life:
+// every lane loads its MFMA A fragments for ALL of K once (KP/2 registers: wave w holds rows 32 w .. 32 w + 31) and then
+// walks a range of coordinate panels, streaming only bmat through LDS (LDS-DMA, one chunk ahead, continuing across
+// panels -- no per-tile prologue).  Same MFMA order per output element as blend_gemm_kernel: identical bits.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void blend_dma16(unsigned voff, const float* sbase, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
+
+template <int KP>
+__global__ __launch_bounds__(256, 2) void blend_gemm_sa_kernel(const float* __restrict__ xt, const float* __restrict__ bmat,
+                                                               const float* __restrict__ v_template,
+                                                               float* __restrict__ out, int M, int N, int mp, int np,
+                                                               int tiles_n, int n_splits, int ld_out) {
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr int SBK = 32;                            // K rows per streamed chunk (64 MFMAs per wave between barriers)
+    constexpr int NCH = KP / SBK;                      // chunks per panel
+    constexpr int PPW = SBK / 8;                       // one-KiB DMA pieces per wave per chunk (a piece = 2 rows of 512 B)
+    static_assert(KP % SBK == 0, "K must be a multiple of the chunk");
+    __shared__ __attribute__((aligned(16))) float sB[2][SBK][BN];
+    const int tile_m = blockIdx.x / n_splits, split = blockIdx.x % n_splits;
+    const int per = (tiles_n + n_splits - 1) / n_splits;
+    const int nt_begin = split * per, nt_end = min(tiles_n, nt_begin + per);
+    if (nt_begin >= nt_end) return;
+    const int m0 = tile_m * BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kl = lane >> 5, il = lane & 31;
+    const bool vec_ok = (ld_out & 3) == 0 && ((size_t)out & 15) == 0 && ((size_t)v_template & 15) == 0;
+
+    // A fragments of rows m0 + 32 wave + il for every k pair: element p is xt[2 p + kl][row]
+    float areg[KP / 2];
+    {
+        const float* src = xt + (size_t)kl * mp + m0 + wave * 32 + il;
+#pragma unroll
+        for (int p = 0; p < KP / 2; ++p) areg[p] = src[(size_t)(2 * p) * mp];
+    }
+
+    // bmat stream: piece q of a chunk covers rows 2 q, 2 q + 1; wave w issues pieces PPW w .. PPW w + PPW - 1
+    const int q0 = wave * PPW;
+    unsigned b_off[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) b_off[j] = (unsigned)(((2 * (q0 + j) + (lane >> 5)) * np + (lane & 31) * 4) * 4);
+    const unsigned lds_b = (unsigned)(size_t)(lptr_t)(&sB[0][0][0]) + (unsigned)q0 * 2 * BN * 4;
+    const float* b_src = bmat + (size_t)nt_begin * BN;        // chunk 0 of the first panel
+    int c_next = 0, nt_next = nt_begin;                         // the chunk the next DMA fetches
+    auto dma_next = [&](int buf) {
+        const unsigned lb = __builtin_amdgcn_readfirstlane(lds_b + buf * SBK * BN * 4);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) blend_dma16(b_off[j], b_src, lb + j * 2 * BN * 4);
+        if (++c_next < NCH) b_src += (size_t)SBK * np;
+        else { c_next = 0; ++nt_next; b_src += (size_t)BN - (size_t)(NCH - 1) * SBK * np; }
+    };
+
+    int buf = 0;
+    dma_next(0);
+    for (int nt = nt_begin; nt < nt_end; ++nt) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (nt_next < nt_end) dma_next(buf ^ 1);
+#pragma unroll
+            for (int k = 0; k < SBK; k += 2) {
+                const float a = areg[(c * SBK + k) / 2];
+                const float* brow = &sB[buf][k + kl][il];
+                const float b0 = brow[0], b1 = brow[32], b2 = brow[64], b3 = brow[96];
+                // the bmat fragment is the MFMA's row operand, the mesh fragment its column operand (products commute,
+                // same k order): a lane ends with ONE mesh (column = lane & 31) and quads of consecutive coordinates
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2, a, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(b3, a, acc[3], 0, 0, 0);
+            }
+            buf ^= 1;
+        }
+        // epilogue: row (coordinate) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column (mesh) = lane & 31:
+        // 16-byte stores of four consecutive coordinates when the rows of `out` are 16-byte aligned
+        const int n0 = nt * BN;
+        const int m = m0 + wave * 32 + il;
+        if (m < M) {
+            float* orow = out + (size_t)m * ld_out;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + j * 32 + 8 * q + 4 * kl;
+                    if (vec_ok && n + 3 < N) {
+                        const float4 vt = *reinterpret_cast<const float4*>(v_template + n);
+                        *reinterpret_cast<float4*>(orow + n) = make_float4(vt.x + acc[j][4 * q], vt.y + acc[j][4 * q + 1],
+                                                                           vt.z + acc[j][4 * q + 2], vt.w + acc[j][4 * q + 3]);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (n + t < N) orow[n + t] = v_template[n + t] + acc[j][4 * q + t];
+                    }
+                }
+        }
+    }
+}
+
 }  // namespace hps
 
 using namespace hps;
+
+static int g_blend_mode = 0;      // hps_dev_blend_mode: 0 / 1 = tiled kernel (default), 2 = stationary-A kernel
+extern "C" int hps_dev_blend_mode(int mode) {
+    g_blend_mode = mode;
+    return HPS_OK;
+}
 
 extern "C" int hps_smpl_blend(const float* xt, const float* bmat, const float* v_template, float* v_posed, int M,
                               int N, int kp, int mp, int np, int ld_out, hps_stream_t stream) {
@@ -115,6 +232,19 @@ extern "C" int hps_smpl_blend(const float* xt, const float* bmat, const float* v
     if (ld_out < N) return bad_arg("hps_smpl_blend: ld_out < N");
     if (M <= 0 || N <= 0) return HPS_OK;
     const int tiles_m = ceil_div(M, BM), tiles_n = ceil_div(N, BN);
+    if (kp == 224 && g_blend_mode == 2 && (size_t)kp * np * 4 < 0xffffffffull) {
+        // stationary-A kernel (opt-in, hps_dev_blend_mode(2)): alone it is 15 % faster than the tiled kernel (0.54 vs
+        // 0.65 ms at 6 528 meshes, 120 vs 102 TF/s at 16 032), but inside the pipelined step the difference shrinks to
+        // 5 % (529 vs 558 us) and the LBS kernel that reads its output right after runs 3 % slower (16-byte store
+        // segments instead of whole 128-byte lines): +0.4 % images/s, -2 points of LBS roofline -- not the default.
+        // one resident round: at most 512 workgroups (2 per CU), never a sparsely filled second round
+        int n_splits = 512 / tiles_m;
+        if (n_splits < 1) n_splits = 1;
+        if (n_splits > tiles_n) n_splits = tiles_n;
+        hipLaunchKernelGGL(blend_gemm_sa_kernel<224>, dim3(tiles_m * n_splits), dim3(256), 0, (hipStream_t)stream, xt, bmat,
+                           v_template, v_posed, M, N, mp, np, tiles_n, n_splits, ld_out);
+        return check_launch("hps_smpl_blend");
+    }
     hipLaunchKernelGGL(blend_gemm_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, (hipStream_t)stream, xt, bmat,
                        v_template, v_posed, M, N, kp, mp, np, tiles_n, ld_out);
     return check_launch("hps_smpl_blend");

@@ -266,6 +266,9 @@ int hps_head_pose_levels(const float* embed, int embed_dim, int hidden, const in
                          float* f_host_pinned, float* usv_host_pinned, int B, int num_body_joints,
                          int svd_threads, hps_stream_t stream);
 
+/* Tuning hook (tests/dev only): kernel choice of hps_smpl_blend: 0 / 1 = tiled (default), 2 = stationary-A (same bits). */
+int hps_dev_blend_mode(int mode);
+
 /* Tuning hook (tests/dev only): kernel choice of hps_vertex_uncertainty: 0 = automatic, 1 = two-sweep, 2 = single pass
  * with 128 vertices per workgroup in LDS, 3 = with 64. */
 int hps_dev_unc_mode(int mode);

@@ -127,6 +127,35 @@ def sec_smpl_perf():
             print("unc err", err(su.vertex_uncertainty(vs)[3], ref_u))
 
 
+def sec_blend_modes():
+    """hps_smpl_blend: tiled kernel vs stationary-A kernel, time and bit equality, at the bench size and others."""
+    model, params, smpl = make_smpl()
+    from hierarchicalprobabilistic3dhuman_amd import _capi
+    P = _capi.ptr
+    s = _capi.stream()
+    V = 6890
+    for M in (6528, 16032, 130, 1):
+        betas = torch.randn(M, 10, device=dev)
+        aa = torch.randn(M * 24, 3, device=dev) * 0.5
+        R = rtu.batch_rodrigues(aa).view(M, 24, 3, 3)
+        smpl.keep_intermediates = True
+        smpl(betas=betas, body_pose=R[:, 1:].contiguous(), global_orient=R[:, :1].contiguous(), pose2rot=False)
+        L = smpl._last
+        outs, line = {}, "blend M=%d:" % M
+        for mode, name in ((1, "tiled"), (2, "stationary-A"), (0, "auto")):      # auto = tiled
+            _capi.call("hps_dev_blend_mode", mode)
+            buf = torch.full_like(L["v_posed_raw"], float("nan"))
+            fn = lambda: _capi.call("hps_smpl_blend", P(L["xt"]), P(smpl._bmat), P(smpl._v_template_flat), P(buf), M, 3 * V,
+                                    smpl._kp, L["xt"].shape[1], smpl._np, L["ldv"], s)
+            fn()
+            outs[name] = buf[:, :3 * V].clone()
+            t = timeit(fn, 10, 3)
+            line += "  %s %.3f ms (%.1f TF)" % (name, t, 2.0 * M * 217 * 20670 / t / 1e9)
+        _capi.call("hps_dev_blend_mode", 0)
+        print(line, " identical:", bool(torch.equal(outs["tiled"], outs["stationary-A"])), bool(torch.equal(outs["auto"], outs["tiled"])),
+              "finite:", bool(torch.isfinite(outs["stationary-A"]).all()))
+
+
 def sec_blend_conv():
     """The blend GEMM run by the halo-padded convolution kernel as a 1x1 'convolution' (row-major operands)."""
     model, params, smpl = make_smpl()

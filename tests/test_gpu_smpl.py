@@ -138,6 +138,22 @@ def test_full_size_properties_6528_meshes(dev, smpl_gpu, smpl_assets):
     assert maxerr(out_t.joints[:, 45:], torch.einsum("jv,bvk->bjk", reg, out_t.vertices)) <= TOL
 
 
+def test_blend_kernels_agree_bitwise(dev, smpl_gpu):
+    """The opt-in stationary-A blend GEMM (mesh fragments resident in registers, bmat streamed) gives the bits of the
+    default tiled kernel, for ragged mesh counts too."""
+    g = torch.Generator().manual_seed(11)
+    for M in (1, 130, 700):
+        betas = torch.randn(M, 10, generator=g).to(dev)
+        pose = (torch.randn(M, 72, generator=g) * 0.4).to(dev)
+        ref = smpl_gpu(betas=betas, body_pose=pose[:, 3:], global_orient=pose[:, :3]).vertices.clone()
+        try:
+            _capi.call("hps_dev_blend_mode", 2)
+            got = smpl_gpu(betas=betas, body_pose=pose[:, 3:], global_orient=pose[:, :3]).vertices
+        finally:
+            _capi.call("hps_dev_blend_mode", 0)
+        assert torch.equal(got, ref), M
+
+
 def test_vertex_uncertainty_kernel(dev):
     g = torch.Generator().manual_seed(3)
     v = torch.randn(3, 17, 6890, 3, generator=g)
