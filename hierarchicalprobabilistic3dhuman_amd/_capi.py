@@ -3,7 +3,11 @@
 PyTorch is only plumbing here: tensors own device memory, ``data_ptr()`` and the current HIP stream
 are handed to the library.  There is no CPU implementation behind these calls -- if the library or a
 HIP device is missing the call fails loudly.
+
+``dev_library()`` is a context manager for tests / tests/dev only: inside it every call goes to libhps_dev.so
+(include/hps_dev.h: the product code plus earlier kernel generations, alternate variants, tuning switches).
 """
+import contextlib
 import ctypes
 import os
 
@@ -11,6 +15,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libhps.so")
+DEV_LIB_PATH = os.path.join(_PKG_DIR, "libhps_dev.so")
 
 _c = ctypes
 _P = _c.c_void_p
@@ -23,7 +28,8 @@ _PROTOTYPES = {
     "hps_smpl_pose_prep": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
     "hps_smpl_blend": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hps_smpl_lbs": [_P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
-    "hps_dev_lbs_variant": [_P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P],
+    "hps_smpl_mesh_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "hps_smpl_mesh_fused_np": [_I],
     "hps_smpl_joints": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
     "hps_vertex_uncertainty": [_P, _P, _I, _I, _I, _P],
     "hps_mf_sample": [_P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _c.c_float, _P, _P, _P, _c.c_uint64,
@@ -36,19 +42,12 @@ _PROTOTYPES = {
     "hps_host_svd3_packed": [_P, _P, _I, _I],
     "hps_host_bind_lapack": [_c.c_char_p],
     "hps_head_svd_finish": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
-    "hps_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
-    "hps_conv2d_bn_act": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "hps_conv2d_bn_act_v2": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "hps_conv2d_bn_act_v3": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "hps_canny_edges": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _I, _P],
     "hps_proxy_rep": [_P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _P],
     "hps_pointset_errors": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "hps_heatmaps_to_joints2d": [_P, _P, _P, _I, _I, _I, _c.c_float, _P],
     "hps_sample_joints2d_error": [_P, _P, _I, _P, _P, _P, _c.c_float, _P, _I, _I, _P],
     "hps_conv2d_bn_act_pad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
-    "hps_dev_conv_pad_ablate": [_I],
-    "hps_dev_unc_mode": [_I],
-    "hps_dev_blend_mode": [_I],
     "hps_sizeof_enc_op": [],
     "hps_encoder_run": [_P, _I, _P],
     "hps_head_pose_levels": [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _P, _P, _P,
@@ -56,14 +55,29 @@ _PROTOTYPES = {
     "hps_nchw_to_padded_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "hps_maxpool3x3s2_pad": [_P, _P, _I, _I, _I, _I, _I, _P],
     "hps_global_avgpool_pad": [_P, _P, _I, _I, _I, _I, _I, _P],
+}
+# extra entry points of libhps_dev.so (include/hps_dev.h)
+_DEV_PROTOTYPES = {
+    "hps_dev_lbs_variant": [_P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P],
+    "hps_conv2d_bn_act": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "hps_conv2d_bn_act_v2": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "hps_conv2d_bn_act_v3": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "hps_dev_conv_pad_ablate": [_I],
+    "hps_dev_unc_mode": [_I],
+    "hps_dev_blend_mode": [_I],
+    "hps_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "hps_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P],
     "hps_global_avgpool": [_P, _P, _I, _I, _I, _P],
+    "hps_dev_mesh_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
 }
 _RESTYPES = {"hps_last_error": _c.c_char_p}
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
+DEV_EXPORTED_SYMBOLS = tuple(_DEV_PROTOTYPES)
 
 _lib = None
+_dev_lib = None
+_use_dev = False
 
 
 class EncOp(_c.Structure):
@@ -80,17 +94,13 @@ class HpsError(RuntimeError):
     pass
 
 
-def load():
-    """dlopen libhps.so and attach prototypes; raises if the library has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(path, prototypes, what):
+    if not os.path.exists(path):
         raise HpsError(
-            "libhps.so is missing (%s). Build it with `python -m hierarchicalprobabilistic3dhuman_amd.build` "
-            "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path." % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, argtypes in _PROTOTYPES.items():
+            "%s is missing (%s). Build it with `python -m hierarchicalprobabilistic3dhuman_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path." % (what, path))
+    lib = ctypes.CDLL(path)
+    for name, argtypes in prototypes.items():
         fn = getattr(lib, name)          # AttributeError if the build is stale: fail loudly
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, _I)
@@ -98,8 +108,30 @@ def load():
     torch_cpu = os.path.join(os.path.dirname(torch.__file__), "lib", "libtorch_cpu.so")
     if os.path.exists(torch_cpu):
         lib.hps_host_bind_lapack(torch_cpu.encode())
-    _lib = lib
     return lib
+
+
+def load(dev=False):
+    """dlopen libhps.so (dev=True: libhps_dev.so) and attach prototypes; raises if the library has not been built."""
+    global _lib, _dev_lib
+    if dev:
+        if _dev_lib is None:
+            _dev_lib = _open(DEV_LIB_PATH, dict(_PROTOTYPES, **_DEV_PROTOTYPES), "libhps_dev.so")
+        return _dev_lib
+    if _lib is None:
+        _lib = _open(LIB_PATH, _PROTOTYPES, "libhps.so")
+    return _lib
+
+
+@contextlib.contextmanager
+def dev_library():
+    """Route every call inside the block to libhps_dev.so (tests and tests/dev only)."""
+    global _use_dev
+    prev, _use_dev = _use_dev, True
+    try:
+        yield load(dev=True)
+    finally:
+        _use_dev = prev
 
 
 def require_device(t, what="tensor"):
@@ -130,7 +162,7 @@ def stream():
 
 
 def call(name, *args):
-    lib = load()
+    lib = load(dev=_use_dev)
     rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.hps_last_error()

@@ -1,7 +1,10 @@
-"""Build recipe for libhps.so (hand-written HIP for gfx950, C ABI declared in include/hps.h).
+"""Build recipe for libhps.so (hand-written HIP for gfx950, C ABI declared in include/hps.h) and for
+libhps_dev.so, the same sources plus csrc/conv.hip compiled with -DHPS_DEV_BUILD (include/hps_dev.h: earlier kernel
+generations kept as bit-level cross-checks, alternate variants, tuning switches, profiling ablations).  The product
+library contains the product path only; only tests/ and tests/dev/ load the dev library.
 
-hipcc cross-compiles without a GPU; the shared object is written next to this file so that it
-travels with the source tree (it is git-ignored, not gpurun-ignored).
+hipcc cross-compiles without a GPU; the shared objects are written next to this file so that they
+travel with the source tree (git-ignored, not gpurun-ignored).
 """
 import hashlib
 import os
@@ -13,9 +16,15 @@ REPO_ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 LIB_PATH = os.path.join(PKG_DIR, "libhps.so")
-STAMP_PATH = os.path.join(PKG_DIR, "libhps.stamp")
+DEV_LIB_PATH = os.path.join(PKG_DIR, "libhps_dev.so")
 
-SOURCES = ["api.hip", "smpl.hip", "blend_gemm.hip", "mf_sample.hip", "head.hip", "conv.hip", "conv_pad.hip", "composite.hip", "host_svd.hip", "frontend.hip", "metrics.hip"]
+SOURCES = ["api.hip", "smpl.hip", "blend_gemm.hip", "mesh_fused.hip", "mf_sample.hip", "head.hip", "conv_pad.hip", "composite.hip",
+           "host_svd.hip", "frontend.hip", "metrics.hip"]
+DEV_ONLY_SOURCES = ["conv.hip"]
+# per-file flags.  mesh_fused.hip: hipcc's SLP vectoriser turns the skinning epilogue into v_pk_fma_f32 plus one v_mov
+# per packed operand (525 moves, 2 051 instructions); unpacked it is 1 963 instructions with 109 moves, and packed fp32
+# VALU next to MFMAs is slower on gfx950 (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
+FILE_FLAGS = {"mesh_fused.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function"]
 
@@ -27,35 +36,46 @@ def _hipcc():
     return "hipcc"
 
 
-def _source_digest():
+def _config(dev):
+    if dev:
+        return DEV_LIB_PATH, SOURCES + DEV_ONLY_SOURCES, FLAGS + ["-DHPS_DEV_BUILD"], "build_dev"
+    return LIB_PATH, SOURCES, FLAGS, "build"
+
+
+def _source_digest(dev=False):
+    _, sources, flags, _ = _config(dev)
     h = hashlib.sha256()
-    files = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "hps_common.h"),
-                                                         os.path.join(INCLUDE, "hps.h")]
+    files = [os.path.join(CSRC, s) for s in sources] + [os.path.join(CSRC, "hps_common.h"), os.path.join(INCLUDE, "hps.h"),
+                                                         os.path.join(INCLUDE, "hps_dev.h")]
     for f in files:
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(flags).encode())
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
-def is_current():
-    if not (os.path.exists(LIB_PATH) and os.path.exists(STAMP_PATH)):
+def is_current(dev=False):
+    lib = _config(dev)[0]
+    stamp = lib.replace(".so", ".stamp")
+    if not (os.path.exists(lib) and os.path.exists(stamp)):
         return False
-    with open(STAMP_PATH) as f:
-        return f.read().strip() == _source_digest()
+    with open(stamp) as f:
+        return f.read().strip() == _source_digest(dev)
 
 
-def build(force=False, verbose=True):
-    """Compile every translation unit for gfx950 and link libhps.so. Returns the library path."""
-    if not force and is_current():
-        return LIB_PATH
-    objdir = os.path.join(PKG_DIR, "build")
+def build(force=False, verbose=True, dev=False):
+    """Compile every translation unit for gfx950 and link libhps.so (dev=True: libhps_dev.so). Returns the library path."""
+    lib_path, sources, flags, objname = _config(dev)
+    if not force and is_current(dev):
+        return lib_path
+    objdir = os.path.join(PKG_DIR, objname)
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     procs = []
-    for src in SOURCES:
+    for src in sources:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-I", INCLUDE, "-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + flags + FILE_FLAGS.get(src, []) + ["-I", INCLUDE, "-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -67,15 +87,19 @@ def build(force=False, verbose=True):
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl", "-lpthread"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs + ["-ldl", "-lpthread"]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    with open(STAMP_PATH, "w") as f:
-        f.write(_source_digest())
-    return LIB_PATH
+    with open(lib_path.replace(".so", ".stamp"), "w") as f:
+        f.write(_source_digest(dev))
+    return lib_path
+
+
+def build_all(force=False, verbose=True):
+    return build(force, verbose, dev=False), build(force, verbose, dev=True)
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB_PATH)
+    for path in build_all(force="--force" in sys.argv):
+        print(path)

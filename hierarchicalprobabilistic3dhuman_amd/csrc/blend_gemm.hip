@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void blend_gemm_kernel(const float* __restrict
     }
 }
 
+#ifdef HPS_DEV_BUILD      // alternate kernel kept for A/B runs in the dev library only
 // ---------------------------------------------------------------------------------------------
 // Stationary-A form.  With K = 224 a 128 x 128 tile is only 7-14 K-chunks long, so the tile prologue (first operand
 // fetch) and epilogue are ~20 % of blend_gemm_kernel.  Here a workgroup owns one 128-mesh slice of xt for its whole life:
@@ -110,13 +111,6 @@ __global__ __launch_bounds__(256) void blend_gemm_kernel(const float* __restrict
 // walks a range of coordinate panels, streaming only bmat through LDS (LDS-DMA, one chunk ahead, continuing across
 // panels -- no per-tile prologue).  Same MFMA order per output element as blend_gemm_kernel: identical bits.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void blend_dma16(unsigned voff, const float* sbase, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_addr)
-                 : "memory");
-}
 
 template <int KP>
 __global__ __launch_bounds__(256, 2) void blend_gemm_sa_kernel(const float* __restrict__ xt, const float* __restrict__ bmat,
@@ -157,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void blend_gemm_sa_kernel(const float* __re
     auto dma_next = [&](int buf) {
         const unsigned lb = __builtin_amdgcn_readfirstlane(lds_b + buf * SBK * BN * 4);
 #pragma unroll
-        for (int j = 0; j < PPW; ++j) blend_dma16(b_off[j], b_src, lb + j * 2 * BN * 4);
+        for (int j = 0; j < PPW; ++j) lds_dma16(b_off[j], b_src, lb + j * 2 * BN * 4);
         if (++c_next < NCH) b_src += (size_t)SBK * np;
         else { c_next = 0; ++nt_next; b_src += (size_t)BN - (size_t)(NCH - 1) * SBK * np; }
     };
@@ -214,15 +208,19 @@ __global__ __launch_bounds__(256, 2) void blend_gemm_sa_kernel(const float* __re
     }
 }
 
+#endif  // HPS_DEV_BUILD
+
 }  // namespace hps
 
 using namespace hps;
 
+#ifdef HPS_DEV_BUILD
 static int g_blend_mode = 0;      // hps_dev_blend_mode: 0 / 1 = tiled kernel (default), 2 = stationary-A kernel
 extern "C" int hps_dev_blend_mode(int mode) {
     g_blend_mode = mode;
     return HPS_OK;
 }
+#endif
 
 extern "C" int hps_smpl_blend(const float* xt, const float* bmat, const float* v_template, float* v_posed, int M,
                               int N, int kp, int mp, int np, int ld_out, hps_stream_t stream) {
@@ -232,6 +230,7 @@ extern "C" int hps_smpl_blend(const float* xt, const float* bmat, const float* v
     if (ld_out < N) return bad_arg("hps_smpl_blend: ld_out < N");
     if (M <= 0 || N <= 0) return HPS_OK;
     const int tiles_m = ceil_div(M, BM), tiles_n = ceil_div(N, BN);
+#ifdef HPS_DEV_BUILD
     if (kp == 224 && g_blend_mode == 2 && (size_t)kp * np * 4 < 0xffffffffull) {
         // stationary-A kernel (opt-in, hps_dev_blend_mode(2)): alone it is 15 % faster than the tiled kernel (0.54 vs
         // 0.65 ms at 6 528 meshes, 120 vs 102 TF/s at 16 032), but inside the pipelined step the difference shrinks to
@@ -245,6 +244,7 @@ extern "C" int hps_smpl_blend(const float* xt, const float* bmat, const float* v
                            v_template, v_posed, M, N, mp, np, tiles_n, n_splits, ld_out);
         return check_launch("hps_smpl_blend");
     }
+#endif
     hipLaunchKernelGGL(blend_gemm_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, (hipStream_t)stream, xt, bmat,
                        v_template, v_posed, M, N, kp, mp, np, tiles_n, ld_out);
     return check_launch("hps_smpl_blend");

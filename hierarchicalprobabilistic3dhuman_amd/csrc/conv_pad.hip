@@ -51,7 +51,11 @@ struct PadGeom {
     unsigned magic_howo, magic_wo;
     int ablate;                            // tuning only (hps_dev_conv_pad_ablate): 1 = no epilogue
 };
-static int g_pad_ablate = 0;
+#ifdef HPS_DEV_BUILD
+static int g_pad_ablate = 0;               // dev library only (hps_dev_conv_pad_ablate)
+#else
+constexpr int g_pad_ablate = 0;            // product library: no process-global switches
+#endif
 
 // offset (floats) of output pixel m, channel 0, in the output frame
 __device__ __forceinline__ unsigned out_pixel_offset(unsigned m, const PadGeom& g) {
@@ -429,10 +433,12 @@ extern "C" int hps_conv2d_bn_act_pad(const float* x, const float* wn, const floa
     }
 }
 
+#ifdef HPS_DEV_BUILD
 extern "C" int hps_dev_conv_pad_ablate(int mode) {
     g_pad_ablate = mode;
     return HPS_OK;
 }
+#endif
 
 extern "C" int hps_nchw_to_padded_nhwc(const float* x, float* y, int B, int C, int H, int W, int P, hps_stream_t stream) {
     if (!x || !y) return bad_arg("hps_nchw_to_padded_nhwc: null pointer");

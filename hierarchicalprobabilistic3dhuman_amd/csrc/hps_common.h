@@ -5,6 +5,9 @@
 #include <stdio.h>
 
 #include "hps.h"
+#ifdef HPS_DEV_BUILD
+#include "hps_dev.h"
+#endif
 
 namespace hps {
 
@@ -78,6 +81,45 @@ __device__ __forceinline__ void rodrigues_dev(float rx, float ry, float rz, floa
     mat3_mul(k, k, k2);
 #pragma unroll
     for (int i = 0; i < 9; ++i) r[i] = ((i % 4 == 0) ? 1.0f : 0.0f) + s * k[i] + c * k2[i];
+}
+
+
+// Linear blend skinning of one vertex (smplx lbs step (5)): T = sum_k w_k A[idx_k] (3x4, idx pre-multiplied by 12),
+// out = T [p; 1] + t.  One definition with explicit fused multiply-adds, shared by lbs_kernel and the fused mesh kernel,
+// so that both paths produce the same bits.
+template <int K>
+__device__ __forceinline__ f3 skin_vertex(const float* Am, const int (&idx)[K], const float (&w)[K], const f3 pv, float tx,
+                                          float ty, float tz) {
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float4* t4 = reinterpret_cast<const float4*>(Am + idx[k]);
+        const float4 r0 = t4[0], r1 = t4[1], r2 = t4[2];
+        const float wk = w[k];
+        T[0] = __builtin_fmaf(wk, r0.x, T[0]); T[1] = __builtin_fmaf(wk, r0.y, T[1]);
+        T[2] = __builtin_fmaf(wk, r0.z, T[2]); T[3] = __builtin_fmaf(wk, r0.w, T[3]);
+        T[4] = __builtin_fmaf(wk, r1.x, T[4]); T[5] = __builtin_fmaf(wk, r1.y, T[5]);
+        T[6] = __builtin_fmaf(wk, r1.z, T[6]); T[7] = __builtin_fmaf(wk, r1.w, T[7]);
+        T[8] = __builtin_fmaf(wk, r2.x, T[8]); T[9] = __builtin_fmaf(wk, r2.y, T[9]);
+        T[10] = __builtin_fmaf(wk, r2.z, T[10]); T[11] = __builtin_fmaf(wk, r2.w, T[11]);
+    }
+    f3 o;
+    o.x = __builtin_fmaf(T[2], pv.z, __builtin_fmaf(T[1], pv.y, T[0] * pv.x)) + T[3] + tx;
+    o.y = __builtin_fmaf(T[6], pv.z, __builtin_fmaf(T[5], pv.y, T[4] * pv.x)) + T[7] + ty;
+    o.z = __builtin_fmaf(T[10], pv.z, __builtin_fmaf(T[9], pv.y, T[8] * pv.x)) + T[11] + tz;
+    return o;
+}
+
+// One 1 KiB LDS-DMA piece: every lane moves 16 bytes from sbase + voff (bytes) to LDS[lds_addr + 16 * lane].
+__device__ __forceinline__ void lds_dma16(unsigned voff, const float* sbase, unsigned lds_addr) {
+    unsigned keep;
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);       // wave-uniform by construction; M0 needs an SGPR
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
 }
 
 }  // namespace hps

@@ -188,23 +188,7 @@ __global__ __launch_bounds__(256) void lbs_kernel(const float* __restrict__ v_po
             if (transl && m < m_end) { tx = transl[m * 3 + 0]; ty = transl[m * 3 + 1]; tz = transl[m * 3 + 2]; }
 #pragma unroll
             for (int q = 0; q < VPT; ++q) {
-                float T[12];
-#pragma unroll
-                for (int e = 0; e < 12; ++e) T[e] = 0.0f;
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const float4* t4 = reinterpret_cast<const float4*>(Am + idx[q][k]);
-                    const float4 r0 = t4[0], r1 = t4[1], r2 = t4[2];
-                    const float wk = w[q][k];
-                    T[0] += wk * r0.x; T[1] += wk * r0.y; T[2] += wk * r0.z; T[3] += wk * r0.w;
-                    T[4] += wk * r1.x; T[5] += wk * r1.y; T[6] += wk * r1.z; T[7] += wk * r1.w;
-                    T[8] += wk * r2.x; T[9] += wk * r2.y; T[10] += wk * r2.z; T[11] += wk * r2.w;
-                }
-                const f3 pv = p[g][q];
-                f3 o;
-                o.x = T[0] * pv.x + T[1] * pv.y + T[2] * pv.z + T[3] + tx;
-                o.y = T[4] * pv.x + T[5] * pv.y + T[6] * pv.z + T[7] + ty;
-                o.z = T[8] * pv.x + T[9] * pv.y + T[10] * pv.z + T[11] + tz;
+                const f3 o = skin_vertex<K>(Am, idx[q], w[q], p[g][q], tx, ty, tz);
                 if (live[q] && m < m_end) verts[(size_t)m * V + vtx[q]] = o;
             }
         }
@@ -267,13 +251,19 @@ __global__ __launch_bounds__(256) void uncertainty_kernel(const f3* __restrict__
     unc[(size_t)b * V + v] = acc / N;
 }
 
+constexpr int UG = 8;             // sample groups of the single-pass uncertainty kernels
+#ifdef HPS_DEV_BUILD
+static int g_unc_mode = 0;        // hps_dev_unc_mode: 0 = automatic, 1 = two-sweep, 2 = LDS with 128 vertices, 3 = LDS with 64, 4 = registers
+#else
+constexpr int g_unc_mode = 0;     // product library: no process-global switches
+#endif
+
+#ifdef HPS_DEV_BUILD              // the LDS-resident forms the register-resident kernel replaced (same bits): A/B runs only
 // Single-pass form: one workgroup = one image x 128 vertices, 1024 lanes = 8 sample groups x 128 vertices.  The
 // image's N x 128 vertex positions are read from HBM once into LDS (N * 1536 bytes: N <= 100 fits the 160 KiB of a
 // CU), the mean and the mean distance are then formed from LDS -- half the HBM traffic of the two-sweep kernel.
 // UV = 64 halves the footprint (N = 100: 80 KiB): a second workgroup -- e.g. of the next batch's convolution, beside
 // which this kernel runs in the pipelined loop -- can share the CU.
-constexpr int UG = 8;
-static int g_unc_mode = 0;        // hps_dev_unc_mode: 0 = automatic, 1 = two-sweep, 2 = LDS with 128 vertices, 3 = LDS with 64, 4 = registers
 
 template <int UV>
 __global__ __launch_bounds__(UV * UG) void uncertainty_lds_kernel(const f3* __restrict__ verts, float* __restrict__ unc,
@@ -323,6 +313,8 @@ __global__ __launch_bounds__(UV * UG) void uncertainty_lds_kernel(const f3* __re
         unc[(size_t)b * V + vg] = t / N;
     }
 }
+
+#endif  // HPS_DEV_BUILD
 
 // Register-resident single pass: a workgroup is 64 vertices x 8 sample groups (one wave per group); lane (v, g) keeps
 // its samples s = g, g + 8, ... (SPT of them, 3 floats each) in registers, so the samples are read from HBM once, the
@@ -430,13 +422,15 @@ static int launch_lbs(const float* v_posed, int ldv, const float* a, const int32
                       const float* transl, float* verts, int M, int V, int variant, int target_blocks, hipStream_t s) {
     if (target_blocks <= 0) target_blocks = 1536;
     switch (variant) {
-        case 0: return launch_lbs_cfg<K, 4, 1>(v_posed, ldv, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
         case 1: return launch_lbs_cfg<K, 8, 1>(v_posed, ldv, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
+#ifdef HPS_DEV_BUILD
+        case 0: return launch_lbs_cfg<K, 4, 1>(v_posed, ldv, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
         case 2: return launch_lbs_cfg<K, 4, 2>(v_posed, ldv, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
         case 3: return launch_lbs_cfg<K, 2, 2>(v_posed, ldv, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
         case 4: return launch_lbs_cfg<K, 2, 1>(v_posed, ldv, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
         case 5: return launch_lbs_cfg<K, 8, 2>(v_posed, ldv, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
         case 6: return launch_lbs_cfg<K, 16, 1>(v_posed, ldv, a, w_idx, w_val, J, transl, verts, M, V, target_blocks, s);
+#endif
         default: set_error("hps_smpl_lbs: unknown variant %d", variant); return HPS_E_BADARG;
     }
 }
@@ -464,12 +458,14 @@ extern "C" int hps_smpl_lbs(const float* v_posed, int ld_vposed, const float* a,
     return lbs_dispatch(v_posed, ld_vposed, a, w_idx, w_val, K, num_joints, transl, verts, M, V, 1, 24576, (hipStream_t)stream);
 }
 
+#ifdef HPS_DEV_BUILD
 extern "C" int hps_dev_lbs_variant(const float* v_posed, int ld_vposed, const float* a, const int32_t* w_idx,
                                    const float* w_val, int K, int num_joints, const float* transl, float* verts, int M,
                                    int V, int variant, int target_blocks, hps_stream_t stream) {
     return lbs_dispatch(v_posed, ld_vposed, a, w_idx, w_val, K, num_joints, transl, verts, M, V, variant, target_blocks,
                         (hipStream_t)stream);
 }
+#endif
 
 extern "C" int hps_smpl_joints(const float* verts, const float* j_posed, const int32_t* csr_ptr,
                                const int32_t* csr_col, const float* csr_val, int n_rows, int num_joints,
@@ -481,15 +477,19 @@ extern "C" int hps_smpl_joints(const float* verts, const float* j_posed, const i
     return check_launch("hps_smpl_joints");
 }
 
+#ifdef HPS_DEV_BUILD
 extern "C" int hps_dev_unc_mode(int mode) {
     g_unc_mode = mode;
     return HPS_OK;
 }
+#endif
 
 extern "C" int hps_vertex_uncertainty(const float* verts, float* unc, int B, int N, int V, hps_stream_t stream) {
     if (!verts || !unc) return bad_arg("hps_vertex_uncertainty: null pointer");
     if (B <= 0 || N <= 0 || V <= 0) return HPS_OK;
+#ifdef HPS_DEV_BUILD
     auto lds_bytes = [&](int uv) { return ((size_t)N * 3 * uv + (size_t)(UG / 2) * 3 * uv) * sizeof(float); };
+#endif
     // N <= 128 samples: register-resident single pass (mode 4 forces it, modes 1-3 select the older kernels)
     if ((g_unc_mode == 0 || g_unc_mode == 4) && N >= 8 && N <= 16 * UG) {
         const int spt = ceil_div(N, UG);
@@ -500,6 +500,7 @@ extern "C" int hps_vertex_uncertainty(const float* verts, float* unc, int B, int
         if (spt <= 13) return launch_unc_reg<13>(verts, unc, B, N, V, st);
         return launch_unc_reg<16>(verts, unc, B, N, V, st);
     }
+#ifdef HPS_DEV_BUILD
     int uv = 0;
     if (g_unc_mode == 0) uv = (N >= 8 && lds_bytes(128) <= 160 * 1024) ? 128 : 0;
     else if (g_unc_mode == 2) uv = 128;
@@ -527,6 +528,7 @@ extern "C" int hps_vertex_uncertainty(const float* verts, float* unc, int B, int
                            reinterpret_cast<const f3*>(verts), unc, N, V);
         return check_launch("hps_vertex_uncertainty");
     }
+#endif
     hipLaunchKernelGGL(uncertainty_kernel, dim3(ceil_div(V, 256), B), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const f3*>(verts), unc, N, V);
     return check_launch("hps_vertex_uncertainty");

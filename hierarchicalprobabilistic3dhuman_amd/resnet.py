@@ -173,7 +173,7 @@ class ResNet(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
         self._prepared = None
-        self.layout = "padded"    # "padded": halo-padded NHWC + scalar-base LDS-DMA kernel; "plain": the conv.hip kernels
+        self.layout = "padded"    # "padded": halo-padded NHWC + scalar-base LDS-DMA kernel (product); "plain": the conv.hip kernels of libhps_dev.so (tests)
         self.composite = True     # padded layout: issue the launch list through hps_encoder_run (one call) instead of one by one
         self._frames = _FrameCache()
 
@@ -300,6 +300,14 @@ class ResNet(nn.Module):
         B, C, H, W = x.shape
         if self._padded_ok(C, H, W):
             return self._forward_padded(prep, x)
+        if self.layout != "plain":
+            raise _capi.HpsError("encoder input (C=%d, W=%d) is not supported by the halo-padded product kernels "
+                                 "(C in {4, 18, 64} with 16-byte aligned rows)" % (C, W))
+        with _capi.dev_library():          # earlier kernel generation: cross-check only, lives in libhps_dev.so
+            return self._forward_plain(prep, x)
+
+    def _forward_plain(self, prep, x):
+        B, C, H, W = x.shape
         s = _capi.stream()
         P = _capi.ptr
         cp = self._cin_pad

@@ -7,8 +7,9 @@ smplx.SMPL that appends 9 + 19 + 17 regressed joints -> 90), executed by hand-wr
 
 Kernel sequence per call (all on the current HIP stream, no host synchronisation):
   hps_smpl_pose_prep  Rodrigues, rest joints, forward kinematics, blend-GEMM operand
-  hps_smpl_blend      v_template + [betas | pose feature] @ [shapedirs ; posedirs]   (fp32 MFMA)
-  hps_smpl_lbs        linear blend skinning over 6890 vertices                     (HBM bound)
+  hps_smpl_mesh_fused v_template + [betas | pose feature] @ [shapedirs ; posedirs] (fp32 MFMA) skinned in the GEMM
+                      epilogue: v_posed never exists in HBM.  ``fused_mesh = False`` selects the unfused pair
+                      hps_smpl_blend + hps_smpl_lbs (bit-identical vertices; the definition SURVEY 8(d)'s LBS bytes use)
   hps_smpl_joints     24 kinematic joints + 21 vertex picks + 45 regressed joints
 """
 from collections import namedtuple
@@ -52,6 +53,7 @@ class SMPL(nn.Module):
         self.keep_intermediates = False
         self.lbs_events = None
         self.pad_v_posed = True
+        self.fused_mesh = True
 
         f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
         v_template = np.asarray(model["v_template"], np.float64)
@@ -89,6 +91,14 @@ class SMPL(nn.Module):
         bmat[:nb, :self._N] = shapedirs.reshape(self._N, nb).T                    # row l: d v[n] / d beta_l
         bmat[nb:nb + n_pose, :self._N] = posedirs_v3k.reshape(self._N, n_pose).T
         self.register_buffer("_bmat", f32(bmat), persistent=False)
+        # the same matrix with panel-permuted columns for the fused kernel (include/hps.h: hps_smpl_mesh_fused):
+        # col(v, c) = (v // 128) * 384 + c * 128 + v % 128
+        self._np_fused = -(-V // 128) * 384
+        vi = np.arange(V)
+        bmat_p = np.zeros((self._kp, self._np_fused), np.float64)
+        for c in range(3):
+            bmat_p[:, (vi // 128) * 384 + c * 128 + vi % 128] = bmat[:, 3 * vi + c]
+        self.register_buffer("_bmat_p", f32(bmat_p), persistent=False)
         self.register_buffer("_v_template_flat", f32(v_template.reshape(-1)), persistent=False)
         # joint regression folded through the linear shape blend: J = J_reg (v_t + S beta)
         self.register_buffer("_j_template", f32(J_regressor @ v_template), persistent=False)                 # (J,3)
@@ -162,23 +172,33 @@ class SMPL(nn.Module):
         xt = torch.empty(self._kp, mp, **f32)
         a = torch.empty(M, J, 12, **f32)
         j_posed = torch.empty(M, J, 3, **f32)
-        ldv = self._np if self.pad_v_posed else N          # row pitch of v_posed in floats (128-byte aligned rows)
-        v_posed = torch.empty(M, ldv, **f32)
-        verts = torch.empty(M, V, 3, **f32)
-        joints = torch.empty(M, J + self._n_joint_rows, 3, **f32)
         s = _capi.stream()
         P = _capi.ptr
+        verts = torch.empty(M, V, 3, **f32)
+        joints = torch.empty(M, J + self._n_joint_rows, 3, **f32)
         _capi.call("hps_smpl_pose_prep", P(g), P(b), is_rotmat, P(be), self.num_betas, P(self._j_template),
                    P(self._j_shapedirs), _capi.iptr(self._parents_i32), _capi.iptr(self._depth_i32), J, P(xt),
                    self._kp, mp, P(a), P(j_posed), None, M, s)
-        _capi.call("hps_smpl_blend", P(xt), P(self._bmat), P(self._v_template_flat), P(v_posed), M, N, self._kp,
-                   mp, self._np, ldv, s)
         ev = None
-        if self.lbs_events is not None:      # bench.py: HIP events around the LBS launch, on its own stream
+        if self.lbs_events is not None:      # bench.py: HIP events around the mesh kernel launch, on its own stream
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-        _capi.call("hps_smpl_lbs", P(v_posed), ldv, P(a), _capi.iptr(self._w_idx), P(self._w_val), self._lbs_k, J,
-                   P(tr) if tr is not None else None, P(verts), M, V, s)
+        trp = P(tr) if tr is not None else None
+        v_posed = None
+        if self.fused_mesh:
+            if ev is not None:
+                ev[0].record()
+            _capi.call("hps_smpl_mesh_fused", P(xt), P(self._bmat_p), P(self._v_template_flat), P(a),
+                       _capi.iptr(self._w_idx), P(self._w_val), self._lbs_k, J, trp, P(verts), M, V, self._kp, mp,
+                       self._np_fused, s)
+        else:
+            ldv = self._np if self.pad_v_posed else N          # row pitch of v_posed in floats (128-byte aligned rows)
+            v_posed = torch.empty(M, ldv, **f32)
+            _capi.call("hps_smpl_blend", P(xt), P(self._bmat), P(self._v_template_flat), P(v_posed), M, N, self._kp,
+                       mp, self._np, ldv, s)
+            if ev is not None:
+                ev[0].record()
+            _capi.call("hps_smpl_lbs", P(v_posed), ldv, P(a), _capi.iptr(self._w_idx), P(self._w_val), self._lbs_k, J,
+                       trp, P(verts), M, V, s)
         if ev is not None:
             ev[1].record()
             self.lbs_events.append((M, ev[0], ev[1]))
@@ -186,6 +206,8 @@ class SMPL(nn.Module):
                    P(self._csr_val), self._n_joint_rows, J, P(tr) if tr is not None else None, P(joints), M, V, s)
         full_pose = torch.cat([g, b], dim=1) if return_full_pose else None
         if self.keep_intermediates:                                         # tests / profiling only
-            self._last = dict(xt=xt, a=a, j_posed=j_posed, v_posed=v_posed[:, :N].reshape(M, V, 3), v_posed_raw=v_posed, ldv=ldv)
+            self._last = dict(xt=xt, a=a, j_posed=j_posed)
+            if v_posed is not None:
+                self._last.update(v_posed=v_posed[:, :N].reshape(M, V, 3), v_posed_raw=v_posed, ldv=ldv)
         return SMPLOutput(vertices=verts if return_verts else None, joints=joints, full_pose=full_pose,
                           betas=betas, global_orient=global_orient, body_pose=body_pose)

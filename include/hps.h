@@ -81,11 +81,22 @@ int hps_smpl_lbs(const float* v_posed, int ld_vposed, const float* a, const int3
                  const float* w_val, int K, int num_joints, const float* transl, float* verts, int M,
                  int V, hps_stream_t stream);
 
-/* Development / tuning entry: hps_smpl_lbs with an explicit kernel variant (0..4: meshes per barrier G and
- * vertices per lane VPT = (4,1) (8,1) (4,2) (2,2) (2,1)) and resident-workgroup target. Same results. */
-int hps_dev_lbs_variant(const float* v_posed, int ld_vposed, const float* a, const int32_t* w_idx,
-                        const float* w_val, int K, int num_joints, const float* transl, float* verts,
-                        int M, int V, int variant, int target_blocks, hps_stream_t stream);
+/* Fused blend shapes + linear blend skinning: lbs steps (1), (3), (5) in ONE kernel -- the blend GEMM tile stays in the
+ * MFMA accumulators and is skinned in the epilogue, so v_posed never exists in HBM (the product path of SMPL.forward;
+ * hps_smpl_blend + hps_smpl_lbs remain as the unfused definition the LBS roofline bytes of SURVEY section 8(d) refer to).
+ *   verts[m,v] = (sum_k w[v,k] A[m, idx[v,k]]) . [v_template[v] + sum_k xt[k,m] bmat_p[k, col(v,c)]; 1] (+ transl[m])
+ * bmat_p: the blend matrix of hps_smpl_blend with PANEL-PERMUTED columns, (kp, np) k-major, np = hps_smpl_mesh_fused_np(V):
+ *   col(v, c) = (v / 128) * 384 + c * 128 + v % 128  (x, y, z of a 128-vertex panel as three 128-wide column groups),
+ *   unused columns zero.  xt, a: from hps_smpl_pose_prep (mp a multiple of 64 covering M).  w_idx / w_val / K / transl /
+ *   verts as for hps_smpl_lbs.  Bit-identical to hps_smpl_blend followed by hps_smpl_lbs (same MFMA k order, same
+ *   skinning arithmetic).  Bound: fp32 MFMA, 2 * kp * 3 V FLOP per mesh; HBM traffic = the 12 V bytes of verts per mesh.
+ * Replaces smplx 0.1.26 lbs (reached from models/smpl_official.py:29) steps blend_shapes, pose_feature @ posedirs,
+ * W @ A and T @ v_posed. */
+int hps_smpl_mesh_fused(const float* xt, const float* bmat_p, const float* v_template, const float* a,
+                        const int32_t* w_idx, const float* w_val, int K, int num_joints, const float* transl,
+                        float* verts, int M, int V, int kp, int mp, int np, hps_stream_t stream);
+/* Column count of bmat_p for a model with V vertices (384 per started panel of 128 vertices). */
+int hps_smpl_mesh_fused_np(int V);
 
 /* Joints: out[m, 0:J] = j_posed[m] ; out[m, J + r] = sum_e csr_val[e] * verts[m, csr_col[e]]
  * for CSR rows r = 0..n_rows-1 (the 21 smplx vertex picks as 1-entry rows, then the extra / cocoplus /
@@ -181,39 +192,6 @@ int hps_head_svd_finish(const float* usv_level, const int32_t* joint_ids, int n_
  * ResNet-18 encoder  (models/resnet.py:202-217) -- NHWC activations
  * ---------------------------------------------------------------------------------------- */
 
-/* (B,C,H,W) -> (B,H,W,Cp) with channels zero-padded to Cp. */
-int hps_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, int Cp,
-                     hps_stream_t stream);
-
-/* Implicit-GEMM convolution on fp32 MFMA with fused eval-mode BatchNorm, residual add and ReLU:
- *   y[b,ho,wo,co] = act( scale[co] * sum_{kh,kw,ci} x[b, ho*s-p+kh, wo*s-p+kw, ci] * wk[(kh,kw,ci), co]
- *                        + shift[co] (+ residual[b,ho,wo,co]) )
- * x (B,H,W,Cin) NHWC, wk (ceil16(KH*KW*Cin), Cout) k-major filter (rows zero-padded to a multiple of
- * 16), scale/shift (Cout,) from BN running stats
- * (models/resnet.py:62-78, :202-206).  Cin % 4 == 0 (pad), Cout % 64 == 0. */
-int hps_conv2d_bn_act(const float* x, const float* wk, const float* scale, const float* shift,
-                      const float* residual, float* y, int B, int H, int W, int Cin, int Cout,
-                      int KH, int KW, int stride, int pad, int relu, hps_stream_t stream);
-
-/* Same convolution for Cin % 32 == 0 (all of ResNet-18 after the stem), faster kernel: K-chunks of 32 inside one
- * filter tap, 128-bit LDS fragment traffic.  wn: filter stored n-major (Cout, KH*KW*Cin) = weight.permute(0,2,3,1).
- * variant: 0 automatic tile choice, 1 = 128x128, 2 = 128x64, 3 = 64x64 workgroup tiles (tuning). */
-int hps_conv2d_bn_act_v2(const float* x, const float* wn, const float* scale, const float* shift,
-                         const float* residual, float* y, int B, int H, int W, int Cin, int Cout,
-                         int KH, int KW, int stride, int pad, int relu, int variant,
-                         hps_stream_t stream);
-
-/* As hps_conv2d_bn_act_v2 but the LDS tiles are filled by direct global->LDS DMA (global_load_lds_dwordx4) with a
- * source-side XOR swizzle.  zeros: device buffer of >= 64 zero bytes (source of out-of-image taps).
- * variant: 0 automatic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x64 workgroup tiles (2x / 3x: tuning ablations).
- * ksplit > 1 (Cout % 128 == 0, KH*KW*Cin/32 divisible by ksplit): split-K over ksplit slices on 128x128 tiles for
- * layers with too few output tiles to fill 256 CUs; splitk_ws: (ksplit, B*Ho*Wo, Cout) floats of workspace; the slices
- * are summed in slice order by a second kernel that also applies BN / residual / ReLU (deterministic, no atomics). */
-int hps_conv2d_bn_act_v3(const float* x, const float* wn, const float* zeros, const float* scale,
-                         const float* shift, const float* residual, float* y, int B, int H, int W,
-                         int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, int variant,
-                         int ksplit, float* splitk_ws, hps_stream_t stream);
-
 /* Halo-padded generation of the convolution (csrc/conv_pad.hip), same arithmetic and summation order as
  * hps_conv2d_bn_act_v3.  x is (B, H + 2 ipad, W + 2 ipad, Cin) NHWC with a ZERO halo of ipad >= pad pixels, so every
  * filter tap is in bounds; y (and residual) are frames (B, Ho + 2 opad, Wo + 2 opad, Cout) of which only the interior
@@ -266,16 +244,6 @@ int hps_head_pose_levels(const float* embed, int embed_dim, int hidden, const in
                          float* f_host_pinned, float* usv_host_pinned, int B, int num_body_joints,
                          int svd_threads, hps_stream_t stream);
 
-/* Tuning hook (tests/dev only): kernel choice of hps_smpl_blend: 0 / 1 = tiled (default), 2 = stationary-A (same bits). */
-int hps_dev_blend_mode(int mode);
-
-/* Tuning hook (tests/dev only): kernel choice of hps_vertex_uncertainty: 0 = automatic, 1 = two-sweep, 2 = single pass
- * with 128 vertices per workgroup in LDS, 3 = with 64. */
-int hps_dev_unc_mode(int mode);
-
-/* Tuning hook (tests/dev only): 1 = hps_conv2d_bn_act_pad skips its epilogue (results are garbage), 0 = normal. */
-int hps_dev_conv_pad_ablate(int mode);
-
 /* (B,C,H,W) -> interior of the (B, H + 2P, W + 2P, C) NHWC frame; C in {4, 18, 64}
  * (predict/predict_poseMF_shapeGaussian_net.py:103 hands the net an NCHW proxy representation). */
 int hps_nchw_to_padded_nhwc(const float* x, float* y, int B, int C, int H, int W, int P, hps_stream_t stream);
@@ -286,12 +254,6 @@ int hps_maxpool3x3s2_pad(const float* x, float* y, int B, int H, int W, int C, i
 
 /* AdaptiveAvgPool2d((1,1)) + flatten (models/resnet.py:214-215) over the interior of a (B, H + 2P, W + 2P, C) frame. */
 int hps_global_avgpool_pad(const float* x, float* y, int B, int H, int W, int C, int P, hps_stream_t stream);
-
-/* nn.MaxPool2d(3, stride 2, pad 1) on NHWC (models/resnet.py:152, :207). */
-int hps_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, hps_stream_t stream);
-
-/* AdaptiveAvgPool2d((1,1)) + flatten on NHWC (models/resnet.py:214-215): (B,H,W,C) -> (B,C). */
-int hps_global_avgpool(const float* x, float* y, int B, int HW, int C, hps_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Proxy-representation front end  

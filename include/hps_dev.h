@@ -1,0 +1,85 @@
+/*
+ * hps_dev.h -- development / cross-check entry points of libhps_dev.so (the library built with -DHPS_DEV_BUILD).
+ *
+ * NOT part of the product ABI: libhps.so exports none of these.  The dev library contains the product code plus
+ *   - the earlier, un-padded convolution generations (csrc/conv.hip: v1 / v2 / v3) and their relayout / pool kernels,
+ *     kept as a bit-level cross-check of the halo-padded product kernels (tests, layout = "plain");
+ *   - alternate kernel variants (stationary-A blend GEMM, LDS-resident uncertainty kernels, LBS launch geometries);
+ *   - process-global tuning switches (hps_dev_*) and ablation launches for profiling.
+ * Only tests/ and tests/dev/ load it (_capi.dev_library()).
+ */
+#ifndef HPS_DEV_H_
+#define HPS_DEV_H_
+
+#include "hps.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Development / tuning entry: hps_smpl_lbs with an explicit kernel variant (0..4: meshes per barrier G and
+ * vertices per lane VPT = (4,1) (8,1) (4,2) (2,2) (2,1)) and resident-workgroup target. Same results. */
+int hps_dev_lbs_variant(const float* v_posed, int ld_vposed, const float* a, const int32_t* w_idx,
+                        const float* w_val, int K, int num_joints, const float* transl, float* verts,
+                        int M, int V, int variant, int target_blocks, hps_stream_t stream);
+
+/* (B,C,H,W) -> (B,H,W,Cp) with channels zero-padded to Cp. */
+int hps_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, int Cp,
+                     hps_stream_t stream);
+
+/* Implicit-GEMM convolution on fp32 MFMA with fused eval-mode BatchNorm, residual add and ReLU:
+ *   y[b,ho,wo,co] = act( scale[co] * sum_{kh,kw,ci} x[b, ho*s-p+kh, wo*s-p+kw, ci] * wk[(kh,kw,ci), co]
+ *                        + shift[co] (+ residual[b,ho,wo,co]) )
+ * x (B,H,W,Cin) NHWC, wk (ceil16(KH*KW*Cin), Cout) k-major filter (rows zero-padded to a multiple of
+ * 16), scale/shift (Cout,) from BN running stats
+ * (models/resnet.py:62-78, :202-206).  Cin % 4 == 0 (pad), Cout % 64 == 0. */
+int hps_conv2d_bn_act(const float* x, const float* wk, const float* scale, const float* shift,
+                      const float* residual, float* y, int B, int H, int W, int Cin, int Cout,
+                      int KH, int KW, int stride, int pad, int relu, hps_stream_t stream);
+
+/* Same convolution for Cin % 32 == 0 (all of ResNet-18 after the stem), faster kernel: K-chunks of 32 inside one
+ * filter tap, 128-bit LDS fragment traffic.  wn: filter stored n-major (Cout, KH*KW*Cin) = weight.permute(0,2,3,1).
+ * variant: 0 automatic tile choice, 1 = 128x128, 2 = 128x64, 3 = 64x64 workgroup tiles (tuning). */
+int hps_conv2d_bn_act_v2(const float* x, const float* wn, const float* scale, const float* shift,
+                         const float* residual, float* y, int B, int H, int W, int Cin, int Cout,
+                         int KH, int KW, int stride, int pad, int relu, int variant,
+                         hps_stream_t stream);
+
+/* As hps_conv2d_bn_act_v2 but the LDS tiles are filled by direct global->LDS DMA (global_load_lds_dwordx4) with a
+ * source-side XOR swizzle.  zeros: device buffer of >= 64 zero bytes (source of out-of-image taps).
+ * variant: 0 automatic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x64 workgroup tiles (2x / 3x: tuning ablations).
+ * ksplit > 1 (Cout % 128 == 0, KH*KW*Cin/32 divisible by ksplit): split-K over ksplit slices on 128x128 tiles for
+ * layers with too few output tiles to fill 256 CUs; splitk_ws: (ksplit, B*Ho*Wo, Cout) floats of workspace; the slices
+ * are summed in slice order by a second kernel that also applies BN / residual / ReLU (deterministic, no atomics). */
+int hps_conv2d_bn_act_v3(const float* x, const float* wn, const float* zeros, const float* scale,
+                         const float* shift, const float* residual, float* y, int B, int H, int W,
+                         int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, int variant,
+                         int ksplit, float* splitk_ws, hps_stream_t stream);
+
+/* Tuning hook (tests/dev only): kernel choice of hps_smpl_blend: 0 / 1 = tiled (default), 2 = stationary-A (same bits). */
+int hps_dev_blend_mode(int mode);
+
+/* Tuning hook (tests/dev only): kernel choice of hps_vertex_uncertainty: 0 = automatic, 1 = two-sweep, 2 = single pass
+ * with 128 vertices per workgroup in LDS, 3 = with 64. */
+int hps_dev_unc_mode(int mode);
+
+/* Tuning hook (tests/dev only): 1 = hps_conv2d_bn_act_pad skips its epilogue (results are garbage), 0 = normal. */
+int hps_dev_conv_pad_ablate(int mode);
+
+/* nn.MaxPool2d(3, stride 2, pad 1) on NHWC (models/resnet.py:152, :207). */
+int hps_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, hps_stream_t stream);
+
+/* AdaptiveAvgPool2d((1,1)) + flatten on NHWC (models/resnet.py:214-215): (B,H,W,C) -> (B,C). */
+int hps_global_avgpool(const float* x, float* y, int B, int HW, int C, hps_stream_t stream);
+
+/* Profiling ablations of hps_smpl_mesh_fused (K = 4 only): 1 = no skinning (stores v_posed), 2 = no MFMA, 3 = K loop only
+ * (no A fetch, no skinning, no stores), 4 = no operand DMA (garbage results).  0 = the product kernel.
+ * stagger: start delay of the second-slot workgroups in s_sleep(127) units (the product uses 8). */
+int hps_dev_mesh_fused(const float* xt, const float* bmat_p, const float* v_template, const float* a,
+                       const int32_t* w_idx, const float* w_val, int K, int num_joints, const float* transl,
+                       float* verts, int M, int V, int kp, int mp, int np, int ablate, int stagger, hps_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPS_DEV_H_ */

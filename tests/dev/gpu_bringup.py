@@ -127,6 +127,53 @@ def sec_smpl_perf():
             print("unc err", err(su.vertex_uncertainty(vs)[3], ref_u))
 
 
+def sec_mesh_fused():
+    """Fused blend + skinning kernel against the unfused pair: bits and time, at the bench sizes."""
+    model, params, smpl = make_smpl()
+    for M in (6528, 16032):
+        g = torch.Generator().manual_seed(5)
+        betas = torch.randn(M, 10, generator=g).to(dev)
+        pose = (torch.randn(M, 72, generator=g) * 0.5).to(dev)
+        run = lambda: smpl(betas=betas, body_pose=pose[:, 3:], global_orient=pose[:, :3])
+        smpl.fused_mesh = True
+        vf = run().vertices.clone()
+        t_f = timeit(run, iters=20)
+        smpl.fused_mesh = False
+        vu = run().vertices.clone()
+        t_u = timeit(run, iters=20)
+        smpl.fused_mesh = True
+        flop = 2.0 * 224 * 3 * 6890 * M
+        print("mesh_fused M=%d: equal=%s  whole SMPL call fused %.3f ms, unfused %.3f ms  (blend FLOP at fused-call time: %.1f TF/s)"
+              % (M, torch.equal(vf, vu), t_f, t_u, flop / (t_f * 1e-3) / 1e12), flush=True)
+        # the kernel alone
+        smpl.lbs_events = []
+        for _ in range(10):
+            run()
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for (_, a, b) in smpl.lbs_events][2:]
+        smpl.lbs_events = None
+        t = sum(ms) / len(ms)
+        print("   hps_smpl_mesh_fused alone: %.3f ms = %.1f TF/s fp32 MFMA (of 157.3), LBS-definition %.0f GB/s"
+              % (t, flop / (t * 1e-3) / 1e12, 166896.0 * M / (t * 1e-3) / 1e9), flush=True)
+        # ablations (libhps_dev.so): what each phase of the kernel costs
+        from hierarchicalprobabilistic3dhuman_amd import _capi
+        smpl.keep_intermediates = True
+        run()
+        L = smpl._last
+        smpl.keep_intermediates = False
+        P = _capi.ptr
+        verts = torch.empty(M, 6890, 3, device=dev)
+        mp = L["xt"].shape[1]
+        for ab, what, stg in ((0, "product", 8), (1, "no skinning (stores v_posed)", 8), (2, "no MFMA", 8), (3, "K loop only", 8),
+                              (4, "no operand DMA", 8), (0, "stagger 0", 0), (0, "stagger 2", 2), (0, "stagger 4", 4),
+                              (0, "stagger 6", 6), (0, "stagger 10", 10), (0, "stagger 14", 14), (0, "stagger 20", 20)):
+            fn = lambda: _capi.call("hps_dev_mesh_fused", P(L["xt"]), P(smpl._bmat_p), P(smpl._v_template_flat), P(L["a"]),
+                                    _capi.iptr(smpl._w_idx), P(smpl._w_val), 4, 24, None, P(verts), M, 6890, smpl._kp, mp,
+                                    smpl._np_fused, ab, stg, _capi.stream())
+            t = timeit(fn, iters=20)
+            print("   ablate %d %-30s %.3f ms  (%.1f TF/s)" % (ab, what, t, flop / (t * 1e-3) / 1e12), flush=True)
+
+
 def sec_blend_modes():
     """hps_smpl_blend: tiled kernel vs stationary-A kernel, time and bit equality, at the bench size and others."""
     model, params, smpl = make_smpl()
@@ -553,8 +600,10 @@ def sec_e2e():
 
 
 if __name__ == "__main__":
-    for name in sys.argv[1:]:
-        print("==== %s ====" % name, flush=True)
-        t0 = time.time()
-        globals()["sec_" + name]()
-        print("---- %s done in %.1f s" % (name, time.time() - t0), flush=True)
+    from hierarchicalprobabilistic3dhuman_amd import _capi as _capi_main
+    with _capi_main.dev_library():          # every section runs on libhps_dev.so (tuning switches, earlier generations, ablations)
+        for name in sys.argv[1:]:
+            print("==== %s ====" % name, flush=True)
+            t0 = time.time()
+            globals()["sec_" + name]()
+            print("---- %s done in %.1f s" % (name, time.time() - t0), flush=True)

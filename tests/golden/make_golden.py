@@ -9,6 +9,10 @@ Recipes (so that tests can rebuild the inputs without the reference):
                 (asserted here to be identical, tensor for tensor, between the reference class and ours)
   net input   : torch.rand(2,18,256,256, generator=torch.Generator().manual_seed(0))
   sampler     : torch.manual_seed(0) then pose_matrix_fisher_sampling_torch(U,S,V, N, sample_on_cpu=True)
+  A9          : torch.manual_seed(5) then the reference's compute_vertex_uncertainties_by_poseMF_shapeGaussian_sampling
+                (utils/sampling_utils.py:146-192) on image 0 of the net outputs, N = 4, both use_mean_shape values, with
+                the oracle's SMPL (synthetic model, seed 0) injected as ``smpl_model`` -- smplx itself is absent, so this
+                pins the function's own logic (sampling call, shape expand / sample, global_orient expand, mean, norm)
 """
 import os
 import sys
@@ -27,6 +31,7 @@ sys.path.insert(1, ROOT)
 from models.poseMF_shapeGaussian_net import PoseMFShapeGaussianNet as RefNet  # noqa: E402
 from utils.sampling_utils import pose_matrix_fisher_sampling_torch as ref_sampling  # noqa: E402
 from utils.sampling_utils import bingham_sampling_for_matrix_fisher_torch as ref_bingham  # noqa: E402
+from utils.sampling_utils import compute_vertex_uncertainties_by_poseMF_shapeGaussian_sampling as ref_vertex_unc  # noqa: E402
 import utils.rigid_transform_utils as ref_rtu  # noqa: E402
 from losses.matrix_fisher_loss import LogMFNormConstant  # noqa: E402
 
@@ -57,6 +62,27 @@ def main():
     for N in (1, 4, 100):
         torch.manual_seed(0)
         out["sampler_R_N%d" % N] = ref_sampling(U, S, V, N, sample_on_cpu=True)
+    # ---- A9: per-vertex uncertainty by sampling (utils/sampling_utils.py:146-192), oracle SMPL injected ----
+    from types import SimpleNamespace
+    from oracle import ref_cpu as O
+    from hierarchicalprobabilistic3dhuman_amd import smpl_data
+    smpl_params = O.SMPLParams(smpl_data.synthetic_smpl_model(0), smpl_data.load_extra_joint_regressors(None),
+                               configs.SMPLX_EXTRA_VERTEX_IDS)
+
+    def oracle_smpl(body_pose, global_orient, betas, pose2rot=True):
+        o = O.smpl_forward(smpl_params, betas=betas, body_pose=body_pose, global_orient=global_orient, pose2rot=pose2rot)
+        return SimpleNamespace(vertices=o["vertices"], joints=o["joints"])
+
+    glob_R = ref_rtu.rot6d_to_rotmat(glob[:1])
+    out["a9_glob_rotmats"] = glob_R
+    for tag, mean_shape in (("mean", True), ("samp", False)):
+        torch.manual_seed(5)
+        with torch.no_grad():
+            unc, vs, js = ref_vertex_unc(U[:1], S[:1], V[:1], torch.distributions.Normal(sd.loc[:1], sd.scale[:1]), glob_R, 4,
+                                         oracle_smpl, use_mean_shape=mean_shape)
+        assert unc.shape == (6890,) and vs.shape == (4, 6890, 3) and js.shape == (4, 90, 3)
+        out["a9_%s_unc" % tag], out["a9_%s_joints" % tag] = unc, js
+        out["a9_%s_verts_sub" % tag] = vs[:, ::10].contiguous()          # every 10th vertex keeps the fixture small
     # a concentration sweep with random proper U, V (SURVEY.md section 8(d) stress set)
     S_sweep = torch.tensor([[0., 0., 0.], [1.9, .78, .6], [5., 5., 5.], [20., 15., 10.], [100., 80., 50.],
                             [500., 400., 300.], [50., 1., .1]])

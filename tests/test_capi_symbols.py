@@ -12,10 +12,16 @@ from hierarchicalprobabilistic3dhuman_amd import _capi, build as hps_build
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "hps.h")).read()
+def _declared_symbols(header="hps.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(hps_[a-z0-9_]+)\s*\(", text)))
+
+
+def _exported(path):
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
+    return {line.split()[-1] for line in out.splitlines() if line.split()[-1].startswith("hps_")}
 
 
 def test_library_builds_and_exports_all_declared_symbols():
@@ -26,6 +32,17 @@ def test_library_builds_and_exports_all_declared_symbols():
     for name in declared:
         assert hasattr(lib, name), "libhps.so does not export %s" % name
     assert set(declared) == set(_capi.EXPORTED_SYMBOLS), "ctypes prototypes out of sync with include/hps.h"
+    # the product library is the product path only: exactly the declared ABI, no tuning switches, no legacy kernels
+    assert _exported(path) == set(declared)
+    assert not [n for n in declared if n.startswith("hps_dev_")]
+
+
+def test_dev_library_is_separate_and_exports_the_dev_header():
+    path = hps_build.build(force=False, verbose=False, dev=True)
+    dev_declared = set(_declared_symbols("hps_dev.h")) - set(_declared_symbols())
+    assert dev_declared == set(_capi.DEV_EXPORTED_SYMBOLS), "ctypes prototypes out of sync with include/hps_dev.h"
+    assert _exported(path) == dev_declared | set(_declared_symbols())
+    assert os.path.basename(path) == "libhps_dev.so" and path != _capi.LIB_PATH
 
 
 def test_version_and_error_string():

@@ -29,11 +29,16 @@ def test_rotmat_route_matches_oracle(M, dev, smpl_gpu, smpl_assets):
     R = O.batch_rodrigues(aa.view(-1, 3)).view(M, 24, 3, 3)
     ref = O.smpl_forward(p, betas=betas, body_pose=R[:, 1:], global_orient=R[:, :1], pose2rot=False, transl=transl,
                          return_intermediates=True)
-    smpl_gpu.keep_intermediates = True
-    out = smpl_gpu(betas=betas.to(dev), body_pose=R[:, 1:].to(dev), global_orient=R[:, :1].to(dev), pose2rot=False,
-                   transl=transl.to(dev))
-    L = smpl_gpu._last
-    smpl_gpu.keep_intermediates = False
+    args = dict(betas=betas.to(dev), body_pose=R[:, 1:].to(dev), global_orient=R[:, :1].to(dev), pose2rot=False,
+                transl=transl.to(dev))
+    out = smpl_gpu(**args)                                    # product path: fused blend + skinning kernel
+    smpl_gpu.keep_intermediates, smpl_gpu.fused_mesh = True, False
+    try:
+        out_unfused = smpl_gpu(**args)                        # unfused pair: exposes v_posed
+        L = smpl_gpu._last
+    finally:
+        smpl_gpu.keep_intermediates, smpl_gpu.fused_mesh = False, True
+    assert torch.equal(out.vertices, out_unfused.vertices) and torch.equal(out.joints, out_unfused.joints)
     assert maxerr(L["v_posed"], ref["v_posed"]) <= TOL
     assert maxerr(L["a"].view(M, 24, 3, 4), ref["A"][:, :, :3, :]) <= TOL
     assert maxerr(L["j_posed"], ref["J_posed"]) <= TOL
@@ -99,6 +104,9 @@ def test_dense_skin_weights_use_wider_kernel(dev, smpl_assets):
         ref = O.smpl_forward(p2, betas=betas, body_pose=aa[:, 1:].reshape(3, 69), global_orient=aa[:, 0])
         out = smpl(betas=betas.to(dev), body_pose=aa[:, 1:].reshape(3, 69).to(dev), global_orient=aa[:, 0].to(dev))
         assert maxerr(out.vertices, ref["vertices"]) <= TOL
+        smpl.fused_mesh = False                                  # the unfused pair's K = 8 / 24 instantiations: same bits
+        out_u = smpl(betas=betas.to(dev), body_pose=aa[:, 1:].reshape(3, 69).to(dev), global_orient=aa[:, 0].to(dev))
+        assert torch.equal(out.vertices, out_u.vertices)
 
 
 def test_full_size_properties_6528_meshes(dev, smpl_gpu, smpl_assets):
@@ -145,13 +153,39 @@ def test_blend_kernels_agree_bitwise(dev, smpl_gpu):
     for M in (1, 130, 700):
         betas = torch.randn(M, 10, generator=g).to(dev)
         pose = (torch.randn(M, 72, generator=g) * 0.4).to(dev)
-        ref = smpl_gpu(betas=betas, body_pose=pose[:, 3:], global_orient=pose[:, :3]).vertices.clone()
+        smpl_gpu.fused_mesh = False
         try:
-            _capi.call("hps_dev_blend_mode", 2)
-            got = smpl_gpu(betas=betas, body_pose=pose[:, 3:], global_orient=pose[:, :3]).vertices
+            ref = smpl_gpu(betas=betas, body_pose=pose[:, 3:], global_orient=pose[:, :3]).vertices.clone()
+            with _capi.dev_library():            # alternate kernels and their switches live in libhps_dev.so only
+                try:
+                    _capi.call("hps_dev_blend_mode", 2)
+                    got = smpl_gpu(betas=betas, body_pose=pose[:, 3:], global_orient=pose[:, :3]).vertices
+                finally:
+                    _capi.call("hps_dev_blend_mode", 0)
         finally:
-            _capi.call("hps_dev_blend_mode", 0)
+            smpl_gpu.fused_mesh = True
         assert torch.equal(got, ref), M
+
+
+@pytest.mark.parametrize("M", [1, 63, 64, 65, 130, 700, 6528])
+def test_fused_mesh_kernel_gives_the_bits_of_blend_plus_lbs(M, dev, smpl_gpu):
+    """hps_smpl_mesh_fused (GEMM tile skinned in the MFMA epilogue, no v_posed in HBM) against hps_smpl_blend followed by
+    hps_smpl_lbs -- the unfused definition SURVEY 8(d) counts the LBS bytes on: same MFMA k order and the same
+    skin_vertex arithmetic, so vertices and joints are bit-identical, for ragged mesh tiles and with a translation."""
+    g = torch.Generator().manual_seed(1000 + M)
+    betas = torch.randn(M, 10, generator=g).to(dev)
+    pose = (torch.randn(M, 72, generator=g) * 0.5).to(dev)
+    transl = torch.randn(M, 3, generator=g).to(dev) if M % 2 else None
+    args = dict(betas=betas, body_pose=pose[:, 3:], global_orient=pose[:, :3], transl=transl)
+    fused = smpl_gpu(**args)
+    smpl_gpu.fused_mesh = False
+    try:
+        unfused = smpl_gpu(**args)
+    finally:
+        smpl_gpu.fused_mesh = True
+    assert torch.isfinite(fused.vertices).all()
+    assert torch.equal(fused.vertices, unfused.vertices), float((fused.vertices - unfused.vertices).abs().max())
+    assert torch.equal(fused.joints, unfused.joints)
 
 
 def test_vertex_uncertainty_kernel(dev):
@@ -169,12 +203,13 @@ def test_vertex_uncertainty_kernel(dev):
         got_n = su.vertex_uncertainty(vv.to(dev))
         assert maxerr(got_n, want_n) <= 1e-5, n
         if n <= 100:
-            try:
-                for mode in (2, 3):
-                    _capi.call("hps_dev_unc_mode", mode)
-                    assert torch.equal(su.vertex_uncertainty(vv.to(dev)), got_n), (n, mode)
-            finally:
-                _capi.call("hps_dev_unc_mode", 0)
+            with _capi.dev_library():
+                try:
+                    for mode in (2, 3):
+                        _capi.call("hps_dev_unc_mode", mode)
+                        assert torch.equal(su.vertex_uncertainty(vv.to(dev)), got_n), (n, mode)
+                finally:
+                    _capi.call("hps_dev_unc_mode", 0)
 
 
 def test_c_abi_rejects_unsupported_k(dev, smpl_gpu):
@@ -183,3 +218,6 @@ def test_c_abi_rejects_unsupported_k(dev, smpl_gpu):
     with pytest.raises(_capi.HpsError):
         _capi.call("hps_smpl_lbs", _capi.ptr(z), 3, _capi.ptr(z), _capi.iptr(zi), _capi.ptr(z), 5, 24, None, _capi.ptr(z), 1, 1,
                    _capi.stream())
+    with pytest.raises(_capi.HpsError):
+        _capi.call("hps_smpl_mesh_fused", _capi.ptr(z), _capi.ptr(z), _capi.ptr(z), _capi.ptr(z), _capi.iptr(zi), _capi.ptr(z),
+                   5, 24, None, _capi.ptr(z), 1, 1, 16, 64, 384, _capi.stream())
