@@ -27,6 +27,7 @@ from hierarchicalprobabilistic3dhuman_amd.predict_poseMF_shapeGaussian_net impor
 from hierarchicalprobabilistic3dhuman_amd.smpl_official import SMPL  # noqa: E402
 
 LBS_BYTES_PER_MESH = 166896          # 82,680 (v_posed) + 1,536 (A) + 82,680 (verts)
+BLEND_FLOP_PER_MESH = 2 * (207 + 10) * 3 * 6890   # pose blend 8.56 MFLOP + shape blend 0.41 MFLOP per mesh
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8 TB/s
 ENCODER_GFLOP_PER_IMAGE = 6.279      # 3.139 GMAC per 18x256x256 image
 MFMA_FP32_PEAK_TF = 157.3            # MI355X_MICROARCH.md: dense fp32 matrix peak
@@ -82,6 +83,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--num-samples", type=int, default=100)
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after another on one stream")
+    ap.add_argument("--unfused-mesh", action="store_true", help="blend GEMM + LBS as two kernels (the unfused definition) instead of the fused mesh kernel")
     ap.add_argument("--trace-steps", action="store_true", help="print host-side per-step times to stderr (debugging)")
     ap.add_argument("--cpu-images", type=int, default=16, help="images in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -102,6 +104,7 @@ def main():
     net_state = {k: v.clone() for k, v in net.state_dict().items()} if rank == 0 else None
     net = net.to(dev)
     smpl = SMPL(smpl_data.synthetic_smpl_model(0), batch_size=1, gender="neutral", num_betas=10).to(dev)
+    smpl.fused_mesh = not args.unfused_mesh
 
     lo, hi = sharding.shard_range(B * world, rank, world)               # weak scaling: B images per GPU
     x = synthetic_inputs(lo, hi).to(dev)
@@ -190,10 +193,14 @@ def main():
         secondary["sampler"] = {"avg_ms": t, "proposals_per_s": B * 23 * 8 * N / (t * 1e-3),
                                 "unit": "matrix-Fisher proposals/s (8N per image and joint, Philox)"}
 
+    fused = bool(getattr(smpl, "fused_mesh", False))
+    mesh_kernel = "hps::mesh_fused_kernel<4,0,24,false>" if fused else "hps::lbs_kernel<4,8,1>"
     # HBM traffic of the same kernel from the PMC counters: collected in separate rocprofv3 passes of this very
     # command (tools/collect_profiles.sh), corrected as MI355X_MICROARCH.md prescribes, committed under profiles/
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "lbs_pmc_latest.json")
+    pmc_name = "mesh_fused_pmc_latest.json" if fused else "lbs_pmc_latest.json"
+    pmc_path = os.path.join(ROOT, "profiles", pmc_name)
+    traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % pmc_name
     if os.path.exists(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)
@@ -216,12 +223,27 @@ def main():
                                    "poseMF_shapeGaussian head (seed 0), Philox sampling" % (B, N),
                        "images_per_gpu": B, "global_batch": B * world, "num_samples": N,
                        "meshes_per_step_per_gpu": M, "parallelism": "images sharded over %d GPU(s)" % world,
-                       "step_pipelining": "none" if args.no_pipeline else "encoder of step i+1 (own stream) overlaps the host-paced head of step i (high-priority stream); blend GEMM / LBS / joints of a batch run alone"},
-            "roofline": {"bound": "hbm", "kernel": "hps::lbs_kernel<4,8,1>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                       "mesh_kernel": "fused blend GEMM + LBS" if fused else "blend GEMM, then LBS",
+                       "step_pipelining": "none" if args.no_pipeline else "encoder of step i+1 (own stream) overlaps the host-paced head of step i (high-priority stream); the mesh kernels (pose prep / blend + LBS / joints) of a batch run alone"},
+            # The mesh kernel is FUSED (blend GEMM tile skinned in the MFMA epilogue, no v_posed round trip).  SURVEY 8(d):
+            # it is still reported against the UNFUSED LBS definition (166,896 B per mesh), over the fused kernel's
+            # whole launch time -- which also contains the 8.97 MFLOP/mesh blend GEMM that really bounds it (roofline_mfma).
+            "roofline": {"bound": "hbm", "kernel": mesh_kernel, "fused": fused,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "traffic_source": "profiles/lbs_pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
+                         "traffic_source": traffic_source if traffic else None,
                          "avg_launch_ms": lbs_avg_ms, "launches": len(lbs_ms),
-                         "algorithmic_bytes_per_launch": LBS_BYTES_PER_MESH * M},
+                         "algorithmic_bytes_per_launch": LBS_BYTES_PER_MESH * M,
+                         "note": ("fused kernel: the launch time covers blend GEMM + skinning; the bytes are SURVEY 8(d)'s "
+                                  "unfused LBS definition (v_posed read + A read + verts write), of which only the verts "
+                                  "write still exists" if fused else "unfused hps_smpl_lbs launch")},
+            "roofline_mfma": ({"bound": "mfma", "kernel": mesh_kernel, "achieved": BLEND_FLOP_PER_MESH * M / (lbs_avg_ms * 1e-3) / 1e12,
+                               "peak": MFMA_FP32_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": BLEND_FLOP_PER_MESH * M / (lbs_avg_ms * 1e-3) / 1e12 / MFMA_FP32_PEAK_TF,
+                               "algorithmic_flop_per_launch": BLEND_FLOP_PER_MESH * M,
+                               "note": "fp32 MFMA: the bound of the fused kernel (K = 217 algorithmic, 224 issued); fp32 VALU "
+                                       "work of the skinning epilogue does not overlap with fp32 MFMA on gfx950 "
+                                       "(tools/mfma_valu_overlap.hip)"} if fused and lbs_ms else None),
             "secondary": secondary,
             "metric_checksums": {"images": float(total[0]), "sum_unc": float(total[1]),
                                  "sum_abs_verts_mode": float(total[2]), "sum_abs_joints_samples": float(total[3])},

@@ -32,7 +32,8 @@ _PROTOTYPES = {
     "hps_smpl_mesh_fused_np": [_I],
     "hps_smpl_joints": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
     "hps_vertex_uncertainty": [_P, _P, _I, _I, _I, _P],
-    "hps_mf_sample": [_P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _c.c_float, _P, _P, _P, _c.c_uint64,
+    "hps_query_workspace": [_I, _c.c_int64, _c.c_int64, _c.c_int64],
+    "hps_mf_sample": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _c.c_float, _P, _P, _P, _c.c_uint64,
                       _c.c_int64, _I, _P, _P, _P, _P],
     "hps_quat_to_rotmat": [_P, _P, _I, _P],
     "hps_rot6d_to_rotmat": [_P, _P, _I, _P],
@@ -68,9 +69,9 @@ _DEV_PROTOTYPES = {
     "hps_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "hps_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P],
     "hps_global_avgpool": [_P, _P, _I, _I, _I, _P],
-    "hps_dev_mesh_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "hps_dev_mesh_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
 }
-_RESTYPES = {"hps_last_error": _c.c_char_p}
+_RESTYPES = {"hps_last_error": _c.c_char_p, "hps_query_workspace": _c.c_int64}
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
 DEV_EXPORTED_SYMBOLS = tuple(_DEV_PROTOTYPES)
@@ -139,6 +140,12 @@ def require_device(t, what="tensor"):
         raise HpsError(
             "%s must live on a HIP (MI355X) device; this package has no CPU path "
             "(the CPU oracle under oracle/ is test infrastructure only)" % what)
+    if t.device.index != torch.cuda.current_device():
+        # kernels are launched on the CURRENT device's current stream (stream()): a tensor of another device would be
+        # addressed from the wrong GPU.  The reference's `device` arguments become torch.cuda.set_device(device).
+        raise HpsError("%s lives on cuda:%d but the current device is cuda:%d; call torch.cuda.set_device(%d) "
+                       "(or use `with torch.cuda.device(...)`) before calling into libhps"
+                       % (what, t.device.index, torch.cuda.current_device(), t.device.index))
 
 
 def ptr(t, dtype=torch.float32, what="tensor"):
@@ -167,6 +174,17 @@ def call(name, *args):
     if rc != 0:
         msg = lib.hps_last_error()
         raise HpsError("%s failed (code %d): %s" % (name, rc, msg.decode() if msg else ""))
+
+
+WS_CONV_SPLITK, WS_SMPL_MP, WS_SMPL_XT, WS_SMPL_A, WS_SMPL_VPOSED, WS_HEAD_F, WS_HEAD_USV = range(7)
+
+
+def query_workspace(what, d0=0, d1=0, d2=0):
+    """include/hps.h: hps_query_workspace -- bytes (HPS_WS_SMPL_MP: a count) of a caller-provided scratch buffer."""
+    n = load(dev=_use_dev).hps_query_workspace(int(what), int(d0), int(d1), int(d2))
+    if n < 0:
+        raise HpsError("hps_query_workspace(%d, %d, %d, %d) failed" % (what, d0, d1, d2))
+    return int(n)
 
 
 def f32c(t):

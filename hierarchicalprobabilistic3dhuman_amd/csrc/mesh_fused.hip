@@ -9,17 +9,24 @@
 // the epilogue, so the only HBM stream left is the write of verts.  The kernel is bound by the fp32 MFMA rate
 // (2 * 224 * 3 * 6 890 FLOP per mesh), not by HBM.
 //
-// Workgroup = 512 threads = 8 waves as 2 (mesh groups of 32) x 4 (vertex groups of 32); tile = 64 meshes x 128 vertices.
-// The blend matrix is stored panel-permuted (bmat_p): the 384 columns of a 128-vertex panel are [x of the 128 vertices |
+// Workgroup = 256 threads = 4 waves as 2 (mesh groups of 32) x 2 (vertex groups of 32); tile = 64 meshes x 64 vertices.
+// The blend matrix is stored panel-permuted (bmat_p): the 192 columns of a 64-vertex panel are [x of the 64 vertices |
 // y | z], so the three 32x32 MFMA tiles of a wave are the x, y and z coordinates of the SAME 32 vertices: with the mesh
 // fragment as the MFMA's row operand and the blend-matrix fragment as its column operand a lane ends with one vertex
 // (column = lane & 31) and 16 meshes (rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) -- x, y, z in registers, no transpose.
 // K loop: 16-row chunks of both operands (k-major, exactly as they lie in HBM) land in LDS by LDS-DMA, one chunk ahead;
 // fragments are conflict-free 32-lane row reads.  MFMA k order = blend_gemm_kernel's (pairs (2i, 2i+1), ascending):
-// identical bits.  Epilogue: the 64 meshes' skinning transforms A (64 x J x 12 floats = 72 KiB for SMPL) are DMA'd
-// into the LDS that held the operand chunks, and every lane skins its vertex for its 16 meshes with skin_vertex<K>
-// (the function lbs_kernel uses) and stores 12-byte records: 384 contiguous bytes per mesh per wave instruction.
-// Two workgroups share a CU (LDS 72 KiB each), so one's epilogue (VALU / LDS / stores) runs under the other's MFMAs.
+// identical bits.  Epilogue: the skinning transforms A of the tile's meshes are DMA'd into the LDS that held the operand
+// chunks, in two passes of 32 meshes (36 KiB for SMPL: the first / second half of each wave's 32 meshes), and every lane
+// skins its vertex for its 16 meshes with skin_vertex<K> (the function lbs_kernel uses) and stores 12-byte records:
+// 384 contiguous bytes per mesh per wave instruction.
+//
+// Why small workgroups: tools/mfma_valu_overlap.hip shows that on gfx950 fp32 VALU work does NOT overlap with
+// v_mfma_f32_32x32x2_f32, neither in one wave nor across the waves of a SIMD (times add) -- so the epilogue's VALU
+// work is a fixed cost and what can be hidden is only latency (operand / A DMA, barriers, stores).  36 KiB of LDS and
+// <= 128 registers put four independent workgroups on a CU (one wave of each per SIMD), each in its own phase.  The first
+// version (512 threads, 64 meshes x 128 vertices, all 72 KiB of A at once: two workgroups per CU) ran 0.60 ms at 6 528
+// meshes against 0.46 ms for its K loop alone.
 // Block -> (mesh tile, panel): block ids congruent mod 8 (one XCD) own the same mesh tiles, and every XCD walks the
 // panels in order, so an XCD's L2 holds its own xt / A slices plus the few panels in flight; bmat_p streams from the
 // memory-side cache once per XCD.
@@ -32,39 +39,36 @@ namespace hps {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int FM = 64;            // meshes per workgroup tile
-constexpr int FV = 128;           // vertices per panel
+constexpr int FV = 64;            // vertices per panel
 constexpr int FN = 3 * FV;        // blend-matrix columns per panel
 constexpr int FBK = 16;           // K rows per chunk
-constexpr int F_STAGGER = 8;       // start delay of second-slot workgroups, in s_sleep(127) units (~3.4 us each)
-constexpr int F_CHUNK_FLOATS = FBK * (FM + FN);          // 7 168 floats = 28 KiB: [FBK][FM] then [FBK][FN]
+constexpr int FT = 256;           // threads per workgroup
+constexpr int FW = FT / 64;       // waves
+constexpr int F_CHUNK_FLOATS = FBK * (FM + FN);          // 4 096 floats = 16 KiB: [FBK][FM] then [FBK][FN]
+constexpr int F_XP = FBK * FM / 256;                     // 1 KiB DMA pieces of the mesh operand per chunk (4)
+constexpr int F_BP = FBK * FN / 256;                     // ... of the blend matrix per chunk (12)
+static_assert(F_XP == FW && F_BP % FW == 0, "DMA pieces must divide evenly over the waves");
 
 // ABL: profiling ablations, dev library only (hps_dev_mesh_fused); the product instantiates ABL = 0.
 // JC: joints per mesh as a compile-time constant (24 = SMPL: every LDS offset of the epilogue folds into an immediate), 0 = runtime J;
 // HAS_T: a per-mesh translation is added (smplx SMPL.forward step (7)).
 template <int K, int ABL, int JC, bool HAS_T>
-__global__ __launch_bounds__(512, 4) void mesh_fused_kernel(
+__global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
     const float* __restrict__ xt, const float* __restrict__ bmat_p, const float* __restrict__ v_template,
     const float* __restrict__ a, const int32_t* __restrict__ w_idx, const float* __restrict__ w_val, int J,
     const float* __restrict__ transl, f3* __restrict__ verts, int M, int V, int kp, int mp, int np, int tiles_m,
-    int tiles_m_per_xcd, int stagger) {
+    int tiles_m_per_xcd) {
     typedef __attribute__((address_space(3))) void* lptr_t;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // union: 2 operand chunks | A of the tile's meshes
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // union: 2 operand chunks | A of 32 of the tile's meshes
 
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     const int tile_m = (local % tiles_m_per_xcd) * 8 + xcd, panel = local / tiles_m_per_xcd;
     if (tile_m >= tiles_m) return;
     const int m0 = tile_m * FM;
-    // De-phase the two workgroups of a CU.  All workgroups start together and take the same time, so without this the
-    // pair on a CU stays in lock step: both in the K loop (sharing the MFMA pipe), then both in the skinning epilogue
-    // (MFMA pipe idle) -- measured: product 0.64 ms = K loop alone 0.46 ms + epilogue alone 0.18 ms, no overlap.  The
-    // second-slot workgroups of the first dispatch round (ids 256..511: the first 256 ids fill one slot of every CU)
-    // start late by about half a tile; every later workgroup inherits the offset of the slot it takes over.
-    if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
-        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kl = lane >> 5, il = lane & 31;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave >> 1, wn = wave & 1;
 
     // this lane's vertex and its skinning weights (kept in registers through the K loop)
     const int v = panel * FV + wn * 32 + il;
@@ -79,27 +83,27 @@ __global__ __launch_bounds__(512, 4) void mesh_fused_kernel(
     }
     const f3 vt = reinterpret_cast<const f3*>(v_template)[vc];
 
-    // LDS-DMA pieces (1 KiB each): a chunk is 4 pieces of xt rows ([FBK][FM]) and 24 of bmat_p rows ([FBK][FN]);
-    // wave w moves blend-matrix pieces w, w + 8, w + 16 and, for w < 4, mesh-operand piece w.
-    unsigned b_off[3];
+    // LDS-DMA pieces (1 KiB each): a chunk is F_XP pieces of xt rows ([FBK][FM]) and F_BP of bmat_p rows ([FBK][FN]);
+    // wave w moves mesh-operand piece w and blend-matrix pieces w, w + 4, w + 8.
+    unsigned b_off[F_BP / FW];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int f = 256 * (wave + 8 * j) + 4 * lane;
+    for (int j = 0; j < F_BP / FW; ++j) {
+        const int f = 256 * (wave + FW * j) + 4 * lane;
         b_off[j] = (unsigned)(((f / FN) * np + (f % FN)) * 4);
     }
     unsigned x_off;
     {
-        const int f = 256 * (wave & 3) + 4 * lane;
+        const int f = 256 * wave + 4 * lane;
         x_off = (unsigned)(((f / FM) * mp + (f % FM)) * 4);
     }
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)(smem);
     const float* b_src = bmat_p + (size_t)panel * FN;
     const float* x_src = xt + m0;
     auto dma_chunk = [&](int buf) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf * F_CHUNK_FLOATS * 4);
-        if (wave < 4) lds_dma16(x_off, x_src, base + (unsigned)wave * 1024);
+        const unsigned base = lds0 + (unsigned)buf * F_CHUNK_FLOATS * 4;
+        lds_dma16(x_off, x_src, base + (unsigned)wave * 1024);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) lds_dma16(b_off[j], b_src, base + FBK * FM * 4 + (unsigned)(wave + 8 * j) * 1024);
+        for (int j = 0; j < F_BP / FW; ++j) lds_dma16(b_off[j], b_src, base + FBK * FM * 4 + (unsigned)(wave + FW * j) * 1024);
         b_src += (size_t)FBK * np;
         x_src += (size_t)FBK * mp;
     };
@@ -146,59 +150,65 @@ __global__ __launch_bounds__(512, 4) void mesh_fused_kernel(
         if (t == 12345.678f) verts[0].x = t;
         return;
     }
-    // skinning transforms of the tile's meshes -> LDS (contiguous in HBM: meshes m0 .. m0 + 63, J * 12 floats each)
-    __syncthreads();                                       // operand chunks are dead
-    const int a_stride = JC ? JC * 12 : J * 12;
-    {
-        const unsigned valid = (unsigned)(min(FM, M - m0) * a_stride * 4);     // bytes that exist in `a`
-        const unsigned total = (unsigned)(FM * a_stride * 4);
-        const float* a_src = a + (size_t)m0 * a_stride;
-        for (unsigned piece = wave; piece * 1024u < total; piece += 8) {
-            const unsigned off = piece * 1024u + lane * 16u;
-            const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + piece * 1024u);
-            if (off < valid) lds_dma16(off, a_src, base);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 
-    // Branch-free skinning of the lane's vertex for its 16 meshes (MFMA C rows (r & 3) + 8 (r >> 2) + 4 kl of the wave's
-    // 32): the per-lane parts of every address are formed once, the per-r parts are compile-time / wave-uniform.
-    const int mrow0 = wm * 32 + 4 * kl;                    // the lane's first mesh within the tile
-    int aoff[K];                                           // float offset of A[mrow0][joint_k] in LDS
+    // Skinning, two passes of 32 meshes: pass p stages A of meshes [16 p, 16 p + 16) and [32 + 16 p, 32 + 16 p + 16) of the
+    // tile -- the meshes of accumulator registers r = 8 p .. 8 p + 7 of both mesh groups -- as LDS slots 0..15 and 16..31.
+    const int a_stride = JC ? JC * 12 : J * 12;
+    const int half_bytes = 16 * a_stride * 4;              // one contiguous source range; a multiple of 1 KiB (J * 768)
+    const int slot0 = wm * 16 + 4 * kl;                    // the lane's first slot
+    int aoff[K];                                           // float offset of A[slot0][joint_k] in LDS
 #pragma unroll
-    for (int k = 0; k < K; ++k) aoff[k] = mrow0 * a_stride + idx[k];
+    for (int k = 0; k < K; ++k) aoff[k] = slot0 * a_stride + idx[k];
     char* const vbase = reinterpret_cast<char*>(verts) + (size_t)(m0 + wm * 32) * V * 12;      // wave-uniform
     const unsigned voff = ((unsigned)(4 * kl) * (unsigned)V + (unsigned)v) * 12u;              // per lane
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int dr = (r & 3) + 8 * (r >> 2);             // mesh row step of accumulator register r
-        const int m = m0 + mrow0 + dr;
-        float tx = 0.f, ty = 0.f, tz = 0.f;
-        if (HAS_T) {
-            const float* t = transl + (size_t)min(m, M - 1) * 3;
-            tx = t[0]; ty = t[1]; tz = t[2];
-        }
-        f3 pv;
-        pv.x = vt.x + acc[0][r]; pv.y = vt.y + acc[1][r]; pv.z = vt.z + acc[2][r];
-        f3 o;
-        if (ABL == 1) {
-            o = pv;
-        } else {
-            int ao[K];
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();                                   // operand chunks / the previous pass's transforms are dead
 #pragma unroll
-            for (int k = 0; k < K; ++k) ao[k] = aoff[k] + dr * a_stride;
-            o = skin_vertex<K>(smem, ao, w, pv, tx, ty, tz);
+        for (int h = 0; h < 2; ++h) {
+            const int mh = m0 + 32 * h + 16 * pass;                                              // first mesh of this range
+            const int valid = max(0, min(16, M - mh)) * a_stride * 4;                          // bytes that exist in `a`
+            const float* a_src = a + (size_t)mh * a_stride;
+            for (int piece = wave; piece * 1024 < half_bytes; piece += FW) {
+                const int off = piece * 1024 + lane * 16;
+                if (off < valid) lds_dma16((unsigned)off, a_src, lds0 + (unsigned)(h * half_bytes + piece * 1024));
+            }
         }
-        if (live_v && m < M) *reinterpret_cast<f3*>(vbase + (size_t)dr * V * 12 + voff) = o;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // branch-free: the per-lane parts of every address were formed once, the per-r parts are compile-time / wave-uniform
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int r = 8 * pass + q;
+            const int dr = (r & 3) + 8 * (r >> 2);         // mesh row step of accumulator register r (within the wave's 32)
+            const int ds = (q & 3) + 8 * (q >> 2);         // ... within the pass's 16 slots of this mesh group
+            const int m = m0 + wm * 32 + 4 * kl + dr;
+            float tx = 0.f, ty = 0.f, tz = 0.f;
+            if (HAS_T) {
+                const float* t = transl + (size_t)min(m, M - 1) * 3;
+                tx = t[0]; ty = t[1]; tz = t[2];
+            }
+            f3 pv;
+            pv.x = vt.x + acc[0][r]; pv.y = vt.y + acc[1][r]; pv.z = vt.z + acc[2][r];
+            f3 o;
+            if (ABL == 1) {
+                o = pv;
+            } else {
+                int ao[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) ao[k] = aoff[k] + ds * a_stride;
+                o = skin_vertex<K>(smem, ao, w, pv, tx, ty, tz);
+            }
+            if (live_v && m < M) *reinterpret_cast<f3*>(vbase + (size_t)dr * V * 12 + voff) = o;
+        }
     }
 }
 
 template <int K, int ABL, int JC, bool HAS_T>
 static int launch_fused_cfg(const float* xt, const float* bmat_p, const float* v_template, const float* a, const int32_t* w_idx,
                         const float* w_val, int J, const float* transl, float* verts, int M, int V, int kp, int mp, int np,
-                        int stagger, hipStream_t s) {
-    const size_t lds = (size_t)4 * max(2 * F_CHUNK_FLOATS, FM * J * 12);
+                        hipStream_t s) {
+    const size_t lds = (size_t)4 * max(2 * F_CHUNK_FLOATS, 32 * J * 12);
     static std::once_flag once;      // LDS above 64 KiB has to be granted once per kernel (no behaviour depends on it)
     std::call_once(once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mesh_fused_kernel<K, ABL, JC, HAS_T>),
@@ -206,19 +216,19 @@ static int launch_fused_cfg(const float* xt, const float* bmat_p, const float* v
     });
     const int tiles_m = ceil_div(M, FM), n_panels = ceil_div(V, FV);
     const int tiles_m_per_xcd = ceil_div(tiles_m, 8);
-    hipLaunchKernelGGL((mesh_fused_kernel<K, ABL, JC, HAS_T>), dim3(tiles_m_per_xcd * 8 * n_panels), dim3(512), lds, s, xt, bmat_p, v_template,
-                       a, w_idx, w_val, J, transl, reinterpret_cast<f3*>(verts), M, V, kp, mp, np, tiles_m, tiles_m_per_xcd, stagger);
+    hipLaunchKernelGGL((mesh_fused_kernel<K, ABL, JC, HAS_T>), dim3(tiles_m_per_xcd * 8 * n_panels), dim3(FT), lds, s, xt, bmat_p, v_template,
+                       a, w_idx, w_val, J, transl, reinterpret_cast<f3*>(verts), M, V, kp, mp, np, tiles_m, tiles_m_per_xcd);
     return check_launch("hps_smpl_mesh_fused");
 }
 
 template <int K, int ABL = 0>
 static int launch_fused(const float* xt, const float* bmat_p, const float* v_template, const float* a, const int32_t* w_idx,
                         const float* w_val, int J, const float* transl, float* verts, int M, int V, int kp, int mp, int np,
-                        int stagger, hipStream_t s) {
-    if (J == 24 && !transl) return launch_fused_cfg<K, ABL, 24, false>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, stagger, s);
-    if (J == 24) return launch_fused_cfg<K, ABL, 24, true>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, stagger, s);
-    if (!transl) return launch_fused_cfg<K, ABL, 0, false>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, stagger, s);
-    return launch_fused_cfg<K, ABL, 0, true>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, stagger, s);
+                        hipStream_t s) {
+    if (J == 24 && !transl) return launch_fused_cfg<K, ABL, 24, false>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s);
+    if (J == 24) return launch_fused_cfg<K, ABL, 24, true>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s);
+    if (!transl) return launch_fused_cfg<K, ABL, 0, false>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s);
+    return launch_fused_cfg<K, ABL, 0, true>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s);
 }
 
 }  // namespace hps
@@ -245,10 +255,10 @@ extern "C" int hps_smpl_mesh_fused(const float* xt, const float* bmat_p, const f
     if (rc != HPS_OK) return rc > 0 ? HPS_OK : rc;
     hipStream_t s = (hipStream_t)stream;
     switch (K) {
-        case 4: return launch_fused<4>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, F_STAGGER, s);
-        case 8: return launch_fused<8>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, F_STAGGER, s);
-        case 12: return launch_fused<12>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, F_STAGGER, s);
-        case 24: return launch_fused<24>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, F_STAGGER, s);
+        case 4: return launch_fused<4>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, s);
+        case 8: return launch_fused<8>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, s);
+        case 12: return launch_fused<12>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, s);
+        case 24: return launch_fused<24>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, s);
         default: set_error("hps_smpl_mesh_fused: K=%d unsupported (4, 8, 12, 24)", K); return HPS_E_UNSUPPORTED;
     }
 }
@@ -256,17 +266,17 @@ extern "C" int hps_smpl_mesh_fused(const float* xt, const float* bmat_p, const f
 #ifdef HPS_DEV_BUILD
 extern "C" int hps_dev_mesh_fused(const float* xt, const float* bmat_p, const float* v_template, const float* a,
                                   const int32_t* w_idx, const float* w_val, int K, int num_joints, const float* transl,
-                                  float* verts, int M, int V, int kp, int mp, int np, int ablate, int stagger, hps_stream_t stream) {
+                                  float* verts, int M, int V, int kp, int mp, int np, int ablate, hps_stream_t stream) {
     const int rc = fused_check_args(xt, bmat_p, v_template, a, w_idx, w_val, verts, num_joints, M, V, kp, mp, np);
     if (rc != HPS_OK) return rc > 0 ? HPS_OK : rc;
     if (K != 4) return bad_arg("hps_dev_mesh_fused: K = 4 only");
     hipStream_t s = (hipStream_t)stream;
     switch (ablate) {
-        case 0: return launch_fused<4, 0>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, stagger, s);
-        case 1: return launch_fused<4, 1>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, stagger, s);
-        case 2: return launch_fused<4, 2>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, stagger, s);
-        case 3: return launch_fused<4, 3>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, stagger, s);
-        case 4: return launch_fused<4, 4>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, stagger, s);
+        case 0: return launch_fused<4, 0>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, s);
+        case 1: return launch_fused<4, 1>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, s);
+        case 2: return launch_fused<4, 2>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, s);
+        case 3: return launch_fused<4, 3>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, s);
+        case 4: return launch_fused<4, 4>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, s);
         default: return bad_arg("hps_dev_mesh_fused: ablate 0..4");
     }
 }

@@ -39,7 +39,7 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
 
 __global__ __launch_bounds__(64) void mf_sample_kernel(
     const float* __restrict__ pose_u, const float* __restrict__ pose_s, const float* __restrict__ pose_v,
-    const float* __restrict__ bingham_a, int nj, int N, int n_prop, float b, float m_star, const float* __restrict__ eps, const float* __restrict__ wun,
+    const float* __restrict__ bingham_a, const float* __restrict__ acg_override, int nj, int N, int n_prop, float b, float m_star, const float* __restrict__ eps, const float* __restrict__ wun,
     const int32_t* __restrict__ draw_idx, uint64_t seed, int64_t call_offset, int max_rounds,
     float* __restrict__ r_out, float* __restrict__ quat_out, int32_t* __restrict__ accepted) {
     const int c = blockIdx.x;
@@ -69,6 +69,10 @@ __global__ __launch_bounds__(64) void mf_sample_kernel(
     for (int e = 0; e < 4; ++e) {
         Om[e] = 1.0f + 2.0f * A[e] / b;                         // :123
         sd[e] = 1.0f / sqrtf(Om[e]);                            // :124  Omega ** -0.5
+    }
+    if (acg_override) {                                         // caller-supplied Omega / Gaussian_std (:42-45 are only defaults)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { Om[e] = acg_override[(size_t)c * 8 + e]; sd[e] = acg_override[(size_t)c * 8 + 4 + e]; }
     }
 
     const bool host_noise = (eps != nullptr);
@@ -148,6 +152,14 @@ __global__ __launch_bounds__(64) void mf_sample_kernel(
         if (total >= N || host_noise) break;         // host noise: the caller supplies the next draw
     }
     if (lane == 0) accepted[c] = total;
+    if (total < N && !host_noise) {
+        // max_rounds exhausted (NaN / Inf concentrations make every accept test false): the reference would loop for ever
+        // printing 'Failed sampling' (:68-69).  Make the failure loud instead of leaving the outputs uninitialised.
+        const float nan = __builtin_nanf("");
+        for (int i = lane; i < N * 9; i += 64) r_out[(((size_t)img * N + i / 9) * nj + joint) * 9 + i % 9] = nan;
+        if (quat_out)
+            for (int i = lane; i < N * 4; i += 64) quat_out[(((size_t)img * N + i / 4) * nj + joint) * 4 + i % 4] = nan;
+    }
 }
 
 __global__ void quat_to_rotmat_kernel(const float* __restrict__ q, float* __restrict__ r, int n) {
@@ -191,7 +203,7 @@ __global__ void rodrigues_kernel(const float* __restrict__ aa, float* __restrict
 using namespace hps;
 
 extern "C" int hps_mf_sample(const float* pose_u, const float* pose_s, const float* pose_v, const float* bingham_a,
-                             int C, int num_joints, int num_samples, int n_prop, float b, float m_star, const float* eps, const float* w,
+                             const float* acg_override, int C, int num_joints, int num_samples, int n_prop, float b, float m_star, const float* eps, const float* w,
                              const int32_t* draw_idx, uint64_t seed, int64_t call_offset, int max_rounds,
                              float* r_out, float* quat_out, int32_t* accepted, hps_stream_t stream) {
     if (!pose_u || !pose_s || !pose_v || !r_out || !accepted) return bad_arg("hps_mf_sample: null pointer");
@@ -201,7 +213,7 @@ extern "C" int hps_mf_sample(const float* pose_u, const float* pose_s, const flo
     if (max_rounds < 1) max_rounds = 1;
     if (C == 0) return HPS_OK;
     hipLaunchKernelGGL(mf_sample_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, pose_u, pose_s, pose_v,
-                       bingham_a, num_joints, num_samples, n_prop, b, m_star, eps, w, draw_idx, seed, call_offset, max_rounds,
+                       bingham_a, acg_override, num_joints, num_samples, n_prop, b, m_star, eps, w, draw_idx, seed, call_offset, max_rounds,
                        r_out, quat_out, accepted);
     return check_launch("hps_mf_sample");
 }

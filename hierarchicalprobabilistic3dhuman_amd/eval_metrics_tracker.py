@@ -109,6 +109,11 @@ class EvalMetricsTracker:
         self.total_samples = int(round(float(total[0])))
         for i, k in enumerate(keys):
             self.metric_sums[k] = total[1 + i]
+        # per-frame vectors of every rank in rank order = dataset order (ranks own contiguous blocks: sharding.shard_dataset)
+        if self.save_per_frame_metrics and getattr(self, "per_frame_metrics", None) is not None and sharding.world_info()[1] > 1:
+            for m, chunks in self.per_frame_metrics.items():
+                local = torch.cat([c.reshape(-1) for c in chunks]).cpu().numpy() if chunks else np.zeros(0)
+                self.per_frame_metrics[m] = [torch.from_numpy(sharding.gather_per_frame(local))]
 
     def compute_final_metrics(self, verbose=True):
         """metrics/eval_metrics_tracker.py:332-368: per-point means (metres / pixels); prints millimetres for 3D metrics."""
@@ -127,7 +132,7 @@ class EvalMetricsTracker:
                 final[m] = float(self.metric_sums[m]) / (self.total_samples * num_per_sample)
             if verbose:
                 print(m, "{:.2f}".format(final[m] * mult))
-        if self.save_per_frame_metrics and self.save_path is not None:
+        if self.save_per_frame_metrics and self.save_path is not None and sharding.world_info()[0] == 0:
             for m in self.metrics_to_track:
                 if "samples" not in m:
                     np.save(os.path.join(self.save_path, m + "_per_frame.npy"),

@@ -5,8 +5,10 @@ Per batch: Canny + heat-maps -> net -> SMPL(mode) -> SMPL(T-pose, mean shape) ->
 SMPL(samples), SMPL(T-pose samples)] -> metrics on the device.  Differences from the reference, none of which change
 the numbers beyond fp32 rounding: any batch size (the reference's DataLoader uses 1); targets are posed from rotation
 matrices directly instead of going through cv2.Rodrigues' log map and back (:84-92); metric sums stay on the device
-and are reduced across ranks once at the end.  The silhouette / 2D-joint metrics need the pytorch3d renderer and the
-detector outputs and are out of scope.
+and are reduced across ranks once at the end.  Under torch.distributed every rank evaluates its contiguous block of
+``eval_dataset`` (sharding.shard_dataset) and the one collective sums the blocks; per-frame records are gathered in
+dataset order and rank 0 writes them.  The silhouette / 2D-joint metrics need the pytorch3d renderer and the detector
+outputs and are out of scope.
 
 The 3DPW frames and the licensed SMPL_{MALE,FEMALE}.pkl files are external assets; any ``eval_dataset`` yielding the
 item dict of data/pw3d_eval_dataset.py:72-77 works (tests use a synthetic one).
@@ -15,7 +17,7 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader
 
-from . import _capi
+from . import _capi, sharding
 from .eval_metrics_tracker import EvalMetricsTracker
 from .label_conversions import ALL_JOINTS_TO_H36M_MAP, H36M_TO_J14
 from .rigid_transform_utils import batch_rodrigues, rot6d_to_rotmat
@@ -30,6 +32,11 @@ def evaluate_pose_MF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mo
                                        edge_detect_model, device, eval_dataset, metrics, save_path, num_workers=4,
                                        pin_memory=True, save_per_frame_metrics=True, num_samples_for_metrics=10,
                                        sample_on_cpu=False, batch_size=1, reduce_across_ranks=True):
+    device = torch.device(device)
+    if device.type == "cuda":
+        torch.cuda.set_device(device)              # libhps launches on the current device's current stream
+    if reduce_across_ranks:
+        eval_dataset = sharding.shard_dataset(eval_dataset)          # this rank's contiguous block of frames
     loader = DataLoader(eval_dataset, batch_size=batch_size, shuffle=False, drop_last=False, num_workers=num_workers,
                         pin_memory=pin_memory)
     tracker = EvalMetricsTracker(metrics, save_path=save_path, save_per_frame_metrics=save_per_frame_metrics)
@@ -113,13 +120,19 @@ def evaluate_pose_MF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mo
                 poses.append(torch.cat([glob_R[:, None], mode], dim=1).cpu().numpy())
                 shapes.append(shape_dist.loc.cpu().numpy())
                 cams.append(cam.cpu().numpy())
+    from .sampling_utils import check_sampling
+    check_sampling()                                           # deferred: a sampling call that never reached N accepts
     if reduce_across_ranks:
         tracker.reduce_across_ranks()
-    final = tracker.compute_final_metrics()
+    final = tracker.compute_final_metrics(verbose=sharding.world_info()[0] == 0)
     if save_per_frame_metrics and save_path is not None:
         import os
-        np.save(os.path.join(save_path, "fname_per_frame.npy"), np.array(fnames))
-        np.save(os.path.join(save_path, "pose_per_frame.npy"), np.concatenate(poses, axis=0))
-        np.save(os.path.join(save_path, "shape_per_frame.npy"), np.concatenate(shapes, axis=0))
-        np.save(os.path.join(save_path, "cam_per_frame.npy"), np.concatenate(cams, axis=0))
+        cat = lambda parts, tail: np.concatenate(parts, axis=0) if parts else np.zeros((0,) + tail, np.float32)
+        records = {"fname_per_frame.npy": np.array(fnames), "pose_per_frame.npy": cat(poses, (24, 3, 3)),
+                   "shape_per_frame.npy": cat(shapes, (pose_shape_model.num_shape_params,)), "cam_per_frame.npy": cat(cams, (3,))}
+        if reduce_across_ranks:
+            records = {k: sharding.gather_per_frame(v) for k, v in records.items()}
+        if sharding.world_info()[0] == 0:
+            for name, arr in records.items():
+                np.save(os.path.join(save_path, name), arr)
     return final

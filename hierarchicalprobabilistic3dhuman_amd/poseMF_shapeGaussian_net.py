@@ -51,6 +51,11 @@ def immediate_parents_to_all_parents(immediate_parents):
     return all_parents
 
 
+def _invalidate_after_load(module, incompatible_keys):
+    """load_state_dict post hook (fires for sub-modules too); module level so that the module stays picklable."""
+    module.invalidate()
+
+
 class PoseMFShapeGaussianNet(nn.Module):
     def __init__(self, smpl_parents, config):
         super().__init__()
@@ -87,6 +92,7 @@ class PoseMFShapeGaussianNet(nn.Module):
         self.levels = [[j for j in range(self.num_joints) if depth[j] == d] for d in range(max(depth) + 1)]
         self._prepared = None
         self._pinned_bufs = {}
+        self.register_load_state_dict_post_hook(_invalidate_after_load)
         self.composite_head = True     # joint loop through hps_head_pose_levels (one call) instead of per-level Python
 
     # ---- kernel-side weights; rebuilt after .to() / load_state_dict ----
@@ -94,16 +100,32 @@ class PoseMFShapeGaussianNet(nn.Module):
         self._prepared = None
         return super()._apply(fn, *args, **kwargs)
 
-    def load_state_dict(self, *args, **kwargs):
+    def invalidate(self):
+        """Drop the kernel-side weight copies / pointer tables (rebuilt by the next forward).  Automatic after .to() and after
+        any load_state_dict that reaches this module, directly or through a parent (post hook); call it by hand after
+        editing parameters in place."""
         self._prepared = None
-        return super().load_state_dict(*args, **kwargs)
+
+    def __getstate__(self):
+        # copy.deepcopy / pickle: the pointer tables hold raw device addresses of THIS module's tensors and the staging
+        # buffers are page-locked host memory -- a copy must rebuild its own
+        state = self.__dict__.copy()
+        state["_prepared"] = None
+        state["_pinned_bufs"] = {}
+        return state
 
     def _pinned(self, name, numel):
-        """Reusable page-locked host staging buffer (fp32) of at least ``numel`` elements."""
-        buf = self._pinned_bufs.get(name)
+        """Reusable page-locked host staging buffer (fp32) of at least ``numel`` elements, one per (name, stream): the last
+        level's upload is still in flight when forward returns, and only a later forward ON THE SAME STREAM is ordered
+        behind it (its first stream synchronisation retires the copy) -- a forward on another stream gets its own buffer."""
+        stream = torch.cuda.current_stream()
+        key = (name, stream.cuda_stream)
+        buf = self._pinned_bufs.get(key)
         if buf is None or buf.numel() < numel:
+            if buf is not None:
+                stream.synchronize()          # never free a staging block with a copy in flight
             buf = torch.empty(max(numel, 1024), dtype=torch.float32, pin_memory=True)
-            self._pinned_bufs[name] = buf
+            self._pinned_bufs[key] = buf
         return buf[:numel]
 
     def prepare(self):
@@ -190,10 +212,12 @@ class PoseMFShapeGaussianNet(nn.Module):
             # the whole joint loop in one call across the C ABI (csrc/composite.hip: same launches, same order)
             sizes = p["level_sizes_host"]
             max_n = int(sizes.max())
-            f_dev = torch.empty(B * max_n * 9, **f32)
-            usv_dev = torch.empty(B * max_n * 21, **f32)
-            f_host = self._pinned("f", B * max_n * 9)
-            usv_host = self._pinned("usv", B * max_n * 21)
+            n_f = _capi.query_workspace(_capi.WS_HEAD_F, B, max_n) // 4
+            n_usv = _capi.query_workspace(_capi.WS_HEAD_USV, B, max_n) // 4
+            f_dev = torch.empty(n_f, **f32)
+            usv_dev = torch.empty(n_usv, **f32)
+            f_host = self._pinned("f", n_f)
+            usv_host = self._pinned("usv", n_usv)
             VP = _capi._P
             _capi.call("hps_head_pose_levels", P(embed), embed_dim, embed_dim // 2, _capi.iptr(p["level_joints"]),
                        VP(sizes.data_ptr()), len(p["levels"]), _capi.iptr(p["anc_ptr"]), _capi.iptr(p["anc_idx"]),

@@ -3,10 +3,10 @@ predict/predict_poseMF_shapeGaussian_net.py:103-165 (``infer``) and a ``predict_
 with the reference's signature (:19-32) that feeds it.
 
 Everything between the proxy representation and the sampled meshes runs on the device through
-libhps.so.  The stages before it (image IO, HRNet keypoints, cropping, Canny edges, heatmaps; :61-100) and
-after it (rendering, PNG writing; :167-333) are out of scope and stay
-injected objects: ``hrnet_model`` / ``edge_detect_model`` / ``object_detect_model`` are whatever the caller
-built, and ``proxy_rep_fn`` may replace the whole front end.
+libhps.so.  The front end before it (:61-100) is assembled from the injected ``hrnet_model`` / ``object_detect_model``
+(the detectors themselves are out of scope), the crop glue of image_utils / predict_hrnet
+and the Canny / heat-map kernels of SURVEY 8(f)1; ``proxy_rep_fn`` may replace it.  What comes after (rendering, PNG
+writing; :167-333) is out of scope (rows 14, 20): results go to ``result_fn`` or to .pt files.
 """
 import os
 
@@ -14,7 +14,7 @@ import torch
 
 from . import _capi
 from .rigid_transform_utils import rot6d_to_rotmat, batch_rodrigues
-from .sampling_utils import pose_matrix_fisher_sampling_torch, vertex_uncertainty
+from .sampling_utils import pose_matrix_fisher_sampling_torch, vertex_uncertainty, check_sampling
 from .label_conversions import make_proxy_representation
 
 
@@ -179,15 +179,18 @@ def predict_poseMF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mode
                                      result_fn=None):
     """Signature of predict/predict_poseMF_shapeGaussian_net.py:19-32 plus three keyword extensions.
 
-    proxy_rep_fn(image_path) -> (1,18,D,D) tensor replaces the reference's front end (:61-100: cv2 image
-    load, HRNet, crop, Canny, heatmaps), which depends on cv2 / torchvision detectors that are outside the
-    hot path; without it the injected hrnet_model / edge_detect_model must be callables with the
-    reference's interfaces and cv2 must be importable.  result_fn(image_name, result_dict) receives the
+    Called exactly like the reference (run_predict.py:77-89) it runs the reference's front end (:61-100) on the injected
+    ``hrnet_model`` / ``object_detect_model`` (any callables with the reference's interfaces) and ``edge_detect_model``
+    (canny_edge_detector.CannyEdgeDetector), image files read by cv2 or PIL.  proxy_rep_fn(image_path) -> (1,18,D,D) tensor
+    optionally replaces that whole front end.  result_fn(image_name, result_dict) receives the
     outputs instead of the reference's pytorch3d renderer; by default vertices / joints / uncertainties are
     saved as <save_dir>/<image>.pt.
     """
+    device = torch.device(device)
+    if device.type == "cuda":
+        torch.cuda.set_device(device)              # libhps launches on the current device's current stream
     pose_shape_model.eval()
-    image_fnames = sorted(f for f in os.listdir(image_dir) if f.lower().endswith((".png", ".jpg", ".jpeg")))
+    image_fnames = sorted(f for f in os.listdir(image_dir) if f.lower().endswith((".png", ".jpg", ".jpeg", ".npy")))
     if proxy_rep_fn is None:
         proxy_rep_fn = _reference_front_end(pose_shape_cfg, hrnet_model, hrnet_cfg, edge_detect_model,
                                             object_detect_model, joints2Dvisib_threshold, device)
@@ -196,6 +199,7 @@ def predict_poseMF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mode
         names = image_fnames[i0:i0 + batch_size]
         proxy = torch.cat([proxy_rep_fn(os.path.join(image_dir, n)).to(device).float() for n in names], dim=0)
         res = infer(pose_shape_model, smpl_model, proxy, num_samples=num_samples, use_mean_shape=True)
+        check_sampling()
         for k, n in enumerate(names):
             item = {key: val[k] for key, val in res.items()}
             if result_fn is not None:
@@ -206,14 +210,47 @@ def predict_poseMF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mode
                            os.path.join(save_dir, os.path.splitext(n)[0] + ".pt"))
 
 
+def load_rgb_image(path):
+    """predict/...:63: the image as (H,W,3) uint8 RGB.  cv2 when it is installed (what the reference uses), PIL otherwise;
+    ``.npy`` files holding such an array are accepted too."""
+    import numpy as np
+    if path.lower().endswith(".npy"):
+        return np.load(path)
+    try:
+        import cv2
+        return cv2.cvtColor(cv2.imread(path), cv2.COLOR_BGR2RGB)
+    except ImportError:
+        from PIL import Image
+        return np.asarray(Image.open(path).convert("RGB"))
+
+
 def _reference_front_end(pose_shape_cfg, hrnet_model, hrnet_cfg, edge_detect_model, object_detect_model,
                          joints2Dvisib_threshold, device):
-    """Front end of predict/...:61-100 assembled from the injected reference-interface objects."""
-    try:
-        import cv2  # noqa: F401
-    except ImportError as e:
-        raise _capi.HpsError(
-            "the image front end (cv2 + HRNet + Canny, predict/predict_poseMF_shapeGaussian_net.py:61-100) is "
-            "outside this package's hot path; pass proxy_rep_fn= or install cv2 and inject the reference's "
-            "hrnet_model / edge_detect_model") from e
-    raise _capi.HpsError("pass proxy_rep_fn=: the HRNet/Canny front end is not part of this package")
+    """predict/predict_poseMF_shapeGaussian_net.py:61-100 assembled from the injected reference-interface objects:
+    image -> person box + HRNet keypoints (predict_hrnet) -> crop to the proxy-representation size -> Canny edges and
+    visibility-masked Gaussian heat-maps (the hps_canny_edges / hps_proxy_rep kernels).  Returns image_path -> (1,18,D,D)."""
+    from .predict_hrnet import predict_hrnet
+    from .image_utils import batch_crop_pytorch_affine
+    hrnet_model.eval()
+    if object_detect_model is not None:
+        object_detect_model.eval()
+    D = pose_shape_cfg.DATA.PROXY_REP_SIZE
+
+    @torch.no_grad()
+    def front_end(image_path):
+        image = torch.from_numpy(load_rgb_image(image_path).transpose(2, 0, 1).copy()).float().to(device) / 255.0       # :63-65
+        hr = predict_hrnet(hrnet_model=hrnet_model, hrnet_config=hrnet_cfg, object_detect_model=object_detect_model,
+                           image=image, object_detect_threshold=pose_shape_cfg.DATA.BBOX_THRESHOLD,
+                           bbox_scale_factor=pose_shape_cfg.DATA.BBOX_SCALE_FACTOR)                                 # :67-72
+        crop_h, crop_w = hr["cropped_image"].shape[1:]
+        centre = torch.tensor([[crop_h, crop_w]], dtype=torch.float32, device=device) * 0.5                        # :75-78
+        height = torch.tensor([crop_h], dtype=torch.float32, device=device)                                        # :79-81
+        cropped = batch_crop_pytorch_affine(input_wh=(hrnet_cfg.MODEL.IMAGE_SIZE[0], hrnet_cfg.MODEL.IMAGE_SIZE[1]),
+                                            output_wh=(D, D), num_to_crop=1, device=device, joints2D=hr["joints2D"][None],
+                                            rgb=hr["cropped_image"][None], bbox_centres=centre, bbox_heights=height,
+                                            bbox_widths=height.clone(), orig_scale_factor=1.0)                      # :82-91
+        visib = hr["joints2Dconfs"] > joints2Dvisib_threshold                                                      # :98
+        visib[[0, 1, 2, 3, 4, 5, 6, 11, 12]] = True                                                                # :99
+        return proxy_representation(cropped["rgb"], cropped["joints2D"], visib[None], edge_detect_model, pose_shape_cfg)
+
+    return front_end

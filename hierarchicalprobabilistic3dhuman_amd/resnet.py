@@ -100,6 +100,11 @@ class _ConvBN:
         return (H + 2 * self.pad - self.kh) // self.stride + 1, (W + 2 * self.pad - self.kw) // self.stride + 1
 
     def __call__(self, x, residual=None, relu=True):
+        """The un-padded kernel generations (csrc/conv.hip): cross-check only, they live in libhps_dev.so."""
+        with _capi.dev_library():
+            return self._call_plain(x, residual, relu)
+
+    def _call_plain(self, x, residual=None, relu=True):
         B, H, W, C = x.shape
         assert C == self.cin_p
         Ho = (H + 2 * self.pad - self.kh) // self.stride + 1
@@ -150,6 +155,11 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
 
+def _invalidate_after_load(module, incompatible_keys):
+    """load_state_dict post hook (fires for sub-modules too); module level so that the module stays picklable."""
+    module.invalidate()
+
+
 class ResNet(nn.Module):
     """models/resnet.py:125-217 for BasicBlock stacks."""
 
@@ -176,6 +186,7 @@ class ResNet(nn.Module):
         self.layout = "padded"    # "padded": halo-padded NHWC + scalar-base LDS-DMA kernel (product); "plain": the conv.hip kernels of libhps_dev.so (tests)
         self.composite = True     # padded layout: issue the launch list through hps_encoder_run (one call) instead of one by one
         self._frames = _FrameCache()
+        self.register_load_state_dict_post_hook(_invalidate_after_load)
 
     def _make_layer(self, planes, blocks, stride=1):
         downsample = None
@@ -194,9 +205,20 @@ class ResNet(nn.Module):
         self._frames = _FrameCache()
         return super()._apply(fn, *args, **kwargs)
 
-    def load_state_dict(self, *args, **kwargs):
+    def invalidate(self):
+        """Drop the folded BatchNorm / filter copies and the cached launch lists; the next forward rebuilds them from the
+        current parameters.  Called automatically by .to() and by any load_state_dict that reaches this module (also through
+        a parent: nn.Module.load_state_dict recurses with _load_from_state_dict and never calls a child's load_state_dict
+        override, so the reset hangs on a post hook).  Call it by hand after editing parameters in place."""
         self._prepared = None
-        return super().load_state_dict(*args, **kwargs)
+        self._frames = _FrameCache()
+
+    def __getstate__(self):
+        # copies / pickles never carry device-bound caches (raw pointers into the original's tensors)
+        state = self.__dict__.copy()
+        state["_prepared"] = None
+        state["_frames"] = _FrameCache()
+        return state
 
     def prepare(self):
         cin = self.conv1.in_channels
@@ -231,7 +253,8 @@ class ResNet(nn.Module):
             ent = {"c1": z(B, h + 2, w + 2, c1.cout), "c2": z(B, h + 2, w + 2, c2.cout),
                    "down": z(B, h + 2, w + 2, down.cout) if down is not None else None}
             ks = max(c._auto_ksplit(h * w) if c.ksplit == 0 else c.ksplit for c in (c1, c2))
-            ent["ws"] = torch.empty(ks, B * h * w, c1.cout, device=device, dtype=torch.float32) if ks > 1 else None
+            ws_bytes = _capi.query_workspace(_capi.WS_CONV_SPLITK, ks, B * h * w, c1.cout)
+            ent["ws"] = torch.empty(ws_bytes // 4, device=device, dtype=torch.float32) if ws_bytes else None
             fs["blocks"].append(ent)
         fs["hw"] = (h, w)
         # the launch list of hps_encoder_run: every pointer but the input image and the feature output is fixed

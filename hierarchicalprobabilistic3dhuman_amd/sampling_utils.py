@@ -19,6 +19,7 @@ import torch
 from . import _capi
 
 _MAX_ROUNDS = 64
+last_accepted = None        # (B*23,) int32 device tensor of the most recent Philox launch: accepted proposals of the final round per call
 launch_events = None        # bench.py: list collecting (start, end) HIP events around every hps_mf_sample launch
 
 
@@ -28,7 +29,7 @@ def _m_star(b):
 
 
 def _launch(pose_U, pose_S, pose_V, num_samples, n_prop, b, eps=None, w=None, draw_idx=None, seed=0,
-            call_offset=0, bingham_a=None, want_quat=False):
+            call_offset=0, bingham_a=None, want_quat=False, acg_override=None, m_star=None):
     B, nj = pose_U.shape[:2]
     C = B * nj
     dev = pose_U.device
@@ -41,7 +42,8 @@ def _launch(pose_U, pose_S, pose_V, num_samples, n_prop, b, eps=None, w=None, dr
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     _capi.call("hps_mf_sample", P(pose_U), P(pose_S), P(pose_V), P(bingham_a) if bingham_a is not None else None,
-               C, nj, num_samples, n_prop, float(b), _m_star(b),
+               P(acg_override) if acg_override is not None else None,
+               C, nj, num_samples, n_prop, float(b), _m_star(b) if m_star is None else float(m_star),
                P(eps) if eps is not None else None, P(w) if w is not None else None,
                _capi.iptr(draw_idx) if draw_idx is not None else None,
                int(seed) & 0xFFFFFFFFFFFFFFFF, int(call_offset), _MAX_ROUNDS,
@@ -52,7 +54,8 @@ def _launch(pose_U, pose_S, pose_V, num_samples, n_prop, b, eps=None, w=None, dr
     return R, quat, accepted
 
 
-def _host_stream_sampling(pose_U, pose_S, pose_V, num_samples, n_prop, b, bingham_a=None, want_quat=False):
+def _host_stream_sampling(pose_U, pose_S, pose_V, num_samples, n_prop, b, bingham_a=None, want_quat=False, acg_override=None,
+                          m_star=None):
     """Reference-order host noise; rare discarded rounds (fewer than N accepted, :68-69) shift every later
     call one draw further down the stream, exactly as the sequential reference loop would."""
     B, nj = pose_U.shape[:2]
@@ -71,7 +74,8 @@ def _host_stream_sampling(pose_U, pose_S, pose_V, num_samples, n_prop, b, bingha
         eps = torch.stack(eps_l).to(dev)
         w = torch.stack(w_l).to(dev)
         R, quat, accepted = _launch(pose_U, pose_S, pose_V, num_samples, n_prop, b, eps=eps, w=w,
-                                    draw_idx=assign.to(dev), bingham_a=bingham_a, want_quat=want_quat)
+                                    draw_idx=assign.to(dev), bingham_a=bingham_a, want_quat=want_quat,
+                                    acg_override=acg_override, m_star=m_star)
         fails = (accepted.cpu() < num_samples).nonzero().flatten()
         if fails.numel() == 0:
             return R, quat, accepted
@@ -90,27 +94,27 @@ def bingham_sampling_for_matrix_fisher_torch(A, num_samples, Omega=None, Gaussia
                                              oversampling_ratio=8, sample_on_cpu=False, seed=None):
     """utils/sampling_utils.py:10-71: A (4,) diagonal Bingham parameter -> (samples (N,4), accept_ratio).
 
-    Omega / Gaussian_std / M_star are derived from A and b in the kernel (their defaults at :42-46);
-    passing different values is not supported."""
+    Omega / Gaussian_std / M_star default to the values derived from A and b (:42-46); caller-supplied values are used as
+    given, like the reference does."""
     _capi.require_device(A, "A")
     assert A.shape == (4,)
     assert A.min() >= 0
-    for given, derived, name in ((Omega, 1 + 2 * A / b, "Omega"),
-                                 (Gaussian_std, (1 + 2 * A / b) ** -0.5, "Gaussian_std")):
-        if given is not None and not torch.allclose(given.to(A.device), derived, rtol=1e-5, atol=1e-6):
-            raise NotImplementedError("%s must be the value derived from A and b" % name)
-    if M_star is not None and abs(float(M_star) - _m_star(b)) > 1e-6:
-        raise NotImplementedError("M_star must be the value derived from b")
     dev = A.device
+    override = None
+    if Omega is not None or Gaussian_std is not None:
+        om = (1.0 + 2.0 * A / b) if Omega is None else Omega.to(dev).float().reshape(4)                 # :42-43
+        sd = om ** (-0.5) if Gaussian_std is None else Gaussian_std.to(dev).float().reshape(4)        # :44-45
+        override = torch.cat([om, sd]).reshape(1, 8).contiguous()
     eye = torch.eye(3, device=dev).reshape(1, 1, 3, 3).contiguous()
     S = torch.zeros(1, 1, 3, device=dev)
     a = _capi.f32c(A).reshape(1, 4)
     n_prop = num_samples * oversampling_ratio
     if sample_on_cpu:
-        _, quat, accepted = _host_stream_sampling(eye, S, eye, num_samples, n_prop, b, bingham_a=a, want_quat=True)
+        _, quat, accepted = _host_stream_sampling(eye, S, eye, num_samples, n_prop, b, bingham_a=a, want_quat=True,
+                                                  acg_override=override, m_star=M_star)
     else:
         _, quat, accepted = _launch(eye, S, eye, num_samples, n_prop, b, seed=_philox_seed(seed), bingham_a=a,
-                                    want_quat=True)
+                                    want_quat=True, acg_override=override, m_star=M_star)
     accept_ratio = int(accepted[0].item()) / num_samples * 4            # :67 (as meaningless as the original)
     return quat[0, :, 0, :], accept_ratio
 
@@ -129,8 +133,25 @@ def pose_matrix_fisher_sampling_torch(pose_U, pose_S, pose_V, num_samples, b=1.5
         R, _, _ = _host_stream_sampling(U, S, V, num_samples, n_prop, b)
     else:
         nj = U.shape[1]
-        R, _, _ = _launch(U, S, V, num_samples, n_prop, b, seed=_philox_seed(seed), call_offset=image_offset * nj)
+        R, _, accepted = _launch(U, S, V, num_samples, n_prop, b, seed=_philox_seed(seed), call_offset=image_offset * nj)
+        # A call that does not reach N accepts within _MAX_ROUNDS rounds (NaN / Inf pose_S from a bad checkpoint) gets NaN
+        # rotations from the kernel -- loud downstream.  The counts stay on the device (no sync on the hot path);
+        # check_sampling() is the deferred test the harnesses run per batch.
+        global last_accepted
+        last_accepted = (accepted, num_samples)
     return R
+
+
+def check_sampling():
+    """Raise if the most recent Philox sampling launch had a call that never reached N accepted proposals (synchronises)."""
+    if last_accepted is None:
+        return
+    accepted, n = last_accepted
+    bad = int((accepted < n).sum().item())
+    if bad:
+        raise _capi.HpsError("matrix-Fisher sampling failed for %d (image, joint) calls within %d rounds "
+                             "(the reference prints 'Failed sampling' and loops, utils/sampling_utils.py:68-69); "
+                             "are pose_S / pose_U / pose_V finite?" % (bad, _MAX_ROUNDS))
 
 
 def vertex_uncertainty(vertices_samples):
@@ -159,6 +180,11 @@ def compute_vertex_uncertainties_by_poseMF_shapeGaussian_sampling(pose_U, pose_S
                                           sample_on_cpu=sample_on_cpu, seed=seed, image_offset=image_offset)
     if use_mean_shape:
         shape = shape_distribution.loc[:, None, :].expand(B, num_samples, -1)                   # :178-179
+    elif sample_on_cpu:
+        # the reference's seed-reproducible route: Normal.sample on the host, drawn from torch's global CPU generator
+        # right after the pose noise (:180-181 follows :172-177), then uploaded
+        host = torch.distributions.Normal(shape_distribution.loc.cpu(), shape_distribution.scale.cpu(), validate_args=False)
+        shape = host.sample([num_samples]).transpose(0, 1).to(pose_U.device)                     # (B,N,nb)
     else:
         shape = shape_distribution.sample([num_samples]).transpose(0, 1)                        # :180-181, (B,N,nb)
     glob = glob_rotmats.reshape(B, 1, 1, 3, 3).expand(B, num_samples, 1, 3, 3)

@@ -11,6 +11,7 @@ import os
 
 import torch
 import torch.distributed as dist
+import torch.utils.data
 
 
 def init_distributed(backend=None):
@@ -55,6 +56,38 @@ def gather_metric_sums(local_sums):
     for r in range(per_rank.shape[0]):
         total = total + per_rank[r]
     return per_rank, total
+
+
+def world_info():
+    """(rank, world size) of the initialised process group, (0, 1) without one."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_dataset(dataset, rank=None, world=None):
+    """The contiguous block of ``dataset`` this rank evaluates (evaluate/evaluate_poseMF_shapeGaussian_net.py:35-40 builds ONE
+    loader over the whole set; with R ranks each rank must see 1/R of the frames, or the all-gathered metric sums would
+    count every frame R times).  Returns the dataset itself for world size 1."""
+    if rank is None or world is None:
+        rank, world = world_info()
+    if world == 1:
+        return dataset
+    lo, hi = shard_range(len(dataset), rank, world)
+    return torch.utils.data.Subset(dataset, range(lo, hi))
+
+
+def gather_per_frame(local_array):
+    """Per-frame records (numpy array, first axis = this rank's frames, in dataset order) of every rank concatenated in rank
+    order = dataset order, on every rank.  A few KB per rank (optional per-frame gather)."""
+    import numpy as np
+    local_array = np.asarray(local_array)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local_array
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, local_array)
+    parts = [p for p in parts if p is not None and len(p)]
+    return np.concatenate(parts, axis=0) if parts else local_array
 
 
 _COUNTS = {}

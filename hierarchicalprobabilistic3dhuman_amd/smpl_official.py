@@ -92,12 +92,12 @@ class SMPL(nn.Module):
         bmat[nb:nb + n_pose, :self._N] = posedirs_v3k.reshape(self._N, n_pose).T
         self.register_buffer("_bmat", f32(bmat), persistent=False)
         # the same matrix with panel-permuted columns for the fused kernel (include/hps.h: hps_smpl_mesh_fused):
-        # col(v, c) = (v // 128) * 384 + c * 128 + v % 128
-        self._np_fused = -(-V // 128) * 384
+        # col(v, c) = (v // 64) * 192 + c * 64 + v % 64
+        self._np_fused = -(-V // 64) * 192
         vi = np.arange(V)
         bmat_p = np.zeros((self._kp, self._np_fused), np.float64)
         for c in range(3):
-            bmat_p[:, (vi // 128) * 384 + c * 128 + vi % 128] = bmat[:, 3 * vi + c]
+            bmat_p[:, (vi // 64) * 192 + c * 64 + vi % 64] = bmat[:, 3 * vi + c]
         self.register_buffer("_bmat_p", f32(bmat_p), persistent=False)
         self.register_buffer("_v_template_flat", f32(v_template.reshape(-1)), persistent=False)
         # joint regression folded through the linear shape blend: J = J_reg (v_t + S beta)
@@ -167,7 +167,7 @@ class SMPL(nn.Module):
         tr = None if transl is None else _capi.f32c(transl).reshape(M, 3)
 
         V, N = self.num_verts, self._N
-        mp = _round_up(M, 128)
+        mp = _capi.query_workspace(_capi.WS_SMPL_MP, M)                  # padded mesh count of the blend operand
         f32 = dict(device=dev, dtype=torch.float32)
         xt = torch.empty(self._kp, mp, **f32)
         a = torch.empty(M, J, 12, **f32)

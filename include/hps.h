@@ -8,11 +8,17 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless the name ends in _host; row-major contiguous fp32
  *     (int32 for indices); the caller owns all memory (PyTorch tensors in the shipped binding);
- *   - stream is a hipStream_t passed as void*; calls only enqueue work (no allocation, no
- *     synchronisation, no host round trip);
+ *   - stream is a hipStream_t passed as void*; calls only enqueue work (no allocation, no synchronisation, no host round
+ *     trip) -- with three documented exceptions: hps_head_pose_levels in its host-LAPACK parity mode (it waits for each
+ *     kinematic level's matrices: svd_mode HPS_SVD_HOST), hps_host_svd3_packed (a host routine) and
+ *     hps_host_bind_lapack (dlopen, once per process);
  *   - return value: 0 on success, otherwise a hipError_t value (> 0) or a negative HPS_E_* code;
  *     hps_last_error() returns a thread-local description of the last failure;
- *   - no mutable global state: safe to call from several host threads on different streams.
+ *   - no behaviour-changing global state: the library has no tuning switches (those live in libhps_dev.so,
+ *     include/hps_dev.h).  What IS process-global: the LAPACK routine bound by hps_host_bind_lapack, the host-SVD worker pool
+ *     it feeds, and one-time per-kernel attribute grants (LDS above 64 KiB) -- none alters results.  Safe to call from several
+ *     host threads on different streams;
+ *   - workspace sizes come from hps_query_workspace (nothing is allocated inside the library).
  */
 #ifndef HPS_H_
 #define HPS_H_
@@ -36,6 +42,19 @@ typedef void* hps_stream_t; /* hipStream_t */
 
 int hps_version(void);
 const char* hps_last_error(void);
+
+/* Scratch / workspace sizes in BYTES for the buffers the caller hands to the entry points below (the library never allocates):
+ *   HPS_WS_CONV_SPLITK (d0 = ksplit, d1 = B*Ho*Wo, d2 = Cout)  splitk_ws of hps_conv2d_bn_act_pad (0 when ksplit <= 1)
+ *   HPS_WS_SMPL_MP     (d0 = M)                                 NOT bytes: the padded mesh count mp (M rounded up to 128)
+ *   HPS_WS_SMPL_XT     (d0 = M, d1 = kp)                        xt of hps_smpl_pose_prep: kp * mp floats
+ *   HPS_WS_SMPL_A      (d0 = M, d1 = num_joints)                a of hps_smpl_pose_prep: M * J * 12 floats
+ *   HPS_WS_SMPL_VPOSED (d0 = M, d1 = V)                         v_posed of the unfused hps_smpl_blend with 128-byte aligned rows
+ *   HPS_WS_HEAD_F      (d0 = B, d1 = largest level size)        f_level_dev / f_host_pinned of hps_head_pose_levels
+ *   HPS_WS_HEAD_USV    (d0 = B, d1 = largest level size)        usv_level_dev / usv_host_pinned of hps_head_pose_levels
+ * Unused dims are ignored.  Returns -1 (and sets hps_last_error) for an unknown `what` or negative dims. */
+enum { HPS_WS_CONV_SPLITK = 0, HPS_WS_SMPL_MP = 1, HPS_WS_SMPL_XT = 2, HPS_WS_SMPL_A = 3, HPS_WS_SMPL_VPOSED = 4,
+       HPS_WS_HEAD_F = 5, HPS_WS_HEAD_USV = 6 };
+int64_t hps_query_workspace(int what, int64_t d0, int64_t d1, int64_t d2);
 
 /* ------------------------------------------------------------------------------------------
  * SMPL forward  (models/smpl_official.py:27-41 -> smplx 0.1.26 SMPL.forward / lbs)
@@ -86,7 +105,7 @@ int hps_smpl_lbs(const float* v_posed, int ld_vposed, const float* a, const int3
  * hps_smpl_blend + hps_smpl_lbs remain as the unfused definition the LBS roofline bytes of SURVEY section 8(d) refer to).
  *   verts[m,v] = (sum_k w[v,k] A[m, idx[v,k]]) . [v_template[v] + sum_k xt[k,m] bmat_p[k, col(v,c)]; 1] (+ transl[m])
  * bmat_p: the blend matrix of hps_smpl_blend with PANEL-PERMUTED columns, (kp, np) k-major, np = hps_smpl_mesh_fused_np(V):
- *   col(v, c) = (v / 128) * 384 + c * 128 + v % 128  (x, y, z of a 128-vertex panel as three 128-wide column groups),
+ *   col(v, c) = (v / 64) * 192 + c * 64 + v % 64  (x, y, z of a 64-vertex panel as three 64-wide column groups),
  *   unused columns zero.  xt, a: from hps_smpl_pose_prep (mp a multiple of 64 covering M).  w_idx / w_val / K / transl /
  *   verts as for hps_smpl_lbs.  Bit-identical to hps_smpl_blend followed by hps_smpl_lbs (same MFMA k order, same
  *   skinning arithmetic).  Bound: fp32 MFMA, 2 * kp * 3 V FLOP per mesh; HBM traffic = the 12 V bytes of verts per mesh.
@@ -95,7 +114,7 @@ int hps_smpl_lbs(const float* v_posed, int ld_vposed, const float* a, const int3
 int hps_smpl_mesh_fused(const float* xt, const float* bmat_p, const float* v_template, const float* a,
                         const int32_t* w_idx, const float* w_val, int K, int num_joints, const float* transl,
                         float* verts, int M, int V, int kp, int mp, int np, hps_stream_t stream);
-/* Column count of bmat_p for a model with V vertices (384 per started panel of 128 vertices). */
+/* Column count of bmat_p for a model with V vertices (192 per started panel of 64 vertices). */
 int hps_smpl_mesh_fused_np(int V);
 
 /* Joints: out[m, 0:J] = j_posed[m] ; out[m, J + r] = sum_e csr_val[e] * verts[m, csr_col[e]]
@@ -121,6 +140,8 @@ int hps_vertex_uncertainty(const float* verts, float* unc, int B, int N, int V, 
  * accepted (C,) int32 receives the number of accepted proposals of the round that was used.
  * bingham_a: optional (C,4) Bingham parameter used instead of the one derived from pose_s -- the
  * entry point of bingham_sampling_for_matrix_fisher_torch (:10-71), which takes A directly.
+ * acg_override: optional (C,8) = [Omega (4) | Gaussian_std (4)] used instead of the values derived from A and b
+ * (:42-45 make those only the DEFAULTS of the reference's entry point; m_star is always the caller's).
  *
  * Noise source
  *   eps/w != NULL : proposals come from host-drawn noise, eps (D, n_prop, 4) standard normals and
@@ -130,10 +151,11 @@ int hps_vertex_uncertainty(const float* verts, float* unc, int B, int N, int V, 
  *                   the next draw, as the reference does at :68-69).
  *   eps == NULL   : counter-based Philox4x32-10 in the kernel, keyed by (seed, call_offset + c,
  *                   round, proposal) so results do not depend on how images are sharded over GPUs;
- *                   rounds are redrawn in-kernel until N proposals are accepted (max_rounds bound).
+ *                   rounds are redrawn in-kernel until N proposals are accepted; a call that exhausts
+ *                   max_rounds (non-finite concentrations) gets NaN outputs and accepted[c] < N.
  */
 int hps_mf_sample(const float* pose_u, const float* pose_s, const float* pose_v,
-                  const float* bingham_a, int C, int num_joints, int num_samples, int n_prop,
+                  const float* bingham_a, const float* acg_override, int C, int num_joints, int num_samples, int n_prop,
                   float b, float m_star,
                   const float* eps, const float* w, const int32_t* draw_idx, uint64_t seed,
                   int64_t call_offset, int max_rounds, float* r_out, float* quat_out,

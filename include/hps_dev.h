@@ -73,11 +73,10 @@ int hps_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, hps_s
 int hps_global_avgpool(const float* x, float* y, int B, int HW, int C, hps_stream_t stream);
 
 /* Profiling ablations of hps_smpl_mesh_fused (K = 4 only): 1 = no skinning (stores v_posed), 2 = no MFMA, 3 = K loop only
- * (no A fetch, no skinning, no stores), 4 = no operand DMA (garbage results).  0 = the product kernel.
- * stagger: start delay of the second-slot workgroups in s_sleep(127) units (the product uses 8). */
+ * (no A fetch, no skinning, no stores), 4 = no operand DMA (garbage results).  0 = the product kernel. */
 int hps_dev_mesh_fused(const float* xt, const float* bmat_p, const float* v_template, const float* a,
                        const int32_t* w_idx, const float* w_val, int K, int num_joints, const float* transl,
-                       float* verts, int M, int V, int kp, int mp, int np, int ablate, int stagger, hps_stream_t stream);
+                       float* verts, int M, int V, int kp, int mp, int np, int ablate, hps_stream_t stream);
 
 #ifdef __cplusplus
 }

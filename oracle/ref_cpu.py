@@ -353,6 +353,25 @@ def vertex_uncertainty(verts_samples):
     return torch.norm(verts_samples - mean_v, dim=-1).mean(dim=0)
 
 
+def compute_vertex_uncertainties(p, pose_U, pose_S, pose_V, shape_loc, shape_scale, glob_rotmats, num_samples,
+                                 use_mean_shape=False):
+    """utils/sampling_utils.py:146-192 (compute_vertex_uncertainties_by_poseMF_shapeGaussian_sampling) for one image
+    (:171 asserts B = 1), with this module's SMPL as ``smpl_model``.  Random draws in the reference's order: pose noise
+    (:172-177), then -- only if not use_mean_shape -- Normal(loc, scale).sample([N]) (:181).  Pinned by the golden vectors
+    a9_* that tests/golden/make_golden.py produced from the reference function with this SMPL injected.
+    Returns (unc (V,), vertices (N,V,3), joints (N,90,3))."""
+    assert pose_U.shape[0] == pose_S.shape[0] == pose_V.shape[0] == 1
+    R = pose_matrix_fisher_sampling(pose_U, pose_S, pose_V, num_samples)               # :172-177
+    if use_mean_shape:
+        shape = shape_loc.expand(num_samples, -1)                                       # :178-179
+    else:
+        shape = torch.distributions.Normal(shape_loc, shape_scale).sample([num_samples])[:, 0, :]   # :180-181
+    out = smpl_forward(p, body_pose=R[0], global_orient=glob_rotmats.unsqueeze(1).expand(num_samples, -1, -1, -1),
+                       betas=shape, pose2rot=False)                                     # :182-185
+    verts = out['vertices']
+    return vertex_uncertainty(verts), verts, out['joints']                              # :189-192
+
+
 # ----------------------------------------------------------------------------------------------
 # Proxy-representation front end (SURVEY.md section 8(f) item 1) -- models/canny_edge_detector.py, utils/label_conversions.py
 # ----------------------------------------------------------------------------------------------
@@ -424,6 +443,75 @@ def proxy_representation(rgb, joints2D, joints2D_visib, edge_nms=True, edge_thre
     edge = edges["thresholded_thin_edges"] if edge_nms else edges["thresholded_grad_magnitude"]
     heat = joints2d_to_gaussian_heatmaps(joints2D, img_wh, heatmap_std) * joints2D_visib[:, :, None, None]
     return torch.cat([edge, heat], dim=1).float()
+
+
+def batch_crop_affine(input_wh, output_wh, rgb, bbox_centres, bbox_heights, bbox_widths, joints2D=None, scale_factor=1.2):
+    """utils/image_utils.py:234-372 for given boxes (the inference use, predict/predict_hrnet.py:86-95 and
+    predict/predict_poseMF_shapeGaussian_net.py:78-87), CPU tensors.  Pinned by the golden vectors crop*.
+    Returns (rgb_cropped (B,3,oh,ow) or None, joints2D_cropped or None)."""
+    B = bbox_centres.shape[0]
+    iw, ih = float(input_wh[0]), float(input_wh[1])
+    ow, oh = float(output_wh[0]), float(output_wh[1])
+    h, w = bbox_heights.clone().float(), bbox_widths.clone().float()
+    aspect = oh / ow                                                                # :310
+    m = h > w * aspect
+    w[m] = h[m] / aspect                                                            # :311
+    m = h < w * aspect
+    h[m] = w[m] * aspect                                                            # :312
+    h, w = h * scale_factor, w * scale_factor                                       # :321-322
+    A = torch.zeros(B, 2, 3)
+    A[:, 0, 0], A[:, 1, 1] = ow / w, oh / h                                         # :331-332
+    A[:, 0, 2] = ow * 0.5 - (ow / w) * bbox_centres[:, 1]                           # :334 (centres are (vertical, horizontal))
+    A[:, 1, 2] = oh * 0.5 - (oh / h) * bbox_centres[:, 0]
+    joints_out = None
+    if joints2D is not None:                                                        # :365-369
+        homo = torch.cat([joints2D, torch.ones(B, joints2D.shape[1], 1)], dim=-1)
+        joints_out = torch.einsum('bij,bkj->bki', A, homo)
+    rgb_out = None
+    if rgb is not None:
+        T = torch.zeros(B, 2, 3)                                                    # :342-346
+        T[:, 0, 0], T[:, 1, 1] = w / iw, h / ih
+        T[:, 0, 2] = (-A[:, 0, 2] / (ow / w)) / (iw * 0.5) + w / iw - 1
+        T[:, 1, 2] = (-A[:, 1, 2] / (oh / h)) / (ih * 0.5) + h / ih - 1
+        grid = F.affine_grid(T, size=[B, 1, int(oh), int(ow)], align_corners=False)
+        rgb_out = F.grid_sample(rgb, grid, mode='bilinear', padding_mode='zeros', align_corners=False)
+    return rgb_out, joints_out
+
+
+def predict_front_end(image, hrnet_model, hrnet_image_size, hrnet_heatmap_size, proxy_size=256, heatmap_std=4.0,
+                      edge_nms=True, edge_threshold=0.0, edge_std=1.0, edge_size=5, bbox_scale_factor=1.2,
+                      visib_threshold=0.75):
+    """predict/predict_poseMF_shapeGaussian_net.py:63-100 with predict/predict_hrnet.py:34-117 (no object detector: the
+    whole image is the person box), CPU.  image: (3,H,W) RGB in [0,1]; hrnet_model: callable (1,3,h,w) -> (1,17,hh,hw).
+    Only the crops are pinned by reference outputs (predict_hrnet.py needs torchvision and cannot be imported here)."""
+    H, W = image.shape[1:]
+    in_w, in_h = hrnet_image_size
+    centre = torch.tensor([[H * 0.5, W * 0.5]])
+    height, width = torch.tensor([float(H)]), torch.tensor([float(W)])
+    aspect = float(in_h) / float(in_w)                                              # predict_hrnet.py:80-84
+    if height[0] > width[0] * aspect:
+        width = height / aspect
+    elif height[0] < width[0] * aspect:
+        height = width * aspect
+    crop, _ = batch_crop_affine((W, H), (in_w, in_h), image[None], centre, height, width, scale_factor=bbox_scale_factor)
+    mean = torch.tensor([0.485, 0.456, 0.406])[:, None, None]
+    std = torch.tensor([0.229, 0.224, 0.225])[:, None, None]
+    heat = hrnet_model(((crop[0] - mean) / std)[None])                              # predict_hrnet.py:98-100
+    B, K, hh, hw = heat.shape
+    confs, flat = torch.max(heat.reshape(B, K, -1), dim=2)                          # predict_hrnet.py:7-31
+    kps = torch.zeros(B, K, 2)
+    kps[:, :, 0] = flat % hw
+    kps[:, :, 1] = torch.floor(flat / float(hw))
+    kps = kps * (confs > 0.0)[:, :, None]
+    kps = kps * (in_w / hrnet_heatmap_size[0])                                      # :104
+    side = torch.tensor([float(in_h)])
+    rgb2, j2 = batch_crop_affine((in_w, in_h), (proxy_size, proxy_size), crop, torch.tensor([[in_h * 0.5, in_w * 0.5]]), side,
+                                 side.clone(), joints2D=kps, scale_factor=1.0)     # predict/...:74-87
+    visib = confs[0] > visib_threshold                                              # :98-99
+    visib[[0, 1, 2, 3, 4, 5, 6, 11, 12]] = True
+    proxy = proxy_representation(rgb2, j2, visib[None], edge_nms=edge_nms, edge_threshold=edge_threshold, edge_std=edge_std,
+                                 edge_size=edge_size, img_wh=proxy_size, heatmap_std=heatmap_std)
+    return proxy, dict(hrnet_crop=crop, joints2D=kps, confs=confs, rgb=rgb2, joints2D_cropped=j2, visib=visib)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -164,12 +164,11 @@ def sec_mesh_fused():
         P = _capi.ptr
         verts = torch.empty(M, 6890, 3, device=dev)
         mp = L["xt"].shape[1]
-        for ab, what, stg in ((0, "product", 8), (1, "no skinning (stores v_posed)", 8), (2, "no MFMA", 8), (3, "K loop only", 8),
-                              (4, "no operand DMA", 8), (0, "stagger 0", 0), (0, "stagger 2", 2), (0, "stagger 4", 4),
-                              (0, "stagger 6", 6), (0, "stagger 10", 10), (0, "stagger 14", 14), (0, "stagger 20", 20)):
+        for ab, what in ((0, "product"), (0, "product (again)"), (1, "no skinning (stores v_posed)"), (2, "no MFMA"), (3, "K loop only"),
+                         (4, "no operand DMA")):
             fn = lambda: _capi.call("hps_dev_mesh_fused", P(L["xt"]), P(smpl._bmat_p), P(smpl._v_template_flat), P(L["a"]),
                                     _capi.iptr(smpl._w_idx), P(smpl._w_val), 4, 24, None, P(verts), M, 6890, smpl._kp, mp,
-                                    smpl._np_fused, ab, stg, _capi.stream())
+                                    smpl._np_fused, ab, _capi.stream())
             t = timeit(fn, iters=20)
             print("   ablate %d %-30s %.3f ms  (%.1f TF/s)" % (ab, what, t, flop / (t * 1e-3) / 1e12), flush=True)
 

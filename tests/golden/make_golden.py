@@ -124,6 +124,20 @@ def main():
                     out["canny_%s_%s" % (tag, k)] = v
     out["canny_rgb"], out["heat_joints"] = rgb, j2d
     out["heat_out"] = convert_2Djoints_to_gaussian_heatmaps_torch(j2d, 64, 4.0)
+    # ---- bounding-box crops of the predict front end (utils/image_utils.py:234-372): person box -> HRNet input (1.2x box,
+    #      aspect fix), then HRNet input -> proxy-representation size with the 2D joints mapped along (predict/...:78-87) ----
+    import utils.image_utils as ref_iu
+    g = torch.Generator().manual_seed(21)
+    img = torch.rand(1, 3, 120, 160, generator=g)
+    c1 = ref_iu.batch_crop_pytorch_affine(input_wh=(160, 120), output_wh=(72, 96), num_to_crop=1, device="cpu", rgb=img,
+                                          bbox_centres=torch.tensor([[55.0, 83.0]]), bbox_heights=torch.tensor([90.0]),
+                                          bbox_widths=torch.tensor([40.0]), orig_scale_factor=1.2)["rgb"]
+    jc = torch.rand(1, 17, 2, generator=g) * torch.tensor([72.0, 96.0])
+    side = torch.tensor([96.0])
+    c2 = ref_iu.batch_crop_pytorch_affine(input_wh=(72, 96), output_wh=(64, 64), num_to_crop=1, device="cpu", joints2D=jc, rgb=c1,
+                                          bbox_centres=torch.tensor([[48.0, 36.0]]), bbox_heights=side, bbox_widths=side,
+                                          orig_scale_factor=1.0)
+    out.update(crop_img=img, crop1_rgb=c1, crop_joints_in=jc, crop2_rgb=c2["rgb"], crop2_joints=c2["joints2D"])
     # ---- heat-map arg-max (utils/label_conversions.py:127-155) on the case tests/test_frontend.py builds ----
     from utils.label_conversions import convert_heatmaps_to_2Djoints_coordinates_torch
     g4 = torch.Generator().manual_seed(4)

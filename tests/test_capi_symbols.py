@@ -47,8 +47,48 @@ def test_dev_library_is_separate_and_exports_the_dev_header():
 
 def test_version_and_error_string():
     lib = _capi.load()
-    assert lib.hps_version() == 100
+    assert lib.hps_version() == 200
     assert isinstance(lib.hps_last_error(), bytes)
+
+
+def test_query_workspace_is_the_single_source_of_scratch_sizes():
+    """hps_query_workspace(op, dims...) -- every caller-provided scratch size comes from the library."""
+    q = _capi.query_workspace
+    assert q(_capi.WS_CONV_SPLITK, 4, 64 * 8 * 8, 512) == 4 * 64 * 8 * 8 * 512 * 4 and q(_capi.WS_CONV_SPLITK, 1, 10, 10) == 0
+    assert q(_capi.WS_SMPL_MP, 6528) == 6528 and q(_capi.WS_SMPL_MP, 6529) == 6656 and q(_capi.WS_SMPL_MP, 1) == 128
+    assert q(_capi.WS_SMPL_XT, 6528, 224) == 224 * 6528 * 4
+    assert q(_capi.WS_SMPL_A, 3, 24) == 3 * 24 * 12 * 4
+    assert q(_capi.WS_SMPL_VPOSED, 2, 6890) == 2 * 20736 * 4
+    assert q(_capi.WS_HEAD_F, 64, 5) == 64 * 5 * 9 * 4 and q(_capi.WS_HEAD_USV, 64, 5) == 64 * 5 * 21 * 4
+    lib = _capi.load()
+    assert lib.hps_query_workspace(99, 1, 1, 1) == -1 and b"unknown item" in lib.hps_last_error()
+    assert lib.hps_query_workspace(_capi.WS_SMPL_MP, -1, 0, 0) == -1
+    with pytest.raises(_capi.HpsError):
+        q(99)
+
+
+def test_library_has_no_tuning_switches_and_the_header_says_what_is_global():
+    """include/hps.h promised 'no synchronisation / no mutable global state' while hps_dev_* switches were
+    exported.  The switches now exist only in libhps_dev.so and the header names the remaining exceptions."""
+    text = open(os.path.join(ROOT, "include", "hps.h")).read()
+    assert "hps_dev_" not in re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    assert "documented exceptions" in text and "hps_host_bind_lapack" in text
+    assert not [n for n in _exported(_capi.LIB_PATH) if n.startswith("hps_dev_")]
+
+
+def test_modules_are_copyable_and_reload_resets_caches(net_cpu):
+    """ADVICE r1 (no GPU needed): deepcopy / pickle drop the device-bound caches; load_state_dict through the parent resets
+    the encoder's prepared weights as well as the head's."""
+    import copy
+    import pickle
+    net = copy.deepcopy(net_cpu[0])
+    net._prepared, net.image_encoder._prepared, net._pinned_bufs = {"stale": 1}, {"stale": 2}, {"f": torch.zeros(4)}
+    for clone in (copy.deepcopy(net), pickle.loads(pickle.dumps(net))):
+        assert clone._prepared is None and clone.image_encoder._prepared is None and clone._pinned_bufs == {}
+        assert len(clone.image_encoder._frames) == 0
+    assert net._prepared == {"stale": 1}                          # the original keeps its own
+    net.load_state_dict(net_cpu[1])
+    assert net._prepared is None and net.image_encoder._prepared is None
 
 
 def test_argument_validation_needs_no_gpu():

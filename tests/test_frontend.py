@@ -120,3 +120,90 @@ def test_heatmap_argmax_and_sample_ranking(dev, golden):
     want, order = O.joints2d_error_sorted(verts, joints, heat, cam, ALL_JOINTS_TO_COCO_MAP)
     got = joints2D_error_sorted_verts_sampling(verts.to(dev), joints.to(dev), heat.to(dev), cam.to(dev))
     assert torch.equal(got.cpu(), want)
+
+
+# ---------------------------------------------------------------------------------------------
+# The reference-signature predict front end (predict/predict_poseMF_shapeGaussian_net.py:61-100)
+# ---------------------------------------------------------------------------------------------
+def _crop_case(golden):
+    return (golden["crop_img"], torch.tensor([[55.0, 83.0]]), torch.tensor([90.0]), torch.tensor([40.0]), golden["crop_joints_in"])
+
+
+def test_oracle_crops_match_reference(golden):
+    """utils/image_utils.py:234-372 (batch_crop_pytorch_affine) as called by predict_hrnet (:86-95) and by the predict harness
+    (:78-87): the oracle's restatement against the reference's outputs."""
+    img, centre, h, w, jc = _crop_case(golden)
+    c1, _ = O.batch_crop_affine((160, 120), (72, 96), img, centre, h, w, scale_factor=1.2)
+    assert maxerr(c1, golden["crop1_rgb"]) <= 1e-6
+    side = torch.tensor([96.0])
+    c2, j2 = O.batch_crop_affine((72, 96), (64, 64), c1, torch.tensor([[48.0, 36.0]]), side, side.clone(), joints2D=jc, scale_factor=1.0)
+    assert maxerr(c2, golden["crop2_rgb"]) <= 1e-6 and maxerr(j2, golden["crop2_joints"]) <= 1e-5
+
+
+def test_package_crops_match_reference(golden):
+    """The package's crop glue (device-agnostic torch ops, no libhps kernel) against the same reference outputs."""
+    from hierarchicalprobabilistic3dhuman_amd.image_utils import batch_crop_pytorch_affine
+    img, centre, h, w, jc = _crop_case(golden)
+    c1 = batch_crop_pytorch_affine((160, 120), (72, 96), 1, "cpu", rgb=img, bbox_centres=centre, bbox_heights=h, bbox_widths=w,
+                                   orig_scale_factor=1.2)["rgb"]
+    assert maxerr(c1, golden["crop1_rgb"]) <= 1e-6
+    side = torch.tensor([96.0])
+    c2 = batch_crop_pytorch_affine((72, 96), (64, 64), 1, "cpu", joints2D=jc, rgb=c1, bbox_centres=torch.tensor([[48.0, 36.0]]),
+                                   bbox_heights=side, bbox_widths=side, orig_scale_factor=1.0)
+    assert maxerr(c2["rgb"], golden["crop2_rgb"]) <= 1e-6 and maxerr(c2["joints2D"], golden["crop2_joints"]) <= 1e-5
+    with pytest.raises(NotImplementedError):
+        batch_crop_pytorch_affine((72, 96), (64, 64), 1, "cpu", rgb=c1)            # boxes from IUV / seg: training only
+
+
+class _ToyHRNet(torch.nn.Module):
+    """Stand-in for the injected 2D keypoint detector (the real HRNet is out of scope): (1,3,h,w) -> (1,17,h/4,w/4)."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(123)
+        self.conv = torch.nn.Conv2d(3, 17, kernel_size=8, stride=4, padding=2)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+def _hrnet_cfg():
+    from types import SimpleNamespace
+    return SimpleNamespace(MODEL=SimpleNamespace(IMAGE_SIZE=[288, 384], HEATMAP_SIZE=[72, 96]))
+
+
+@pytest.mark.gpu
+def test_predict_harness_with_the_reference_signature(dev, net_gpu, smpl_gpu, tmp_path):
+    """run_predict.py:77-89 calls predict_poseMF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_model, hrnet_model,
+    hrnet_cfg, edge_detect_model, device, image_dir, save_dir, ...) -- no extra keyword.  The front end (:61-100) must run
+    on the injected detector and give the oracle's proxy representation."""
+    import os
+    import numpy as np
+    from PIL import Image
+    from hierarchicalprobabilistic3dhuman_amd import configs
+    from hierarchicalprobabilistic3dhuman_amd.canny_edge_detector import CannyEdgeDetector
+    from hierarchicalprobabilistic3dhuman_amd import predict_poseMF_shapeGaussian_net as P
+    cfg = configs.get_cfg_defaults()
+    rs = np.random.RandomState(3)
+    base = rs.rand(30, 40, 3)
+    img = (np.kron(base, np.ones((10, 10, 1))) * 255).astype(np.uint8)                 # 300 x 400 blocky RGB image
+    image_dir, save_dir = tmp_path / "images", tmp_path / "out"
+    os.makedirs(image_dir)
+    Image.fromarray(img).save(str(image_dir / "person.png"))
+    hrnet = _ToyHRNet().to(dev)
+    edge = CannyEdgeDetector(non_max_suppression=cfg.DATA.EDGE_NMS, gaussian_filter_std=cfg.DATA.EDGE_GAUSSIAN_STD,
+                             gaussian_filter_size=cfg.DATA.EDGE_GAUSSIAN_SIZE, threshold=cfg.DATA.EDGE_THRESHOLD).to(dev)
+    # the proxy representation the front end builds, against the oracle
+    fe = P._reference_front_end(cfg, hrnet, _hrnet_cfg(), edge, None, 0.75, dev)
+    proxy = fe(str(image_dir / "person.png"))
+    assert proxy.shape == (1, 18, 256, 256)
+    image_cpu = torch.from_numpy(img.transpose(2, 0, 1).copy()).float() / 255.0
+    with torch.no_grad():
+        want, aux = O.predict_front_end(image_cpu, _ToyHRNet(), (288, 384), (72, 96))
+    assert maxerr(proxy[:, 1:], want[:, 1:]) <= 1e-4                                  # heat-maps (joint positions agree)
+    diff = (proxy[:, :1].cpu() - want[:, :1]).abs() > 1e-4
+    assert float(diff.float().mean()) <= 2e-3                                          # edge map: rounding ties of the NMS only
+    # the harness, called positionally like run_predict.py does
+    P.predict_poseMF_shapeGaussian_net(net_gpu, cfg, smpl_gpu, hrnet, _hrnet_cfg(), edge, dev, str(image_dir), str(save_dir))
+    saved = torch.load(str(save_dir / "person.pt"))
+    assert saved["verts_mode"].shape == (6890, 3) and saved["unc"].shape == (6890,) and torch.isfinite(saved["verts_mode"]).all()

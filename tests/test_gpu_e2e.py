@@ -2,7 +2,8 @@
 the same seeded inputs (sample_on_cpu route = the reference's seed-reproducible route), BASELINE configs[0]
 (B=1, N=1) and a small batch; full-size BASELINE configs[1] (B=64, N=100) through properties.
 
-Stated tolerance: image -> vertices <= 1e-3 m end to end; observed ~5e-6."""
+Stated tolerance: image -> vertices, joints, uncertainty <= 1e-4 m end to end (SURVEY.md section 8(c) allows 1e-3 m; DESIGN.md
+claims 1e-4 and the tests hold it to that); observed ~6e-6."""
 import pytest
 import torch
 
@@ -27,8 +28,7 @@ def test_infer_matches_oracle(B, N, dev, net_gpu, net_cpu, smpl_gpu, smpl_assets
     out = infer(net_gpu, smpl_gpu, x.to(dev), num_samples=N, sample_on_cpu=True)
     for k in KEYS:
         assert out[k].shape == ref[k].shape, k
-        assert maxerr(out[k], ref[k]) <= 1e-3, k
-    assert maxerr(out["verts_samples"], ref["verts_samples"]) <= 1e-4
+        assert maxerr(out[k], ref[k]) <= 1e-4, k
 
 
 def test_reference_call_sequence_batch_one(dev, net_gpu, net_cpu, smpl_gpu, smpl_assets, golden_input):
@@ -45,8 +45,8 @@ def test_reference_call_sequence_batch_one(dev, net_gpu, net_cpu, smpl_gpu, smpl
     assert unc.shape == (6890,) and verts.shape == (6, 6890, 3) and joints.shape == (6, 90, 3)
     torch.manual_seed(2)
     ref = O.infer(net_cpu[1], smpl_assets[2], configs.SMPL_PARENTS, golden_input[:1], 6)
-    assert maxerr(out_mode.vertices, ref["verts_mode"]) <= 1e-3 and maxerr(out_rest.vertices, ref["verts_tpose"]) <= 1e-3
-    assert maxerr(verts, ref["verts_samples"][0]) <= 1e-3 and maxerr(unc, ref["unc"][0]) <= 1e-3
+    assert maxerr(out_mode.vertices, ref["verts_mode"]) <= 1e-4 and maxerr(out_rest.vertices, ref["verts_tpose"]) <= 2e-5
+    assert maxerr(verts, ref["verts_samples"][0]) <= 1e-4 and maxerr(unc, ref["unc"][0]) <= 1e-4
 
 
 def test_full_size_config_properties(dev, net_gpu, smpl_gpu):

@@ -198,11 +198,18 @@ def test_padded_pooling_and_layout_kernels(dev):
     avg = torch.empty(2, 64, device=dev)
     _capi.call("hps_global_avgpool_pad", P(_frame(yh, 1)), P(avg), 2, 13, 11, 64, 1, _capi.stream())
     plain = torch.empty(2, 64, device=dev)
-    _capi.call("hps_global_avgpool", P(yh), P(plain), 2, 13 * 11, 64, _capi.stream())
+    with _capi.dev_library():                       # the un-padded generation lives in libhps_dev.so
+        _capi.call("hps_global_avgpool", P(yh), P(plain), 2, 13 * 11, 64, _capi.stream())
     assert torch.equal(avg, plain) and maxerr(avg, y.mean(dim=(2, 3))) <= 1e-6
 
 
 def test_pooling_and_layout_kernels(dev):
+    """The un-padded generation's relayout / pooling kernels (libhps_dev.so; the cross-check of the product's padded ones)."""
+    with _capi.dev_library():
+        _pooling_and_layout_kernels(dev)
+
+
+def _pooling_and_layout_kernels(dev):
     P = _capi.ptr
     x = torch.randn(2, 18, 12, 10, generator=torch.Generator().manual_seed(0))
     xh = torch.empty(2, 12, 10, 20, device=dev)
@@ -235,3 +242,31 @@ def test_load_state_dict_invalidates_prepared_weights(dev, net_gpu, net_cpu, gol
     net.load_state_dict(sd)
     out = net(None, input_feats=golden["net_feats"].to(dev))
     assert maxerr(out[7], golden["net_cam"] + 1.0) <= 1e-4
+
+
+def test_reload_through_the_parent_resets_the_encoder_and_copies_own_their_weights(dev, net_gpu, net_cpu, golden, golden_input):
+    """nn.Module.load_state_dict recurses with _load_from_state_dict, so a child's load_state_dict override never
+    runs -- the encoder's folded filters must be reset by a post hook; and a deepcopy of a PREPARED net must not keep the
+    original's device addresses in its pointer tables."""
+    import copy
+    x = golden_input.to(dev)
+    net = copy.deepcopy(net_gpu)
+    feats0 = net.image_encoder(x).clone()                          # prepares encoder (and frames)
+    net(x)                                                          # prepares the head
+    assert net._prepared is not None and net.image_encoder._prepared is not None
+    sd = {k: v.clone() for k, v in net_cpu[1].items()}
+    sd["image_encoder.bn1.weight"] = sd["image_encoder.bn1.weight"] * 0.5
+    net.load_state_dict(sd)                                         # through the PARENT
+    assert net._prepared is None and net.image_encoder._prepared is None
+    feats1 = net.image_encoder(x)
+    assert maxerr(feats1, feats0) > 1e-3                            # the new BatchNorm scale is in effect
+    net.load_state_dict(net_cpu[1])
+    assert maxerr(net.image_encoder(x), golden["net_feats"]) <= 1e-4 * float(golden["net_feats"].abs().max())
+    # a copy of a prepared net rebuilds its own tables; deleting the original must not matter
+    net(x)
+    clone = copy.deepcopy(net)
+    assert clone._prepared is None and clone.image_encoder._prepared is None and clone._pinned_bufs == {}
+    del net
+    torch.cuda.empty_cache()
+    out = clone(x)
+    assert maxerr(out[0], golden["net_F"]) <= 1e-4

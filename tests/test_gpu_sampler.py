@@ -119,3 +119,56 @@ def test_rotation_conversions_reproduce_reference(dev, golden):
     assert maxerr(rtu.batch_rodrigues(aa.to(dev)), O.batch_rodrigues(aa)) <= 1e-6
     x3 = torch.randn(3, 6, generator=torch.Generator().manual_seed(2))      # the reference is wrong at exactly B == 3
     assert maxerr(rtu.rot6d_to_rotmat(x3.to(dev)), O.rot6d_to_rotmat(x3)) <= 1e-6
+
+
+def test_vertex_uncertainty_sampling_reproduces_reference(dev, golden, smpl_gpu):
+    """SURVEY 8 row A9 on the GPU: compute_vertex_uncertainties_by_poseMF_shapeGaussian_sampling (sample_on_cpu=True: the
+    reference's random stream) against the outputs of the REFERENCE function (utils/sampling_utils.py:146-192, oracle SMPL
+    injected; tests/golden/make_golden.py), both use_mean_shape routes.  Tolerance: SMPL's 2e-5 m (vertices, joints),
+    1e-5 on the uncertainty."""
+    from torch.distributions import Normal
+    U, S, V = (golden[k][:1].to(dev) for k in ("net_U", "net_S", "net_V"))
+    dist = Normal(golden["net_shape_loc"][:1].to(dev), golden["net_shape_scale"][:1].to(dev))
+    glob_R = golden["a9_glob_rotmats"].to(dev)
+    for tag, mean_shape in (("mean", True), ("samp", False)):
+        torch.manual_seed(5)
+        unc, verts, joints = su.compute_vertex_uncertainties_by_poseMF_shapeGaussian_sampling(
+            U, S, V, dist, glob_R, 4, smpl_gpu, use_mean_shape=mean_shape, sample_on_cpu=True)
+        assert unc.shape == (6890,) and verts.shape == (4, 6890, 3) and joints.shape == (4, 90, 3)
+        assert maxerr(verts[:, ::10], golden["a9_%s_verts_sub" % tag]) <= 2e-5, tag
+        assert maxerr(joints, golden["a9_%s_joints" % tag]) <= 2e-5, tag
+        assert maxerr(unc, golden["a9_%s_unc" % tag]) <= 1e-5, tag
+
+
+def test_bingham_entry_accepts_caller_parameters(dev):
+    """utils/sampling_utils.py:10-46: Omega / Gaussian_std / M_star are ARGUMENTS of the reference's entry point (their
+    derivation from A and b is only the default).  Same host random stream, caller's envelope -> the oracle's samples."""
+    A = torch.tensor([0.0, 2.76, 5.0, 5.36])
+    b = 1.5
+    for omega_scale, m_scale in ((1.0, 1.0), (0.7, 1.6)):
+        Omega = (1.0 + 2.0 * A / b) * omega_scale
+        std = Omega ** (-0.5)
+        M_star = O.m_star(b) * m_scale
+        torch.manual_seed(9)
+        want = O.bingham_sampling(A, 16, Omega, std, M_star)
+        torch.manual_seed(9)
+        got, _ = su.bingham_sampling_for_matrix_fisher_torch(A.to(dev), 16, Omega=Omega.to(dev), Gaussian_std=std.to(dev), b=b,
+                                                              M_star=M_star, sample_on_cpu=True)
+        assert maxerr(got, want) <= 1e-6, (omega_scale, m_scale)
+    # Philox route with an override: unit quaternions, finite
+    q, _ = su.bingham_sampling_for_matrix_fisher_torch(A.to(dev), 64, Omega=(1.0 + 2.0 * A / b).to(dev) * 0.8, b=b, seed=4)
+    assert torch.isfinite(q).all() and maxerr(q.norm(dim=-1), torch.ones(64)) <= 1e-5
+
+
+def test_failed_sampling_is_loud(dev):
+    """NaN concentrations make every accept test false; the Philox route must not hand back uninitialised memory."""
+    from hierarchicalprobabilistic3dhuman_amd import _capi
+    eye = torch.eye(3, device=dev).expand(1, 23, 3, 3).contiguous()
+    S = torch.full((1, 23, 3), float("nan"), device=dev)
+    R = su.pose_matrix_fisher_sampling_torch(eye, S, eye, 4, seed=1)
+    assert torch.isnan(R).all()
+    with pytest.raises(_capi.HpsError):
+        su.check_sampling()
+    R = su.pose_matrix_fisher_sampling_torch(eye, torch.ones(1, 23, 3, device=dev), eye, 4, seed=1)
+    su.check_sampling()
+    assert torch.isfinite(R).all()

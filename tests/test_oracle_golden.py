@@ -63,3 +63,22 @@ def test_sampler_first_moment_matches_normalising_constant_gradient(golden):
     # (0.95/0.91 where the true value is ~0.999), so it is excluded; Monte-Carlo sigma of the mean <= 0.004
     rows = [0, 1, 2, 3, 4, 6]
     assert maxerr(D[rows], want[rows]) <= 0.025
+
+
+def test_vertex_uncertainty_sampling_matches_reference(golden, smpl_assets):
+    """the oracle's restatement of compute_vertex_uncertainties_by_poseMF_shapeGaussian_sampling
+    (utils/sampling_utils.py:146-192) against the outputs of the REFERENCE function (oracle SMPL injected as smpl_model,
+    tests/golden/make_golden.py), for both use_mean_shape routes (:178-181)."""
+    U, S, V = golden["net_U"][:1], golden["net_S"][:1], golden["net_V"][:1]
+    loc, scale = golden["net_shape_loc"][:1], golden["net_shape_scale"][:1]
+    for tag, mean_shape in (("mean", True), ("samp", False)):
+        torch.manual_seed(5)
+        unc, verts, joints = O.compute_vertex_uncertainties(smpl_assets[2], U, S, V, loc, scale, golden["a9_glob_rotmats"], 4,
+                                                            use_mean_shape=mean_shape)
+        assert unc.shape == (6890,) and verts.shape == (4, 6890, 3) and joints.shape == (4, 90, 3)
+        assert maxerr(unc, golden["a9_%s_unc" % tag]) <= 1e-7, tag
+        assert maxerr(verts[:, ::10], golden["a9_%s_verts_sub" % tag]) <= 1e-7, tag
+        assert maxerr(joints, golden["a9_%s_joints" % tag]) <= 1e-7, tag
+    assert maxerr(golden["a9_glob_rotmats"], O.rot6d_to_rotmat(golden["net_glob"][:1])) <= 1e-7
+    # the two routes differ (sampled betas), so the fixture really exercises :180-181
+    assert maxerr(golden["a9_mean_unc"], golden["a9_samp_unc"]) > 1e-4
