@@ -40,6 +40,9 @@ _PROTOTYPES = {
     "hps_batch_rodrigues": [_P, _P, _I, _P],
     "hps_linear": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "hps_head_joint_level": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _I, _I, _P],
+    "hps_head_joint_level_svd": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _P, _I, _I, _P],
+    "hps_svd3_packed": [_P, _P, _I, _P],
+    "hps_host_svd3_emulated": [_P, _P, _I],
     "hps_host_svd3_packed": [_P, _P, _I, _I],
     "hps_host_bind_lapack": [_c.c_char_p],
     "hps_head_svd_finish": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
@@ -52,7 +55,7 @@ _PROTOTYPES = {
     "hps_sizeof_enc_op": [],
     "hps_encoder_run": [_P, _I, _P],
     "hps_head_pose_levels": [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _P, _P, _P,
-                             _P, _P, _I, _I, _I, _P],
+                             _P, _P, _I, _I, _I, _I, _P],
     "hps_nchw_to_padded_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "hps_maxpool3x3s2_pad": [_P, _P, _I, _I, _I, _I, _I, _P],
     "hps_global_avgpool_pad": [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -89,6 +92,7 @@ class EncOp(_c.Structure):
 
 
 ENC_RELAYOUT, ENC_CONV, ENC_MAXPOOL, ENC_AVGPOOL = 0, 1, 2, 3
+SVD_HOST, SVD_DEVICE = 0, 1
 
 
 class HpsError(RuntimeError):

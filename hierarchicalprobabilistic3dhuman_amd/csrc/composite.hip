@@ -53,9 +53,24 @@ extern "C" int hps_head_pose_levels(const float* embed, int embed_dim, int hidde
                                     float* s_proper, float* mode, float delta_i_weight, float* pose_f, float* pose_u,
                                     float* pose_s, float* pose_v, float* f_level_dev, float* usv_level_dev,
                                     float* f_host_pinned, float* usv_host_pinned, int B, int num_body_joints,
-                                    int svd_threads, hps_stream_t stream) {
-    if (!embed || !level_joints || !level_sizes_host || !f_level_dev || !usv_level_dev || !f_host_pinned || !usv_host_pinned)
-        return bad_arg("hps_head_pose_levels: null pointer");
+                                    int svd_threads, int svd_mode, hps_stream_t stream) {
+    if (!embed || !level_joints || !level_sizes_host) return bad_arg("hps_head_pose_levels: null pointer");
+    if (svd_mode == HPS_SVD_DEVICE) {
+        // every level is ONE kernel (MLPs + in-kernel gesdd-faithful SVD + proper fix): stream-ordered, no host round trip
+        int first_d = 0;
+        for (int l = 0; l < n_levels; ++l) {
+            const int n_level = level_sizes_host[l];
+            const int rc = hps_head_joint_level_svd(embed, embed_dim, hidden, level_joints + first_d, n_level, anc_ptr, anc_idx,
+                                                    w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper, s_proper, mode, delta_i_weight,
+                                                    pose_f, pose_u, pose_s, pose_v, B, num_body_joints, stream);
+            if (rc != HPS_OK) return rc;
+            first_d += n_level;
+        }
+        return HPS_OK;
+    }
+    if (svd_mode != HPS_SVD_HOST) return bad_arg("hps_head_pose_levels: svd_mode");
+    if (!f_level_dev || !usv_level_dev || !f_host_pinned || !usv_host_pinned)
+        return bad_arg("hps_head_pose_levels: the host-LAPACK mode needs the staging buffers");
     hipStream_t s = (hipStream_t)stream;
     int first = 0;
     for (int l = 0; l < n_levels; ++l) {

@@ -3,6 +3,7 @@
 // The 23 sequential joints of the reference loop (:121-160) are grouped by kinematic depth; one
 // launch evaluates every joint of a level for the whole batch.
 #include "hps_common.h"
+#include "svd3_gesdd.h"
 
 namespace hps {
 
@@ -91,14 +92,38 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 }
 
 // One kinematic level: grid = (n_level joints, batch tiles), 1024 threads = 8 K-slices x HID columns.
-template <int HID>
+// proper SVD + mode (models/poseMF_shapeGaussian_net.py:139-152) of one joint of one image from its raw factors
+__device__ __forceinline__ void proper_svd_store(float* U, const float* S, float* V, size_t o, float* __restrict__ pose_u,
+                                                 float* __restrict__ pose_s, float* __restrict__ pose_v, float* u_proper,
+                                                 float* s_proper, float* mode) {
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { pose_u[o * 9 + e] = U[e]; pose_v[o * 9 + e] = V[e]; }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) pose_s[o * 3 + e] = S[e];
+    const float dU = det3(U), dV = det3(V);
+    U[2] *= dU; U[5] *= dU; U[8] *= dU;
+    V[2] *= dV; V[5] *= dV; V[8] *= dV;
+    float Mo[9];
+    mat3_mul_bt(U, V, Mo);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { u_proper[o * 9 + e] = U[e]; mode[o * 9 + e] = Mo[e]; }
+    s_proper[o * 3 + 0] = S[0];
+    s_proper[o * 3 + 1] = S[1];
+    s_proper[o * 3 + 2] = S[2] * (dU * dV);
+}
+
+// DEVSVD: the level's 3x3 SVDs run inside the kernel (svd3_gesdd.h: LAPACK's sgesdd followed step by step, so that the
+// singular vectors carry the signs the reference's torch.svd would give them), followed by the proper-SVD fix -- the level
+// needs no host round trip.  u_proper / s_proper / mode are read for ancestor joints (earlier levels) and written for this
+// level's joints: no element is both read and written by one launch.
+template <int HID, bool DEVSVD>
 __global__ __launch_bounds__(1024) void joint_level_kernel(
     const float* __restrict__ embed, int embed_dim, const int32_t* __restrict__ joint_ids,
     const int32_t* __restrict__ anc_ptr, const int32_t* __restrict__ anc_idx, const float* const* __restrict__ w1t_ptrs,
     const float* const* __restrict__ b1_ptrs, const float* const* __restrict__ w2_ptrs,
-    const float* const* __restrict__ b2_ptrs, const float* __restrict__ u_proper, const float* __restrict__ s_proper,
-    const float* __restrict__ mode, float delta_i_weight, float* __restrict__ pose_f, float* __restrict__ f_level,
-    int B, int NJ) {
+    const float* const* __restrict__ b2_ptrs, float* u_proper, float* s_proper,
+    float* mode, float delta_i_weight, float* __restrict__ pose_f, float* __restrict__ f_level,
+    float* __restrict__ pose_u, float* __restrict__ pose_s, float* __restrict__ pose_v, int B, int NJ) {
     constexpr int KS = 1024 / HID;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int joint = joint_ids[blockIdx.x];
@@ -164,6 +189,17 @@ __global__ __launch_bounds__(1024) void joint_level_kernel(
                 pose_f[((size_t)(b0 + r) * NJ + joint) * 9 + e] = v;
                 if (f_level) f_level[((size_t)(b0 + r) * gridDim.x + blockIdx.x) * 9 + e] = v;
             }
+            if (DEVSVD) red[r * 9 + e] = v;                 // the partial-sum buffer is free by now
+        }
+    }
+    if (DEVSVD) {
+        __syncthreads();
+        if (threadIdx.x < TB && b0 + threadIdx.x < B) {
+            float F[9], U[9], S[3], V[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) F[e] = red[threadIdx.x * 9 + e];
+            gesdd3::svd3(F, U, S, V);
+            proper_svd_store(U, S, V, (size_t)(b0 + threadIdx.x) * NJ + joint, pose_u, pose_s, pose_v, u_proper, s_proper, mode);
         }
     }
 }
@@ -183,20 +219,21 @@ __global__ void svd_finish_kernel(const float* __restrict__ usv, const int32_t* 
     for (int e = 0; e < 9; ++e) { U[e] = src[e]; V[e] = src[12 + e]; }
 #pragma unroll
     for (int e = 0; e < 3; ++e) S[e] = src[9 + e];
+    proper_svd_store(U, S, V, o, pose_u, pose_s, pose_v, u_proper, s_proper, mode);
+}
+
+// n row-major 3x3 matrices -> packed [U | S | V] (21 floats each), the layout of hps_host_svd3_packed
+__global__ void svd3_packed_kernel(const float* __restrict__ f, float* __restrict__ usv, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float F[9], U[9], S[3], V[9];
 #pragma unroll
-    for (int e = 0; e < 9; ++e) { pose_u[o * 9 + e] = U[e]; pose_v[o * 9 + e] = V[e]; }
+    for (int e = 0; e < 9; ++e) F[e] = f[(size_t)i * 9 + e];
+    gesdd3::svd3(F, U, S, V);
+    float* o = usv + (size_t)i * 21;
 #pragma unroll
-    for (int e = 0; e < 3; ++e) pose_s[o * 3 + e] = S[e];
-    const float dU = det3(U), dV = det3(V);
-    U[2] *= dU; U[5] *= dU; U[8] *= dU;
-    V[2] *= dV; V[5] *= dV; V[8] *= dV;
-    float Mo[9];
-    mat3_mul_bt(U, V, Mo);
-#pragma unroll
-    for (int e = 0; e < 9; ++e) { u_proper[o * 9 + e] = U[e]; mode[o * 9 + e] = Mo[e]; }
-    s_proper[o * 3 + 0] = S[0];
-    s_proper[o * 3 + 1] = S[1];
-    s_proper[o * 3 + 2] = S[2] * (dU * dV);
+    for (int e = 0; e < 9; ++e) { o[e] = U[e]; o[12 + e] = V[e]; }
+    o[9] = S[0]; o[10] = S[1]; o[11] = S[2];
 }
 
 }  // namespace hps
@@ -215,24 +252,60 @@ extern "C" int hps_linear(const float* x, int ldx, const float* wt, const float*
     return check_launch("hps_linear");
 }
 
-extern "C" int hps_head_joint_level(const float* embed, int embed_dim, int hidden, const int32_t* joint_ids,
-                                    int n_level, const int32_t* anc_ptr, const int32_t* anc_idx,
-                                    const float* const* w1t_ptrs, const float* const* b1_ptrs,
-                                    const float* const* w2_ptrs, const float* const* b2_ptrs, const float* u_proper,
-                                    const float* s_proper, const float* mode, float delta_i_weight, float* pose_f,
-                                    float* f_level, int B, int num_body_joints, hps_stream_t stream) {
+static int joint_level_launch(const float* embed, int embed_dim, int hidden, const int32_t* joint_ids, int n_level,
+                              const int32_t* anc_ptr, const int32_t* anc_idx, const float* const* w1t_ptrs,
+                              const float* const* b1_ptrs, const float* const* w2_ptrs, const float* const* b2_ptrs,
+                              float* u_proper, float* s_proper, float* mode, float delta_i_weight, float* pose_f,
+                              float* f_level, float* pose_u, float* pose_s, float* pose_v, int B, int num_body_joints,
+                              hps_stream_t stream) {
+    const bool devsvd = pose_u != nullptr;
     if (!embed || !joint_ids || !anc_ptr || !anc_idx || !w1t_ptrs || !b1_ptrs || !w2_ptrs || !b2_ptrs || !u_proper ||
-        !s_proper || !mode || !pose_f)
+        !s_proper || !mode || !pose_f || (devsvd && (!pose_s || !pose_v)))
         return bad_arg("hps_head_joint_level: null pointer");
     if (hidden != 128) { set_error("hps_head_joint_level: hidden=%d unsupported (128 = EMBED_DIM/2)", hidden); return HPS_E_UNSUPPORTED; }
     if (B <= 0 || n_level <= 0) return HPS_OK;
     const int max_in = embed_dim + 21 * num_body_joints;
     size_t lds = ((size_t)((max_in * TB + 3) & ~3) + 128 * TB + (1024 / 128) * TB * 128) * sizeof(float);
     if (lds > 64 * 1024) { set_error("hps_head_joint_level: embed_dim=%d too large", embed_dim); return HPS_E_UNSUPPORTED; }
-    hipLaunchKernelGGL((joint_level_kernel<128>), dim3(n_level, ceil_div(B, TB)), dim3(1024), lds, (hipStream_t)stream,
-                       embed, embed_dim, joint_ids, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper,
-                       s_proper, mode, delta_i_weight, pose_f, f_level, B, num_body_joints);
+    if (devsvd)
+        hipLaunchKernelGGL((joint_level_kernel<128, true>), dim3(n_level, ceil_div(B, TB)), dim3(1024), lds, (hipStream_t)stream,
+                           embed, embed_dim, joint_ids, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper,
+                           s_proper, mode, delta_i_weight, pose_f, f_level, pose_u, pose_s, pose_v, B, num_body_joints);
+    else
+        hipLaunchKernelGGL((joint_level_kernel<128, false>), dim3(n_level, ceil_div(B, TB)), dim3(1024), lds, (hipStream_t)stream,
+                           embed, embed_dim, joint_ids, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper,
+                           s_proper, mode, delta_i_weight, pose_f, f_level, pose_u, pose_s, pose_v, B, num_body_joints);
     return check_launch("hps_head_joint_level");
+}
+
+extern "C" int hps_head_joint_level(const float* embed, int embed_dim, int hidden, const int32_t* joint_ids,
+                                    int n_level, const int32_t* anc_ptr, const int32_t* anc_idx,
+                                    const float* const* w1t_ptrs, const float* const* b1_ptrs,
+                                    const float* const* w2_ptrs, const float* const* b2_ptrs, const float* u_proper,
+                                    const float* s_proper, const float* mode, float delta_i_weight, float* pose_f,
+                                    float* f_level, int B, int num_body_joints, hps_stream_t stream) {
+    return joint_level_launch(embed, embed_dim, hidden, joint_ids, n_level, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs,
+                              const_cast<float*>(u_proper), const_cast<float*>(s_proper), const_cast<float*>(mode),
+                              delta_i_weight, pose_f, f_level, nullptr, nullptr, nullptr, B, num_body_joints, stream);
+}
+
+extern "C" int hps_head_joint_level_svd(const float* embed, int embed_dim, int hidden, const int32_t* joint_ids,
+                                        int n_level, const int32_t* anc_ptr, const int32_t* anc_idx,
+                                        const float* const* w1t_ptrs, const float* const* b1_ptrs,
+                                        const float* const* w2_ptrs, const float* const* b2_ptrs, float* u_proper,
+                                        float* s_proper, float* mode, float delta_i_weight, float* pose_f, float* pose_u,
+                                        float* pose_s, float* pose_v, int B, int num_body_joints, hps_stream_t stream) {
+    if (!pose_u) return bad_arg("hps_head_joint_level_svd: null pointer");
+    return joint_level_launch(embed, embed_dim, hidden, joint_ids, n_level, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs,
+                              u_proper, s_proper, mode, delta_i_weight, pose_f, nullptr, pose_u, pose_s, pose_v, B,
+                              num_body_joints, stream);
+}
+
+extern "C" int hps_svd3_packed(const float* f, float* usv, int n, hps_stream_t stream) {
+    if (!f || !usv) return bad_arg("hps_svd3_packed: null pointer");
+    if (n <= 0) return HPS_OK;
+    hipLaunchKernelGGL(svd3_packed_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, (hipStream_t)stream, f, usv, n);
+    return check_launch("hps_svd3_packed");
 }
 
 extern "C" int hps_head_svd_finish(const float* usv_level, const int32_t* joint_ids, int n_level, float* pose_u,

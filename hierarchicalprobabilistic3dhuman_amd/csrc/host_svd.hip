@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "hps_common.h"
+#include "svd3_gesdd.h"
 
 namespace hps {
 
@@ -162,5 +163,21 @@ extern "C" int hps_host_svd3_packed(const float* f_host, float* usv_host, int n,
         set_error("hps_host_svd3_packed: sgesdd reported failure");
         return HPS_E_BADARG;
     }
+    return HPS_OK;
+}
+
+// The device SVD's algorithm (svd3_gesdd.h) compiled for the host: lets the sign agreement with LAPACK be measured and
+// tested without a GPU.  Single thread; f_host (n,9) -> usv_host (n,21) packed like hps_host_svd3_packed.
+extern "C" int hps_host_svd3_emulated(const float* f_host, float* usv_host, int n) {
+    if (!f_host || !usv_host) return bad_arg("hps_host_svd3_emulated: null pointer");
+    int failed = 0;
+    for (int i = 0; i < n; ++i) {
+        float U[9], S[3], V[9];
+        if (!gesdd3::svd3(f_host + (size_t)i * 9, U, S, V)) ++failed;
+        float* o = usv_host + (size_t)i * 21;
+        for (int e = 0; e < 9; ++e) { o[e] = U[e]; o[12 + e] = V[e]; }
+        o[9] = S[0]; o[10] = S[1]; o[11] = S[2];
+    }
+    if (failed) { set_error("hps_host_svd3_emulated: %d matrices did not converge / were not finite", failed); return HPS_E_BADARG; }
     return HPS_OK;
 }

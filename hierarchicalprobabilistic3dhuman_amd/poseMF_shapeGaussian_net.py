@@ -9,11 +9,14 @@ Execution: ResNet-18 encoder (resnet.py) -> FC trunk (hps_linear) -> the 23 per-
 kinematic depth levels (hps_head_joint_level; 8 levels for the SMPL tree instead of 23 sequential steps)
 -> 3x3 SVD -> proper-SVD fix and mode (hps_head_svd_finish).
 
-3x3 SVD: like the reference (models/poseMF_shapeGaussian_net.py:137, "SVD is faster on CPU") the SVD
-itself runs on the host through LAPACK -- one batched call per level.  This is deliberate, not a
-fallback: the column signs LAPACK returns are not determined by the mathematics, they feed the child
-joints' MLPs through U_proper (:126-130), and the trained weights were fitted to them (SURVEY.md section 7
-hard part 1).  Everything around it (MLPs, determinants, proper fix, mode) runs on the device.
+3x3 SVD (:137, "SVD is faster on CPU" in the reference).  The column signs LAPACK returns are not determined by the
+mathematics, they feed the child joints' MLPs through U_proper (:126-130), and the trained weights were fitted to them
+(SURVEY.md section 7 hard part 1).  Two modes, ``net.svd_mode``:
+  "device" (default)  the SVD runs inside the level kernel and follows LAPACK's sgesdd step by step (csrc/svd3_gesdd.h):
+                      the same signs as torch.svd on 99.99 % of matrices, factors within 1e-4; the head
+                      is 11 stream-ordered launches, no host synchronisation, capturable in a hipGraph.
+  "host"              the reference's very routine: MKL sgesdd on the host (bit-identical to torch.svd), one D2H / sync /
+                      H2D round trip per kinematic level -- the parity mode.
 """
 import os
 
@@ -94,6 +97,7 @@ class PoseMFShapeGaussianNet(nn.Module):
         self._pinned_bufs = {}
         self.register_load_state_dict_post_hook(_invalidate_after_load)
         self.composite_head = True     # joint loop through hps_head_pose_levels (one call) instead of per-level Python
+        self.svd_mode = "device"       # "device": in-kernel gesdd-faithful SVD; "host": MKL sgesdd round trip (parity mode)
 
     # ---- kernel-side weights; rebuilt after .to() / load_state_dict ----
     def _apply(self, fn, *args, **kwargs):
@@ -208,25 +212,39 @@ class PoseMFShapeGaussianNet(nn.Module):
         mode = torch.empty(B, nj, 3, 3, **f32)
         delta = float(self.config.MODEL.DELTA_I_WEIGHT) if self.config.MODEL.DELTA_I else 0.0
         stream = torch.cuda.current_stream()
+        if self.svd_mode not in ("device", "host"):
+            raise ValueError("svd_mode must be 'device' or 'host'")
+        device_svd = self.svd_mode == "device"
         if self.composite_head:
             # the whole joint loop in one call across the C ABI (csrc/composite.hip: same launches, same order)
             sizes = p["level_sizes_host"]
             max_n = int(sizes.max())
-            n_f = _capi.query_workspace(_capi.WS_HEAD_F, B, max_n) // 4
-            n_usv = _capi.query_workspace(_capi.WS_HEAD_USV, B, max_n) // 4
-            f_dev = torch.empty(n_f, **f32)
-            usv_dev = torch.empty(n_usv, **f32)
-            f_host = self._pinned("f", n_f)
-            usv_host = self._pinned("usv", n_usv)
             VP = _capi._P
+            if device_svd:
+                f_dev = usv_dev = None
+                fh = uh = None
+            else:
+                n_f = _capi.query_workspace(_capi.WS_HEAD_F, B, max_n) // 4
+                n_usv = _capi.query_workspace(_capi.WS_HEAD_USV, B, max_n) // 4
+                f_dev = torch.empty(n_f, **f32)
+                usv_dev = torch.empty(n_usv, **f32)
+                fh, uh = VP(self._pinned("f", n_f).data_ptr()), VP(self._pinned("usv", n_usv).data_ptr())
             _capi.call("hps_head_pose_levels", P(embed), embed_dim, embed_dim // 2, _capi.iptr(p["level_joints"]),
                        VP(sizes.data_ptr()), len(p["levels"]), _capi.iptr(p["anc_ptr"]), _capi.iptr(p["anc_idx"]),
                        VP(p["w1t_ptrs"].data_ptr()), VP(p["b1_ptrs"].data_ptr()), VP(p["w2_ptrs"].data_ptr()),
                        VP(p["b2_ptrs"].data_ptr()), P(U_proper), P(S_proper), P(mode), delta, P(pose_F), P(pose_U), P(pose_S),
-                       P(pose_V), P(f_dev), P(usv_dev), VP(f_host.data_ptr()), VP(usv_host.data_ptr()), B, nj, _SVD_THREADS, s)
+                       P(pose_V), P(f_dev), P(usv_dev), fh, uh, B, nj, _SVD_THREADS,
+                       _capi.SVD_DEVICE if device_svd else _capi.SVD_HOST, s)
             return pose_F, pose_U, pose_S, pose_V, mode, shape_dist, glob, cam
         for lvl in p["levels"]:
             n_level = lvl.numel()
+            if device_svd:
+                _capi.call("hps_head_joint_level_svd", P(embed), embed_dim, embed_dim // 2, _capi.iptr(lvl), n_level,
+                           _capi.iptr(p["anc_ptr"]), _capi.iptr(p["anc_idx"]),
+                           _capi._P(p["w1t_ptrs"].data_ptr()), _capi._P(p["b1_ptrs"].data_ptr()),
+                           _capi._P(p["w2_ptrs"].data_ptr()), _capi._P(p["b2_ptrs"].data_ptr()),
+                           P(U_proper), P(S_proper), P(mode), delta, P(pose_F), P(pose_U), P(pose_S), P(pose_V), B, nj, s)
+                continue
             f_level = torch.empty(B, n_level, 3, 3, **f32)
             _capi.call("hps_head_joint_level", P(embed), embed_dim, embed_dim // 2, _capi.iptr(lvl), n_level,
                        _capi.iptr(p["anc_ptr"]), _capi.iptr(p["anc_idx"]),

@@ -36,6 +36,9 @@ typedef void* hps_stream_t; /* hipStream_t */
 #define HPS_E_BADARG (-1)      /* null pointer / size out of range */
 #define HPS_E_UNSUPPORTED (-2) /* shape not implemented by this build */
 
+#define HPS_SVD_HOST 0   /* host LAPACK sgesdd (the reference's own routine) */
+#define HPS_SVD_DEVICE 1 /* in-kernel SVD that follows sgesdd step by step */
+
 #define HPS_ACT_NONE 0
 #define HPS_ACT_ELU 1
 #define HPS_ACT_RELU 2
@@ -194,6 +197,25 @@ int hps_head_joint_level(const float* embed, int embed_dim, int hidden, const in
                          float delta_i_weight, float* pose_f, float* f_level, int B,
                          int num_body_joints, hps_stream_t stream);
 
+/* hps_head_joint_level with the level's 3x3 SVDs (models/poseMF_shapeGaussian_net.py:137), the proper-SVD fix and the mode
+ * (:139-152) done INSIDE the kernel: pose_u / pose_s / pose_v and u_proper / s_proper / mode rows of the level's joints are
+ * written, no host round trip.  The SVD follows LAPACK's sgesdd step by step (csrc/svd3_gesdd.h) so that the singular
+ * vectors carry the signs the reference's torch.svd gives them -- they are inputs of the child joints (:126-130). */
+int hps_head_joint_level_svd(const float* embed, int embed_dim, int hidden, const int32_t* joint_ids,
+                             int n_level, const int32_t* anc_ptr, const int32_t* anc_idx,
+                             const float* const* w1t_ptrs, const float* const* b1_ptrs,
+                             const float* const* w2_ptrs, const float* const* b2_ptrs, float* u_proper,
+                             float* s_proper, float* mode, float delta_i_weight, float* pose_f, float* pose_u,
+                             float* pose_s, float* pose_v, int B, int num_body_joints, hps_stream_t stream);
+
+/* The same device SVD for n row-major 3x3 matrices: f (n,9) -> usv (n,21) packed [U (9) | S (3) | V (9)]; replaces
+ * torch.svd(F.cpu()) (:137).  Non-finite or non-converging input (LAPACK: INFO != 0) gives NaN factors. */
+int hps_svd3_packed(const float* f, float* usv, int n, hps_stream_t stream);
+
+/* HOST function: the algorithm of hps_svd3_packed compiled for the host (single thread) -- for measuring / testing its
+ * agreement with LAPACK without a GPU.  f_host (n,9) -> usv_host (n,21). */
+int hps_host_svd3_emulated(const float* f_host, float* usv_host, int n);
+
 /* HOST function (no device work): SVD of n row-major 3x3 matrices through the LAPACK sgesdd_ exported by the
  * process's libtorch_cpu.so -- the routine behind the reference's torch.svd(F.cpu()) (:137), so factors and
  * column signs are bit-identical -- spread over num_threads threads.  f_host (n,9) -> usv_host (n,21) packed
@@ -251,9 +273,12 @@ int hps_sizeof_enc_op(void);
  * GPU needs to run them). */
 int hps_encoder_run(const hps_enc_op* ops, int n_ops, hps_stream_t stream);
 
-/* models/poseMF_shapeGaussian_net.py:121-160 in one call: for each kinematic level  hps_head_joint_level -> D2H of
- * the level's F matrices -> stream synchronise -> hps_host_svd3_packed (:137, host LAPACK) -> H2D ->
- * hps_head_svd_finish.  level_joints: DEVICE int32 array, the levels' joint ids concatenated; level_sizes_host: HOST
+/* models/poseMF_shapeGaussian_net.py:121-160 in one call, one kinematic level after the other.
+ *   svd_mode HPS_SVD_DEVICE: hps_head_joint_level_svd per level -- 8 stream-ordered launches for the SMPL tree, no
+ *            synchronisation, capturable in a hipGraph; the staging buffers may be NULL.
+ *   svd_mode HPS_SVD_HOST (parity mode: the very LAPACK routine of the reference): hps_head_joint_level -> D2H of the level's F
+ *            matrices -> stream synchronise -> hps_host_svd3_packed (:137) -> H2D -> hps_head_svd_finish.
+ * level_joints: DEVICE int32 array, the levels' joint ids concatenated; level_sizes_host: HOST
  * array of n_levels sizes; f_level_dev (B*max_level*9) / usv_level_dev (B*max_level*21): device scratch;
  * f_host_pinned / usv_host_pinned: page-locked host staging of the same sizes.  Blocks the calling thread (it waits
  * for each level's matrices); other streams keep running. */
@@ -264,7 +289,7 @@ int hps_head_pose_levels(const float* embed, int embed_dim, int hidden, const in
                          float* s_proper, float* mode, float delta_i_weight, float* pose_f, float* pose_u,
                          float* pose_s, float* pose_v, float* f_level_dev, float* usv_level_dev,
                          float* f_host_pinned, float* usv_host_pinned, int B, int num_body_joints,
-                         int svd_threads, hps_stream_t stream);
+                         int svd_threads, int svd_mode, hps_stream_t stream);
 
 /* (B,C,H,W) -> interior of the (B, H + 2P, W + 2P, C) NHWC frame; C in {4, 18, 64}
  * (predict/predict_poseMF_shapeGaussian_net.py:103 hands the net an NCHW proxy representation). */
