@@ -1,0 +1,226 @@
+// Winograd F(2x2, 3x3) convolution for the stride-1 3x3 layers of the ResNet-18 encoder (models/resnet.py:62-78: conv1 /
+// conv2 of the BasicBlocks), fused with BatchNorm, residual and ReLU, on the fp32 MFMA pipe.
+//
+// Why: the encoder is bound by the fp32 MFMA rate (157 TF/s peak, 136 TF/s sustained on random data) and the direct
+// implicit-GEMM kernel (conv_pad.hip) already runs at 120-131 TF/s -- the only large lever left is doing fewer
+// multiplications.  F(2x2, 3x3) computes a 2x2 output tile from a 4x4 input patch with 16 multiplications per
+// (cin, cout) instead of 36: 2.25 x fewer MFMA FLOPs for 62 % of the encoder's arithmetic.
+//
+//   V = B^T d B   (input transform, 4x4 patch d, per channel: 32 additions)
+//   M_p[tile, cout] = sum_cin V_p[tile, cin] * U_p[cin, cout]        p = 16 positions: 16 independent GEMMs on the MFMA pipe
+//   Y = A^T M A   (output transform: 24 additions per (tile, cout)), then scale * Y + shift (+ residual) (ReLU)
+//   U = G g G^T is precomputed on the host when the weights are prepared (resnet.py).
+//
+// Workgroup = 256 threads = 4 waves as 2 (tile groups of 32) x 2 (cout groups of 32); it owns 64 tiles x 64 output
+// channels x all 16 positions: a wave keeps 16 accumulators of 32x32 (256 registers), one wave per SIMD.  K = Cin is
+// streamed in chunks of 8 channels: the transformed filters U (laid out chunk-contiguous by the host) arrive by LDS-DMA
+// one chunk ahead; the input patches are loaded into registers two chunks ahead (thread = (tile, channel pair): 16 loads of 8
+// bytes), transformed by VALU and written to LDS one chunk ahead.  Operand chunks live in LDS as [position][k-quad][row][4]:
+// a fragment read is one conflict-free ds_read_b128 per lane (16 consecutive lanes = 256 contiguous bytes), and per position
+// and chunk a wave issues 2 reads and 4 MFMAs (k pairs (j, 4 + j)).
+// The activations are halo-padded NHWC frames (conv_pad.hip): every 4x4 patch is in bounds.
+// Accuracy: the transforms use only +-1 and +-1/2 -- exact scalings; the result differs from the direct convolution by
+// fp32 rounding of a different summation order (measured <= 2e-6 relative per layer, tests/test_gpu_net.py).
+// The summation order depends on the layer only, never on the batch size (sharding invariance).
+#include "hps_common.h"
+
+namespace hps {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WT = 64;            // tiles per workgroup
+constexpr int WC = 64;            // output channels per workgroup
+constexpr int WK = 8;             // input channels per chunk
+constexpr int W_OPER = 16 * 2 * 64 * 4;                   // floats of one operand chunk: [16 positions][2 k-quads][64 rows][4]
+
+struct WinoGeom {
+    int in_row, in_img;           // input frame pitches in floats: (W + 2 ipad) * Cin, (H + 2 ipad) * that
+    int out_row, out_img;         // output frame pitches
+    int ipad, opad;
+    int tiles_x, tiles_img;       // tiles per row / per image
+    int Cin, Cout, n_ct, relu;
+    unsigned magic_img, magic_x;
+};
+
+__device__ __forceinline__ unsigned wino_div(unsigned n, unsigned d, unsigned magic) {
+    unsigned q = __umulhi(n, magic);
+    if (n - q * d >= d) ++q;
+    return q;
+}
+
+__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restrict__ x, const float* __restrict__ u,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ residual, float* __restrict__ y,
+                                                           const WinoGeom g) {
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // sA[2][W_OPER] | sB[2][W_OPER]
+    float* sA = smem;
+    float* sB = smem + 2 * W_OPER;
+
+    const int ct = blockIdx.x % g.n_ct, tb = blockIdx.x / g.n_ct;     // cout tile fastest: neighbours share the input block in L2
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kl = lane >> 5, il = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- input loader role: thread = (tile tid >> 2, channel pair tid & 3) ----
+    const int ltile = tid >> 2, cp = tid & 3;
+    const float* in_base;
+    {
+        const unsigned t = (unsigned)(tb * WT + ltile);
+        const unsigned b = wino_div(t, (unsigned)g.tiles_img, g.magic_img), rem = t - b * g.tiles_img;
+        const unsigned ty = wino_div(rem, (unsigned)g.tiles_x, g.magic_x), tx = rem - ty * g.tiles_x;
+        in_base = x + (size_t)b * g.in_img + (size_t)(2 * ty + g.ipad - 1) * g.in_row + (size_t)(2 * tx + g.ipad - 1) * g.Cin + cp * 2;
+    }
+    // LDS float offset of this thread's (tile, channel pair) slot of position 0; position p adds p * 512
+    const int a_slot = ((cp >> 1) * 64 + ltile) * 4 + (cp & 1) * 2;
+
+    float2 d[16];
+    auto load_patch = [&](int chunk) {
+        const float* p0 = in_base + chunk * WK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                d[i * 4 + j] = *reinterpret_cast<const float2*>(p0 + (size_t)i * g.in_row + j * g.Cin);
+    };
+    auto transform_store = [&](int buf) {
+        float* dst = sA + buf * W_OPER + a_slot;
+        float2 t[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {          // t = B^T d
+            t[0 * 4 + j] = make_float2(d[0 * 4 + j].x - d[2 * 4 + j].x, d[0 * 4 + j].y - d[2 * 4 + j].y);
+            t[1 * 4 + j] = make_float2(d[1 * 4 + j].x + d[2 * 4 + j].x, d[1 * 4 + j].y + d[2 * 4 + j].y);
+            t[2 * 4 + j] = make_float2(d[2 * 4 + j].x - d[1 * 4 + j].x, d[2 * 4 + j].y - d[1 * 4 + j].y);
+            t[3 * 4 + j] = make_float2(d[1 * 4 + j].x - d[3 * 4 + j].x, d[1 * 4 + j].y - d[3 * 4 + j].y);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {          // v = t B
+            const float2 v0 = make_float2(t[i * 4 + 0].x - t[i * 4 + 2].x, t[i * 4 + 0].y - t[i * 4 + 2].y);
+            const float2 v1 = make_float2(t[i * 4 + 1].x + t[i * 4 + 2].x, t[i * 4 + 1].y + t[i * 4 + 2].y);
+            const float2 v2 = make_float2(t[i * 4 + 2].x - t[i * 4 + 1].x, t[i * 4 + 2].y - t[i * 4 + 1].y);
+            const float2 v3 = make_float2(t[i * 4 + 1].x - t[i * 4 + 3].x, t[i * 4 + 1].y - t[i * 4 + 3].y);
+            *reinterpret_cast<float2*>(dst + (i * 4 + 0) * 512) = v0;
+            *reinterpret_cast<float2*>(dst + (i * 4 + 1) * 512) = v1;
+            *reinterpret_cast<float2*>(dst + (i * 4 + 2) * 512) = v2;
+            *reinterpret_cast<float2*>(dst + (i * 4 + 3) * 512) = v3;
+        }
+    };
+
+    // ---- transformed filters: chunk c of cout tile ct is W_OPER contiguous floats; wave w moves pieces 8 w .. 8 w + 7 ----
+    const unsigned lds_b0 = (unsigned)(size_t)(lptr_t)(sB);
+    const float* u_src = u + (size_t)ct * W_OPER;
+    const size_t u_step = (size_t)g.n_ct * W_OPER;
+    auto dma_filters = [&](int buf) {
+        const unsigned base = lds_b0 + (unsigned)(buf * W_OPER * 4 + wave * 8 * 1024);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) lds_dma16((unsigned)((wave * 8 + q) * 1024 + lane * 16), u_src, base + q * 1024);
+        u_src += u_step;
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+
+    const int nchunks = g.Cin / WK;
+    load_patch(0);
+    dma_filters(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    transform_store(0);
+    if (nchunks > 1) load_patch(1);
+
+    const float* fa = sA + (kl * 64 + wm * 32 + il) * 4;          // this lane's fragment slot of position 0, buffer 0
+    const float* fb = sB + (kl * 64 + wn * 32 + il) * 4;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // filters of chunk c landed; the patch registers hold chunk c + 1
+        __syncthreads();                                     // operand chunk c complete for everyone; buffers buf ^ 1 are free
+        if (c + 1 < nchunks) {
+            transform_store(buf ^ 1);
+            dma_filters(buf ^ 1);
+            if (c + 2 < nchunks) load_patch(c + 2);
+        }
+        const float* pa = fa + buf * W_OPER;
+        const float* pb = fb + buf * W_OPER;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const float4 a4 = *reinterpret_cast<const float4*>(pa + p * 512);
+            const float4 b4 = *reinterpret_cast<const float4*>(pb + p * 512);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[p], 0, 0, 0);
+        }
+    }
+
+    // ---- output transform Y = A^T M A, BatchNorm, residual, ReLU.  A lane owns one output channel (MFMA column) and 16
+    //      tiles (MFMA rows (r & 3) + 8 (r >> 2) + 4 kl of the wave's 32): per pixel a half-wave stores 128 contiguous bytes ----
+    const int co = ct * WC + wn * 32 + il;
+    const float sc = scale[co], sh = shift[co];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned t = (unsigned)(tb * WT + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl);
+        const unsigned b = wino_div(t, (unsigned)g.tiles_img, g.magic_img), rem = t - b * g.tiles_img;
+        const unsigned ty = wino_div(rem, (unsigned)g.tiles_x, g.magic_x), tx = rem - ty * g.tiles_x;
+        const size_t o = (size_t)b * g.out_img + (size_t)(2 * ty + g.opad) * g.out_row + (size_t)(2 * tx + g.opad) * g.Cout + co;
+        // s = A^T M  (2 x 4), A^T = [1 1 1 0; 0 1 -1 -1]
+        float s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] = acc[0 * 4 + j][r] + acc[1 * 4 + j][r] + acc[2 * 4 + j][r];
+            s1[j] = acc[1 * 4 + j][r] - acc[2 * 4 + j][r] - acc[3 * 4 + j][r];
+        }
+        float yv[4];
+        yv[0] = s0[0] + s0[1] + s0[2];
+        yv[1] = s0[1] - s0[2] - s0[3];
+        yv[2] = s1[0] + s1[1] + s1[2];
+        yv[3] = s1[1] - s1[2] - s1[3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t oo = o + (size_t)(q >> 1) * g.out_row + (size_t)(q & 1) * g.Cout;
+            float v = yv[q] * sc + sh;
+            if (residual) v += residual[oo];
+            if (g.relu) v = fmaxf(v, 0.0f);
+            y[oo] = v;
+        }
+    }
+}
+
+static unsigned wino_magic(unsigned d) { return d <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / d); }
+
+}  // namespace hps
+
+using namespace hps;
+
+extern "C" int hps_conv3x3_winograd(const float* x, const float* u, const float* scale, const float* shift, const float* residual,
+                                    float* y, int B, int H, int W, int ipad, int Cin, int Cout, int opad, int relu,
+                                    hps_stream_t stream) {
+    if (!x || !u || !scale || !shift || !y) return bad_arg("hps_conv3x3_winograd: null pointer");
+    if (B <= 0) return HPS_OK;
+    if (H <= 0 || W <= 0 || (H & 1) || (W & 1)) return bad_arg("hps_conv3x3_winograd: H and W must be even");
+    if (Cin <= 0 || Cin % WK != 0 || Cout <= 0 || Cout % WC != 0) return bad_arg("hps_conv3x3_winograd: Cin % 8 == 0 and Cout % 64 == 0 required");
+    if (ipad < 1 || opad < 0) return bad_arg("hps_conv3x3_winograd: the input frame needs a halo of at least one pixel");
+    const long tiles = (long)B * (H / 2) * (W / 2);
+    if (tiles % WT != 0) return bad_arg("hps_conv3x3_winograd: B * (H/2) * (W/2) must be a multiple of 64");
+    if ((size_t)B * (H + 2 * ipad) * (W + 2 * ipad) * Cin * 4 >= 0xffffffffull * 4ull) return bad_arg("hps_conv3x3_winograd: tensor too large");
+    WinoGeom g;
+    g.in_row = (W + 2 * ipad) * Cin;
+    g.in_img = (H + 2 * ipad) * g.in_row;
+    g.out_row = (W + 2 * opad) * Cout;
+    g.out_img = (H + 2 * opad) * g.out_row;
+    g.ipad = ipad; g.opad = opad;
+    g.tiles_x = W / 2;
+    g.tiles_img = (H / 2) * (W / 2);
+    g.Cin = Cin; g.Cout = Cout; g.n_ct = Cout / WC; g.relu = relu;
+    g.magic_img = wino_magic((unsigned)g.tiles_img);
+    g.magic_x = wino_magic((unsigned)g.tiles_x);
+    const size_t lds = (size_t)4 * W_OPER * sizeof(float);           // 128 KiB
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)(tiles / WT * g.n_ct)), dim3(256), lds, (hipStream_t)stream, x, u, scale, shift,
+                       residual, y, g);
+    return check_launch("hps_conv3x3_winograd");
+}

@@ -198,9 +198,56 @@ __global__ void rodrigues_kernel(const float* __restrict__ aa, float* __restrict
     for (int e = 0; e < 9; ++e) r[(size_t)i * 9 + e] = R[e];
 }
 
+// Inputs of the one flattened SMPL call of the inference core, meshes ordered [mode (B) | T-pose (B) | samples (B N)]
+// (predict/predict_poseMF_shapeGaussian_net.py:112-115, :136, utils/sampling_utils.py:178-185): thread per output element.
+//   body (M, nj, 9): rows [0, B) = pose_rotmats_mode, rows [B, 2B) = identity; rows [2B, M) are the sampler's output (untouched)
+//   glob_all (M, 9): glob_rotmats[b] for the mode and the samples of image b, identity for the T-pose meshes
+//   betas_all (M, nb): shape mean of image b, or betas_samples (B, N, nb) for the sample meshes when given
+__global__ void infer_assemble_kernel(const float* __restrict__ mode, const float* __restrict__ glob_rotmats,
+                                      const float* __restrict__ loc, const float* __restrict__ betas_samples,
+                                      float* __restrict__ body, float* __restrict__ glob_all, float* __restrict__ betas_all,
+                                      int B, int N, int nj, int nb) {
+    const long M = (long)B * (N + 2);
+    const long n_body = 2L * B * nj * 9, n_glob = M * 9, n_beta = M * nb;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_body) {
+        const long m = i / (nj * 9);
+        const int e = (int)(i % 9);
+        body[i] = m < B ? mode[i] : ((e % 4 == 0) ? 1.0f : 0.0f);
+        return;
+    }
+    i -= n_body;
+    if (i < n_glob) {
+        const long m = i / 9;
+        const int e = (int)(i % 9);
+        const long b = m < B ? m : (m < 2L * B ? -1 : (m - 2L * B) / N);
+        glob_all[i] = b < 0 ? ((e % 4 == 0) ? 1.0f : 0.0f) : glob_rotmats[b * 9 + e];
+        return;
+    }
+    i -= n_glob;
+    if (i < n_beta) {
+        const long m = i / nb;
+        const int e = (int)(i % nb);
+        if (m >= 2L * B && betas_samples) betas_all[i] = betas_samples[(m - 2L * B) * nb + e];
+        else betas_all[i] = loc[(m < B ? m : (m < 2L * B ? m - B : (m - 2L * B) / N)) * nb + e];
+    }
+}
+
 }  // namespace hps
 
 using namespace hps;
+
+extern "C" int hps_infer_assemble(const float* mode, const float* glob_rotmats, const float* loc, const float* betas_samples,
+                                  float* body, float* glob_all, float* betas_all, int B, int N, int num_body_joints,
+                                  int num_betas, hps_stream_t stream) {
+    if (!mode || !glob_rotmats || !loc || !body || !glob_all || !betas_all) return bad_arg("hps_infer_assemble: null pointer");
+    if (B <= 0 || N < 0 || num_body_joints <= 0 || num_betas <= 0) return bad_arg("hps_infer_assemble: dims");
+    const long M = (long)B * (N + 2);
+    const long total = 2L * B * num_body_joints * 9 + M * 9 + M * num_betas;
+    hipLaunchKernelGGL(infer_assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mode,
+                       glob_rotmats, loc, betas_samples, body, glob_all, betas_all, B, N, num_body_joints, num_betas);
+    return check_launch("hps_infer_assemble");
+}
 
 extern "C" int hps_mf_sample(const float* pose_u, const float* pose_s, const float* pose_v, const float* bingham_a,
                              const float* acg_override, int C, int num_joints, int num_samples, int n_prop, float b, float m_star, const float* eps, const float* w,

@@ -40,21 +40,29 @@ def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mea
         glob_rotmats = batch_rodrigues(glob)
     else:
         glob_rotmats = rot6d_to_rotmat(glob)
-    R = pose_matrix_fisher_sampling_torch(pose_U, pose_S, pose_V, N, b=1.5, oversampling_ratio=8,
-                                          sample_on_cpu=sample_on_cpu, seed=seed, image_offset=image_offset)
-    loc = shape_dist.loc
-    if use_mean_shape:                                                            # sampling_utils.py:178-181
-        betas_s = loc[:, None, :].expand(B, N, -1)
-    else:
-        betas_s = shape_dist.sample([N]).transpose(0, 1)
-    # One flattened SMPL call over B*(N+2) meshes: [mode | T-pose | samples].  The reference makes three
-    # calls per image (:112-115, :136, sampling_utils.py:182-185); SMPL is per-mesh so the results are the
-    # same, and the zero axis-angle pose of :136 is exactly the identity rotation under smplx's Rodrigues.
-    eye = torch.eye(3, device=dev)
-    body = torch.cat([mode, eye.expand(B, nj, 3, 3), R.reshape(B * N, nj, 3, 3)], dim=0)
-    glob_all = torch.cat([glob_rotmats, eye.expand(B, 3, 3),
-                          glob_rotmats[:, None].expand(B, N, 3, 3).reshape(B * N, 3, 3)], dim=0).unsqueeze(1)
-    betas_all = torch.cat([loc, loc, betas_s.reshape(B * N, -1)], dim=0)
+    # One flattened SMPL call over M = B (N + 2) meshes: [mode | T-pose | samples].  The reference makes three calls per image
+    # (:112-115, :136, sampling_utils.py:182-185); SMPL is per-mesh so the results are the same, and the zero axis-angle pose
+    # of :136 is exactly the identity rotation under smplx's Rodrigues.  The sampler writes its rotations straight into the
+    # sample rows of the pose buffer and one kernel (hps_infer_assemble) fills everything else: no torch cat / expand glue.
+    M = B * (N + 2)
+    f32 = dict(device=dev, dtype=torch.float32)
+    body = torch.empty(M, nj, 3, 3, **f32)
+    R = pose_matrix_fisher_sampling_torch(pose_U, pose_S, pose_V, N, b=1.5, oversampling_ratio=8, sample_on_cpu=sample_on_cpu,
+                                          seed=seed, image_offset=image_offset, out=body[2 * B:].view(B, N, nj, 3, 3))
+    loc = _capi.f32c(shape_dist.loc)
+    nb = loc.shape[1]
+    betas_s = None
+    if not use_mean_shape:                                                        # sampling_utils.py:178-181
+        if sample_on_cpu:
+            host = torch.distributions.Normal(loc.cpu(), shape_dist.scale.cpu(), validate_args=False)
+            betas_s = host.sample([N]).transpose(0, 1).contiguous().to(dev)
+        else:
+            betas_s = shape_dist.sample([N]).transpose(0, 1).contiguous()
+    glob_all = torch.empty(M, 1, 3, 3, **f32)
+    betas_all = torch.empty(M, nb, **f32)
+    P = _capi.ptr
+    _capi.call("hps_infer_assemble", P(_capi.f32c(mode)), P(_capi.f32c(glob_rotmats)), P(loc), P(betas_s) if betas_s is not None else None,
+               P(body), P(glob_all), P(betas_all), B, N, nj, nb, _capi.stream())
     if _before_meshes is not None:          # InferencePipeline: the heavy mesh kernels wait here; sampling and the input
         _before_meshes()                    # assembly above are small and may run beside the next batch's encoder
     out = smpl_model(body_pose=body, global_orient=glob_all, betas=betas_all, pose2rot=False)

@@ -29,11 +29,13 @@ def _m_star(b):
 
 
 def _launch(pose_U, pose_S, pose_V, num_samples, n_prop, b, eps=None, w=None, draw_idx=None, seed=0,
-            call_offset=0, bingham_a=None, want_quat=False, acg_override=None, m_star=None):
+            call_offset=0, bingham_a=None, want_quat=False, acg_override=None, m_star=None, out=None):
     B, nj = pose_U.shape[:2]
     C = B * nj
     dev = pose_U.device
-    R = torch.empty(B, num_samples, nj, 3, 3, device=dev, dtype=torch.float32)
+    if out is not None:        # caller-provided destination (e.g. the sample rows of the flattened SMPL pose buffer)
+        assert out.shape == (B, num_samples, nj, 3, 3) and out.is_contiguous() and out.dtype == torch.float32
+    R = out if out is not None else torch.empty(B, num_samples, nj, 3, 3, device=dev, dtype=torch.float32)
     quat = torch.empty(B, num_samples, nj, 4, device=dev, dtype=torch.float32) if want_quat else None
     accepted = torch.empty(C, device=dev, dtype=torch.int32)
     P = _capi.ptr
@@ -55,7 +57,7 @@ def _launch(pose_U, pose_S, pose_V, num_samples, n_prop, b, eps=None, w=None, dr
 
 
 def _host_stream_sampling(pose_U, pose_S, pose_V, num_samples, n_prop, b, bingham_a=None, want_quat=False, acg_override=None,
-                          m_star=None):
+                          m_star=None, out=None):
     """Reference-order host noise; rare discarded rounds (fewer than N accepted, :68-69) shift every later
     call one draw further down the stream, exactly as the sequential reference loop would."""
     B, nj = pose_U.shape[:2]
@@ -75,7 +77,7 @@ def _host_stream_sampling(pose_U, pose_S, pose_V, num_samples, n_prop, b, bingha
         w = torch.stack(w_l).to(dev)
         R, quat, accepted = _launch(pose_U, pose_S, pose_V, num_samples, n_prop, b, eps=eps, w=w,
                                     draw_idx=assign.to(dev), bingham_a=bingham_a, want_quat=want_quat,
-                                    acg_override=acg_override, m_star=m_star)
+                                    acg_override=acg_override, m_star=m_star, out=out)
         fails = (accepted.cpu() < num_samples).nonzero().flatten()
         if fails.numel() == 0:
             return R, quat, accepted
@@ -120,20 +122,21 @@ def bingham_sampling_for_matrix_fisher_torch(A, num_samples, Omega=None, Gaussia
 
 
 def pose_matrix_fisher_sampling_torch(pose_U, pose_S, pose_V, num_samples, b=1.5, oversampling_ratio=8,
-                                      sample_on_cpu=False, seed=None, image_offset=0):
+                                      sample_on_cpu=False, seed=None, image_offset=0, out=None):
     """utils/sampling_utils.py:74-143: (B,23,3,3), (B,23,3), (B,23,3,3) -> R_samples (B,N,23,3,3).
 
     ``image_offset``: global index of the first image of this batch (multi-GPU sharding); only used by
-    the Philox route."""
+    the Philox route.  ``out``: optional contiguous (B,N,23,3,3) destination the kernel writes into."""
     for t, name in ((pose_U, "pose_U"), (pose_S, "pose_S"), (pose_V, "pose_V")):
         _capi.require_device(t, name)
     U, S, V = _capi.f32c(pose_U), _capi.f32c(pose_S), _capi.f32c(pose_V)
     n_prop = num_samples * oversampling_ratio
     if sample_on_cpu:
-        R, _, _ = _host_stream_sampling(U, S, V, num_samples, n_prop, b)
+        R, _, _ = _host_stream_sampling(U, S, V, num_samples, n_prop, b, out=out)
     else:
         nj = U.shape[1]
-        R, _, accepted = _launch(U, S, V, num_samples, n_prop, b, seed=_philox_seed(seed), call_offset=image_offset * nj)
+        R, _, accepted = _launch(U, S, V, num_samples, n_prop, b, seed=_philox_seed(seed), call_offset=image_offset * nj,
+                                 out=out)
         # A call that does not reach N accepts within _MAX_ROUNDS rounds (NaN / Inf pose_S from a bad checkpoint) gets NaN
         # rotations from the kernel -- loud downstream.  The counts stay on the device (no sync on the hot path);
         # check_sampling() is the deferred test the harnesses run per batch.

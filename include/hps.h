@@ -164,6 +164,15 @@ int hps_mf_sample(const float* pose_u, const float* pose_s, const float* pose_v,
                   int64_t call_offset, int max_rounds, float* r_out, float* quat_out,
                   int32_t* accepted, hps_stream_t stream);
 
+/* Inputs of ONE flattened SMPL call over the M = B (N + 2) meshes [mode (B) | T-pose (B) | samples (B N)] of the inference
+ * core (predict/predict_poseMF_shapeGaussian_net.py:112-115 mode mesh, :136 T-pose mesh, utils/sampling_utils.py:178-185 sample
+ * meshes): body (M, J-1, 3, 3) rows [0, 2B) (mode rotations, then identities; rows [2B, M) are where hps_mf_sample wrote its
+ * samples), glob_all (M, 3, 3) (glob_rotmats of the image; identity for the T-pose), betas_all (M, nb) (the shape mean of the
+ * image, or betas_samples (B, N, nb) for the sample meshes if non-NULL: use_mean_shape = False, :180-181). */
+int hps_infer_assemble(const float* mode, const float* glob_rotmats, const float* loc, const float* betas_samples,
+                       float* body, float* glob_all, float* betas_all, int B, int N, int num_body_joints,
+                       int num_betas, hps_stream_t stream);
+
 /* utils/rigid_transform_utils.py:113-133 */
 int hps_quat_to_rotmat(const float* quat, float* rotmat, int n, hps_stream_t stream);
 /* utils/rigid_transform_utils.py:80-94 (cross product along dim 1 for every batch size) */

@@ -1,0 +1,94 @@
+"""Per-layer view of the encoder at the benchmark shape (B = 64, 18x256x256), on the GPU box.
+
+    python tools/encoder_layers.py time   -> gpurun_out/enc_layers_time.json: every operation of hps_encoder_run's launch list run
+                                             ALONE (20 launches between HIP events): time, algorithmic GFLOP, TF/s
+    python tools/encoder_layers.py once   -> runs the whole list 3 times (target of the rocprofv3 --pmc passes of tools/encoder_pmc.sh)
+tools/summarize_encoder_layers.py merges both into profiles/<tag>_encoder_layers.{json,md}."""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from hierarchicalprobabilistic3dhuman_amd import _capi, configs  # noqa: E402
+from hierarchicalprobabilistic3dhuman_amd.poseMF_shapeGaussian_net import PoseMFShapeGaussianNet  # noqa: E402
+
+
+def op_names(enc):
+    names = ["relayout NCHW->padded NHWC", "conv1 7x7/2 18->64 (stem, row mode)", "maxpool 3x3/2"]
+    for li, layer in enumerate((enc.layer1, enc.layer2, enc.layer3, enc.layer4), 1):
+        for bi, blk in enumerate(layer):
+            if blk.downsample is not None:
+                names.append("layer%d.%d.downsample 1x1/2" % (li, bi))
+            names.append("layer%d.%d.conv1 3x3%s" % (li, bi, "/2" if blk.stride == 2 else ""))
+            names.append("layer%d.%d.conv2 3x3" % (li, bi))
+    names.append("global avgpool")
+    return names
+
+
+def main():
+    mode = sys.argv[1] if len(sys.argv) > 1 else "time"
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = PoseMFShapeGaussianNet(configs.SMPL_PARENTS, configs.get_cfg_defaults()).eval().to(dev)
+    enc = net.image_encoder
+    x = torch.rand(B, 18, 256, 256, generator=torch.Generator().manual_seed(1)).to(dev)
+    with torch.no_grad():
+        feats = enc(x)                                    # builds the frames and the launch list
+        torch.cuda.synchronize()
+        fs = next(iter(enc._frames.values()))
+        ops, n = fs["ops"], len(fs["ops"])
+        names = op_names(enc)
+        assert len(names) == n, (len(names), n)
+        ops[0].x = x.data_ptr()
+        ops[n - 1].y = feats.data_ptr()
+        s = _capi.stream()
+        if mode == "once":
+            for _ in range(3):
+                _capi.call("hps_encoder_run", ops, n, s)
+            torch.cuda.synchronize()
+            return
+        rows = []
+        for i in range(n):
+            o = ops[i]
+            one = (_capi.EncOp * 1)(o)
+            for _ in range(3):
+                _capi.call("hps_encoder_run", one, 1, s)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                _capi.call("hps_encoder_run", one, 1, s)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            row = {"op": names[i], "ms_alone": ms}
+            if o.kind == _capi.ENC_CONV:
+                Ho = (o.H + 2 * o.pad - o.KH) // o.stride + 1
+                Wo = (o.W + 2 * o.pad - o.KW) // o.stride + 1
+                cin = 18 if o.row_mode else o.Cin
+                gflop = 2.0 * o.B * Ho * Wo * o.Cout * o.KH * o.KW * cin / 1e9
+                row.update(gflop=gflop, tflops=gflop / ms, out_hw=[Ho, Wo], cin=cin, cout=o.Cout, ksplit=o.ksplit,
+                           launches=2 if o.ksplit > 1 else 1)
+            rows.append(row)
+            print("%-40s %.4f ms %s" % (names[i], ms, ("%.1f TF/s" % row["tflops"]) if "tflops" in row else ""), flush=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            _capi.call("hps_encoder_run", ops, n, s)
+        e0.record()
+        for _ in range(20):
+            _capi.call("hps_encoder_run", ops, n, s)
+        e1.record()
+        torch.cuda.synchronize()
+        whole = e0.elapsed_time(e1) / 20
+        out = {"batch": B, "whole_encoder_ms": whole, "sum_alone_ms": sum(r["ms_alone"] for r in rows),
+               "encoder_tflops": 6.279 * B / whole, "ops": rows}
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump(out, open(os.path.join(ROOT, "gpurun_out", "enc_layers_time.json"), "w"), indent=1)
+        print("whole encoder %.3f ms = %.1f TF/s; sum of the operations alone %.3f ms" % (whole, out["encoder_tflops"], out["sum_alone_ms"]))
+
+
+if __name__ == "__main__":
+    main()
