@@ -22,6 +22,9 @@
 // Accuracy: the transforms use only +-1 and +-1/2 -- exact scalings; the result differs from the direct convolution by
 // fp32 rounding of a different summation order (measured <= 2e-6 relative per layer, tests/test_gpu_net.py).
 // The summation order depends on the layer only, never on the batch size (sharding invariance).
+#include <mutex>
+#include <type_traits>
+
 #include "hps_common.h"
 
 namespace hps {
@@ -48,6 +51,8 @@ __device__ __forceinline__ unsigned wino_div(unsigned n, unsigned d, unsigned ma
     return q;
 }
 
+// AB: profiling ablations (compile-time; the product instantiates AB = 0 only): see hps_dev_conv3x3_winograd
+template <int AB>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ residual, float* __restrict__ y,
@@ -64,34 +69,40 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
 
     // ---- input loader role: thread = (tile tid >> 2, channel pair tid & 3) ----
     const int ltile = tid >> 2, cp = tid & 3;
-    const float* in_base;
+    unsigned in_off;                     // byte offset of this thread's patch pixel (0,0), channel pair cp, chunk 0 (tensor < 4 GiB)
     {
         const unsigned t = (unsigned)(tb * WT + ltile);
         const unsigned b = wino_div(t, (unsigned)g.tiles_img, g.magic_img), rem = t - b * g.tiles_img;
         const unsigned ty = wino_div(rem, (unsigned)g.tiles_x, g.magic_x), tx = rem - ty * g.tiles_x;
-        in_base = x + (size_t)b * g.in_img + (size_t)(2 * ty + g.ipad - 1) * g.in_row + (size_t)(2 * tx + g.ipad - 1) * g.Cin + cp * 2;
+        in_off = (b * (unsigned)g.in_img + (2 * ty + g.ipad - 1) * (unsigned)g.in_row + (2 * tx + g.ipad - 1) * (unsigned)g.Cin + cp * 2) * 4u;
     }
     // LDS float offset of this thread's (tile, channel pair) slot of position 0; position p adds p * 512
     const int a_slot = ((cp >> 1) * 64 + ltile) * 4 + (cp & 1) * 2;
 
-    float2 d[16];
-    auto load_patch = [&](int chunk) {
-        const float* p0 = in_base + chunk * WK;
+    // Patch registers hold FOUR chunks (32 channels = one 128-byte line per pixel): the thread's four 8-byte loads of a pixel go
+    // out back to back and meet in one L1 line fill.  (Loading one chunk at a time re-fetched every line four times -- 32-byte
+    // accesses, 4 x read amplification -- and the kernel ran at the CU's L2 bandwidth instead of the MFMA rate.)
+    float2 d[64];
+    auto load_group = [&](int grp) {
+        const char* p0 = reinterpret_cast<const char*>(x + grp * 4 * WK);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                d[i * 4 + j] = *reinterpret_cast<const float2*>(p0 + (size_t)i * g.in_row + j * g.Cin);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    d[k * 16 + i * 4 + j] = *reinterpret_cast<const float2*>(p0 + (size_t)(i * g.in_row + j * g.Cin + k * WK) * 4 + in_off);
     };
-    auto transform_store = [&](int buf) {
+    auto transform_store = [&](int buf, auto KC) {
+        constexpr int k0 = decltype(KC)::value * 16;
         float* dst = sA + buf * W_OPER + a_slot;
         float2 t[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {          // t = B^T d
-            t[0 * 4 + j] = make_float2(d[0 * 4 + j].x - d[2 * 4 + j].x, d[0 * 4 + j].y - d[2 * 4 + j].y);
-            t[1 * 4 + j] = make_float2(d[1 * 4 + j].x + d[2 * 4 + j].x, d[1 * 4 + j].y + d[2 * 4 + j].y);
-            t[2 * 4 + j] = make_float2(d[2 * 4 + j].x - d[1 * 4 + j].x, d[2 * 4 + j].y - d[1 * 4 + j].y);
-            t[3 * 4 + j] = make_float2(d[1 * 4 + j].x - d[3 * 4 + j].x, d[1 * 4 + j].y - d[3 * 4 + j].y);
+            t[0 * 4 + j] = make_float2(d[k0 + 0 * 4 + j].x - d[k0 + 2 * 4 + j].x, d[k0 + 0 * 4 + j].y - d[k0 + 2 * 4 + j].y);
+            t[1 * 4 + j] = make_float2(d[k0 + 1 * 4 + j].x + d[k0 + 2 * 4 + j].x, d[k0 + 1 * 4 + j].y + d[k0 + 2 * 4 + j].y);
+            t[2 * 4 + j] = make_float2(d[k0 + 2 * 4 + j].x - d[k0 + 1 * 4 + j].x, d[k0 + 2 * 4 + j].y - d[k0 + 1 * 4 + j].y);
+            t[3 * 4 + j] = make_float2(d[k0 + 1 * 4 + j].x - d[k0 + 3 * 4 + j].x, d[k0 + 1 * 4 + j].y - d[k0 + 3 * 4 + j].y);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {          // v = t B
@@ -123,47 +134,86 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
 
-    const int nchunks = g.Cin / WK;
-    load_patch(0);
-    dma_filters(0);
+    const int nchunks = g.Cin / WK;                       // a multiple of 4
+    constexpr int ab = AB;
+    if (ab != 1) load_group(0);
+    if (ab != 3) dma_filters(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    transform_store(0);
-    if (nchunks > 1) load_patch(1);
+    if (ab != 1) transform_store(0, std::integral_constant<int, 0>());
 
     const float* fa = sA + (kl * 64 + wm * 32 + il) * 4;          // this lane's fragment slot of position 0, buffer 0
     const float* fb = sB + (kl * 64 + wn * 32 + il) * 4;
-    for (int c = 0; c < nchunks; ++c) {
+    auto chunk_step = [&](int c, auto KC) {
+        constexpr int k = decltype(KC)::value;             // c & 3
         const int buf = c & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // filters of chunk c landed; the patch registers hold chunk c + 1
         __syncthreads();                                     // operand chunk c complete for everyone; buffers buf ^ 1 are free
         if (c + 1 < nchunks) {
-            transform_store(buf ^ 1);
-            dma_filters(buf ^ 1);
-            if (c + 2 < nchunks) load_patch(c + 2);
+            if (ab != 1) transform_store(buf ^ 1, std::integral_constant<int, (k + 1) & 3>());
+            if (ab != 3) dma_filters(buf ^ 1);
+            if (ab != 1 && k == 2 && c + 2 < nchunks) load_group((c + 2) >> 2);      // the last chunk of the group left the registers
         }
         const float* pa = fa + buf * W_OPER;
         const float* pb = fb + buf * W_OPER;
+        // one wave per SIMD: nothing hides an LDS round trip but the wave's own MFMAs, so the fragments of position p + 1 are
+        // requested before the four MFMAs of position p are issued (hipcc would otherwise sink each read to its use)
+        float4 a4[2], b4[2];
+        a4[0] = *reinterpret_cast<const float4*>(pa);
+        b4[0] = *reinterpret_cast<const float4*>(pb);
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
-            const float4 a4 = *reinterpret_cast<const float4*>(pa + p * 512);
-            const float4 b4 = *reinterpret_cast<const float4*>(pb + p * 512);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[p], 0, 0, 0);
+            if (p < 15) {
+                a4[(p + 1) & 1] = *reinterpret_cast<const float4*>(pa + (p + 1) * 512);
+                b4[(p + 1) & 1] = *reinterpret_cast<const float4*>(pb + (p + 1) * 512);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 a = a4[p & 1], b = b4[p & 1];
+            if (ab == 2) { acc[p][0] += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; continue; }
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[p], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    for (int c = 0; c < nchunks; c += 4) {
+        chunk_step(c, std::integral_constant<int, 0>());
+        chunk_step(c + 1, std::integral_constant<int, 1>());
+        chunk_step(c + 2, std::integral_constant<int, 2>());
+        chunk_step(c + 3, std::integral_constant<int, 3>());
     }
 
     // ---- output transform Y = A^T M A, BatchNorm, residual, ReLU.  A lane owns one output channel (MFMA column) and 16
     //      tiles (MFMA rows (r & 3) + 8 (r >> 2) + 4 kl of the wave's 32): per pixel a half-wave stores 128 contiguous bytes ----
+    if (ab == 4) {
+        float t = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[p][r];
+        if (t == 12345.678f) y[0] = t;
+        return;
+    }
     const int co = ct * WC + wn * 32 + il;
     const float sc = scale[co], sh = shift[co];
+    unsigned ooff[16];                                     // float offset of pixel (0,0) of each of the lane's tiles, channel co
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const unsigned t = (unsigned)(tb * WT + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl);
         const unsigned b = wino_div(t, (unsigned)g.tiles_img, g.magic_img), rem = t - b * g.tiles_img;
         const unsigned ty = wino_div(rem, (unsigned)g.tiles_x, g.magic_x), tx = rem - ty * g.tiles_x;
-        const size_t o = (size_t)b * g.out_img + (size_t)(2 * ty + g.opad) * g.out_row + (size_t)(2 * tx + g.opad) * g.Cout + co;
+        ooff[r] = b * (unsigned)g.out_img + (2 * ty + g.opad) * (unsigned)g.out_row + (2 * tx + g.opad) * (unsigned)g.Cout + co;
+    }
+    // all 64 residual values of the lane are requested before the first one is used: one memory round trip, not 64
+    float res[64];
+    if (residual) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) res[r * 4 + q] = residual[ooff[r] + (q >> 1) * g.out_row + (q & 1) * g.Cout];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
         // s = A^T M  (2 x 4), A^T = [1 1 1 0; 0 1 -1 -1]
         float s0[4], s1[4];
 #pragma unroll
@@ -178,11 +228,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
         yv[3] = s1[1] - s1[2] - s1[3];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const size_t oo = o + (size_t)(q >> 1) * g.out_row + (size_t)(q & 1) * g.Cout;
             float v = yv[q] * sc + sh;
-            if (residual) v += residual[oo];
+            if (residual) v += res[r * 4 + q];
             if (g.relu) v = fmaxf(v, 0.0f);
-            y[oo] = v;
+            y[ooff[r] + (q >> 1) * g.out_row + (q & 1) * g.Cout] = v;
         }
     }
 }
@@ -193,17 +242,18 @@ static unsigned wino_magic(unsigned d) { return d <= 1 ? 0xffffffffu : (unsigned
 
 using namespace hps;
 
-extern "C" int hps_conv3x3_winograd(const float* x, const float* u, const float* scale, const float* shift, const float* residual,
-                                    float* y, int B, int H, int W, int ipad, int Cin, int Cout, int opad, int relu,
-                                    hps_stream_t stream) {
+static int wino_launch(const float* x, const float* u, const float* scale, const float* shift, const float* residual,
+                       float* y, int B, int H, int W, int ipad, int Cin, int Cout, int opad, int relu, int ablate,
+                       hps_stream_t stream) {
     if (!x || !u || !scale || !shift || !y) return bad_arg("hps_conv3x3_winograd: null pointer");
     if (B <= 0) return HPS_OK;
     if (H <= 0 || W <= 0 || (H & 1) || (W & 1)) return bad_arg("hps_conv3x3_winograd: H and W must be even");
-    if (Cin <= 0 || Cin % WK != 0 || Cout <= 0 || Cout % WC != 0) return bad_arg("hps_conv3x3_winograd: Cin % 8 == 0 and Cout % 64 == 0 required");
+    if (Cin <= 0 || Cin % (4 * WK) != 0 || Cout <= 0 || Cout % WC != 0) return bad_arg("hps_conv3x3_winograd: Cin % 32 == 0 and Cout % 64 == 0 required");
     if (ipad < 1 || opad < 0) return bad_arg("hps_conv3x3_winograd: the input frame needs a halo of at least one pixel");
     const long tiles = (long)B * (H / 2) * (W / 2);
     if (tiles % WT != 0) return bad_arg("hps_conv3x3_winograd: B * (H/2) * (W/2) must be a multiple of 64");
-    if ((size_t)B * (H + 2 * ipad) * (W + 2 * ipad) * Cin * 4 >= 0xffffffffull * 4ull) return bad_arg("hps_conv3x3_winograd: tensor too large");
+    if ((size_t)B * (H + 2 * ipad) * (W + 2 * ipad) * Cin * 4 >= 0xffffffffull || (size_t)B * (H + 2 * opad) * (W + 2 * opad) * Cout * 4 >= 0xffffffffull)
+        return bad_arg("hps_conv3x3_winograd: tensor exceeds the 32-bit lane offsets");
     WinoGeom g;
     g.in_row = (W + 2 * ipad) * Cin;
     g.in_img = (H + 2 * ipad) * g.in_row;
@@ -216,11 +266,38 @@ extern "C" int hps_conv3x3_winograd(const float* x, const float* u, const float*
     g.magic_img = wino_magic((unsigned)g.tiles_img);
     g.magic_x = wino_magic((unsigned)g.tiles_x);
     const size_t lds = (size_t)4 * W_OPER * sizeof(float);           // 128 KiB
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)(tiles / WT * g.n_ct)), dim3(256), lds, (hipStream_t)stream, x, u, scale, shift,
-                       residual, y, g);
+    const dim3 grid((unsigned)(tiles / WT * g.n_ct));
+    auto launch = [&](auto AB) {
+        constexpr int ab = decltype(AB)::value;
+        static std::once_flag once;
+        std::call_once(once, [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<ab>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
+        hipLaunchKernelGGL(conv_wino_kernel<ab>, grid, dim3(256), lds, (hipStream_t)stream, x, u, scale, shift, residual, y, g);
+    };
+    switch (ablate) {
+        case 0: launch(std::integral_constant<int, 0>()); break;
+#ifdef HPS_DEV_BUILD
+        case 1: launch(std::integral_constant<int, 1>()); break;
+        case 2: launch(std::integral_constant<int, 2>()); break;
+        case 3: launch(std::integral_constant<int, 3>()); break;
+        case 4: launch(std::integral_constant<int, 4>()); break;
+#endif
+        default: return bad_arg("hps_conv3x3_winograd: ablate");
+    }
     return check_launch("hps_conv3x3_winograd");
 }
+
+extern "C" int hps_conv3x3_winograd(const float* x, const float* u, const float* scale, const float* shift, const float* residual,
+                                    float* y, int B, int H, int W, int ipad, int Cin, int Cout, int opad, int relu,
+                                    hps_stream_t stream) {
+    return wino_launch(x, u, scale, shift, residual, y, B, H, W, ipad, Cin, Cout, opad, relu, 0, stream);
+}
+
+#ifdef HPS_DEV_BUILD
+extern "C" int hps_dev_conv3x3_winograd(const float* x, const float* u, const float* scale, const float* shift, const float* residual,
+                                        float* y, int B, int H, int W, int ipad, int Cin, int Cout, int opad, int relu, int ablate,
+                                        hps_stream_t stream) {
+    return wino_launch(x, u, scale, shift, residual, y, B, H, W, ipad, Cin, Cout, opad, relu, ablate, stream);
+}
+#endif

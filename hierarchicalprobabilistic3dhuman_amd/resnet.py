@@ -44,6 +44,15 @@ class _ConvBN:
             wr = torch.zeros(cout, kh, ck, device=w.device, dtype=torch.float32)
             wr[:, :, :kw * cin] = w.permute(0, 2, 3, 1).reshape(cout, kh, kw * cin)
             self.wrow = wr.reshape(cout, kh * ck).contiguous()
+        # Winograd F(2x2, 3x3) form of a stride-1 3x3 layer (csrc/conv_wino.hip): U = G g G^T in the kernel's layout
+        #   [cin / 8][cout / 64][position 4a + b][(cin % 8) / 4][cout % 64][cin % 4]
+        self.wino_u = None
+        if kh == 3 and kw == 3 and self.stride == 1 and self.pad == 1 and cin % 32 == 0 and cout % 64 == 0:
+            G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
+            U = torch.einsum("ai,ocij,bj->abco", G, w.double(), G)                       # (4,4,cin,cout)
+            U = U.reshape(16, cin // 8, 2, 4, cout // 64, 64)                            # p, chunk, kq, j, ct, n
+            self.wino_u = U.permute(1, 4, 0, 2, 5, 3).contiguous().float()              # chunk, ct, p, kq, n, j
+        self.use_winograd = True
         self.kernel = "v3"        # "v3" direct global->LDS (default), "v2" register-staged, "v1" generic (any Cin % 4 == 0)
         self.variant = 0          # tile choice of the v2 / v3 kernels (0 = automatic)
         self.ksplit = 0           # split-K slices of the v3 kernel (0 = automatic, 1 = off)
@@ -60,11 +69,25 @@ class _ConvBN:
             return 4
         return 1
 
+    def winograd_ok(self, H, W, ipad):
+        """Winograd F(2x2, 3x3) applies: a 3x3 / 1 / 1 layer on an even-sized map whose tiles per IMAGE fill whole 64-tile
+        workgroups -- a rule on the layer and the image size only, never on the batch size (the summation order of a pixel, and
+        with it the last bit of every feature, must not depend on how images are batched or sharded)."""
+        return (self.use_winograd and self.wino_u is not None and ipad >= 1 and H % 2 == 0 and W % 2 == 0
+                and ((H // 2) * (W // 2)) % 64 == 0)
+
     def padded(self, xp, ipad, out, opad, residual=None, relu=True, ws=None):
         """Halo-padded generation (csrc/conv_pad.hip): xp (B, H+2*ipad, W+2*ipad, Cin) with a zero halo; writes the interior
         of ``out`` (B, Ho+2*opad, Wo+2*opad, Cout) -- the caller owns the halo (zeroed once); ``residual`` has out's frame."""
         B, Hp, Wp, C = xp.shape
         H, W = Hp - 2 * ipad, Wp - 2 * ipad
+        if self.winograd_ok(H, W, ipad):
+            assert C == self.cin_p and tuple(out.shape) == (B, H + 2 * opad, W + 2 * opad, self.cout)
+            P = _capi.ptr
+            _capi.call("hps_conv3x3_winograd", P(xp), P(self.wino_u), P(self.scale), P(self.shift),
+                       P(residual) if residual is not None else None, P(out), B, H, W, ipad, C, self.cout, opad, 1 if relu else 0,
+                       _capi.stream())
+            return out
         row_mode = self.wn is None
         assert C == (self.cin if row_mode else self.cin_p)
         Ho = (H + 2 * self.pad - self.kh) // self.stride + 1
@@ -84,12 +107,17 @@ class _ConvBN:
         """The hps_enc_op of ``padded(...)`` for hps_encoder_run (same arguments, nothing is launched)."""
         B, Hp, Wp, C = xp.shape
         H, W = Hp - 2 * ipad, Wp - 2 * ipad
+        dp = lambda t: t.data_ptr() if t is not None else None
+        if self.winograd_ok(H, W, ipad):
+            assert tuple(out.shape) == (B, H + 2 * opad, W + 2 * opad, self.cout) and C == self.cin_p
+            return _capi.EncOp(kind=_capi.ENC_CONV_WINOGRAD, x=dp(xp), w=dp(self.wino_u), scale=dp(self.scale), shift=dp(self.shift),
+                               residual=dp(residual), y=dp(out), B=B, H=H, W=W, ipad=ipad, Cin=C, Cout=self.cout, KH=3, KW=3,
+                               stride=1, pad=1, opad=opad, relu=1 if relu else 0, ksplit=1)
         row_mode = self.wn is None
         Ho, Wo = self.out_hw(H, W)
         assert tuple(out.shape) == (B, Ho + 2 * opad, Wo + 2 * opad, self.cout) and C == (self.cin if row_mode else self.cin_p)
         ksplit = 1 if row_mode else (self.ksplit if self.ksplit > 0 else self._auto_ksplit(Ho * Wo))
         assert ksplit == 1 or ws is not None
-        dp = lambda t: t.data_ptr() if t is not None else None
         return _capi.EncOp(kind=_capi.ENC_CONV, x=dp(xp), w=dp(self.wrow if row_mode else self.wn), scale=dp(self.scale),
                            shift=dp(self.shift), residual=dp(residual), y=dp(out), splitk_ws=dp(ws) if ksplit > 1 else None,
                            B=B, H=H, W=W, ipad=ipad, Cin=C, Cout=self.cout, KH=self.kh, KW=self.kw, stride=self.stride,
@@ -205,6 +233,13 @@ class ResNet(nn.Module):
         self._frames = _FrameCache()
         return super()._apply(fn, *args, **kwargs)
 
+    def set_winograd(self, on):
+        """Product default True: the stride-1 3x3 layers of layer1-3 run as Winograd F(2x2, 3x3) (csrc/conv_wino.hip); False runs
+        every layer on the direct implicit-GEMM kernel (csrc/conv_pad.hip) -- the cross-check of the tests."""
+        prep = self._prepared or self.prepare()
+        for c in [prep["stem"]] + [c for blk in prep["blocks"] for c in blk if c is not None]:
+            c.use_winograd = bool(on)
+
     def invalidate(self):
         """Drop the folded BatchNorm / filter copies and the cached launch lists; the next forward rebuilds them from the
         current parameters.  Called automatically by .to() and by any load_state_dict that reaches this module (also through
@@ -280,7 +315,7 @@ class ResNet(nn.Module):
     @staticmethod
     def _variant_state(prep):
         convs = [prep["stem"]] + [c for blk in prep["blocks"] for c in blk if c is not None]
-        return tuple((c.variant, c.ksplit) for c in convs)
+        return tuple((c.variant, c.ksplit, c.use_winograd) for c in convs)
 
     def _padded_ok(self, C, H, W):
         # row-mode stem (csrc/conv_pad.hip): 16-byte aligned window starts and rows

@@ -257,11 +257,24 @@ int hps_conv2d_bn_act_pad(const float* x, const float* wn, const float* scale, c
                           int KH, int KW, int stride, int pad, int opad, int relu, int row_mode, int variant,
                           int ksplit, float* splitk_ws, hps_stream_t stream);
 
+/* 3x3 / stride 1 / pad 1 convolution + BatchNorm (+ residual) (+ ReLU) by Winograd F(2x2, 3x3) on the fp32 MFMA pipe
+ * (csrc/conv_wino.hip): 16 multiplications per 2x2 output tile and (cin, cout) pair instead of 36 -- the stride-1 3x3
+ * layers of the BasicBlocks (models/resnet.py:62-78).  x / y / residual are halo-padded NHWC frames as for
+ * hps_conv2d_bn_act_pad (ipad >= 1).  u: the transformed filters U = G g G^T, prepared once by the host in the layout
+ *   u[chunk = cin / 8][cout tile = cout / 64][position p = 4 a + b][k-quad = (cin % 8) / 4][cout % 64][cin % 4]
+ * with G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1].  Requirements: H, W even, Cin % 32 == 0, Cout % 64 == 0,
+ * B * (H/2) * (W/2) a multiple of 64.  Results equal the direct convolution up to fp32 rounding of a different summation
+ * order; the order depends on the layer only, never on the batch size. */
+int hps_conv3x3_winograd(const float* x, const float* u, const float* scale, const float* shift,
+                         const float* residual, float* y, int B, int H, int W, int ipad, int Cin, int Cout,
+                         int opad, int relu, hps_stream_t stream);
+
 /* One launch of the encoder's operation list (hps_encoder_run).  kind: HPS_ENC_RELAYOUT = hps_nchw_to_padded_nhwc
  * (x, y, B, Cin = C, H, W, opad = P), HPS_ENC_CONV = hps_conv2d_bn_act_pad (all fields), HPS_ENC_MAXPOOL =
  * hps_maxpool3x3s2_pad (x, y, B, H, W, Cin = C, opad), HPS_ENC_AVGPOOL = hps_global_avgpool_pad (x, y, B, H, W,
- * Cin = C, ipad = P). */
-enum { HPS_ENC_RELAYOUT = 0, HPS_ENC_CONV = 1, HPS_ENC_MAXPOOL = 2, HPS_ENC_AVGPOOL = 3 };
+ * Cin = C, ipad = P), HPS_ENC_CONV_WINOGRAD = hps_conv3x3_winograd (x, w = u, scale, shift, residual, y, B, H, W, ipad, Cin,
+ * Cout, opad, relu). */
+enum { HPS_ENC_RELAYOUT = 0, HPS_ENC_CONV = 1, HPS_ENC_MAXPOOL = 2, HPS_ENC_AVGPOOL = 3, HPS_ENC_CONV_WINOGRAD = 4 };
 typedef struct hps_enc_op {
     int kind;
     const float* x;

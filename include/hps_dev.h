@@ -78,6 +78,12 @@ int hps_dev_mesh_fused(const float* xt, const float* bmat_p, const float* v_temp
                        const int32_t* w_idx, const float* w_val, int K, int num_joints, const float* transl,
                        float* verts, int M, int V, int kp, int mp, int np, int ablate, hps_stream_t stream);
 
+/* Profiling ablations of hps_conv3x3_winograd: 1 = no patch loads / input transform, 2 = no MFMA, 3 = no filter DMA,
+ * 4 = no epilogue (results are garbage); 0 = the product kernel. */
+int hps_dev_conv3x3_winograd(const float* x, const float* u, const float* scale, const float* shift,
+                             const float* residual, float* y, int B, int H, int W, int ipad, int Cin, int Cout,
+                             int opad, int relu, int ablate, hps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

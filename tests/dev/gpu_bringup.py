@@ -173,6 +173,33 @@ def sec_mesh_fused():
             print("   ablate %d %-30s %.3f ms  (%.1f TF/s)" % (ab, what, t, flop / (t * 1e-3) / 1e12), flush=True)
 
 
+def sec_wino():
+    """Winograd convolution: time and ablations per layer shape (B = 64)."""
+    from hierarchicalprobabilistic3dhuman_amd import _capi
+    from hierarchicalprobabilistic3dhuman_amd.resnet import _ConvBN
+    import torch.nn.functional as F
+    P = _capi.ptr
+    for (H, C) in ((64, 64), (32, 128), (16, 256)):
+        conv = torch.nn.Conv2d(C, C, 3, 1, 1, bias=False).to(dev)
+        bn = torch.nn.BatchNorm2d(C).eval().to(dev)
+        cb = _ConvBN(conv, bn)
+        x = F.pad(torch.relu(torch.randn(64, H, H, C, device=dev)), (0, 0, 1, 1, 1, 1)).contiguous()
+        out = torch.zeros(64, H + 2, H + 2, C, device=dev)
+        res = torch.randn(64, H + 2, H + 2, C, device=dev)
+        gflop = 2.0 * 64 * H * H * C * C * 9 / 1e9
+        for ab, what in ((0, "product"), (0, "product + residual"), (1, "no patch loads / transform"), (2, "no MFMA"), (3, "no filter DMA"),
+                         (4, "no epilogue")):
+            r = P(res) if "residual" in what else None
+            fn = lambda: _capi.call("hps_dev_conv3x3_winograd", P(x), P(cb.wino_u), P(cb.scale), P(cb.shift), r, P(out), 64, H, H, 1, C, C,
+                                    1, 1, ab, _capi.stream())
+            t = timeit(fn, iters=20)
+            print("wino %3dx%-3d C=%3d ablate %d %-28s %.4f ms  (direct-conv-equivalent %.1f TF/s, MFMA %.1f TF/s)"
+                  % (H, H, C, ab, what, t, gflop / t, gflop / 2.25 / t), flush=True)
+        cb.use_winograd = False
+        t = timeit(lambda: cb.padded(x, 1, out, 1, relu=True), iters=20)
+        print("     direct kernel                                   %.4f ms  (%.1f TF/s)" % (t, gflop / t), flush=True)
+
+
 def sec_blend_modes():
     """hps_smpl_blend: tiled kernel vs stationary-A kernel, time and bit equality, at the bench size and others."""
     model, params, smpl = make_smpl()

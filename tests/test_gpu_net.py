@@ -116,6 +116,7 @@ def test_padded_conv_kernel(cfg, dev):
         want_nores = bn(conv(x))
     tol = 1e-4 * max(1.0, float(want.abs().max()))
     cb = _ConvBN(conv.to(dev), bn.to(dev))
+    cb.use_winograd = False                     # this test is about the direct kernel (test_winograd_conv_kernel covers the other)
     xh = x.to(dev).permute(0, 2, 3, 1).contiguous()
     resh = res.to(dev).permute(0, 2, 3, 1).contiguous()
     xp = _frame(xh, ipad)
@@ -317,3 +318,61 @@ def test_head_svd_modes_agree(dev, net_gpu):
     assert maxerr(d[0][clean], h[0][clean]) <= 1e-4 and maxerr(d[4][clean], h[4][clean]) <= 1e-4
     assert maxerr(d[2][clean], h[2][clean]) <= 1e-5 * max(1.0, float(h[2].max()))
     assert maxerr(d[1][clean], h[1][clean]) <= 1e-3 and maxerr(d[3][clean], h[3][clean]) <= 1e-3
+
+
+@pytest.mark.parametrize("cfg", [
+    # B, H, Cin, Cout -- the stride-1 3x3 layers of layer1 / layer2 / layer3 at the 256x256 input, plus an odd batch
+    (2, 64, 64, 64), (2, 32, 128, 128), (3, 16, 256, 256), (1, 16, 64, 128)])
+def test_winograd_conv_kernel(cfg, dev):
+    """csrc/conv_wino.hip (Winograd F(2x2, 3x3) + BatchNorm + residual + ReLU) against torch's convolution and against the direct
+    implicit-GEMM kernel: same results up to fp32 rounding of a different summation order (<= 1e-5 of the output scale)."""
+    B, H, Cin, Cout = cfg
+    torch.manual_seed(sum(cfg))
+    conv = torch.nn.Conv2d(Cin, Cout, 3, 1, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(Cout).eval()
+    bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_()
+    x = torch.randn(B, Cin, H, H)
+    res = torch.randn(B, Cout, H, H)
+    with torch.no_grad():
+        want = F.relu(bn(conv(x)) + res)
+        want_nores = bn(conv(x))
+    scale_ref = max(1.0, float(want.abs().max()))
+    cb = _ConvBN(conv.to(dev), bn.to(dev))
+    assert cb.wino_u is not None and cb.winograd_ok(H, H, 1)
+    xp = _frame(x.to(dev).permute(0, 2, 3, 1).contiguous(), 1)
+    resh = res.to(dev).permute(0, 2, 3, 1).contiguous()
+    for opad in (0, 1):
+        out = torch.full((B, H + 2 * opad, H + 2 * opad, Cout), 7.0, device=dev)
+        cb.padded(xp, 1, out, opad, residual=_frame(resh, opad), relu=True)
+        inner = out[:, opad:opad + H, opad:opad + H]
+        assert maxerr(inner.permute(0, 3, 1, 2), want) <= 1e-5 * scale_ref
+        if opad:        # the halo is never written
+            assert float((out[:, 0] - 7).abs().max()) == 0 and float((out[:, :, -1] - 7).abs().max()) == 0
+        out2 = torch.zeros_like(out)
+        cb.padded(xp, 1, out2, opad, relu=False)
+        assert maxerr(out2[:, opad:opad + H, opad:opad + H].permute(0, 3, 1, 2), want_nores) <= 1e-5 * scale_ref
+        cb.use_winograd = False
+        direct = torch.zeros_like(out)
+        cb.padded(xp, 1, direct, opad, relu=False)
+        cb.use_winograd = True
+        assert maxerr(out2, direct) <= 1e-5 * scale_ref
+    # a map whose tiles per image do not fill 64-tile workgroups (layer4's 8x8) stays on the direct kernel, for every batch size
+    assert not cb.winograd_ok(8, 8, 1) and not cb.winograd_ok(30, 30, 1)
+
+
+def test_winograd_and_direct_encoders_agree_and_are_batch_invariant(dev, net_gpu, golden, golden_input):
+    enc = net_gpu.image_encoder
+    x = golden_input.to(dev)
+    ref = golden["net_feats"]
+    wino = enc(x).clone()
+    try:
+        enc.set_winograd(False)
+        direct = enc(x).clone()
+    finally:
+        enc.set_winograd(True)
+    scale_ref = float(ref.abs().max())
+    assert maxerr(wino, ref) <= 1e-4 * scale_ref and maxerr(direct, ref) <= 1e-4 * scale_ref
+    assert maxerr(wino, direct) <= 2e-5 * scale_ref
+    # per-image features do not depend on the batch they were computed in (bit for bit)
+    big = torch.cat([x, torch.rand(5, 18, 256, 256, generator=torch.Generator().manual_seed(9)).to(dev)])
+    assert torch.equal(enc(big)[:2], wino) and torch.equal(enc(x[1:2]), wino[1:2])
