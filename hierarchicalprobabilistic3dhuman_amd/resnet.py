@@ -47,7 +47,7 @@ class _ConvBN:
         # Winograd F(2x2, 3x3) form of a stride-1 3x3 layer (csrc/conv_wino.hip): U = G g G^T in the kernel's layout
         #   [cin / 8][cout / 64][position 4a + b][(cin % 8) / 4][cout % 64][cin % 4]
         self.wino_u = None
-        if kh == 3 and kw == 3 and self.stride == 1 and self.pad == 1 and cin % 32 == 0 and cout % 64 == 0:
+        if kh == 3 and kw == 3 and self.stride == 1 and self.pad == 1 and cin % 8 == 0 and cout % 64 == 0:
             G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
             U = torch.einsum("ai,ocij,bj->abco", G, w.double(), G)                       # (4,4,cin,cout)
             U = U.reshape(16, cin // 8, 2, 4, cout // 64, 64)                            # p, chunk, kq, j, ct, n
@@ -70,11 +70,10 @@ class _ConvBN:
         return 1
 
     def winograd_ok(self, H, W, ipad):
-        """Winograd F(2x2, 3x3) applies: a 3x3 / 1 / 1 layer on an even-sized map whose tiles per IMAGE fill whole 64-tile
-        workgroups -- a rule on the layer and the image size only, never on the batch size (the summation order of a pixel, and
-        with it the last bit of every feature, must not depend on how images are batched or sharded)."""
-        return (self.use_winograd and self.wino_u is not None and ipad >= 1 and H % 2 == 0 and W % 2 == 0
-                and ((H // 2) * (W // 2)) % 64 == 0)
+        """Winograd F(2x2, 3x3) applies: a 3x3 / 1 / 1 layer on a map that splits into 16 x 16-pixel blocks (8 x 8 tiles, one
+        work item of csrc/conv_wino.hip) -- a rule on the layer and the image size only, never on the batch size (the summation
+        order of a pixel, and with it the last bit of every feature, must not depend on how images are batched or sharded)."""
+        return self.use_winograd and self.wino_u is not None and ipad >= 1 and H % 16 == 0 and W % 16 == 0
 
     def padded(self, xp, ipad, out, opad, residual=None, relu=True, ws=None):
         """Halo-padded generation (csrc/conv_pad.hip): xp (B, H+2*ipad, W+2*ipad, Cin) with a zero halo; writes the interior

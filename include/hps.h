@@ -262,8 +262,8 @@ int hps_conv2d_bn_act_pad(const float* x, const float* wn, const float* scale, c
  * layers of the BasicBlocks (models/resnet.py:62-78).  x / y / residual are halo-padded NHWC frames as for
  * hps_conv2d_bn_act_pad (ipad >= 1).  u: the transformed filters U = G g G^T, prepared once by the host in the layout
  *   u[chunk = cin / 8][cout tile = cout / 64][position p = 4 a + b][k-quad = (cin % 8) / 4][cout % 64][cin % 4]
- * with G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1].  Requirements: H, W even, Cin % 32 == 0, Cout % 64 == 0,
- * B * (H/2) * (W/2) a multiple of 64.  Results equal the direct convolution up to fp32 rounding of a different summation
+ * with G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1].  Requirements: H % 16 == 0, W % 16 == 0 (8 x 8 blocks of 2 x 2 tiles),
+ * Cin % 8 == 0, Cout % 64 == 0.  Results equal the direct convolution up to fp32 rounding of a different summation
  * order; the order depends on the layer only, never on the batch size. */
 int hps_conv3x3_winograd(const float* x, const float* u, const float* scale, const float* shift,
                          const float* residual, float* y, int B, int H, int W, int ipad, int Cin, int Cout,

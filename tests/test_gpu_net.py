@@ -322,7 +322,7 @@ def test_head_svd_modes_agree(dev, net_gpu):
 
 @pytest.mark.parametrize("cfg", [
     # B, H, Cin, Cout -- the stride-1 3x3 layers of layer1 / layer2 / layer3 at the 256x256 input, plus an odd batch
-    (2, 64, 64, 64), (2, 32, 128, 128), (3, 16, 256, 256), (1, 16, 64, 128)])
+    (2, 64, 64, 64), (2, 32, 128, 128), (3, 16, 256, 256), (1, 16, 64, 128), (5, 48, 8, 64), (300, 16, 64, 64)])
 def test_winograd_conv_kernel(cfg, dev):
     """csrc/conv_wino.hip (Winograd F(2x2, 3x3) + BatchNorm + residual + ReLU) against torch's convolution and against the direct
     implicit-GEMM kernel: same results up to fp32 rounding of a different summation order (<= 1e-5 of the output scale)."""
@@ -351,13 +351,14 @@ def test_winograd_conv_kernel(cfg, dev):
         out2 = torch.zeros_like(out)
         cb.padded(xp, 1, out2, opad, relu=False)
         assert maxerr(out2[:, opad:opad + H, opad:opad + H].permute(0, 3, 1, 2), want_nores) <= 1e-5 * scale_ref
-        cb.use_winograd = False
-        direct = torch.zeros_like(out)
-        cb.padded(xp, 1, direct, opad, relu=False)
-        cb.use_winograd = True
-        assert maxerr(out2, direct) <= 1e-5 * scale_ref
+        if Cin % 32 == 0:                            # the direct kernel's non-row mode needs 32-channel chunks
+            cb.use_winograd = False
+            direct = torch.zeros_like(out)
+            cb.padded(xp, 1, direct, opad, relu=False)
+            cb.use_winograd = True
+            assert maxerr(out2, direct) <= 1e-5 * scale_ref
     # a map whose tiles per image do not fill 64-tile workgroups (layer4's 8x8) stays on the direct kernel, for every batch size
-    assert not cb.winograd_ok(8, 8, 1) and not cb.winograd_ok(30, 30, 1)
+    assert not cb.winograd_ok(8, 8, 1) and not cb.winograd_ok(30, 30, 1) and not cb.winograd_ok(24, 24, 1)
 
 
 def test_winograd_and_direct_encoders_agree_and_are_batch_invariant(dev, net_gpu, golden, golden_input):
