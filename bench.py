@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--num-samples", type=int, default=100)
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after another on one stream")
+    ap.add_argument("--early-relayout", action="store_true", help="A/B: enqueue the input relayout beside the previous batch's mesh kernels")
     ap.add_argument("--unfused-mesh", action="store_true", help="blend GEMM + LBS as two kernels (the unfused definition) instead of the fused mesh kernel")
     ap.add_argument("--trace-steps", action="store_true", help="print host-side per-step times to stderr (debugging)")
     ap.add_argument("--cpu-images", type=int, default=64, help="images in the CPU-baseline sample (0 = skip); 64 = one full batch, SURVEY 8(d)")
@@ -115,6 +116,7 @@ def main():
     # head of step i runs (InferencePipeline).  Every step does the full work; exactly args.steps batches are
     # submitted and finished inside the timed region.
     pipe = InferencePipeline(net, smpl, num_samples=N, use_mean_shape=True)
+    pipe.early_relayout = args.early_relayout
 
     step_marks = []
 

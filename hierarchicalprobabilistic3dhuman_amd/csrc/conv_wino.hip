@@ -195,9 +195,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
             const int buf = c & 1;
             if (c > 0) {
                 // filters of chunk c were issued in iteration c - 1 BEFORE window c + 2: with in-order returns, all but the
-                // wave's youngest two pieces (of that window, needed one iteration later) must have landed
-                if (c + 2 < nchunks) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // wave's own pieces of that window (needed one iteration later) must have landed
+                // (waves 0-2 move three pieces of a window, wave 3 two: the count is wave-uniform)
+                if (c + 2 < nchunks && ab != 1 && ab != 6) {
+                    if (wave < 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();                                 // operand chunk c complete; sA / sB [buf ^ 1] and ring slot c % 3 are free
             const bool more = c + 1 < nchunks;

@@ -121,6 +121,7 @@ class InferencePipeline:
         self.head_stream = torch.cuda.Stream(priority=-1)
         self._smpl_done = None
         self.enc_events = None
+        self.early_relayout = False   # A/B on one box: +0.4 % images/s, but the mesh kernel it overlaps runs 8 % slower (0.67 vs 0.62 ms)
 
     @torch.no_grad()
     def submit(self, proxy_rep_input, input_ready=None):
@@ -132,8 +133,14 @@ class InferencePipeline:
         main = torch.cuda.current_stream()
         if input_ready is not None:
             self.enc_stream.wait_event(input_ready)
+        gate = None
         if self._smpl_done is None:
             self.enc_stream.wait_stream(main)
+        elif self.early_relayout:
+            # the input relayout (HBM-bound) is enqueued at once and may run beside the previous batch's fused mesh kernel
+            # (MFMA-bound); the convolutions wait for that batch's SMPL kernels
+            prev_done = self._smpl_done
+            gate = lambda: self.enc_stream.wait_event(prev_done)
         else:
             self.enc_stream.wait_event(self._smpl_done)
         with torch.cuda.stream(self.enc_stream):
@@ -141,7 +148,7 @@ class InferencePipeline:
             if self.enc_events is not None:      # bench.py: HIP events around the encoder, on its own stream
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record(self.enc_stream)
-            feats = self.net.image_encoder(proxy_rep_input)
+            feats = self.net.image_encoder(proxy_rep_input, _gate=gate)
             if ev is not None:
                 ev[1].record(self.enc_stream)
                 self.enc_events.append(ev)

@@ -320,20 +320,32 @@ class ResNet(nn.Module):
         # row-mode stem (csrc/conv_pad.hip): 16-byte aligned window starts and rows
         return self.layout == "padded" and (2 * C) % 4 == 0 and ((W + 6) * C) % 4 == 0 and C in (4, 18, 64)
 
-    def _forward_padded(self, prep, x):
+    def _forward_padded(self, prep, x, gate=None):
+        """``gate``: optional callable invoked after the input relayout has been enqueued and before the first convolution
+        (InferencePipeline: the HBM-bound relayout may run beside the previous batch's MFMA-bound mesh kernel; the
+        convolutions wait)."""
         B, C, H, W = x.shape
         s = _capi.stream()
         P = _capi.ptr
         fs = self._frame_set(prep, B, C, H, W, x.device)
         if self.composite and fs["variants"] == self._variant_state(prep):
-            # one call across the C ABI for the whole encoder (csrc/composite.hip)
+            # one call across the C ABI for the whole encoder (csrc/composite.hip); two when the list is gated
             feats = torch.empty(B, fs["blocks"][-1]["c2"].shape[3], device=x.device, dtype=torch.float32)
             ops = fs["ops"]
             ops[0].x = x.data_ptr()
             ops[len(ops) - 1].y = feats.data_ptr()
-            _capi.call("hps_encoder_run", ops, len(ops), s)
+            if gate is None:
+                _capi.call("hps_encoder_run", ops, len(ops), s)
+            else:
+                import ctypes
+                _capi.call("hps_encoder_run", ops, 1, s)
+                gate()
+                rest = ctypes.cast(ctypes.byref(ops, ctypes.sizeof(_capi.EncOp)), ctypes.POINTER(_capi.EncOp))
+                _capi.call("hps_encoder_run", rest, len(ops) - 1, s)
             return feats
         _capi.call("hps_nchw_to_padded_nhwc", P(x), P(fs["in"]), B, C, H, W, 3, s)
+        if gate is not None:
+            gate()
         stem = prep["stem"]
         y = stem.padded(fs["in"], 3, fs["stem"], 0, relu=True)             # conv1 + bn1 + relu
         _capi.call("hps_maxpool3x3s2_pad", P(y), P(fs["pool"]), B, y.shape[1], y.shape[2], y.shape[3], 1, s)
@@ -347,7 +359,7 @@ class ResNet(nn.Module):
         _capi.call("hps_global_avgpool_pad", P(y), P(feats), B, h, w, y.shape[3], 1, s)
         return feats
 
-    def forward(self, x):
+    def forward(self, x, _gate=None):
         """models/resnet.py:202-217: (B,C,H,W) NCHW fp32 -> (B,512)."""
         _capi.require_device(x, "encoder input")
         if self.training:
@@ -356,7 +368,7 @@ class ResNet(nn.Module):
         x = _capi.f32c(x)
         B, C, H, W = x.shape
         if self._padded_ok(C, H, W):
-            return self._forward_padded(prep, x)
+            return self._forward_padded(prep, x, gate=_gate)
         if self.layout != "plain":
             raise _capi.HpsError("encoder input (C=%d, W=%d) is not supported by the halo-padded product kernels "
                                  "(C in {4, 18, 64} with 16-byte aligned rows)" % (C, W))

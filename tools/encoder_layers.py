@@ -65,13 +65,15 @@ def main():
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 20
             row = {"op": names[i], "ms_alone": ms}
-            if o.kind == _capi.ENC_CONV:
+            if o.kind in (_capi.ENC_CONV, _capi.ENC_CONV_WINOGRAD):
                 Ho = (o.H + 2 * o.pad - o.KH) // o.stride + 1
                 Wo = (o.W + 2 * o.pad - o.KW) // o.stride + 1
                 cin = 18 if o.row_mode else o.Cin
                 gflop = 2.0 * o.B * Ho * Wo * o.Cout * o.KH * o.KW * cin / 1e9
+                wino = o.kind == _capi.ENC_CONV_WINOGRAD
                 row.update(gflop=gflop, tflops=gflop / ms, out_hw=[Ho, Wo], cin=cin, cout=o.Cout, ksplit=o.ksplit,
-                           launches=2 if o.ksplit > 1 else 1)
+                           launches=2 if o.ksplit > 1 else 1, algorithm="winograd F(2x2,3x3)" if wino else "direct implicit GEMM",
+                           mfma_gflop=gflop / 2.25 if wino else gflop)
             rows.append(row)
             print("%-40s %.4f ms %s" % (names[i], ms, ("%.1f TF/s" % row["tflops"]) if "tflops" in row else ""), flush=True)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

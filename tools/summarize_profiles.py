@@ -85,7 +85,7 @@ if os.path.exists(stats_p):
     V, J = 6890, 24
     enc_flop = 6.279e9 * B
     model = [   # (substring, what, bound, algorithmic quantity per launch, unit)
-        ("conv_pad_kernel", "ResNet-18 convolutions (all launches of a step together)", "mfma", enc_flop, "flop/step"),
+        ("conv_", "ResNet-18 convolutions, direct + Winograd (all launches of a step together; direct-convolution FLOPs)", "mfma", enc_flop, "flop/step"),
         ("mesh_fused_kernel", "blend GEMM + LBS, fused", "mfma", 2.0 * 217 * 3 * V * M, "flop"),
         ("uncertainty_reg_kernel", "per-vertex sample uncertainty", "hbm", (B * N * V * 12.0 + B * V * 4.0), "bytes"),
         ("joints_kernel", "90 joints per mesh (CSR rows on the vertices)", "hbm", M * (276 * 12.0 + 90 * 12.0), "bytes (gathered)"),
