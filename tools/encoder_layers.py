@@ -76,6 +76,21 @@ def main():
                            mfma_gflop=gflop / 2.25 if wino else gflop)
             rows.append(row)
             print("%-40s %.4f ms %s" % (names[i], ms, ("%.1f TF/s" % row["tflops"]) if "tflops" in row else ""), flush=True)
+        # the same operations in the order of the list, one event between each (20 passes): the in-context time of every operation
+        import ctypes
+        passes = 20
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(n + 1)] for _ in range(passes)]
+        for pi in range(passes):
+            evs[pi][0].record()
+            for i in range(n):
+                one = ctypes.cast(ctypes.byref(ops, i * ctypes.sizeof(_capi.EncOp)), ctypes.POINTER(_capi.EncOp))
+                _capi.call("hps_encoder_run", one, 1, s)
+                evs[pi][i + 1].record()
+        torch.cuda.synchronize()
+        for i in range(n):
+            rows[i]["ms_in_list"] = sum(evs[pi][i].elapsed_time(evs[pi][i + 1]) for pi in range(2, passes)) / (passes - 2)
+            if "gflop" in rows[i]:
+                rows[i]["tflops_in_list"] = rows[i]["gflop"] / rows[i]["ms_in_list"]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):
             _capi.call("hps_encoder_run", ops, n, s)
