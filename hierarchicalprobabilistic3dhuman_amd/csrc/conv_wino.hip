@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
         r_ok[t] = (wave + 4 * t) < W_RAW_PIECES && e < 2 * W_WIN;
         const int px = r_ok[t] ? (e >> 1) : 0;
         r_off[t] = (unsigned)(((px / 18) * g.in_row + (px % 18) * g.Cin + (e & 1) * 4) * 4);
+        if (ab == 7) r_off[t] = (unsigned)((e & 1) * 16);          // profiling: every lane fetches the same line (no memory-system cost)
     }
     const unsigned lds_r0 = (unsigned)(size_t)(lptr_t)(sR);
     const unsigned lds_b0 = (unsigned)(size_t)(lptr_t)(sB);
@@ -111,23 +112,29 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
         const unsigned b = wino_div(blk, (unsigned)g.blocks_img, g.magic_img), rem = blk - b * g.blocks_img;
         const unsigned by = wino_div(rem, (unsigned)g.blocks_x, g.magic_x), bx = rem - by * g.blocks_x;
         x_item = x + (size_t)b * g.in_img + (size_t)(16 * by + g.ipad - 1) * g.in_row + (size_t)(16 * bx + g.ipad - 1) * g.Cin;
+        if (ab == 8) x_item = x + (size_t)(g.ipad - 1) * g.in_row + (size_t)(g.ipad - 1) * g.Cin;      // profiling: every item reads the first window (cache-hot, same line count)
         u_item = u + (size_t)ct * W_OPER;
         out_base = (size_t)b * g.out_img + (size_t)(16 * by + g.opad) * g.out_row + (size_t)(16 * bx + g.opad) * g.Cout;
     };
-    auto dma_raw = [&](int chunk) {                           // window of `chunk` -> ring slot chunk % 3
+    // One DMA instruction at a time: a burst of them stalls the wave at issue while the texture path works through the
+    // line requests (a window piece touches 32 lines), and with one wave per SIMD nothing else issues MFMAs meanwhile --
+    // the main loop spreads the eleven pieces of an interval over its sixteen positions.
+    auto dma_raw_piece = [&](int chunk, int t) {              // window of `chunk` -> ring slot chunk % 3, piece wave + 4 t
         if (ab == 1 || ab == 6) return;
-        const float* src = x_item + chunk * WK;
-        const unsigned base = lds_r0 + (unsigned)((chunk % 3) * W_RAW * 4);
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-            if (r_ok[t]) lds_dma16(r_off[t], src, base + (unsigned)((wave + 4 * t) * 1024));
+        if (r_ok[t]) lds_dma16(r_off[t], x_item + chunk * WK, lds_r0 + (unsigned)((chunk % 3) * W_RAW * 4 + (wave + 4 * t) * 1024));
     };
-    auto dma_filters = [&](int chunk) {                       // filters of `chunk` -> sB[chunk & 1]; wave w moves pieces 8 w .. 8 w + 7
+    auto dma_filter_piece = [&](int chunk, int q) {           // filters of `chunk` -> sB[chunk & 1]; wave w moves pieces 8 w .. 8 w + 7
         if (ab == 3) return;
-        const float* src = u_item + (size_t)chunk * g.n_ct * W_OPER;
-        const unsigned base = lds_b0 + (unsigned)((chunk & 1) * W_OPER * 4 + wave * 8 * 1024);
+        lds_dma16((unsigned)((wave * 8 + q) * 1024 + lane * 16), u_item + (size_t)chunk * g.n_ct * W_OPER,
+                  lds_b0 + (unsigned)((chunk & 1) * W_OPER * 4 + (wave * 8 + q) * 1024));
+    };
+    auto dma_raw = [&](int chunk) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) lds_dma16((unsigned)((wave * 8 + q) * 1024 + lane * 16), src, base + q * 1024);
+        for (int t = 0; t < 3; ++t) dma_raw_piece(chunk, t);
+    };
+    auto dma_filters = [&](int chunk) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dma_filter_piece(chunk, q);
     };
     // input transform of one chunk, in two parts so that the LDS round trip of the reads hides under MFMAs:
     //   t_read : the thread's 16 patch pixels (one channel pair) from the raw ring slot chunk % 3
@@ -212,12 +219,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
             float4 a4[2], b4[2];
             a4[0] = *reinterpret_cast<const float4*>(pa);
             b4[0] = *reinterpret_cast<const float4*>(pb);
-            if (more) {
+            if (more && ab == 9) {                           // profiling: the burst this kernel used to issue
                 dma_filters(c + 1);
                 if (c + 3 < nchunks) dma_raw(c + 3);
             }
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
+                if (more && ab != 9) {                       // filters first, then the window: the vmcnt above counts on that order
+                    if (p < 8) dma_filter_piece(c + 1, p);
+                    else if (p >= 9 && p < 12 && c + 3 < nchunks) dma_raw_piece(c + 3, p - 9);
+                }
                 if (p < 15) {
                     a4[(p + 1) & 1] = *reinterpret_cast<const float4*>(pa + (p + 1) * 512);
                     b4[(p + 1) & 1] = *reinterpret_cast<const float4*>(pb + (p + 1) * 512);
@@ -348,6 +359,9 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
         case 4: launch(std::integral_constant<int, 4>()); break;
         case 5: launch(std::integral_constant<int, 5>()); break;
         case 6: launch(std::integral_constant<int, 6>()); break;
+        case 7: launch(std::integral_constant<int, 7>()); break;
+        case 8: launch(std::integral_constant<int, 8>()); break;
+        case 9: launch(std::integral_constant<int, 9>()); break;
 #endif
         default: return bad_arg("hps_conv3x3_winograd: ablate");
     }

@@ -102,7 +102,6 @@ def test_heatmap_argmax_and_sample_ranking(dev, golden):
     from hierarchicalprobabilistic3dhuman_amd.label_conversions import (convert_heatmaps_to_2Djoints_coordinates_torch,
                                                                         ALL_JOINTS_TO_COCO_MAP)
     from hierarchicalprobabilistic3dhuman_amd.sampling_utils import joints2D_error_sorted_verts_sampling
-    from utils_reference_check import reference_argmax_golden
     g = torch.Generator().manual_seed(4)
     j2d = torch.rand(1, 17, 2, generator=g) * 200 + 20
     heat = O.joints2d_to_gaussian_heatmaps(j2d.round(), 256, 4.0)
@@ -111,7 +110,7 @@ def test_heatmap_argmax_and_sample_ranking(dev, golden):
     j_ref, v_ref = O.heatmaps_to_joints2d(heat)
     j, v = convert_heatmaps_to_2Djoints_coordinates_torch(heat.to(dev))
     assert torch.equal(j.cpu(), j_ref) and torch.equal(v.cpu(), v_ref)
-    reference_argmax_golden(golden, j_ref)
+    assert torch.equal(golden["argmax_joints"], j_ref)                         # the reference's own arg-max on this case (make_golden.py)
     # ranking
     N = 12
     joints = torch.randn(N, 90, 3, generator=g) * 0.4
