@@ -31,7 +31,7 @@ extern "C" int hps_encoder_run(const hps_enc_op* ops, int n_ops, hps_stream_t st
                 break;
             case HPS_ENC_CONV_WINOGRAD:
                 rc = hps_conv3x3_winograd(o.x, o.w, o.scale, o.shift, o.residual, o.y, o.B, o.H, o.W, o.ipad, o.Cin, o.Cout, o.opad,
-                                          o.relu, stream);
+                                          o.relu, o.splitk_ws, stream);
                 break;
             case HPS_ENC_MAXPOOL:
                 rc = hps_maxpool3x3s2_pad(o.x, o.y, o.B, o.H, o.W, o.Cin, o.opad, stream);

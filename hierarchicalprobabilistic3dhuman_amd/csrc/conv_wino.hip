@@ -53,8 +53,11 @@ struct WinoGeom {
     int ipad, opad;
     int blocks_x, blocks_img;     // 8 x 8-tile blocks per row / per image
     int Cin, Cout, n_ct, relu;
-    int items;                    // B * blocks_img * n_ct
+    int items;                    // B * blocks_img * n_ct  (quad geometry: ceil(B / 4) * n_ct * ksplit)
     unsigned magic_ct, magic_img, magic_x;
+    // quad geometry (8 x 8 maps, four images per item, K split into slices that write raw partial sums)
+    int B, ksplit, cps, raw;      // images, K slices, chunks per slice, raw = 1: store Y without BatchNorm / residual / ReLU
+    unsigned magic_ks;
 };
 
 __device__ __forceinline__ unsigned wino_div(unsigned n, unsigned d, unsigned magic) {
@@ -64,7 +67,11 @@ __device__ __forceinline__ unsigned wino_div(unsigned n, unsigned d, unsigned ma
 }
 
 // AB: profiling ablations (compile-time; the product instantiates AB = 0 only): see hps_dev_conv3x3_winograd
-template <int AB>
+// QUAD: the item is the 8 x 8 maps of four consecutive images (layer4: an 8 x 8 map has 4 x 4 tiles, a quarter of an item) x 64
+// output channels x one slice of K.  The raw ring holds the four 8 x 8 interiors (the halo is not fetched: a patch pixel outside
+// its image reads a zero pixel kept in LDS), wave (wm, kl) of the epilogue owns image 2 wm + kl, and the item writes raw partial
+// sums Y (the output transform is linear: the slices are added, in slice order, by wino_splitk_epilogue_kernel).
+template <int AB, bool QUAD>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ residual, float* __restrict__ y,
@@ -79,25 +86,45 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kl = lane >> 5, il = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
-    const int nchunks = g.Cin / WK;
+    const int nchunks = QUAD ? g.cps : g.Cin / WK;
+    constexpr int RP = QUAD ? 2 : 3;                              // raw DMA pieces per wave and chunk (quad: 8 pieces = 256 pixels)
 
     // ---- raw-window DMA role: piece q = wave + 4 t covers window entries e = 64 q + lane (pixel e >> 1, 16-byte half e & 1) ----
-    unsigned r_off[3];
+    unsigned r_off[3];             // byte offset of the lane's 16 bytes from the item's origin (quad: without the image term)
+    int r_img[3];                  // quad: image of the item (0..3) the lane's pixel belongs to
     bool r_ok[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int e = 64 * (wave + 4 * t) + lane;
-        r_ok[t] = (wave + 4 * t) < W_RAW_PIECES && e < 2 * W_WIN;
-        const int px = r_ok[t] ? (e >> 1) : 0;
-        r_off[t] = (unsigned)(((px / 18) * g.in_row + (px % 18) * g.Cin + (e & 1) * 4) * 4);
-        if (ab == 7) r_off[t] = (unsigned)((e & 1) * 16);          // profiling: every lane fetches the same line (no memory-system cost)
+        if (QUAD) {
+            const int px = e >> 1;                                // [image][y][x]: 4 x 8 x 8
+            r_ok[t] = t < 2;
+            r_img[t] = (px >> 6) & 3;
+            r_off[t] = (unsigned)((((px >> 3) & 7) * g.in_row + (px & 7) * g.Cin + (e & 1) * 4) * 4);
+        } else {
+            r_ok[t] = (wave + 4 * t) < W_RAW_PIECES && e < 2 * W_WIN;
+            const int px = r_ok[t] ? (e >> 1) : 0;
+            r_img[t] = 0;
+            r_off[t] = (unsigned)(((px / 18) * g.in_row + (px % 18) * g.Cin + (e & 1) * 4) * 4);
+            if (ab == 7) r_off[t] = (unsigned)((e & 1) * 16);      // profiling: every lane fetches the same line (no memory-system cost)
+        }
     }
+    unsigned r_cur[3] = {r_off[0], r_off[1], r_off[2]};           // ... of the current item (quad: + the clamped image term)
     const unsigned lds_r0 = (unsigned)(size_t)(lptr_t)(sR);
     const unsigned lds_b0 = (unsigned)(size_t)(lptr_t)(sB);
 
     // ---- transform role: thread = (tile (ty, tx) = (tid >> 5, (tid >> 2) & 7), channel pair tid & 3) ----
     const int ltile = tid >> 2, cp = tid & 3;
-    const int w_slot = ((2 * (ltile >> 3)) * 18 + 2 * (ltile & 7)) * WK + cp * 2;      // float offset of patch pixel (0,0) in a raw window
+    // float offset of patch pixel (0,0) in a raw window (quad: image (ty >> 2, tx >> 2), pixel (2 ly - 1, 2 lx - 1) of its 8 x 8
+    // interior -- outside the interior for edge tiles, whose edge pixels read the zero pixel instead)
+    const int t_ly = (ltile >> 3) & 3, t_lx = ltile & 3;
+    const int w_slot = QUAD ? (((((ltile >> 5) * 2 + ((ltile >> 2) & 1)) * 64 + (2 * t_ly - 1) * 8 + (2 * t_lx - 1)) * WK) + cp * 2)
+                            : ((2 * (ltile >> 3)) * 18 + 2 * (ltile & 7)) * WK + cp * 2;
+    const bool e_top = t_ly == 0, e_bot = t_ly == 3, e_left = t_lx == 0, e_right = t_lx == 3;
+    constexpr int W_ZERO = 4 * 64 * WK;                           // quad: the zero pixel sits behind slot 0's 256 pixels
+    if (QUAD) {
+        if (tid < WK) sR[W_ZERO + tid] = 0.0f;                    // visible after the first barrier of the item loop
+    }
     const int a_slot = ((cp >> 1) * 64 + ltile) * 4 + (cp & 1) * 2;                     // ... of the (tile, pair) slot of position 0 in sA
 
     const float* fa = sA + (kl * 64 + wm * 32 + il) * 4;          // this lane's fragment slot of position 0, buffer 0
@@ -106,7 +133,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
     // per-item state (wave-uniform)
     const float* x_item = nullptr;     // input window origin of the item, chunk 0
     const float* u_item = nullptr;     // transformed filters of the item's cout tile, chunk 0
+    int nimg = 4;                      // quad: images of the item that exist (the last item of a batch may hold fewer)
     auto locate = [&](int item, int& ct, size_t& out_base) {
+        if (QUAD) {
+            const unsigned t = wino_div((unsigned)item, (unsigned)g.ksplit, g.magic_ks), ks = item - t * g.ksplit;
+            const unsigned qd = wino_div(t, (unsigned)g.n_ct, g.magic_ct);
+            ct = t - qd * g.n_ct;
+            const int b0 = 4 * qd;
+            nimg = min(4, g.B - b0);
+            x_item = x + (size_t)b0 * g.in_img + (size_t)g.ipad * g.in_row + (size_t)g.ipad * g.Cin + (size_t)ks * g.cps * WK;
+            u_item = u + ((size_t)ks * g.cps * g.n_ct + ct) * W_OPER;
+            out_base = (size_t)ks * g.B * g.out_img + (size_t)b0 * g.out_img + (size_t)g.opad * g.out_row + (size_t)g.opad * g.Cout;
+#pragma unroll
+            for (int t2 = 0; t2 < RP; ++t2) r_cur[t2] = r_off[t2] + (unsigned)(min(r_img[t2], nimg - 1) * g.in_img * 4);
+            return;
+        }
         const unsigned blk = wino_div((unsigned)item, (unsigned)g.n_ct, g.magic_ct);
         ct = item - blk * g.n_ct;
         const unsigned b = wino_div(blk, (unsigned)g.blocks_img, g.magic_img), rem = blk - b * g.blocks_img;
@@ -121,7 +162,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
     // the main loop spreads the eleven pieces of an interval over its sixteen positions.
     auto dma_raw_piece = [&](int chunk, int t) {              // window of `chunk` -> ring slot chunk % 3, piece wave + 4 t
         if (ab == 1 || ab == 6) return;
-        if (r_ok[t]) lds_dma16(r_off[t], x_item + chunk * WK, lds_r0 + (unsigned)((chunk % 3) * W_RAW * 4 + (wave + 4 * t) * 1024));
+        if (t < RP && r_ok[t]) lds_dma16(r_cur[t], x_item + chunk * WK, lds_r0 + (unsigned)((chunk % 3) * W_RAW * 4 + (wave + 4 * t) * 1024));
     };
     auto dma_filter_piece = [&](int chunk, int q) {           // filters of `chunk` -> sB[chunk & 1]; wave w moves pieces 8 w .. 8 w + 7
         if (ab == 3) return;
@@ -143,6 +184,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
     auto t_read2 = [&](int chunk, int q) {     // patch pixels 2 q and 2 q + 1 (q = 0..7)
         if (ab == 1 || ab == 5) return;
         const float* src = sR + (chunk % 3) * W_RAW + w_slot;
+        if (QUAD) {
+#pragma unroll
+            for (int n = 2 * q; n < 2 * q + 2; ++n) {
+                const int i = n >> 2, j = n & 3;                  // compile-time after unrolling
+                const bool halo = (i == 0 && e_top) || (i == 3 && e_bot) || (j == 0 && e_left) || (j == 3 && e_right);
+                const float* a = halo ? sR + W_ZERO + cp * 2 : src + (i * 8 + j) * WK;
+                d[n] = *reinterpret_cast<const float2*>(a);
+            }
+            return;
+        }
         d[2 * q] = *reinterpret_cast<const float2*>(src + (((2 * q) >> 2) * 18 + ((2 * q) & 3)) * WK);
         d[2 * q + 1] = *reinterpret_cast<const float2*>(src + (((2 * q + 1) >> 2) * 18 + ((2 * q + 1) & 3)) * WK);
     };
@@ -205,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
                 // wave's own pieces of that window (needed one iteration later) must have landed
                 // (waves 0-2 move three pieces of a window, wave 3 two: the count is wave-uniform)
                 if (c + 2 < nchunks && ab != 1 && ab != 6) {
-                    if (wave < 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    if (!QUAD && wave < 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -227,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
             for (int p = 0; p < 16; ++p) {
                 if (more && ab != 9) {                       // filters first, then the window: the vmcnt above counts on that order
                     if (p < 8) dma_filter_piece(c + 1, p);
-                    else if (p >= 9 && p < 12 && c + 3 < nchunks) dma_raw_piece(c + 3, p - 9);
+                    else if (p >= 9 && p < 9 + RP && c + 3 < nchunks) dma_raw_piece(c + 3, p - 9);
                 }
                 if (p < 15) {
                     a4[(p + 1) & 1] = *reinterpret_cast<const float4*>(pa + (p + 1) * 512);
@@ -252,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
         }
 
         // ---- the next item's first DMAs go out before this item's epilogue (which touches no LDS) ----
-        const int cur_ct = ct;
+        const int cur_ct = ct, cur_nimg = nimg;
         const size_t cur_out = out_base;
         const int next = item + gridDim.x;
         __syncthreads();                                     // everyone is done with this item's LDS
@@ -267,7 +318,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
         if (ab != 4) {
             const int co = cur_ct * WC + wn * 32 + il;
             const float sc = scale[co], sh = shift[co];
-            const size_t lane_base = cur_out + (size_t)(8 * wm) * g.out_row + (size_t)(8 * kl) * g.Cout + co;
+            // quad: wave (wm, kl)'s 4 x 4 tiles are the whole map of image 2 wm + kl
+            const size_t lane_base = QUAD ? cur_out + (size_t)(2 * wm + kl) * g.out_img + co
+                                          : cur_out + (size_t)(8 * wm) * g.out_row + (size_t)(8 * kl) * g.Cout + co;
+            const bool store_ok = !QUAD || 2 * wm + kl < cur_nimg;
             float res[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             auto load_res = [&](int r, float (&dst)[4]) {
 #pragma unroll
@@ -291,10 +345,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
                 yv[3] = s1[1] - s1[2] - s1[3];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float v = yv[q] * sc + sh;
-                    if (residual) v += res[r & 1][q];
-                    if (g.relu) v = fmaxf(v, 0.0f);
-                    y[lane_base + (size_t)(2 * (r >> 2) + (q >> 1)) * g.out_row + (size_t)(2 * (r & 3) + (q & 1)) * g.Cout] = v;
+                    float v = yv[q];
+                    if (!QUAD || !g.raw) {
+                        v = v * sc + sh;
+                        if (residual) v += res[r & 1][q];
+                        if (g.relu) v = fmaxf(v, 0.0f);
+                    }
+                    if (store_ok) y[lane_base + (size_t)(2 * (r >> 2) + (q >> 1)) * g.out_row + (size_t)(2 * (r & 3) + (q & 1)) * g.Cout] = v;
                 }
             }
         } else {
@@ -310,22 +367,61 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
     }
 }
 
+// second pass of the quad geometry: y = act(scale * (sum of the K slices, in slice order) + shift + residual) into the padded
+// 8 x 8 output frames; thread per four channels
+__global__ __launch_bounds__(256) void wino_splitk_epilogue_kernel(const float* __restrict__ partial, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, const float* __restrict__ residual,
+                                                                   float* __restrict__ y, int total4, int ksplit, int Cout, int opad,
+                                                                   int relu) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    float4 acc = reinterpret_cast<const float4*>(partial)[i];
+    for (int k = 1; k < ksplit; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(partial)[(size_t)k * total4 + i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const unsigned e = (unsigned)i * 4u;
+    const unsigned m = e / (unsigned)Cout, co = e - m * Cout;               // m = (image * 8 + row) * 8 + column
+    const unsigned b = m >> 6, py = (m >> 3) & 7, px = m & 7, fw = 8 + 2 * opad;
+    const size_t o = ((size_t)(b * fw + py + opad) * fw + px + opad) * Cout + co;
+    const float4 sc = *reinterpret_cast<const float4*>(scale + co), sh = *reinterpret_cast<const float4*>(shift + co);
+    float4 v = make_float4(acc.x * sc.x + sh.x, acc.y * sc.y + sh.y, acc.z * sc.z + sh.z, acc.w * sc.w + sh.w);
+    if (residual) {
+        const float4 r = *reinterpret_cast<const float4*>(residual + o);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4*>(y + o) = v;
+}
+
 static unsigned wino_magic(unsigned d) { return d <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / d); }
 
 }  // namespace hps
 
 using namespace hps;
 
+// K slices of the quad geometry: a rule on the layer only (never on the batch: the summation order of a pixel must not change
+// with B).  Four slices when each still has >= 8 chunks (layer4: 64 chunks -> 4 x 16), else one.
+static int wino_quad_ksplit(int Cin) { return (Cin / WK) % 4 == 0 && (Cin / WK) / 4 >= 8 ? 4 : 1; }
+
+extern "C" size_t hps_conv3x3_winograd_workspace(int B, int H, int W, int Cin, int Cout) {
+    if (H != 8 || W != 8 || B <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)wino_quad_ksplit(Cin) * B * 64 * Cout * sizeof(float);
+}
+
 static int wino_launch(const float* x, const float* u, const float* scale, const float* shift, const float* residual,
-                       float* y, int B, int H, int W, int ipad, int Cin, int Cout, int opad, int relu, int ablate,
+                       float* y, int B, int H, int W, int ipad, int Cin, int Cout, int opad, int relu, float* splitk_ws, int ablate,
                        hps_stream_t stream) {
     if (!x || !u || !scale || !shift || !y) return bad_arg("hps_conv3x3_winograd: null pointer");
     if (B <= 0) return HPS_OK;
-    if (H <= 0 || W <= 0 || (H % 16) || (W % 16)) return bad_arg("hps_conv3x3_winograd: H and W must be multiples of 16 (8 x 8 blocks of 2 x 2 tiles)");
+    const bool quad = H == 8 && W == 8;
+    if (!quad && (H <= 0 || W <= 0 || (H % 16) || (W % 16)))
+        return bad_arg("hps_conv3x3_winograd: H and W must be multiples of 16 (8 x 8 blocks of 2 x 2 tiles), or H = W = 8");
     if (Cin <= 0 || Cin % WK != 0 || Cout <= 0 || Cout % WC != 0) return bad_arg("hps_conv3x3_winograd: Cin % 8 == 0 and Cout % 64 == 0 required");
     if (ipad < 1 || opad < 0) return bad_arg("hps_conv3x3_winograd: the input frame needs a halo of at least one pixel");
     if ((size_t)B * (H + 2 * ipad) * (W + 2 * ipad) * Cin * 4 >= 0xffffffffull || (size_t)B * (H + 2 * opad) * (W + 2 * opad) * Cout * 4 >= 0xffffffffull)
         return bad_arg("hps_conv3x3_winograd: tensor exceeds the 32-bit lane offsets");
+    if (quad && !splitk_ws) return bad_arg("hps_conv3x3_winograd: 8 x 8 maps need splitk_ws (hps_conv3x3_winograd_workspace bytes)");
     WinoGeom g;
     g.in_row = (W + 2 * ipad) * Cin;
     g.in_img = (H + 2 * ipad) * g.in_row;
@@ -336,32 +432,55 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
     g.blocks_img = (H / 16) * (W / 16);
     g.Cin = Cin; g.Cout = Cout; g.n_ct = Cout / WC; g.relu = relu;
     g.items = B * g.blocks_img * g.n_ct;
+    g.B = B; g.ksplit = 1; g.cps = Cin / WK; g.raw = 0;
+    if (quad) {                     // the kernel writes raw partial sums (slice, image, 8, 8, Cout); the second pass finishes
+        g.ksplit = wino_quad_ksplit(Cin);
+        g.cps = Cin / WK / g.ksplit;
+        g.raw = 1;
+        g.out_row = 8 * Cout; g.out_img = 64 * Cout; g.opad = 0;
+        g.items = ((B + 3) / 4) * g.n_ct * g.ksplit;
+    }
     g.magic_ct = wino_magic((unsigned)g.n_ct);
     g.magic_img = wino_magic((unsigned)g.blocks_img);
     g.magic_x = wino_magic((unsigned)g.blocks_x);
+    g.magic_ks = wino_magic((unsigned)g.ksplit);
     const size_t lds = (size_t)(4 * W_OPER + 3 * W_RAW) * sizeof(float);           // 162 176 bytes
     // persistent grid: one workgroup per CU (256 on MI355X), items strided over the workgroups
     const dim3 grid((unsigned)(g.items < 256 ? g.items : 256));
-    auto launch = [&](auto AB) {
+    auto launch = [&](auto AB, auto Q) {
         constexpr int ab = decltype(AB)::value;
+        constexpr bool q = decltype(Q)::value;
         static std::once_flag once;
         std::call_once(once, [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<ab>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<ab, q>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         });
-        hipLaunchKernelGGL(conv_wino_kernel<ab>, grid, dim3(256), lds, (hipStream_t)stream, x, u, scale, shift, residual, y, g);
+        hipLaunchKernelGGL((conv_wino_kernel<ab, q>), grid, dim3(256), lds, (hipStream_t)stream, x, u, scale, shift, quad ? nullptr : residual,
+                           quad ? splitk_ws : y, g);
     };
+    typedef std::integral_constant<bool, false> F;
+    typedef std::integral_constant<bool, true> T;
+    if (quad) {
+        if (ablate != 0) return bad_arg("hps_conv3x3_winograd: ablations exist for the 16 x 16-block geometry only");
+        launch(std::integral_constant<int, 0>(), T());
+        const int rc = check_launch("hps_conv3x3_winograd");
+        if (rc != HPS_OK) return rc;
+        const int total4 = B * 64 * Cout / 4;
+        hipLaunchKernelGGL(wino_splitk_epilogue_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, splitk_ws,
+                           scale, shift, residual, y, total4, g.ksplit, Cout, opad, relu);
+        return check_launch("hps_conv3x3_winograd (slices)");
+    }
     switch (ablate) {
-        case 0: launch(std::integral_constant<int, 0>()); break;
+        case 0: launch(std::integral_constant<int, 0>(), F()); break;
 #ifdef HPS_DEV_BUILD
-        case 1: launch(std::integral_constant<int, 1>()); break;
-        case 2: launch(std::integral_constant<int, 2>()); break;
-        case 3: launch(std::integral_constant<int, 3>()); break;
-        case 4: launch(std::integral_constant<int, 4>()); break;
-        case 5: launch(std::integral_constant<int, 5>()); break;
-        case 6: launch(std::integral_constant<int, 6>()); break;
-        case 7: launch(std::integral_constant<int, 7>()); break;
-        case 8: launch(std::integral_constant<int, 8>()); break;
-        case 9: launch(std::integral_constant<int, 9>()); break;
+        case 1: launch(std::integral_constant<int, 1>(), F()); break;
+        case 2: launch(std::integral_constant<int, 2>(), F()); break;
+        case 3: launch(std::integral_constant<int, 3>(), F()); break;
+        case 4: launch(std::integral_constant<int, 4>(), F()); break;
+        case 5: launch(std::integral_constant<int, 5>(), F()); break;
+        case 6: launch(std::integral_constant<int, 6>(), F()); break;
+        case 7: launch(std::integral_constant<int, 7>(), F()); break;
+        case 8: launch(std::integral_constant<int, 8>(), F()); break;
+        case 9: launch(std::integral_constant<int, 9>(), F()); break;
 #endif
         default: return bad_arg("hps_conv3x3_winograd: ablate");
     }
@@ -370,14 +489,14 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
 
 extern "C" int hps_conv3x3_winograd(const float* x, const float* u, const float* scale, const float* shift, const float* residual,
                                     float* y, int B, int H, int W, int ipad, int Cin, int Cout, int opad, int relu,
-                                    hps_stream_t stream) {
-    return wino_launch(x, u, scale, shift, residual, y, B, H, W, ipad, Cin, Cout, opad, relu, 0, stream);
+                                    float* splitk_ws, hps_stream_t stream) {
+    return wino_launch(x, u, scale, shift, residual, y, B, H, W, ipad, Cin, Cout, opad, relu, splitk_ws, 0, stream);
 }
 
 #ifdef HPS_DEV_BUILD
 extern "C" int hps_dev_conv3x3_winograd(const float* x, const float* u, const float* scale, const float* shift, const float* residual,
-                                        float* y, int B, int H, int W, int ipad, int Cin, int Cout, int opad, int relu, int ablate,
-                                        hps_stream_t stream) {
-    return wino_launch(x, u, scale, shift, residual, y, B, H, W, ipad, Cin, Cout, opad, relu, ablate, stream);
+                                        float* y, int B, int H, int W, int ipad, int Cin, int Cout, int opad, int relu,
+                                        float* splitk_ws, int ablate, hps_stream_t stream) {
+    return wino_launch(x, u, scale, shift, residual, y, B, H, W, ipad, Cin, Cout, opad, relu, splitk_ws, ablate, stream);
 }
 #endif

@@ -71,9 +71,17 @@ class _ConvBN:
 
     def winograd_ok(self, H, W, ipad):
         """Winograd F(2x2, 3x3) applies: a 3x3 / 1 / 1 layer on a map that splits into 16 x 16-pixel blocks (8 x 8 tiles, one
-        work item of csrc/conv_wino.hip) -- a rule on the layer and the image size only, never on the batch size (the summation
-        order of a pixel, and with it the last bit of every feature, must not depend on how images are batched or sharded)."""
-        return self.use_winograd and self.wino_u is not None and ipad >= 1 and H % 16 == 0 and W % 16 == 0
+        work item of csrc/conv_wino.hip) or on 8 x 8 maps (layer4: four images per item, K in slices) -- a rule on the layer
+        and the image size only, never on the batch size (the summation order of a pixel, and with it the last bit of every
+        feature, must not depend on how images are batched or sharded)."""
+        return self.use_winograd and self.wino_u is not None and ipad >= 1 and \
+            ((H % 16 == 0 and W % 16 == 0) or (H == 8 and W == 8))
+
+    def wino_workspace_bytes(self, B, H, W, ipad=1):
+        """Bytes of the K-slice buffer hps_conv3x3_winograd needs for this layer on (H, W) maps (0: none / not Winograd)."""
+        if not self.winograd_ok(H, W, ipad):
+            return 0
+        return int(_capi.load(dev=_capi._use_dev).hps_conv3x3_winograd_workspace(B, H, W, self.cin_p, self.cout))
 
     def padded(self, xp, ipad, out, opad, residual=None, relu=True, ws=None):
         """Halo-padded generation (csrc/conv_pad.hip): xp (B, H+2*ipad, W+2*ipad, Cin) with a zero halo; writes the interior
@@ -83,9 +91,12 @@ class _ConvBN:
         if self.winograd_ok(H, W, ipad):
             assert C == self.cin_p and tuple(out.shape) == (B, H + 2 * opad, W + 2 * opad, self.cout)
             P = _capi.ptr
+            need = self.wino_workspace_bytes(B, H, W, ipad)
+            if need and (ws is None or ws.numel() * 4 < need):
+                ws = torch.empty(need // 4, device=xp.device, dtype=torch.float32)
             _capi.call("hps_conv3x3_winograd", P(xp), P(self.wino_u), P(self.scale), P(self.shift),
                        P(residual) if residual is not None else None, P(out), B, H, W, ipad, C, self.cout, opad, 1 if relu else 0,
-                       _capi.stream())
+                       P(ws) if need else None, _capi.stream())
             return out
         row_mode = self.wn is None
         assert C == (self.cin if row_mode else self.cin_p)
@@ -109,9 +120,11 @@ class _ConvBN:
         dp = lambda t: t.data_ptr() if t is not None else None
         if self.winograd_ok(H, W, ipad):
             assert tuple(out.shape) == (B, H + 2 * opad, W + 2 * opad, self.cout) and C == self.cin_p
+            need = self.wino_workspace_bytes(B, H, W, ipad)
+            assert need == 0 or (ws is not None and ws.numel() * 4 >= need)
             return _capi.EncOp(kind=_capi.ENC_CONV_WINOGRAD, x=dp(xp), w=dp(self.wino_u), scale=dp(self.scale), shift=dp(self.shift),
-                               residual=dp(residual), y=dp(out), B=B, H=H, W=W, ipad=ipad, Cin=C, Cout=self.cout, KH=3, KW=3,
-                               stride=1, pad=1, opad=opad, relu=1 if relu else 0, ksplit=1)
+                               residual=dp(residual), y=dp(out), splitk_ws=dp(ws) if need else None, B=B, H=H, W=W, ipad=ipad,
+                               Cin=C, Cout=self.cout, KH=3, KW=3, stride=1, pad=1, opad=opad, relu=1 if relu else 0, ksplit=1)
         row_mode = self.wn is None
         Ho, Wo = self.out_hw(H, W)
         assert tuple(out.shape) == (B, Ho + 2 * opad, Wo + 2 * opad, self.cout) and C == (self.cin if row_mode else self.cin_p)
@@ -283,11 +296,13 @@ class ResNet(nn.Module):
         fs["pool"] = z(B, h + 2, w + 2, stem.cout)
         fs["blocks"] = []
         for c1, c2, down in prep["blocks"]:
+            hin, win = h, w
             h, w = c1.out_hw(h, w)
             ent = {"c1": z(B, h + 2, w + 2, c1.cout), "c2": z(B, h + 2, w + 2, c2.cout),
                    "down": z(B, h + 2, w + 2, down.cout) if down is not None else None}
             ks = max(c._auto_ksplit(h * w) if c.ksplit == 0 else c.ksplit for c in (c1, c2))
-            ws_bytes = _capi.query_workspace(_capi.WS_CONV_SPLITK, ks, B * h * w, c1.cout)
+            ws_bytes = max(_capi.query_workspace(_capi.WS_CONV_SPLITK, ks, B * h * w, c1.cout),
+                           c1.wino_workspace_bytes(B, hin, win), c2.wino_workspace_bytes(B, h, w))
             ent["ws"] = torch.empty(ws_bytes // 4, device=device, dtype=torch.float32) if ws_bytes else None
             fs["blocks"].append(ent)
         fs["hw"] = (h, w)

@@ -262,18 +262,22 @@ int hps_conv2d_bn_act_pad(const float* x, const float* wn, const float* scale, c
  * layers of the BasicBlocks (models/resnet.py:62-78).  x / y / residual are halo-padded NHWC frames as for
  * hps_conv2d_bn_act_pad (ipad >= 1).  u: the transformed filters U = G g G^T, prepared once by the host in the layout
  *   u[chunk = cin / 8][cout tile = cout / 64][position p = 4 a + b][k-quad = (cin % 8) / 4][cout % 64][cin % 4]
- * with G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1].  Requirements: H % 16 == 0, W % 16 == 0 (8 x 8 blocks of 2 x 2 tiles),
- * Cin % 8 == 0, Cout % 64 == 0.  Results equal the direct convolution up to fp32 rounding of a different summation
- * order; the order depends on the layer only, never on the batch size. */
+ * with G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1].  Requirements: Cin % 8 == 0, Cout % 64 == 0 and either
+ * H % 16 == 0, W % 16 == 0 (items of 8 x 8 tiles of one image) or H == W == 8 (layer4: items of four images; K is cut
+ * into slices whose partial sums go through splitk_ws -- hps_conv3x3_winograd_workspace(B, H, W, Cin, Cout) bytes, 0 for
+ * the first geometry, where splitk_ws may be NULL -- and are added in slice order by a second kernel).  Results equal the
+ * direct convolution up to fp32 rounding of a different summation order; the order depends on the layer only, never on
+ * the batch size. */
 int hps_conv3x3_winograd(const float* x, const float* u, const float* scale, const float* shift,
                          const float* residual, float* y, int B, int H, int W, int ipad, int Cin, int Cout,
-                         int opad, int relu, hps_stream_t stream);
+                         int opad, int relu, float* splitk_ws, hps_stream_t stream);
+size_t hps_conv3x3_winograd_workspace(int B, int H, int W, int Cin, int Cout);
 
 /* One launch of the encoder's operation list (hps_encoder_run).  kind: HPS_ENC_RELAYOUT = hps_nchw_to_padded_nhwc
  * (x, y, B, Cin = C, H, W, opad = P), HPS_ENC_CONV = hps_conv2d_bn_act_pad (all fields), HPS_ENC_MAXPOOL =
  * hps_maxpool3x3s2_pad (x, y, B, H, W, Cin = C, opad), HPS_ENC_AVGPOOL = hps_global_avgpool_pad (x, y, B, H, W,
  * Cin = C, ipad = P), HPS_ENC_CONV_WINOGRAD = hps_conv3x3_winograd (x, w = u, scale, shift, residual, y, B, H, W, ipad, Cin,
- * Cout, opad, relu). */
+ * Cout, opad, relu, splitk_ws). */
 enum { HPS_ENC_RELAYOUT = 0, HPS_ENC_CONV = 1, HPS_ENC_MAXPOOL = 2, HPS_ENC_AVGPOOL = 3, HPS_ENC_CONV_WINOGRAD = 4 };
 typedef struct hps_enc_op {
     int kind;

@@ -191,13 +191,33 @@ def sec_wino():
                          (4, "no epilogue"), (5, "raw DMA but no transform"), (6, "transform but no raw DMA"), (7, "raw DMA from one line"), (8, "raw DMA of one hot window"), (9, "DMAs issued in one burst")):
             r = P(res) if "residual" in what else None
             fn = lambda: _capi.call("hps_dev_conv3x3_winograd", P(x), P(cb.wino_u), P(cb.scale), P(cb.shift), r, P(out), 64, H, H, 1, C, C,
-                                    1, 1, ab, _capi.stream())
+                                    1, 1, None, ab, _capi.stream())
             t = timeit(fn, iters=20)
             print("wino %3dx%-3d C=%3d ablate %d %-28s %.4f ms  (direct-conv-equivalent %.1f TF/s, MFMA %.1f TF/s)"
                   % (H, H, C, ab, what, t, gflop / t, gflop / 2.25 / t), flush=True)
         cb.use_winograd = False
         t = timeit(lambda: cb.padded(x, 1, out, 1, relu=True), iters=20)
         print("     direct kernel                                   %.4f ms  (%.1f TF/s)" % (t, gflop / t), flush=True)
+    # layer4: 8 x 8 maps, four images per item, K in four slices
+    H, C = 8, 512
+    conv = torch.nn.Conv2d(C, C, 3, 1, 1, bias=False).to(dev)
+    bn = torch.nn.BatchNorm2d(C).eval().to(dev)
+    bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0); bn.weight.data.normal_(); bn.bias.data.normal_()
+    cb = _ConvBN(conv, bn)
+    gflop1 = 2.0 * H * H * C * C * 9 / 1e9
+    for B in (64, 16, 5, 1):
+        x = F.pad(torch.relu(torch.randn(B, H, H, C, device=dev)), (0, 0, 1, 1, 1, 1)).contiguous()
+        res = F.pad(torch.randn(B, H, H, C, device=dev), (0, 0, 1, 1, 1, 1)).contiguous()
+        outs = {}
+        for wino in (True, False):
+            cb.use_winograd = wino
+            out = torch.zeros(B, H + 2, H + 2, C, device=dev)
+            t = timeit(lambda: cb.padded(x, 1, out, 1, residual=res, relu=True), iters=20)
+            outs[wino] = out.clone()
+            print("layer4 8x8 C=512 B=%-3d %-9s %.4f ms  (direct-conv-equivalent %.1f TF/s)" % (B, "winograd" if wino else "direct", t, gflop1 * B / t), flush=True)
+        d = (outs[True] - outs[False]).abs().max().item()
+        print("     max |winograd - direct| = %.3g of scale %.3g; halo untouched: %s" % (
+            d, outs[False].abs().max().item(), bool((outs[True][:, 0].abs().max() == 0) and (outs[True][:, :, 0].abs().max() == 0))), flush=True)
 
 
 def sec_blend_modes():

@@ -20,6 +20,6 @@ out = torch.zeros(64, H + 2, H + 2, C, device=dev)
 P = _capi.ptr
 with _capi.dev_library():
     for _ in range(6):
-        _capi.call("hps_dev_conv3x3_winograd", P(x), P(cb.wino_u), P(cb.scale), P(cb.shift), None, P(out), 64, H, H, 1, C, C, 1, 1, ab,
+        _capi.call("hps_dev_conv3x3_winograd", P(x), P(cb.wino_u), P(cb.scale), P(cb.shift), None, P(out), 64, H, H, 1, C, C, 1, 1, None, ab,
                    _capi.stream())
 torch.cuda.synchronize()

@@ -322,7 +322,9 @@ def test_head_svd_modes_agree(dev, net_gpu):
 
 @pytest.mark.parametrize("cfg", [
     # B, H, Cin, Cout -- the stride-1 3x3 layers of layer1 / layer2 / layer3 at the 256x256 input, plus an odd batch
-    (2, 64, 64, 64), (2, 32, 128, 128), (3, 16, 256, 256), (1, 16, 64, 128), (5, 48, 8, 64), (300, 16, 64, 64)])
+    (2, 64, 64, 64), (2, 32, 128, 128), (3, 16, 256, 256), (1, 16, 64, 128), (5, 48, 8, 64), (300, 16, 64, 64),
+    # layer4's 8 x 8 maps: four images per item (full and partial quads), K in four slices (512, 256) or one (64)
+    (4, 8, 512, 512), (5, 8, 512, 512), (1, 8, 256, 128), (7, 8, 64, 64), (70, 8, 256, 64)])
 def test_winograd_conv_kernel(cfg, dev):
     """csrc/conv_wino.hip (Winograd F(2x2, 3x3) + BatchNorm + residual + ReLU) against torch's convolution and against the direct
     implicit-GEMM kernel: same results up to fp32 rounding of a different summation order (<= 1e-5 of the output scale)."""
@@ -357,8 +359,12 @@ def test_winograd_conv_kernel(cfg, dev):
             cb.padded(xp, 1, direct, opad, relu=False)
             cb.use_winograd = True
             assert maxerr(out2, direct) <= 1e-5 * scale_ref
-    # a map whose tiles per image do not fill 64-tile workgroups (layer4's 8x8) stays on the direct kernel, for every batch size
-    assert not cb.winograd_ok(8, 8, 1) and not cb.winograd_ok(30, 30, 1) and not cb.winograd_ok(24, 24, 1)
+    # maps that are neither 16 x 16-pixel blocks nor 8 x 8 stay on the direct kernel, for every batch size
+    assert cb.winograd_ok(8, 8, 1) and not cb.winograd_ok(30, 30, 1) and not cb.winograd_ok(24, 24, 1) and not cb.winograd_ok(4, 4, 1)
+    if H == 8:          # per-image results do not depend on the quad an image sits in (bit for bit)
+        one = torch.zeros(1, H + 2, H + 2, Cout, device=dev)
+        cb.padded(xp[B - 1:B].contiguous(), 1, one, 1, relu=False)
+        assert torch.equal(one[0], out2[B - 1])
 
 
 def test_winograd_and_direct_encoders_agree_and_are_batch_invariant(dev, net_gpu, golden, golden_input):

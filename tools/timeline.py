@@ -5,7 +5,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 30.0
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Queue_Id"]) for r in rows)
-lbs = [e for e in ev if "lbs_kernel" in e[2]]
+lbs = [e for e in ev if "mesh_fused_kernel" in e[2]] or [e for e in ev if "lbs_kernel" in e[2]]   # one per step
 t0, t1 = lbs[3][0], lbs[-1][0]
 n = len(lbs) - 4
 sel = [e for e in ev if t0 <= e[0] < t1]
