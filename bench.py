@@ -152,6 +152,8 @@ def main():
     torch.cuda.synchronize()
     smpl.lbs_events = []
     pipe.enc_events = []
+    if args.trace_steps:
+        pipe.trace = []
     sampling_utils.launch_events = []
     sums = torch.zeros(4, dtype=torch.float64, device=dev)
     barrier()
@@ -183,7 +185,8 @@ def main():
     achieved = LBS_BYTES_PER_MESH * M / (lbs_avg_ms * 1e-3) / 1e9 if lbs_ms else None
     # secondary figures of SURVEY section 8(d), same method (HIP events on the launch stream, timed region only); the
     # encoder shares the GPU with the previous batch's head and uncertainty kernels while it runs
-    enc_ms = [e0.elapsed_time(e1) for (e0, e1) in (pipe.enc_events or [])]
+    enc_events_kept = list(pipe.enc_events or [])
+    enc_ms = [e0.elapsed_time(e1) for (e0, e1) in enc_events_kept]
     smp_ms = [e0.elapsed_time(e1) for (e0, e1) in (sampling_utils.launch_events or [])]
     pipe.enc_events, sampling_utils.launch_events = None, None
     secondary = {}
@@ -211,6 +214,16 @@ def main():
         if pmc.get("meshes_per_launch", M) == M:
             traffic = pmc.get("hbm_bytes_per_launch")
 
+    if args.trace_steps and rank == 0 and pipe.trace and enc_ms:
+        # device-side schedule of a few steady-state batches from HIP events (no profiler): batch j's encoder was the j-th
+        # submit of the timed region, its head / mesh phases the j-th finish
+        evs = enc_events_kept
+        ref = evs[2][0]
+        for j in range(2, min(8, len(pipe.trace))):
+            t = pipe.trace[j]
+            rel = lambda e: ref.elapsed_time(e)
+            print("batch %2d: encoder %7.3f -> %7.3f | head %7.3f -> %7.3f | meshes %7.3f -> %7.3f  (ms)" % (
+                j, rel(evs[j][0]), rel(evs[j][1]), rel(t["head0"]), rel(t["head1"]), rel(t["mesh0"]), rel(t["mesh1"])), file=sys.stderr)
     if args.trace_steps and rank == 0:
         marks = step_marks[-args.steps:]
         print("host ms between step completions:", ["%.2f" % ((b - a) * 1e3) for a, b in zip(marks[:-1], marks[1:])],

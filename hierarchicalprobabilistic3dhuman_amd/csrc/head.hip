@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
     }
 }
 
-// One kinematic level: grid = (n_level joints, batch tiles), 1024 threads = 8 K-slices x HID columns.
+// One kinematic level: grid = (n_level joints, batch tiles of TBL images).
 // proper SVD + mode (models/poseMF_shapeGaussian_net.py:139-152) of one joint of one image from its raw factors
 __device__ __forceinline__ void proper_svd_store(float* U, const float* S, float* V, size_t o, float* __restrict__ pose_u,
                                                  float* __restrict__ pose_s, float* __restrict__ pose_v, float* u_proper,
@@ -116,26 +116,32 @@ __device__ __forceinline__ void proper_svd_store(float* U, const float* S, float
 // singular vectors carry the signs the reference's torch.svd would give them), followed by the proper-SVD fix -- the level
 // needs no host round trip.  u_proper / s_proper / mode are read for ancestor joints (earlier levels) and written for this
 // level's joints: no element is both read and written by one launch.
-template <int HID, bool DEVSVD>
-__global__ __launch_bounds__(1024) void joint_level_kernel(
+// NT threads = (NT / HID) K-slices x HID columns, TBL images per workgroup.  The product uses NT = 256, TBL = 4: a workgroup
+// of four waves, ~110 registers and 18 KB of LDS has the footprint of one workgroup of the kernels it runs beside in the
+// pipelined loop (fused mesh kernel, stem convolution), so it is placed as soon as one of those retires; the former
+// 1024-thread / 60 KB workgroup needed a nearly empty CU and starved behind them (2.2 ms per head instead of 0.5).
+template <int HID, bool DEVSVD, int NT, int TBL>
+__global__ __launch_bounds__(NT) void joint_level_kernel(
     const float* __restrict__ embed, int embed_dim, const int32_t* __restrict__ joint_ids,
     const int32_t* __restrict__ anc_ptr, const int32_t* __restrict__ anc_idx, const float* const* __restrict__ w1t_ptrs,
     const float* const* __restrict__ b1_ptrs, const float* const* __restrict__ w2_ptrs,
     const float* const* __restrict__ b2_ptrs, float* u_proper, float* s_proper,
     float* mode, float delta_i_weight, float* __restrict__ pose_f, float* __restrict__ f_level,
     float* __restrict__ pose_u, float* __restrict__ pose_s, float* __restrict__ pose_v, int B, int NJ) {
-    constexpr int KS = 1024 / HID;
+    constexpr int KS = NT / HID;
+    constexpr int PARTS = NT >= 9 * TBL * 8 ? 8 : 4;       // lanes per output-layer dot product
+    static_assert(NT % HID == 0 && TBL % 4 == 0 && NT >= 9 * TBL * PARTS && KS * HID >= 9, "joint_level_kernel: shape");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int joint = joint_ids[blockIdx.x];
     const int a_lo = anc_ptr[joint], P = anc_ptr[joint + 1] - a_lo;
     const int in_dim = embed_dim + 21 * P;
-    float* xs = smem;                                        // [in_dim][TB]
-    float* hs = smem + (size_t)((in_dim * TB + 3) & ~3);     // [HID][TB]
-    float* red = hs + HID * TB;                              // [KS][TB][HID] partial sums
-    const int b0 = blockIdx.y * TB;
+    float* xs = smem;                                        // [in_dim][TBL]
+    float* hs = smem + (size_t)((in_dim * TBL + 3) & ~3);    // [HID][TBL]
+    float* red = hs + HID * TBL;                             // [KS][TBL][HID] partial sums
+    const int b0 = blockIdx.y * TBL;
 
     // gather: cat[embed, U_proper[anc] (9P), S_proper[anc] (3P), mode[anc] (9P)]   (:126-132)
-    for (int i = threadIdx.x; i < in_dim * TB; i += 1024) {
+    for (int i = threadIdx.x; i < in_dim * TBL; i += NT) {
         const int r = i / in_dim, k = i % in_dim;
         const int b = b0 + r;
         float v = 0.0f;
@@ -148,40 +154,39 @@ __global__ __launch_bounds__(1024) void joint_level_kernel(
                 else { t -= 3 * P; v = mode[((size_t)b * NJ + anc_idx[a_lo + t / 9]) * 9 + t % 9]; }
             }
         }
-        xs[k * TB + r] = v;
+        xs[k * TBL + r] = v;
     }
     __syncthreads();
 
     // hidden layer
     const int n = threadIdx.x % HID, ks = threadIdx.x / HID;
-    float acc[TB];
+    float acc[TBL];
 #pragma unroll
-    for (int r = 0; r < TB; ++r) acc[r] = 0.0f;
+    for (int r = 0; r < TBL; ++r) acc[r] = 0.0f;
     const int kchunk = ceil_div(in_dim, KS);
     const int k_lo = min(in_dim, ks * kchunk), k_hi = min(in_dim, k_lo + kchunk);
-    dot_slice<TB>(w1t_ptrs[joint] + n, (size_t)HID, xs, k_lo, k_hi, acc);
+    dot_slice<TBL>(w1t_ptrs[joint] + n, (size_t)HID, xs, k_lo, k_hi, acc);
 #pragma unroll
-    for (int r = 0; r < TB; ++r) red[(ks * TB + r) * HID + n] = acc[r];
+    for (int r = 0; r < TBL; ++r) red[(ks * TBL + r) * HID + n] = acc[r];
     __syncthreads();
-    if (threadIdx.x < HID * TB) {
-        const int r = threadIdx.x / HID, c = threadIdx.x % HID;
+    for (int i = threadIdx.x; i < HID * TBL; i += NT) {
+        const int r = i / HID, c = i % HID;
         float v = b1_ptrs[joint][c];
 #pragma unroll
-        for (int q = 0; q < KS; ++q) v += red[(q * TB + r) * HID + c];
-        hs[c * TB + r] = elu1(v);
+        for (int q = 0; q < KS; ++q) v += red[(q * TBL + r) * HID + c];
+        hs[c * TBL + r] = elu1(v);
     }
     __syncthreads();
 
-    // output layer: 9 x TB dot products of length HID split over 8 lanes each, + bias + delta_i_weight * I (:134-135)
-    if (threadIdx.x < 9 * TB * 8) {
-        const int part = threadIdx.x & 7, o = threadIdx.x >> 3;
-        const int e = o / TB, r = o % TB;
+    // output layer: 9 x TBL dot products of length HID split over PARTS lanes each, + bias + delta_i_weight * I (:134-135)
+    if (threadIdx.x < 9 * TBL * PARTS) {
+        const int part = threadIdx.x % PARTS, o = threadIdx.x / PARTS;
+        const int e = o / TBL, r = o % TBL;
         const float* w2 = w2_ptrs[joint] + (size_t)e * HID;
         float v = 0.0f;
-        for (int k = part; k < HID; k += 8) v += w2[k] * hs[k * TB + r];
-        v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 4);
+        for (int k = part; k < HID; k += PARTS) v += w2[k] * hs[k * TBL + r];
+#pragma unroll
+        for (int m = 1; m < PARTS; m <<= 1) v += __shfl_xor(v, m);
         if (part == 0) {
             v += b2_ptrs[joint][e];
             if (e % 4 == 0) v += delta_i_weight;
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(1024) void joint_level_kernel(
     }
     if (DEVSVD) {
         __syncthreads();
-        if (threadIdx.x < TB && b0 + threadIdx.x < B) {
+        if (threadIdx.x < TBL && b0 + threadIdx.x < B) {
             float F[9], U[9], S[3], V[9];
 #pragma unroll
             for (int e = 0; e < 9; ++e) F[e] = red[threadIdx.x * 9 + e];
@@ -264,15 +269,16 @@ static int joint_level_launch(const float* embed, int embed_dim, int hidden, con
         return bad_arg("hps_head_joint_level: null pointer");
     if (hidden != 128) { set_error("hps_head_joint_level: hidden=%d unsupported (128 = EMBED_DIM/2)", hidden); return HPS_E_UNSUPPORTED; }
     if (B <= 0 || n_level <= 0) return HPS_OK;
+    constexpr int NT = 256, TBL = 4;
     const int max_in = embed_dim + 21 * num_body_joints;
-    size_t lds = ((size_t)((max_in * TB + 3) & ~3) + 128 * TB + (1024 / 128) * TB * 128) * sizeof(float);
+    size_t lds = ((size_t)((max_in * TBL + 3) & ~3) + 128 * TBL + (NT / 128) * TBL * 128) * sizeof(float);
     if (lds > 64 * 1024) { set_error("hps_head_joint_level: embed_dim=%d too large", embed_dim); return HPS_E_UNSUPPORTED; }
     if (devsvd)
-        hipLaunchKernelGGL((joint_level_kernel<128, true>), dim3(n_level, ceil_div(B, TB)), dim3(1024), lds, (hipStream_t)stream,
+        hipLaunchKernelGGL((joint_level_kernel<128, true, NT, TBL>), dim3(n_level, ceil_div(B, TBL)), dim3(NT), lds, (hipStream_t)stream,
                            embed, embed_dim, joint_ids, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper,
                            s_proper, mode, delta_i_weight, pose_f, f_level, pose_u, pose_s, pose_v, B, num_body_joints);
     else
-        hipLaunchKernelGGL((joint_level_kernel<128, false>), dim3(n_level, ceil_div(B, TB)), dim3(1024), lds, (hipStream_t)stream,
+        hipLaunchKernelGGL((joint_level_kernel<128, false, NT, TBL>), dim3(n_level, ceil_div(B, TBL)), dim3(NT), lds, (hipStream_t)stream,
                            embed, embed_dim, joint_ids, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper,
                            s_proper, mode, delta_i_weight, pose_f, f_level, pose_u, pose_s, pose_v, B, num_body_joints);
     return check_launch("hps_head_joint_level");

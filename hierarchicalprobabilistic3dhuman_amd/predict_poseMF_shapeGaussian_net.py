@@ -121,6 +121,7 @@ class InferencePipeline:
         self.head_stream = torch.cuda.Stream(priority=-1)
         self._smpl_done = None
         self.enc_events = None
+        self.trace = None             # bench.py --trace-steps: list of per-batch dicts of timing events (head / mesh phases)
         self.early_relayout = False   # A/B on one box: +0.4 % images/s, but the mesh kernel it overlaps runs 8 % slower (0.67 vs 0.62 ms)
 
     @torch.no_grad()
@@ -163,15 +164,28 @@ class InferencePipeline:
         main = torch.cuda.current_stream()
         main.wait_event(done)
         feats.record_stream(main)
-        hook = (lambda: main.wait_event(after[1])) if after is not None else None
+        def hook():
+            if after is not None:
+                main.wait_event(after[1])
+            if tr is not None:
+                tr["mesh0"].record(main)
         hs = self.head_stream
+
+        tr = None
+        if self.trace is not None:
+            tr = {k: torch.cuda.Event(enable_timing=True) for k in ("head0", "head1", "mesh0", "mesh1")}
+            self.trace.append(tr)
 
         def run_net(_, input_feats=None):
             # head on the high-priority stream: depends on the encoder only, not on what is still queued on `main`
             hs.wait_event(done)
             input_feats.record_stream(hs)
             with torch.cuda.stream(hs):
+                if tr is not None:
+                    tr["head0"].record(hs)
                 outs = self.net(None, input_feats=input_feats)
+                if tr is not None:
+                    tr["head1"].record(hs)
             main.wait_stream(hs)
             for t in outs:
                 for u in ((t.loc, t.scale) if isinstance(t, torch.distributions.Normal) else (t,)):
@@ -181,6 +195,8 @@ class InferencePipeline:
         def smpl_done():
             self._smpl_done = torch.cuda.Event()
             self._smpl_done.record(main)
+            if tr is not None:
+                tr["mesh1"].record(main)
 
         return infer(self.net, self.smpl, None, num_samples=self.num_samples, use_mean_shape=self.use_mean_shape,
                      sample_on_cpu=self.sample_on_cpu, seed=seed, image_offset=image_offset, input_feats=feats,

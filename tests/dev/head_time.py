@@ -9,6 +9,8 @@ torch.manual_seed(0)
 dev = torch.device("cuda:0")
 net = PoseMFShapeGaussianNet(configs.SMPL_PARENTS, configs.get_cfg_defaults()).eval().to(dev)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+if len(sys.argv) > 2:
+    net.svd_mode = sys.argv[2]
 feats = torch.randn(B, 512, device=dev)
 for _ in range(3):
     net(None, input_feats=feats)
