@@ -63,11 +63,11 @@ def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mea
     P = _capi.ptr
     _capi.call("hps_infer_assemble", P(_capi.f32c(mode)), P(_capi.f32c(glob_rotmats)), P(loc), P(betas_s) if betas_s is not None else None,
                P(body), P(glob_all), P(betas_all), B, N, nj, nb, _capi.stream())
-    if _before_meshes is not None:          # InferencePipeline: the heavy mesh kernels wait here; sampling and the input
-        _before_meshes()                    # assembly above are small and may run beside the next batch's encoder
-    out = smpl_model(body_pose=body, global_orient=glob_all, betas=betas_all, pose2rot=False)
-    if _after_smpl is not None:
-        _after_smpl()
+    # InferencePipeline: the chip-filling mesh kernel waits at _before_meshes and signals at _after_smpl; sampling, the input
+    # assembly, pose prep (before) and the joint regression / uncertainty (after) are small or HBM-bound and may run beside the
+    # neighbouring batches' encoders
+    out = smpl_model(body_pose=body, global_orient=glob_all, betas=betas_all, pose2rot=False,
+                     _before_mesh=_before_meshes, _after_mesh=_after_smpl)
     V = out.vertices.shape[1]
     verts_s = out.vertices[2 * B:].view(B, N, V, 3)
     joints_s = out.joints[2 * B:].view(B, N, -1, 3)

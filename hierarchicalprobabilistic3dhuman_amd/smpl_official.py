@@ -179,6 +179,10 @@ class SMPL(nn.Module):
         _capi.call("hps_smpl_pose_prep", P(g), P(b), is_rotmat, P(be), self.num_betas, P(self._j_template),
                    P(self._j_shapedirs), _capi.iptr(self._parents_i32), _capi.iptr(self._depth_i32), J, P(xt),
                    self._kp, mp, P(a), P(j_posed), None, M, s)
+        # InferencePipeline: only the chip-filling mesh kernel(s) run alone; pose prep (before) and the joint regression (after)
+        # may share the GPU with the neighbouring batches' encoders
+        if kwargs.get("_before_mesh") is not None:
+            kwargs["_before_mesh"]()
         ev = None
         if self.lbs_events is not None:      # bench.py: HIP events around the mesh kernel launch, on its own stream
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -202,6 +206,8 @@ class SMPL(nn.Module):
         if ev is not None:
             ev[1].record()
             self.lbs_events.append((M, ev[0], ev[1]))
+        if kwargs.get("_after_mesh") is not None:
+            kwargs["_after_mesh"]()
         _capi.call("hps_smpl_joints", P(verts), P(j_posed), _capi.iptr(self._csr_ptr), _capi.iptr(self._csr_col),
                    P(self._csr_val), self._n_joint_rows, J, P(tr) if tr is not None else None, P(joints), M, V, s)
         full_pose = torch.cat([g, b], dim=1) if return_full_pose else None
