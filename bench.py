@@ -112,7 +112,7 @@ def main():
     lo, hi = sharding.shard_range(B * world, rank, world)               # weak scaling: B images per GPU
     x = synthetic_inputs(lo, hi).to(dev)
 
-    # Steps are software-pipelined over two HIP streams: the encoder of step i+1 is enqueued before the host-paced
+    # Steps are software-pipelined over three HIP streams: the encoder of step i+1 is enqueued before the latency-bound
     # head of step i runs (InferencePipeline).  Every step does the full work; exactly args.steps batches are
     # submitted and finished inside the timed region.
     pipe = InferencePipeline(net, smpl, num_samples=N, use_mean_shape=True)
@@ -241,7 +241,7 @@ def main():
                        "images_per_gpu": B, "global_batch": B * world, "num_samples": N,
                        "meshes_per_step_per_gpu": M, "parallelism": "images sharded over %d GPU(s)" % world,
                        "mesh_kernel": "fused blend GEMM + LBS" if fused else "blend GEMM, then LBS",
-                       "step_pipelining": "none" if args.no_pipeline else "encoder of step i+1 (own stream) overlaps the host-paced head of step i (high-priority stream); the mesh kernels (pose prep / blend + LBS / joints) of a batch run alone"},
+                       "step_pipelining": "none" if args.no_pipeline else "encoder of step i+1 (own stream) overlaps the latency-bound head of step i (high-priority stream); the mesh kernels (pose prep / blend + LBS / joints) of a batch run alone"},
             # The mesh kernel is FUSED (blend GEMM tile skinned in the MFMA epilogue, no v_posed round trip).  SURVEY 8(d):
             # it is still reported against the UNFUSED LBS definition (166,896 B per mesh), over the fused kernel's
             # whole launch time -- which also contains the 8.97 MFLOP/mesh blend GEMM that really bounds it (roofline_mfma).

@@ -89,12 +89,12 @@ def proxy_representation(rgb, joints2D, joints2D_visib, edge_detect_model, pose_
 
 
 class InferencePipeline:
-    """Two-stage software pipeline over successive batches on two HIP streams.
+    """Software pipeline over successive batches on three HIP streams.
 
-    The head of batch i is host-paced (eight kinematic levels, each with a host LAPACK SVD round trip), which
-    leaves the GPU idle for ~1 ms per batch; the encoder of batch i+1 does not depend on it.  ``submit`` enqueues
-    the encoder on a side stream, ``finish`` runs head -> sampling -> SMPL -> uncertainty on the caller's stream
-    after waiting for the encoder's event, so the next batch's convolutions fill the head's gaps:
+    The head of batch i is a dependency chain of eleven small launches (eight kinematic levels, each an MLP + a serial 3x3 SVD:
+    0.5 ms of latency on a handful of CUs); the encoder of batch i+1 does not depend on it.  ``submit`` enqueues the encoder on a
+    side stream, ``finish`` runs the head on a high-priority stream as soon as its encoder's event fires, then sampling -> SMPL ->
+    uncertainty on the caller's stream:
 
         pipe = InferencePipeline(net, smpl, num_samples=100)
         t = pipe.submit(x0)
@@ -104,20 +104,19 @@ class InferencePipeline:
             t = t_next
         result = pipe.finish(t)
 
-    ``after=`` makes the mesh phase (sampling, blend GEMM, LBS) of this batch start only when the next batch's encoder
-    has drained: the two would otherwise time-share CUs and HBM with little gain in throughput (the GPU is busy either
-    way) while every kernel runs slower than its roofline.  The host-paced head overlaps the encoder, and so does the
-    HBM-bound tail after the SMPL kernels (per-vertex uncertainty, result slicing): the following ``submit`` only waits
-    for the SMPL kernels, so that tail runs beside the MFMA-bound convolutions of the batch after next.
+    ``after=`` makes the mesh kernel (blend GEMM + LBS) of this batch start only when the next batch's encoder has drained, and the
+    encoder after that waits for it: the two fill the chip on their own and would only time-share it.  Everything else -- the head,
+    sampling, pose prep, the joint regression and the HBM-bound uncertainty pass -- is small or memory-bound and runs beside the
+    neighbouring encoders (what that overlap costs, and why the head's workgroups are kept small).
     Results are identical to ``infer`` (same kernels, same order per batch)."""
 
     def __init__(self, pose_shape_model, smpl_model, num_samples=50, use_mean_shape=True, sample_on_cpu=False):
         self.net, self.smpl = pose_shape_model, smpl_model
         self.num_samples, self.use_mean_shape, self.sample_on_cpu = num_samples, use_mean_shape, sample_on_cpu
         self.enc_stream = torch.cuda.Stream()
-        # The head is a chain of ~30 small dependent kernels and copies; next to a convolution that keeps every CU's
-        # LDS full, each of them would otherwise queue behind the convolution's pending workgroups (measured: 240 us
-        # per kinematic level instead of ~130).  A high-priority stream lets its few workgroups take the next free slots.
+        # The head is a chain of small dependent kernels; next to kernels that keep every CU's LDS / registers full each of
+        # them would otherwise queue behind the pending workgroups.  A high-priority stream lets its few (small: 256 threads,
+        # 18 KiB) workgroups take the next free slots.
         self.head_stream = torch.cuda.Stream(priority=-1)
         self._smpl_done = None
         self.enc_events = None

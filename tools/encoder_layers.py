@@ -72,7 +72,9 @@ def main():
                 gflop = 2.0 * o.B * Ho * Wo * o.Cout * o.KH * o.KW * cin / 1e9
                 wino = o.kind == _capi.ENC_CONV_WINOGRAD
                 row.update(gflop=gflop, tflops=gflop / ms, out_hw=[Ho, Wo], cin=cin, cout=o.Cout, ksplit=o.ksplit,
-                           launches=2 if o.ksplit > 1 else 1, algorithm="winograd F(2x2,3x3)" if wino else "direct implicit GEMM",
+                           launches=2 if (o.ksplit > 1 or (wino and o.H == 8 and o.W == 8)) else 1,
+                           algorithm=("winograd F(2x2,3x3), four images per item, K in 4 slices" if o.H == 8 else "winograd F(2x2,3x3)") if wino
+                           else "direct implicit GEMM",
                            mfma_gflop=gflop / 2.25 if wino else gflop)
             rows.append(row)
             print("%-40s %.4f ms %s" % (names[i], ms, ("%.1f TF/s" % row["tflops"]) if "tflops" in row else ""), flush=True)
