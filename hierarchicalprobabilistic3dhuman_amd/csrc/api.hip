@@ -14,7 +14,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace hps
 
-extern "C" int hps_version(void) { return 200; }  // 0.2.0
+extern "C" int hps_version(void) { return 201; }  // 0.2.1: hps_conv3x3_winograd takes splitk_ws
 
 extern "C" int64_t hps_query_workspace(int what, int64_t d0, int64_t d1, int64_t d2) {
     if (d0 < 0 || d1 < 0 || d2 < 0) { hps::set_error("hps_query_workspace: negative dimension"); return -1; }
