@@ -198,13 +198,19 @@ __global__ __launch_bounds__(NT) void joint_level_kernel(
         }
     }
     if (DEVSVD) {
+        // One matrix per WAVE (lane 0 of wave r takes image r), not per lane: the LAPACK sequence is all data-dependent branches
+        // (sweep direction, zero / non-zero shift, 2 x 2 blocks, sweep counts), and lanes of one wave that take different paths
+        // run them one after the other -- 64 different matrices on the lanes of a wave take 45 us, identical ones 9 us
+        // (tests/dev/svd_time.py).  A wave of its own follows one path: the level kernel went from 57 to under 30 us.
+        static_assert(NT / 64 >= TBL, "one wave per image of the tile");
         __syncthreads();
-        if (threadIdx.x < TBL && b0 + threadIdx.x < B) {
+        const int r = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0 && r < TBL && b0 + r < B) {
             float F[9], U[9], S[3], V[9];
 #pragma unroll
-            for (int e = 0; e < 9; ++e) F[e] = red[threadIdx.x * 9 + e];
+            for (int e = 0; e < 9; ++e) F[e] = red[r * 9 + e];
             gesdd3::svd3(F, U, S, V);
-            proper_svd_store(U, S, V, (size_t)(b0 + threadIdx.x) * NJ + joint, pose_u, pose_s, pose_v, u_proper, s_proper, mode);
+            proper_svd_store(U, S, V, (size_t)(b0 + r) * NJ + joint, pose_u, pose_s, pose_v, u_proper, s_proper, mode);
         }
     }
 }

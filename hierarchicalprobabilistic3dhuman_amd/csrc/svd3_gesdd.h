@@ -287,6 +287,10 @@ HPS_HD bool sbdsqr3(float* d0, float* e0, float* u, float* vt) {
             m = m - 2;
             continue;
         }
+        // n = 3: a block that is not 2 x 2 is the whole matrix (1 <= ll <= m - 2, m <= 3).  Saying so turns every index of the
+        // sweeps below into a constant (the device compiler otherwise expands each D[i] / E[i] / row access into select chains).
+        ll = 1;
+        m = 3;
         if (ll > oldm || m < oldll) idir = (fabsf(D[ll]) >= fabsf(D[m])) ? 1 : 2;      // chase from the larger end
         // convergence tests
         bool again = false;
