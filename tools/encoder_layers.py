@@ -35,6 +35,8 @@ def main():
     torch.manual_seed(0)
     net = PoseMFShapeGaussianNet(configs.SMPL_PARENTS, configs.get_cfg_defaults()).eval().to(dev)
     enc = net.image_encoder
+    if len(sys.argv) > 3 and sys.argv[3] == "direct":     # A/B: every layer on the direct kernel
+        enc.set_winograd(False)
     x = torch.rand(B, 18, 256, 256, generator=torch.Generator().manual_seed(1)).to(dev)
     with torch.no_grad():
         feats = enc(x)                                    # builds the frames and the launch list
