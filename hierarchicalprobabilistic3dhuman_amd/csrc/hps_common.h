@@ -90,21 +90,25 @@ __device__ __forceinline__ void rodrigues_dev(float rx, float ry, float rz, floa
 template <int K>
 __device__ __forceinline__ f3 skin_vertex(const float* Am, const int (&idx)[K], const float (&w)[K], const f3 pv, float tx,
                                           float ty, float tz) {
-    float T[12];
+    // The blend T = sum_k w_k A_k as packed fp32 FMAs (v_pk_fma_f32: two IEEE FMAs per lane and instruction, the same bits as
+    // twelve scalar ones at half the issue slots -- VALU time is paid in MFMA time in the fused kernel).
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f P[6];
 #pragma unroll
-    for (int e = 0; e < 12; ++e) T[e] = 0.0f;
+    for (int e = 0; e < 6; ++e) P[e] = (v2f){0.0f, 0.0f};
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const float4* t4 = reinterpret_cast<const float4*>(Am + idx[k]);
         const float4 r0 = t4[0], r1 = t4[1], r2 = t4[2];
-        const float wk = w[k];
-        T[0] = __builtin_fmaf(wk, r0.x, T[0]); T[1] = __builtin_fmaf(wk, r0.y, T[1]);
-        T[2] = __builtin_fmaf(wk, r0.z, T[2]); T[3] = __builtin_fmaf(wk, r0.w, T[3]);
-        T[4] = __builtin_fmaf(wk, r1.x, T[4]); T[5] = __builtin_fmaf(wk, r1.y, T[5]);
-        T[6] = __builtin_fmaf(wk, r1.z, T[6]); T[7] = __builtin_fmaf(wk, r1.w, T[7]);
-        T[8] = __builtin_fmaf(wk, r2.x, T[8]); T[9] = __builtin_fmaf(wk, r2.y, T[9]);
-        T[10] = __builtin_fmaf(wk, r2.z, T[10]); T[11] = __builtin_fmaf(wk, r2.w, T[11]);
+        const v2f wk = (v2f){w[k], w[k]};
+        P[0] = __builtin_elementwise_fma(wk, (v2f){r0.x, r0.y}, P[0]);
+        P[1] = __builtin_elementwise_fma(wk, (v2f){r0.z, r0.w}, P[1]);
+        P[2] = __builtin_elementwise_fma(wk, (v2f){r1.x, r1.y}, P[2]);
+        P[3] = __builtin_elementwise_fma(wk, (v2f){r1.z, r1.w}, P[3]);
+        P[4] = __builtin_elementwise_fma(wk, (v2f){r2.x, r2.y}, P[4]);
+        P[5] = __builtin_elementwise_fma(wk, (v2f){r2.z, r2.w}, P[5]);
     }
+    const float T[12] = {P[0].x, P[0].y, P[1].x, P[1].y, P[2].x, P[2].y, P[3].x, P[3].y, P[4].x, P[4].y, P[5].x, P[5].y};
     f3 o;
     o.x = __builtin_fmaf(T[2], pv.z, __builtin_fmaf(T[1], pv.y, T[0] * pv.x)) + T[3] + tx;
     o.y = __builtin_fmaf(T[6], pv.z, __builtin_fmaf(T[5], pv.y, T[4] * pv.x)) + T[7] + ty;
