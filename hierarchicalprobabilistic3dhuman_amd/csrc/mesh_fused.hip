@@ -199,6 +199,10 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
                 for (int k = 0; k < K; ++k) ao[k] = aoff[k] + ds * a_stride;
                 o = skin_vertex<K>(smem, ao, w, pv, tx, ty, tz);
             }
+            // Pin the result in front of the guard: hipcc otherwise sinks the whole skinning of a mesh (12 LDS reads, the FMAs)
+            // into the guarded store's block, where the reads cannot be issued under the previous mesh's arithmetic and the
+            // block's entry waits vmcnt(0) -- i.e. for the previous mesh's store -- on account of the v_template load.
+            asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z));
             if (live_v && m < M) *reinterpret_cast<f3*>(vbase + (size_t)dr * V * 12 + voff) = o;
         }
     }
