@@ -232,18 +232,53 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
                 *reinterpret_cast<float4*>(patch + il * EP + j * 32 + 8 * q + 4 * kl) =
                     make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
         // wave-private patch: no barrier, the LDS queue is in order per wave
-        unsigned po[32 / PPI];
-        bool live[32 / PPI];
-        float4 res[32 / PPI];
+        constexpr int U = 32 / PPI;
+        if (m0 + BM <= g.Mtot) {
+            // Full tile (every tile of the benchmark shapes): no per-pixel guards, so this is straight-line code -- all patch rows
+            // are requested before the first is used and the stores follow back to back.  (With the guards hipcc put every
+            // row's read, wait and store into a block of its own: 16 exposed LDS round trips per sub-tile.)
+            unsigned po[U];
+            float4 a[U];
 #pragma unroll
-        for (int u = 0; u < 32 / PPI; ++u) {
+            for (int u = 0; u < U; ++u) {
+                po[u] = out_pixel_offset((unsigned)(m0 + wm0 + i * 32 + u * PPI + lane / LPP), g) + (unsigned)co;
+                a[u] = *reinterpret_cast<const float4*>(patch + (u * PPI + lane / LPP) * EP + c4);
+            }
+            if (residual) {
+                float4 res[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) res[u] = *reinterpret_cast<const float4*>(residual + po[u]);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float4 v = make_float4(a[u].x * sc.x + sh.x + res[u].x, a[u].y * sc.y + sh.y + res[u].y,
+                                           a[u].z * sc.z + sh.z + res[u].z, a[u].w * sc.w + sh.w + res[u].w);
+                    if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    *reinterpret_cast<float4*>(y + po[u]) = v;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    // "+ 0" as in the guarded path (residual absent = zero addend): the same bits
+                    float4 v = make_float4(a[u].x * sc.x + sh.x + 0.f, a[u].y * sc.y + sh.y + 0.f, a[u].z * sc.z + sh.z + 0.f,
+                                           a[u].w * sc.w + sh.w + 0.f);
+                    if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    *reinterpret_cast<float4*>(y + po[u]) = v;
+                }
+            }
+            continue;
+        }
+        unsigned po[U];
+        bool live[U];
+        float4 res[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
             const int m = m0 + wm0 + i * 32 + u * PPI + lane / LPP;
             live[u] = m < g.Mtot;
             po[u] = live[u] ? out_pixel_offset((unsigned)m, g) + (unsigned)co : 0u;
             res[u] = (residual && live[u]) ? *reinterpret_cast<const float4*>(residual + po[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int u = 0; u < 32 / PPI; ++u) {
+        for (int u = 0; u < U; ++u) {
             const float4 a = *reinterpret_cast<const float4*>(patch + (u * PPI + lane / LPP) * EP + c4);
             float4 v = make_float4(a.x * sc.x + sh.x + res[u].x, a.y * sc.y + sh.y + res[u].y, a.z * sc.z + sh.z + res[u].z,
                                    a.w * sc.w + sh.w + res[u].w);
