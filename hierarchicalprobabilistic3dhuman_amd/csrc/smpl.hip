@@ -230,6 +230,12 @@ __global__ __launch_bounds__(128) void joints_kernel(const float* __restrict__ v
 // vertex uncertainty: lane per vertex, two sweeps over the image's N samples (the second sweep
 // re-reads lines the first one left in L2 / Infinity Cache).
 // ---------------------------------------------------------------------------------------------
+// one definition with explicit fused multiply-adds: every uncertainty kernel rounds a distance the same way, whatever the
+// compiler would contract in its surroundings
+__device__ __forceinline__ float dist3(float dx, float dy, float dz) {
+    return sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+}
+
 __global__ __launch_bounds__(256) void uncertainty_kernel(const f3* __restrict__ verts, float* __restrict__ unc,
                                                           int N, int V) {
     const int v = blockIdx.x * 256 + threadIdx.x;
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(256) void uncertainty_kernel(const f3* __restrict__
     for (int s = 0; s < N; ++s) {
         f3 p = base[(size_t)s * V];
         const float dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
-        acc += sqrtf(dx * dx + dy * dy + dz * dz);
+        acc += dist3(dx, dy, dz);
     }
     unc[(size_t)b * V + v] = acc / N;
 }
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(UV * UG) void uncertainty_lds_kernel(const f3* __re
     float acc = 0.f;
     for (int s = g; s < N; s += UG) {
         const float dx = sU[(s * 3 + 0) * UV + v] - mx, dy = sU[(s * 3 + 1) * UV + v] - my, dz = sU[(s * 3 + 2) * UV + v] - mz;
-        acc += sqrtf(dx * dx + dy * dy + dz * dz);
+        acc += dist3(dx, dy, dz);
     }
     if (g >= H) sRed[(g - H) * UV + v] = acc;
     __syncthreads();
@@ -329,15 +335,17 @@ __global__ __launch_bounds__(512) void uncertainty_reg_kernel(const f3* __restri
     const int vg = blockIdx.x * RV + v, b = blockIdx.y;
     const bool live = vg < V;
     const f3* base = verts + (size_t)b * N * V + (live ? vg : V - 1);
+    // Guard-free: a sample beyond N re-reads sample N - 1 and contributes +0 (x + 0 = x bit for bit; the sums start at +0 and
+    // can never be -0).  With `if (s < N) { load; add; }` hipcc put every load into a block of its own that ends in
+    // s_waitcnt vmcnt(0): thirteen serialised HBM round trips per lane.
     f3 p[SPT];
     float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
+    for (int i = 0; i < SPT; ++i) p[i] = base[(size_t)min(g + UG * i, N - 1) * V];
+#pragma unroll
     for (int i = 0; i < SPT; ++i) {
-        const int s = g + UG * i;
-        if (s < N) {
-            p[i] = base[(size_t)s * V];
-            sx += p[i].x; sy += p[i].y; sz += p[i].z;
-        }
+        const bool ok = g + UG * i < N;
+        sx += ok ? p[i].x : 0.0f; sy += ok ? p[i].y : 0.0f; sz += ok ? p[i].z : 0.0f;
     }
     if (g >= H) { sRed[((g - H) * 3 + 0) * RV + v] = sx; sRed[((g - H) * 3 + 1) * RV + v] = sy; sRed[((g - H) * 3 + 2) * RV + v] = sz; }
     __syncthreads();
@@ -355,10 +363,9 @@ __global__ __launch_bounds__(512) void uncertainty_reg_kernel(const f3* __restri
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < SPT; ++i) {
-        if (g + UG * i < N) {
-            const float dx = p[i].x - mx, dy = p[i].y - my, dz = p[i].z - mz;
-            acc += sqrtf(dx * dx + dy * dy + dz * dz);
-        }
+        const float dx = p[i].x - mx, dy = p[i].y - my, dz = p[i].z - mz;
+        const float dist = dist3(dx, dy, dz);
+        acc += (g + UG * i < N) ? dist : 0.0f;
     }
     if (g >= H) sRed[(g - H) * RV + v] = acc;
     __syncthreads();
