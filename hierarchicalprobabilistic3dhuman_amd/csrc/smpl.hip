@@ -215,7 +215,21 @@ __global__ __launch_bounds__(128) void joints_kernel(const float* __restrict__ v
             x = s[0] + tx; y = s[1] + ty; z = s[2] + tz;
         } else {
             x = y = z = 0.f;
-            for (int e = csr_ptr[r - J]; e < csr_ptr[r - J + 1]; ++e) {
+            // four entries of the row in flight (column -> vertex is a dependent load chain); added in row order
+            const int e1 = csr_ptr[r - J + 1];
+            int e = csr_ptr[r - J];
+            for (; e + 4 <= e1; e += 4) {
+                float wv[4];
+                f3 p[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    wv[i] = csr_val[e + i];
+                    p[i] = *reinterpret_cast<const f3*>(vm + (size_t)csr_col[e + i] * 3);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { x += wv[i] * p[i].x; y += wv[i] * p[i].y; z += wv[i] * p[i].z; }
+            }
+            for (; e < e1; ++e) {
                 const float wv = csr_val[e];
                 const float* s = vm + (size_t)csr_col[e] * 3;
                 x += wv * s[0]; y += wv * s[1]; z += wv * s[2];
