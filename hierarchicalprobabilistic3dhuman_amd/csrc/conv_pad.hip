@@ -376,9 +376,17 @@ __global__ __launch_bounds__(256) void avgpool_pad_kernel(const float* __restric
     const int b = i / C, c = i % C;
     const int Wp = W + 2 * P;
     const float* s = x + ((size_t)b * (H + 2 * P) + P) * Wp * C + (size_t)P * C + c;
+    // eight pixels requested before the first is added (row-major order kept: the same bits); a column beyond W re-reads
+    // column W - 1 and adds +0
     float acc = 0.0f;
     for (int h = 0; h < H; ++h)
-        for (int w = 0; w < W; ++w) acc += s[((size_t)h * Wp + w) * C];
+        for (int w0 = 0; w0 < W; w0 += 8) {
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = s[((size_t)h * Wp + min(w0 + q, W - 1)) * C];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += (w0 + q < W) ? t[q] : 0.0f;
+        }
     y[i] = acc / (float)(H * W);
 }
 
