@@ -121,9 +121,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
     const int w_slot = QUAD ? (((((ltile >> 5) * 2 + ((ltile >> 2) & 1)) * 64 + (2 * t_ly - 1) * 8 + (2 * t_lx - 1)) * WK) + cp * 2)
                             : ((2 * (ltile >> 3)) * 18 + 2 * (ltile & 7)) * WK + cp * 2;
     const bool e_top = t_ly == 0, e_bot = t_ly == 3, e_left = t_lx == 0, e_right = t_lx == 3;
-    constexpr int W_ZERO = 4 * 64 * WK;                           // quad: the zero pixel sits behind slot 0's 256 pixels
+    constexpr int W_ZERO = 4 * 64 * WK;                           // quad: a zero pixel sits behind each slot's 256 pixels
+    // quad: float offsets (from the ring's start, slot 0) of the thread's 16 patch pixels, halo pixels redirected to the zero pixel,
+    // two 16-bit offsets per register.  (Sixteen separate addresses -- what hipcc made of a select at each read, hoisted out of the
+    // chunk loop -- did not fit beside 256 accumulators: they went to scratch, and every patch read became a scratch reload behind
+    // s_waitcnt vmcnt(0), which also drained the DMAs in flight.)
+    unsigned pk_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (QUAD) {
-        if (tid < WK) sR[W_ZERO + tid] = 0.0f;                    // visible after the first barrier of the item loop
+        if (tid < 3 * WK) sR[(tid / WK) * W_RAW + W_ZERO + tid % WK] = 0.0f;     // a zero pixel behind the 256 pixels of every slot (visible after the first barrier of the item loop)
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const int i = n >> 2, j = n & 3;
+            const bool halo = (i == 0 && e_top) || (i == 3 && e_bot) || (j == 0 && e_left) || (j == 3 && e_right);
+            const unsigned off = (unsigned)(halo ? W_ZERO + cp * 2 : w_slot + (i * 8 + j) * WK);
+            pk_off[n >> 1] |= off << (16 * (n & 1));
+        }
     }
     const int a_slot = ((cp >> 1) * 64 + ltile) * 4 + (cp & 1) * 2;                     // ... of the (tile, pair) slot of position 0 in sA
 
@@ -185,13 +197,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
         if (ab == 1 || ab == 5) return;
         const float* src = sR + (chunk % 3) * W_RAW + w_slot;
         if (QUAD) {
-#pragma unroll
-            for (int n = 2 * q; n < 2 * q + 2; ++n) {
-                const int i = n >> 2, j = n & 3;                  // compile-time after unrolling
-                const bool halo = (i == 0 && e_top) || (i == 3 && e_bot) || (j == 0 && e_left) || (j == 3 && e_right);
-                const float* a = halo ? sR + W_ZERO + cp * 2 : src + (i * 8 + j) * WK;
-                d[n] = *reinterpret_cast<const float2*>(a);
-            }
+            unsigned pk = pk_off[q];
+            asm volatile("" : "+v"(pk));                          // keep the unpacking here (see pk_off)
+            const float* slot = sR + (chunk % 3) * W_RAW;
+            d[2 * q] = *reinterpret_cast<const float2*>(slot + (pk & 0xffffu));
+            d[2 * q + 1] = *reinterpret_cast<const float2*>(slot + (pk >> 16));
             return;
         }
         d[2 * q] = *reinterpret_cast<const float2*>(src + (((2 * q) >> 2) * 18 + ((2 * q) & 3)) * WK);
@@ -284,18 +294,26 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
                     a4[(p + 1) & 1] = *reinterpret_cast<const float4*>(pa + (p + 1) * 512);
                     b4[(p + 1) & 1] = *reinterpret_cast<const float4*>(pb + (p + 1) * 512);
                 }
-                if (p < 8 && more) t_read2(c + 1, p);      // two patch pixels per position: never a long LDS queue ahead of a fragment
                 __builtin_amdgcn_sched_barrier(0);
                 const float4 a = a4[p & 1], b = b4[p & 1];
-                if (ab == 2) { acc[p][0] += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-                else {
+                if (ab == 2) {
+                    if (p < 8 && more) t_read2(c + 1, p);
+                    acc[p][0] += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+                } else {
                     acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[p], 0, 0, 0);
                     acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[p], 0, 0, 0);
+                    // two patch pixels per position, requested in the MIDDLE of the position's MFMAs: hipcc's wait in front of the
+                    // next position's MFMAs allows only the two newest LDS reads to be outstanding, so a patch read issued together
+                    // with the next fragments made every position wait out a fresh LDS round trip
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (p < 8 && more) t_read2(c + 1, p);
+                    if (p == 8 && more) t_write(c + 1);      // ... and the transform + its 16 LDS stores likewise (position 8)
+                    __builtin_amdgcn_sched_barrier(0);
                     acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[p], 0, 0, 0);
                     acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[p], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (p == 8 && more) {
+                if (ab == 2 && p == 8 && more) {
                     t_write(c + 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
