@@ -158,24 +158,33 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
         if (c + 1 < c_end) dma_chunk(buf ^ 1);
         const float* pa = sA + (size_t)buf * BM * PBK + (wm0 + il) * PBK;
         const float* pb = sB + (size_t)buf * BN * PBK + (wn0 + il) * PBK;
+        // Fragments are double-buffered by hand: group gq + 1 is requested before the MFMAs of group gq are issued (the
+        // sched_barriers keep hipcc from sinking the reads to their uses -- left alone it reloads the same 16 registers after
+        // the group's last MFMA and waits out the LDS round trip in front of the next group).
+        float4 a4[2][TM], b4[2][TN];
+        auto load_frags = [&](int gq, int s) {
+            const int slot = ((2 * gq + kl) ^ fsw) * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a4[s][i] = *reinterpret_cast<const float4*>(pa + i * 32 * PBK + slot);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b4[s][j] = *reinterpret_cast<const float4*>(pb + j * 32 * PBK + slot);
+        };
+        load_frags(0, 0);
 #pragma unroll
         for (int gq = 0; gq < PBK / 8; ++gq) {
-            const int slot = ((2 * gq + kl) ^ fsw) * 4;
-            float4 a4[TM], b4[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a4[i] = *reinterpret_cast<const float4*>(pa + i * 32 * PBK + slot);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b4[j] = *reinterpret_cast<const float4*>(pb + j * 32 * PBK + slot);
+            if (gq + 1 < PBK / 8) load_frags(gq + 1, (gq + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
             // k order inside the group is x, y, z, w for every accumulator (same summation order as conv.hip)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[j].x, a4[i].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[j].y, a4[i].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[j].z, a4[i].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[j].w, a4[i].w, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[gq & 1][j].x, a4[gq & 1][i].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[gq & 1][j].y, a4[gq & 1][i].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[gq & 1][j].z, a4[gq & 1][i].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[gq & 1][j].w, a4[gq & 1][i].w, acc[i][j], 0, 0, 0);
                 }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
