@@ -361,18 +361,23 @@ __global__ __launch_bounds__(256) void maxpool_pad_kernel(const float* __restric
     const int wo = (int)(p % Wo); p /= Wo;
     const int ho = (int)(p % Ho);
     const long b = p / Ho;
-    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    // Guard-free: a tap outside the map is clamped onto the nearest row / column, which belongs to the window anyway (max is
+    // idempotent: exact).  All nine loads go out before the first comparison; with `if (outside) continue` every load sat in a
+    // block of its own behind s_waitcnt vmcnt(0).
+    float4 v[9];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
-        const int hi = ho * 2 - 1 + kh;
-        if (hi < 0 || hi >= H) continue;
+        const int hi = min(max(ho * 2 - 1 + kh, 0), H - 1);
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-            const int wi = wo * 2 - 1 + kw;
-            if (wi < 0 || wi >= W) continue;
-            const float4 v = *reinterpret_cast<const float4*>(x + ((b * H + hi) * W + wi) * C + cq * 4);
-            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            const int wi = min(max(wo * 2 - 1 + kw, 0), W - 1);
+            v[kh * 3 + kw] = *reinterpret_cast<const float4*>(x + ((b * H + hi) * W + wi) * C + cq * 4);
         }
+    }
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        m.x = fmaxf(m.x, v[t].x); m.y = fmaxf(m.y, v[t].y); m.z = fmaxf(m.z, v[t].z); m.w = fmaxf(m.w, v[t].w);
     }
     *reinterpret_cast<float4*>(y + ((b * (Ho + 2 * opad) + ho + opad) * (long)(Wo + 2 * opad) + wo + opad) * C + cq * 4) = m;
 }
