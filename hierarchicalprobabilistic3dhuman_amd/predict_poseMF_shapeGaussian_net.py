@@ -121,7 +121,7 @@ class InferencePipeline:
         self._smpl_done = None
         self.enc_events = None
         self.trace = None             # bench.py --trace-steps: list of per-batch dicts of timing events (head / mesh phases)
-        self.early_relayout = False   # A/B on one box: +0.4 % images/s, but the mesh kernel it overlaps runs 8 % slower (0.67 vs 0.62 ms)
+        self.early_relayout = False   # A/B on one box: +0.9 % images/s, but the mesh kernel it overlaps runs 12 % slower (0.657 vs 0.586 ms)
 
     @torch.no_grad()
     def submit(self, proxy_rep_input, input_ready=None):
