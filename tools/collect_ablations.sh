@@ -1,0 +1,46 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): the experiment outputs DESIGN.md section 4 quotes that are not part of the bench line --
+# ablation tables of the Winograd and fused mesh kernels, head / SVD / uncertainty timings alone, the pipelined loop's device-side
+# schedule from HIP events, the cost of the overlapped work, the small-batch A/B of the Winograd layers.  Plain text, one file:
+# gpurun_out/ablations_$TAG.txt (copied to profiles/${TAG}_ablations.txt).
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/ablations_$TAG.txt
+mkdir -p $R/gpurun_out; : > $OUT
+sec() { echo; echo "==== $* ====" ; }
+{
+sec "tests/dev/gpu_bringup.py wino (B = 64; dev library: compile-time ablations of conv_wino_kernel)"
+python $R/tests/dev/gpu_bringup.py wino 2>&1 | grep -E "^wino|^layer4|direct kernel|max \|"
+sec "tests/dev/gpu_bringup.py mesh_fused (ablations of mesh_fused_kernel)"
+python $R/tests/dev/gpu_bringup.py mesh_fused 2>&1 | grep -E "mesh_fused M=|alone|ablate"
+sec "tests/dev/gpu_bringup.py unc_modes"
+python $R/tests/dev/gpu_bringup.py unc_modes 2>&1 | grep -E "^unc|registers =="
+sec "tests/dev/head_time.py 64 (head alone, device SVD)"
+python $R/tests/dev/head_time.py 64 2>&1 | grep "head alone"
+sec "tests/dev/svd_time.py (hps_svd3_packed: one lane per matrix -- divergence)"
+python $R/tests/dev/svd_time.py 2>&1 | grep "^svd3"
+sec "bench.py --steps 20 --warmup 5 --trace-steps (device-side schedule from HIP events, ms)"
+python $R/bench.py --steps 20 --warmup 5 --cpu-images 0 --trace-steps 2>&1 | grep -E "^batch|host ms" | cut -c1-400
+sec "tests/dev/contention.py <drop> --steps 30 (images/s, ms/step, encoder ms inside the loop)"
+for m in none unc sums unc,sums; do
+  python $R/tests/dev/contention.py $m --steps 30 --warmup 5 --cpu-images 0 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('drop %-9s %6d images/s  %.3f ms/step  encoder %.3f ms' % ('$m', d['value'], d['ms_per_step'], d['secondary']['encoder']['avg_ms']))"
+done
+sec "tools/encoder_layers.py time B [direct] (encoder alone, Winograd vs all-direct)"
+for b in 64 16 1; do for m in wino direct; do echo "B=$b $m: $(python $R/tools/encoder_layers.py time $b $m 2>&1 | grep whole)"; done; done
+sec "BASELINE configs[4] (B = 16, N = 1000), Winograd vs all-direct"
+for t in bench.py tests/dev/bench_direct.py; do
+  python $R/$t --batch 16 --num-samples 1000 --steps 10 --warmup 3 --cpu-images 0 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('%-28s %6d images/s  %.3f ms/step  encoder %.3f ms' % ('$t', d['value'], d['ms_per_step'], d['secondary']['encoder']['avg_ms']))"
+done
+sec "bench.py --early-relayout A/B (30 steps)"
+for f in "" "--early-relayout"; do
+  python $R/bench.py --steps 30 --warmup 5 --cpu-images 0 $f 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('%-18s %6d images/s  %.3f ms/step  mesh kernel %.4f ms' % ('$f' or 'default', d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms']))"
+done
+} >> $OUT 2>&1
+python $R/tools/encoder_layers.py time > /dev/null 2>&1     # leave gpurun_out/enc_layers_time.json at the benchmark shape
+echo "wrote $OUT"
