@@ -54,6 +54,9 @@ __device__ __forceinline__ void dot_slice(const float* __restrict__ w, size_t ld
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ wt,
                                                      const float* __restrict__ bias, const float* __restrict__ addend,
                                                      float* __restrict__ out, int ldo, int B, int K, int N, int act) {
+    // The head is a short latency chain that shares SIMDs with MFMA-bound kernels of other streams in the pipelined loop:
+    // its few instructions go first in the SIMD's issue arbitration (they cost the neighbours next to nothing).
+    __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) float smem[];   // xs[K][TB] then red[LKS][TB][LCOLS]
     float* xs = smem;
     float* red = smem + (size_t)((K * TB + 3) & ~3);
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(NT) void joint_level_kernel(
     const float* const* __restrict__ b2_ptrs, float* u_proper, float* s_proper,
     float* mode, float delta_i_weight, float* __restrict__ pose_f, float* __restrict__ f_level,
     float* __restrict__ pose_u, float* __restrict__ pose_s, float* __restrict__ pose_v, int B, int NJ) {
+    __builtin_amdgcn_s_setprio(3);                          // see linear_kernel
     constexpr int KS = NT / HID;
     constexpr int PARTS = NT >= 9 * TBL * 8 ? 8 : 4;       // lanes per output-layer dot product
     static_assert(NT % HID == 0 && TBL % 4 == 0 && NT >= 9 * TBL * PARTS && KS * HID >= 9, "joint_level_kernel: shape");
