@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
                     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __syncthreads();                                 // operand chunk c complete; sA / sB [buf ^ 1] and ring slot c % 3 are free
+            if (ab != 10) __syncthreads();                   // operand chunk c complete; sA / sB [buf ^ 1] and ring slot c % 3 are free (10: profiling, races)
             const bool more = c + 1 < nchunks;
             // one wave per SIMD: a latency is hidden only by this wave's own MFMAs.  Order of the interval: first fragments, the
             // DMAs, positions 0-8 with two patch pixels of chunk c + 1 requested per position, transform + store chunk c + 1 (VALU:
@@ -499,6 +499,7 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
         case 7: launch(std::integral_constant<int, 7>(), F()); break;
         case 8: launch(std::integral_constant<int, 8>(), F()); break;
         case 9: launch(std::integral_constant<int, 9>(), F()); break;
+        case 10: launch(std::integral_constant<int, 10>(), F()); break;
 #endif
         default: return bad_arg("hps_conv3x3_winograd: ablate");
     }

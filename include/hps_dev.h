@@ -80,7 +80,7 @@ int hps_dev_mesh_fused(const float* xt, const float* bmat_p, const float* v_temp
 
 /* Profiling ablations of hps_conv3x3_winograd: 1 = no patch loads / input transform, 2 = no MFMA, 3 = no filter DMA,
  * 4 = no epilogue, 5 = raw DMA but no transform, 6 = transform but no raw DMA, 7 = raw DMA from one line, 8 = every item
- * reads the first window, 9 = DMAs issued in one burst per chunk (results are garbage except for 9); 0 = the product
+ * reads the first window, 9 = DMAs issued in one burst per chunk, 10 = no barrier per chunk (races; results are garbage except for 9); 0 = the product
  * kernel.  16 x 16-block geometry only. */
 int hps_dev_conv3x3_winograd(const float* x, const float* u, const float* scale, const float* shift,
                              const float* residual, float* y, int B, int H, int W, int ipad, int Cin, int Cout,

@@ -188,7 +188,7 @@ def sec_wino():
         res = torch.randn(64, H + 2, H + 2, C, device=dev)
         gflop = 2.0 * 64 * H * H * C * C * 9 / 1e9
         for ab, what in ((0, "product"), (0, "product + residual"), (1, "no patch loads / transform"), (2, "no MFMA"), (3, "no filter DMA"),
-                         (4, "no epilogue"), (5, "raw DMA but no transform"), (6, "transform but no raw DMA"), (7, "raw DMA from one line"), (8, "raw DMA of one hot window"), (9, "DMAs issued in one burst")):
+                         (4, "no epilogue"), (5, "raw DMA but no transform"), (6, "transform but no raw DMA"), (7, "raw DMA from one line"), (8, "raw DMA of one hot window"), (9, "DMAs issued in one burst"), (10, "no barrier per chunk (races)")):
             r = P(res) if "residual" in what else None
             fn = lambda: _capi.call("hps_dev_conv3x3_winograd", P(x), P(cb.wino_u), P(cb.scale), P(cb.shift), r, P(out), 64, H, H, 1, C, C,
                                     1, 1, None, ab, _capi.stream())
