@@ -61,6 +61,11 @@ def test_query_workspace_is_the_single_source_of_scratch_sizes():
     assert q(_capi.WS_SMPL_VPOSED, 2, 6890) == 2 * 20736 * 4
     assert q(_capi.WS_HEAD_F, 64, 5) == 64 * 5 * 9 * 4 and q(_capi.WS_HEAD_USV, 64, 5) == 64 * 5 * 21 * 4
     lib = _capi.load()
+    # the K-slice buffer of the Winograd layer4 geometry: 4 slices x B x 8 x 8 x Cout floats; none for the 16x16-block geometry,
+    # one slice when the 8 x 8 geometry has fewer than 32 chunks
+    w = lib.hps_conv3x3_winograd_workspace
+    assert w(64, 8, 8, 512, 512) == 4 * 64 * 64 * 512 * 4 and w(5, 8, 8, 64, 128) == 1 * 5 * 64 * 128 * 4
+    assert w(64, 16, 16, 256, 256) == 0 and w(64, 64, 64, 64, 64) == 0 and w(0, 8, 8, 512, 512) == 0
     assert lib.hps_query_workspace(99, 1, 1, 1) == -1 and b"unknown item" in lib.hps_last_error()
     assert lib.hps_query_workspace(_capi.WS_SMPL_MP, -1, 0, 0) == -1
     with pytest.raises(_capi.HpsError):
