@@ -55,6 +55,7 @@ _PROTOTYPES = {
     "hps_conv2d_bn_act_pad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "hps_conv3x3_winograd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "hps_conv3x3_winograd_workspace": [_I, _I, _I, _I, _I],
+    "hps_sums_f64": [_P, _P, _P, _I, _c.c_double, _P, _P, _P],
     "hps_sizeof_enc_op": [],
     "hps_encoder_run": [_P, _I, _P],
     "hps_head_pose_levels": [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _P, _P, _P,

@@ -161,9 +161,64 @@ __global__ __launch_bounds__(256) void pointset_error_kernel(const float* __rest
     if (threadIdx.x == 0) err_sum[s] = red[0] + red[1] + red[2] + red[3];
 }
 
+// ---- float64 sums of float tensors (result checksums): two launches for up to four tensors, fixed summation order ----
+constexpr int SUM_BLOCKS = 128;
+struct SumJobs {
+    const float* x[4];
+    long n[4];
+    int take_abs[4];
+};
+
+// block (b, j): elements b * 256 + t, + SUM_BLOCKS * 256, ... of tensor j, each lane in index order, then a fixed tree
+__global__ __launch_bounds__(256) void sums_partial_kernel(const SumJobs jobs, double* __restrict__ partial) {
+    const int j = blockIdx.y;
+    const float* x = jobs.x[j];
+    const long n = jobs.n[j];
+    const bool a = jobs.take_abs[j] != 0;
+    double acc = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)SUM_BLOCKS * 256) {
+        const float v = x[i];
+        acc += (double)(a ? fabsf(v) : v);
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[j * SUM_BLOCKS + blockIdx.x] = red[0];
+}
+
+__global__ void sums_final_kernel(const double* __restrict__ partial, int count, double first, double* __restrict__ out) {
+    const int j = threadIdx.x;
+    if (j == 0) out[0] = first;
+    if (j < count) {
+        double t = 0.0;
+        for (int b = 0; b < SUM_BLOCKS; ++b) t += partial[j * SUM_BLOCKS + b];
+        out[1 + j] = t;
+    }
+}
+
 }  // namespace hps
 
 using namespace hps;
+
+extern "C" int hps_sums_f64(const float* const* xs, const int64_t* ns, const int32_t* take_abs, int count, double first,
+                            double* partial_ws, double* out, hps_stream_t stream) {
+    if (!xs || !ns || !take_abs || !partial_ws || !out) return bad_arg("hps_sums_f64: null pointer");
+    if (count < 1 || count > 4) return bad_arg("hps_sums_f64: 1..4 tensors");
+    SumJobs jobs;
+    for (int j = 0; j < 4; ++j) {
+        jobs.x[j] = j < count ? xs[j] : nullptr;
+        jobs.n[j] = j < count ? (long)ns[j] : 0;
+        jobs.take_abs[j] = j < count ? take_abs[j] : 0;
+        if (j < count && (!xs[j] || ns[j] < 0)) return bad_arg("hps_sums_f64: tensor");
+    }
+    hipLaunchKernelGGL(sums_partial_kernel, dim3(SUM_BLOCKS, count), dim3(256), 0, (hipStream_t)stream, jobs, partial_ws);
+    hipLaunchKernelGGL(sums_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, count, first, out);
+    return check_launch("hps_sums_f64");
+}
 
 extern "C" int hps_pointset_errors(const float* pred, const float* target, int S, int group, int P, int mode,
                                    double* stats_ws, float* xf_ws, double* err_sum, float* transformed,

@@ -371,6 +371,12 @@ int hps_pointset_errors(const float* pred, const float* target, int S, int group
                         double* stats_ws, float* xf_ws, double* err_sum, float* transformed,
                         hps_stream_t stream);
 
+/* Result checksums (bench.py / the sharding-invariance tests; no reference counterpart): out[0] = first, out[1 + j] =
+ * sum of xs[j][0 .. ns[j]) (of |x| where take_abs[j]) accumulated in float64 in a fixed order, for count <= 4 float tensors
+ * in two launches.  xs / ns / take_abs are HOST arrays; partial_ws: 4 * 128 doubles; out: 1 + count doubles (device). */
+int hps_sums_f64(const float* const* xs, const int64_t* ns, const int32_t* take_abs, int count, double first,
+                 double* partial_ws, double* out, hps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,3 +107,17 @@ def test_stress_config_1000_samples_per_image(dev, net_gpu, smpl_gpu):
     assert maxerr(solo["unc"][0], out["unc"][5]) <= 1e-5
     # the uncertainty of the mean shape under many samples is smooth and strictly positive on a posed body
     assert float(out["unc"].min()) > 0.0
+
+
+def test_result_checksums_match_float64_sums(dev):
+    """hps_sums_f64 (the accumulator bench.py and the sharding tests use): float64 sums in a fixed order, repeatable bit for
+    bit, equal to torch's float64 reductions to rounding."""
+    g = torch.Generator().manual_seed(3)
+    res = {"unc": torch.rand(5, 6890, generator=g).to(dev), "verts_mode": torch.randn(5, 6890, 3, generator=g).to(dev),
+           "joints_samples": torch.randn(5, 7, 90, 3, generator=g).to(dev)}
+    a = sharding.batch_metric_sums(res)
+    b = sharding.batch_metric_sums(res)
+    assert a.dtype == torch.float64 and torch.equal(a, b)
+    want = torch.stack([torch.tensor(5.0, dtype=torch.float64, device=dev), res["unc"].double().sum(),
+                        res["verts_mode"].double().abs().sum(), res["joints_samples"].double().abs().sum()])
+    assert maxerr(a, want) <= 1e-12 * float(want.abs().max())
