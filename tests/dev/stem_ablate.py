@@ -1,0 +1,25 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from hierarchicalprobabilistic3dhuman_amd import _capi, configs
+from hierarchicalprobabilistic3dhuman_amd.poseMF_shapeGaussian_net import PoseMFShapeGaussianNet
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+net = PoseMFShapeGaussianNet(configs.SMPL_PARENTS, configs.get_cfg_defaults()).eval().to(dev)
+enc = net.image_encoder
+x = torch.rand(64, 18, 256, 256, device=dev)
+with torch.no_grad(), _capi.dev_library():
+    enc(x); torch.cuda.synchronize()
+    fs = next(iter(enc._frames.values()))
+    ops = fs["ops"]
+    one = (_capi.EncOp * 1)(ops[1])
+    s = _capi.stream()
+    for ab in (0, 1, 0, 1):
+        _capi.call("hps_dev_conv_pad_ablate", ab)
+        for _ in range(3): _capi.call("hps_encoder_run", one, 1, s)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): _capi.call("hps_encoder_run", one, 1, s)
+        e1.record(); torch.cuda.synchronize()
+        print("stem ablate %d: %.4f ms" % (ab, e0.elapsed_time(e1) / 20))
+    _capi.call("hps_dev_conv_pad_ablate", 0)

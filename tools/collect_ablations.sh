@@ -11,6 +11,8 @@ sec() { echo; echo "==== $* ====" ; }
 {
 sec "tests/dev/gpu_bringup.py wino (B = 64; dev library: compile-time ablations of conv_wino_kernel)"
 python $R/tests/dev/gpu_bringup.py wino 2>&1 | grep -E "^wino|^layer4|direct kernel|max \|"
+sec "tests/dev/stem_ablate.py (stem convolution alone: 0 = product, 1 = no epilogue)"
+python $R/tests/dev/stem_ablate.py 2>&1 | grep "^stem"
 sec "tests/dev/gpu_bringup.py mesh_fused (ablations of mesh_fused_kernel)"
 python $R/tests/dev/gpu_bringup.py mesh_fused 2>&1 | grep -E "mesh_fused M=|alone|ablate"
 sec "tests/dev/gpu_bringup.py unc_modes"
