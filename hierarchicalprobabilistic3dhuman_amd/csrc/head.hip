@@ -144,21 +144,38 @@ __global__ __launch_bounds__(NT) void joint_level_kernel(
     float* red = hs + HID * TBL;                             // [KS][TBL][HID] partial sums
     const int b0 = blockIdx.y * TBL;
 
-    // gather: cat[embed, U_proper[anc] (9P), S_proper[anc] (3P), mode[anc] (9P)]   (:126-132)
-    for (int i = threadIdx.x; i < in_dim * TBL; i += NT) {
-        const int r = i / in_dim, k = i % in_dim;
-        const int b = b0 + r;
-        float v = 0.0f;
-        if (b < B) {
-            if (k < embed_dim) v = embed[(size_t)b * embed_dim + k];
-            else {
-                int t = k - embed_dim;
-                if (t < 9 * P) v = u_proper[((size_t)b * NJ + anc_idx[a_lo + t / 9]) * 9 + t % 9];
-                else if ((t -= 9 * P) < 3 * P) v = s_proper[((size_t)b * NJ + anc_idx[a_lo + t / 3]) * 3 + t % 3];
-                else { t -= 3 * P; v = mode[((size_t)b * NJ + anc_idx[a_lo + t / 9]) * 9 + t % 9]; }
+    // gather: cat[embed, U_proper[anc] (9P), S_proper[anc] (3P), mode[anc] (9P)]   (:126-132).  Guard-free and four elements
+    // per lane in flight: the ancestor list goes to LDS first, every source address is then plain arithmetic, rows beyond B read
+    // row B - 1 and store 0.  (As `if (b < B) { if (k < embed_dim) ... else { idx = anc_idx[..]; v = table[idx] } }` every element
+    // was two dependent global loads, each behind s_waitcnt vmcnt(0): ~13 serialised round trips per lane, 9 of the level's 13 us.)
+    int* s_anc = reinterpret_cast<int*>(red);                // the partial-sum buffer is free until the hidden layer
+    if ((int)threadIdx.x < P) s_anc[threadIdx.x] = anc_idx[a_lo + threadIdx.x];
+    __syncthreads();
+    auto source = [&](int i, bool& live) -> const float* {
+        const int r = i / in_dim, k = i - r * in_dim;
+        const int b = min(b0 + r, B - 1);
+        live = b0 + r < B && i < in_dim * TBL;
+        if (k < embed_dim) return embed + (size_t)b * embed_dim + k;
+        int t = k - embed_dim;
+        if (t < 9 * P) return u_proper + ((size_t)b * NJ + s_anc[t / 9]) * 9 + t % 9;
+        t -= 9 * P;
+        if (t < 3 * P) return s_proper + ((size_t)b * NJ + s_anc[t / 3]) * 3 + t % 3;
+        t -= 3 * P;
+        return mode + ((size_t)b * NJ + s_anc[max(0, min(t / 9, P - 1))]) * 9 + t % 9;
+    };
+    for (int i0 = threadIdx.x; i0 < in_dim * TBL; i0 += 4 * NT) {
+        float v[4];
+        bool live[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *source(min(i0 + q * NT, in_dim * TBL - 1), live[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * NT;
+            if (i < in_dim * TBL) {
+                const int r = i / in_dim, k = i - r * in_dim;
+                xs[k * TBL + r] = (b0 + r < B) ? v[q] : 0.0f;
             }
         }
-        xs[k * TBL + r] = v;
     }
     __syncthreads();
 
