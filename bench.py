@@ -89,17 +89,28 @@ def main():
     ap.add_argument("--unfused-mesh", action="store_true", help="blend GEMM + LBS as two kernels (the unfused definition) instead of the fused mesh kernel")
     ap.add_argument("--trace-steps", action="store_true", help="print host-side per-step times to stderr (debugging)")
     ap.add_argument("--cpu-images", type=int, default=64, help="images in the CPU-baseline sample (0 = skip); 64 = one full batch, SURVEY 8(d)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend when launched by torch.distributed.run: nccl (= RCCL over xGMI, the product "
+                         "setting) or gloo (functional runs with more ranks than GPUs: ranks share devices, collectives are "
+                         "host-staged)")
+    ap.add_argument("--as-rank", type=int, nargs=2, metavar=("R", "W"), default=None,
+                    help="single process, no process group: do exactly the work rank R of a W-rank job would do (its image "
+                         "shard, its Philox offsets) -- what the multi-rank tests compare the per-rank checksums against")
+    ap.add_argument("--lbs-unfused-reps", type=int, default=12,
+                    help="after the timed region: launches of the unfused blend + LBS pair timed for secondary.lbs_unfused (0 = skip)")
     args = ap.parse_args()
 
-    rank, world, local_rank = sharding.init_distributed("nccl" if args.gpus > 1 else None)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (HIP) device; there is no CPU fallback for the product path")
+    rank, world, local_rank = sharding.init_distributed(args.backend)
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d must be launched with %d ranks (torch.distributed.run), got WORLD_SIZE=%d"
                          % (args.gpus, args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (HIP) device; there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = sharding.local_device(local_rank)       # local_rank % visible devices (gloo runs may share a device)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     B, N = args.batch, args.num_samples
+    shard_rank, shard_world = (rank, world) if args.as_rank is None else tuple(args.as_rank)
 
     cfg = configs.get_cfg_defaults()
     torch.manual_seed(0)
@@ -109,7 +120,7 @@ def main():
     smpl = SMPL(smpl_data.synthetic_smpl_model(0), batch_size=1, gender="neutral", num_betas=10).to(dev)
     smpl.fused_mesh = not args.unfused_mesh
 
-    lo, hi = sharding.shard_range(B * world, rank, world)               # weak scaling: B images per GPU
+    lo, hi = sharding.shard_range(B * shard_world, shard_rank, shard_world)   # weak scaling: B images per GPU
     x = synthetic_inputs(lo, hi).to(dev)
 
     # Steps are software-pipelined over three HIP streams: the encoder of step i+1 is enqueued before the latency-bound
@@ -134,10 +145,7 @@ def main():
         return res
 
     distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
-
-    def barrier():
-        if distributed:
-            torch.distributed.barrier()
+    barrier = sharding.barrier
 
     # warm-up runs everything the timed region runs (including the metric accumulation and the collective), so
     # no kernel is loaded for the first time inside the timed region
@@ -171,11 +179,7 @@ def main():
     per_rank, total = sharding.gather_metric_sums(sums)                 # the one collective of the run
     torch.cuda.synchronize()
     barrier()
-    dt = time.perf_counter() - t0
-    dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if distributed:
-        torch.distributed.all_reduce(dt_t, op=torch.distributed.ReduceOp.MAX)
-    dt = float(dt_t.item())
+    dt = sharding.all_reduce_max(time.perf_counter() - t0)               # the slowest rank's time
 
     # LBS kernel time from HIP events recorded around each launch on the launch stream
     M = B * (N + 2)
@@ -183,18 +187,45 @@ def main():
     smpl.lbs_events = None
     lbs_avg_ms = sum(lbs_ms) / max(1, len(lbs_ms))
     achieved = LBS_BYTES_PER_MESH * M / (lbs_avg_ms * 1e-3) / 1e9 if lbs_ms else None
+
+    def spread(ms):
+        ms = sorted(ms)
+        return {"median_ms": ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2]),
+                "min_ms": ms[0], "max_ms": ms[-1], "launches": len(ms)} if ms else None
+
     # secondary figures of SURVEY section 8(d), same method (HIP events on the launch stream, timed region only); the
     # encoder shares the GPU with the previous batch's head and uncertainty kernels while it runs
     enc_events_kept = list(pipe.enc_events or [])
     enc_ms = [e0.elapsed_time(e1) for (e0, e1) in enc_events_kept]
     smp_ms = [e0.elapsed_time(e1) for (e0, e1) in (sampling_utils.launch_events or [])]
     pipe.enc_events, sampling_utils.launch_events = None, None
+    # SURVEY 8(d)'s LBS kernel itself (BASELINE's "LBS HBM GB/s"): the product path skins inside the blend GEMM's epilogue,
+    # so after the timed region the same workload is run a few more steps with the unfused pair hps_smpl_blend + hps_smpl_lbs
+    # (bit-identical vertices) and the hps_smpl_lbs launches are timed with HIP events on their stream, like the product kernel.
+    lbs_unfused = None
+    if args.lbs_unfused_reps > 0 and not args.unfused_mesh:
+        smpl.fused_mesh, smpl.lbs_events = False, []
+        for i in range(args.lbs_unfused_reps + 2):
+            infer(net, smpl, x, num_samples=N, use_mean_shape=True, seed=4321 + i, image_offset=lo)
+        torch.cuda.synchronize()
+        ums = [e0.elapsed_time(e1) for (m, e0, e1) in smpl.lbs_events if m == M][2:]      # first two: warm-up
+        smpl.fused_mesh, smpl.lbs_events = True, None
+        if ums:
+            st = spread(ums)
+            gbs = LBS_BYTES_PER_MESH * M / (st["median_ms"] * 1e-3) / 1e9
+            lbs_unfused = dict(st, kernel="hps::lbs_kernel<4,8,1>", bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                               frac=gbs / HBM_PEAK_GBS, algorithmic_bytes_per_launch=LBS_BYTES_PER_MESH * M,
+                               note="hps_smpl_lbs alone (v_posed read + A read + verts write: SURVEY 8(d)'s definition) on the "
+                                    "bench workload, launched after the timed region; not part of the product path, which fuses "
+                                    "skinning into the blend GEMM")
     secondary = {}
     if enc_ms:
         t = sum(enc_ms) / len(enc_ms)
         tf = ENCODER_GFLOP_PER_IMAGE * B / t
         secondary["encoder"] = {"avg_ms": t, "tflops": tf, "peak": MFMA_FP32_PEAK_TF, "frac": tf / MFMA_FP32_PEAK_TF,
                                 "unit": "TFLOP/s fp32 MFMA (6.279 GFLOP/image algorithmic, relayout/pools included in the time)"}
+    if lbs_unfused:
+        secondary["lbs_unfused"] = lbs_unfused
     if smp_ms:
         t = sum(smp_ms) / len(smp_ms)
         secondary["sampler"] = {"avg_ms": t, "proposals_per_s": B * 23 * 8 * N / (t * 1e-3),
@@ -249,7 +280,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_source": traffic_source if traffic else None,
-                         "avg_launch_ms": lbs_avg_ms, "launches": len(lbs_ms),
+                         "avg_launch_ms": lbs_avg_ms, "launches": len(lbs_ms), "launch_spread": spread(lbs_ms),
                          "algorithmic_bytes_per_launch": LBS_BYTES_PER_MESH * M,
                          "note": ("fused kernel: the launch time covers blend GEMM + skinning; the bytes are SURVEY 8(d)'s "
                                   "unfused LBS definition (v_posed read + A read + verts write), of which only the verts "
@@ -264,6 +295,11 @@ def main():
             "secondary": secondary,
             "metric_checksums": {"images": float(total[0]), "sum_unc": float(total[1]),
                                  "sum_abs_verts_mode": float(total[2]), "sum_abs_joints_samples": float(total[3])},
+            # per-rank accumulators as gathered by the one collective (rank order); floats print with repr precision, so
+            # equal strings mean equal bits
+            "metric_checksums_per_rank": [[float(v) for v in row] for row in per_rank.tolist()],
+            "backend": (torch.distributed.get_backend() if distributed else None),
+            "image_range_rank0": [lo, hi],
         }
         if world == 1 and args.cpu_images > 0:
             out["cpu_baseline"] = cpu_baseline(net_state, configs.SMPL_PARENTS, N, args.cpu_images)

@@ -25,7 +25,7 @@ DEV_ONLY_SOURCES = ["conv.hip"]
 # per packed operand (525 moves, 2 051 instructions); unpacked it is 1 963 instructions with 109 moves, and packed fp32
 # VALU next to MFMAs is slower on gfx950 (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
 FILE_FLAGS = {"mesh_fused.hip": ["-fno-slp-vectorize"]}
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
 
 
@@ -52,6 +52,8 @@ def _source_digest(dev=False):
             h.update(fh.read())
     h.update(" ".join(flags).encode())
     h.update(repr(sorted(FILE_FLAGS.items())).encode())
+    with open(os.path.abspath(__file__), "rb") as fh:       # the recipe itself (link line, version script)
+        h.update(fh.read())
     return h.hexdigest()
 
 
@@ -87,7 +89,13 @@ def build(force=False, verbose=True, dev=False):
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs + ["-ldl", "-lpthread"]
+    # Dynamic symbol table = the C ABI and nothing else.  -fvisibility=hidden takes care of the C++ helpers and the kernels' host
+    # stubs; hipcc still gives every __global__ kernel's host-side handle (and its per-TU __hip_cuid_* marker) default visibility,
+    # so a linker version script makes everything but hps_* local.
+    vscript = os.path.join(objdir, "exports.map")
+    with open(vscript, "w") as f:
+        f.write("{ global: hps_*; local: *; };\n")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + vscript, "-o", lib_path] + objs + ["-ldl", "-lpthread"]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -96,7 +104,31 @@ def build(force=False, verbose=True, dev=False):
     return lib_path
 
 
+TOOLS_DIR = os.path.join(REPO_ROOT, "tools")
+
+
+def build_tools(force=False, verbose=True):
+    """The stand-alone gfx950 microbenchmarks under tools/ (mfma_peak: the sustained fp32 MFMA rate on constant / random data;
+    mfma_valu_overlap: does fp32 VALU work overlap fp32 MFMA) -> tools/bin/.  Their outputs are what DESIGN.md section 4's
+    "sustained ceiling" and "VALU is additive" statements rest on (tools/collect_ablations.sh runs them on the GPU box)."""
+    out_dir = os.path.join(TOOLS_DIR, "bin")
+    os.makedirs(out_dir, exist_ok=True)
+    built = []
+    for name in sorted(f for f in os.listdir(TOOLS_DIR) if f.endswith(".hip")):
+        src, exe = os.path.join(TOOLS_DIR, name), os.path.join(out_dir, name[:-4])
+        if not force and os.path.exists(exe) and os.path.getmtime(exe) >= os.path.getmtime(src):
+            built.append(exe)
+            continue
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-result", src, "-o", exe]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        built.append(exe)
+    return built
+
+
 def build_all(force=False, verbose=True):
+    build_tools(force, verbose)
     return build(force, verbose, dev=False), build(force, verbose, dev=True)
 
 

@@ -566,12 +566,8 @@ static int launch_conv_v2(const float* x, const float* wn, const float* scale, c
     const int Mtot = B * Ho * Wo, Kp = KH * KW * Cin;
     const int tiles_m = ceil_div(Mtot, BM), tiles_n = Cout / BN;
     const size_t lds = (size_t)2 * (BM + BN) * VPITCH * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_v2_kernel<BM, BN, WM, WN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    if (lds > 64 * 1024)
+        if (int rc = grant_lds<&conv_igemm_v2_kernel<BM, BN, WM, WN>>((int)lds, "hps_conv2d_bn_act_v2")) return rc;
     hipLaunchKernelGGL((conv_igemm_v2_kernel<BM, BN, WM, WN>), dim3(tiles_m * tiles_n), dim3(256), lds, s, x, wn, scale,
                        shift, residual, y, H, W, Cin, Cout, KW, stride, pad, Ho, Wo, Mtot, Kp, relu, tiles_m);
     return check_launch("hps_conv2d_bn_act_v2");
@@ -586,12 +582,8 @@ static int launch_conv_v3(const float* x, const float* wn, const float* zeros, c
     const int tiles_m = ceil_div(Mtot, BM), tiles_n = Cout / BN;
     if (ksplit < 1 || (Kp / VBK) % ksplit != 0 || (ksplit > 1 && !partial)) return bad_arg("hps_conv2d_bn_act_v3: ksplit");
     const size_t lds = (size_t)2 * (BM + BN) * VBK * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_v3_kernel<BM, BN, WM, WN, ABLATE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    if (lds > 64 * 1024)
+        if (int rc = grant_lds<&conv_igemm_v3_kernel<BM, BN, WM, WN, ABLATE>>((int)lds, "hps_conv2d_bn_act_v3")) return rc;
     hipLaunchKernelGGL((conv_igemm_v3_kernel<BM, BN, WM, WN, ABLATE>), dim3(tiles_m * tiles_n, ksplit), dim3(256), lds, s, x,
                        wn, zeros, scale, shift, residual, y, H, W, Cin, Cout, KW, stride, pad, Ho, Wo, Mtot, Kp, relu, tiles_m,
                        ksplit, partial);

@@ -410,12 +410,8 @@ static int launch_conv_pad(const float* x, const float* wn, const float* scale, 
     g.tiles_m = ceil_div(g.Mtot, BM);
     const int tiles_n = g.Cout / BN;
     const size_t lds = (size_t)2 * (BM + BN) * PBK * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pad_kernel<BM, BN, WM, WN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    if (lds > 64 * 1024)
+        if (int rc = grant_lds<&conv_pad_kernel<BM, BN, WM, WN>>((int)lds, "hps_conv2d_bn_act_pad")) return rc;
     hipLaunchKernelGGL((conv_pad_kernel<BM, BN, WM, WN>), dim3(g.tiles_m * tiles_n, g.ksplit), dim3(256), lds, s, x, wn, scale,
                        shift, residual, y, partial, g);
     if (g.ksplit > 1) {

@@ -30,7 +30,6 @@
 // Accuracy: the transforms use only +-1 and +-1/2 -- exact scalings; the result differs from the direct convolution by
 // fp32 rounding of a different summation order (<= 1e-5 of the output scale, tests/test_gpu_net.py).
 // The summation order depends on the layer only, never on the batch size (sharding invariance).
-#include <mutex>
 #include <type_traits>
 
 #include "hps_common.h"
@@ -465,13 +464,11 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
     const size_t lds = (size_t)(4 * W_OPER + 3 * W_RAW) * sizeof(float);           // 162 176 bytes
     // persistent grid: one workgroup per CU (256 on MI355X), items strided over the workgroups
     const dim3 grid((unsigned)(g.items < 256 ? g.items : 256));
+    int grant_rc = HPS_OK;
     auto launch = [&](auto AB, auto Q) {
         constexpr int ab = decltype(AB)::value;
         constexpr bool q = decltype(Q)::value;
-        static std::once_flag once;
-        std::call_once(once, [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<ab, q>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        });
+        if ((grant_rc = grant_lds<&conv_wino_kernel<ab, q>>(160 * 1024, "hps_conv3x3_winograd")) != HPS_OK) return;
         hipLaunchKernelGGL((conv_wino_kernel<ab, q>), grid, dim3(256), lds, (hipStream_t)stream, x, u, scale, shift, quad ? nullptr : residual,
                            quad ? splitk_ws : y, g);
     };
@@ -480,6 +477,7 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
     if (quad) {
         if (ablate != 0) return bad_arg("hps_conv3x3_winograd: ablations exist for the 16 x 16-block geometry only");
         launch(std::integral_constant<int, 0>(), T());
+        if (grant_rc != HPS_OK) return grant_rc;
         const int rc = check_launch("hps_conv3x3_winograd");
         if (rc != HPS_OK) return rc;
         const int total4 = B * 64 * Cout / 4;
@@ -503,6 +501,7 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
 #endif
         default: return bad_arg("hps_conv3x3_winograd: ablate");
     }
+    if (grant_rc != HPS_OK) return grant_rc;
     return check_launch("hps_conv3x3_winograd");
 }
 

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "hps.h"
 #ifdef HPS_DEV_BUILD
 #include "hps_dev.h"
@@ -29,6 +31,25 @@ inline int bad_arg(const char* what) {
 }
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Dynamic LDS above 64 KiB has to be granted per kernel function AND per device (the attribute lives with the device's copy
+// of the code object): once per (kernel instantiation, current device), safe from several host threads, result checked.
+// No behaviour depends on it.  Returns HPS_OK or the hipError_t.
+template <auto Kernel>
+inline int grant_lds(int bytes, const char* what) {
+    static std::atomic<uint64_t> granted{0};               // bit d: done on device d
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess && dev < 64 && ((granted.load(std::memory_order_acquire) >> dev) & 1ull)) return HPS_OK;
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        set_error("%s: granting %d bytes of dynamic LDS failed: %s", what, bytes, hipGetErrorString(e));
+        return (int)e;
+    }
+    if (dev < 64) granted.fetch_or(1ull << dev, std::memory_order_release);
+    return HPS_OK;
+}
 
 // 12-byte vertex record: one global_load_dwordx3 / global_store_dwordx3 per lane, lane-contiguous.
 struct __attribute__((packed, aligned(4))) f3 {

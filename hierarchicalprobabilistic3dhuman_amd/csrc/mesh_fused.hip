@@ -30,7 +30,6 @@
 // Block -> (mesh tile, panel): block ids congruent mod 8 (one XCD) own the same mesh tiles, and every XCD walks the
 // panels in order, so an XCD's L2 holds its own xt / A slices plus the few panels in flight; bmat_p streams from the
 // memory-side cache once per XCD.
-#include <mutex>
 
 #include "hps_common.h"
 
@@ -213,11 +212,7 @@ static int launch_fused_cfg(const float* xt, const float* bmat_p, const float* v
                         const float* w_val, int J, const float* transl, float* verts, int M, int V, int kp, int mp, int np,
                         hipStream_t s) {
     const size_t lds = (size_t)4 * max(2 * F_CHUNK_FLOATS, 32 * J * 12);
-    static std::once_flag once;      // LDS above 64 KiB has to be granted once per kernel (no behaviour depends on it)
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mesh_fused_kernel<K, ABL, JC, HAS_T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
+    if (int rc = grant_lds<&mesh_fused_kernel<K, ABL, JC, HAS_T>>(160 * 1024, "hps_smpl_mesh_fused")) return rc;
     const int tiles_m = ceil_div(M, FM), n_panels = ceil_div(V, FV);
     const int tiles_m_per_xcd = ceil_div(tiles_m, 8);
     hipLaunchKernelGGL((mesh_fused_kernel<K, ABL, JC, HAS_T>), dim3(tiles_m_per_xcd * 8 * n_panels), dim3(FT), lds, s, xt, bmat_p, v_template,

@@ -544,23 +544,13 @@ extern "C" int hps_vertex_uncertainty(const float* verts, float* unc, int B, int
     else if (g_unc_mode == 3) uv = 64;
     if (uv && (N < 8 || lds_bytes(uv) > 160 * 1024)) uv = 0;
     if (uv == 128) {       // the image's samples of 128 vertices fit in LDS: read HBM once
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&uncertainty_lds_kernel<128>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
+        if (int rc = grant_lds<&uncertainty_lds_kernel<128>>(160 * 1024, "hps_vertex_uncertainty")) return rc;
         hipLaunchKernelGGL(uncertainty_lds_kernel<128>, dim3(ceil_div(V, 128), B), dim3(1024), lds_bytes(128), (hipStream_t)stream,
                            reinterpret_cast<const f3*>(verts), unc, N, V);
         return check_launch("hps_vertex_uncertainty");
     }
     if (uv == 64) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&uncertainty_lds_kernel<64>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
+        if (int rc = grant_lds<&uncertainty_lds_kernel<64>>(160 * 1024, "hps_vertex_uncertainty")) return rc;
         hipLaunchKernelGGL(uncertainty_lds_kernel<64>, dim3(ceil_div(V, 64), B), dim3(512), lds_bytes(64), (hipStream_t)stream,
                            reinterpret_cast<const f3*>(verts), unc, N, V);
         return check_launch("hps_vertex_uncertainty");

@@ -20,7 +20,7 @@
 #include <math.h>
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define HPS_HD __host__ __device__ __forceinline__
 #else
 #define HPS_HD inline

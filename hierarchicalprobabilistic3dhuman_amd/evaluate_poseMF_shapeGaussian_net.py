@@ -7,7 +7,13 @@ the numbers beyond fp32 rounding: any batch size (the reference's DataLoader use
 matrices directly instead of going through cv2.Rodrigues' log map and back (:84-92); metric sums stay on the device
 and are reduced across ranks once at the end.  Under torch.distributed every rank evaluates its contiguous block of
 ``eval_dataset`` (sharding.shard_dataset) and the one collective sums the blocks; per-frame records are gathered in
-dataset order and rank 0 writes them.  The silhouette / 2D-joint metrics need the pytorch3d renderer and the detector
+dataset order and rank 0 writes them.  The random samples of a frame are keyed by the frame's index in the whole dataset
+(Philox pose samples: seed + global index; shape noise: a host generator seeded per frame), so every metric is the same
+for any world size and batch size.
+
+``svd_mode`` selects the head's 3x3 SVD for this evaluation ("host": MKL sgesdd, the reference's very routine, bit-exact
+signs; "device": the in-kernel restatement of sgesdd).  Default: "host" when ``sample_on_cpu`` (the reference's
+seed-reproducible evaluation route, run_evaluate.py:83-94 -- parity first), the model's own ``svd_mode`` otherwise.  The silhouette / 2D-joint metrics need the pytorch3d renderer and the detector
 outputs and are out of scope.
 
 The 3DPW frames and the licensed SMPL_{MALE,FEMALE}.pkl files are external assets; any ``eval_dataset`` yielding the
@@ -21,7 +27,7 @@ from . import _capi, sharding
 from .eval_metrics_tracker import EvalMetricsTracker
 from .label_conversions import ALL_JOINTS_TO_H36M_MAP, H36M_TO_J14
 from .rigid_transform_utils import batch_rodrigues, rot6d_to_rotmat
-from .sampling_utils import pose_matrix_fisher_sampling_torch
+from .sampling_utils import pose_matrix_fisher_sampling_torch, check_sampling, _philox_seed
 
 
 def _h36mlsp(joints):
@@ -31,12 +37,22 @@ def _h36mlsp(joints):
 def evaluate_pose_MF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_model, smpl_model_male, smpl_model_female,
                                        edge_detect_model, device, eval_dataset, metrics, save_path, num_workers=4,
                                        pin_memory=True, save_per_frame_metrics=True, num_samples_for_metrics=10,
-                                       sample_on_cpu=False, batch_size=1, reduce_across_ranks=True):
+                                       sample_on_cpu=False, batch_size=1, reduce_across_ranks=True, svd_mode=None, seed=None):
     device = torch.device(device)
     if device.type == "cuda":
         torch.cuda.set_device(device)              # libhps launches on the current device's current stream
+    if svd_mode is None:
+        svd_mode = "host" if sample_on_cpu else pose_shape_model.svd_mode
+    if svd_mode not in ("host", "device"):
+        raise ValueError("svd_mode must be 'host' or 'device'")
+    frame0 = 0                                     # index in the whole dataset of this rank's first frame
     if reduce_across_ranks:
+        rank, world = sharding.world_info()
+        frame0 = sharding.shard_range(len(eval_dataset), rank, world)[0]
         eval_dataset = sharding.shard_dataset(eval_dataset)          # this rank's contiguous block of frames
+    # one seed for the whole evaluation, from torch's global CPU generator (torch.manual_seed controls it; ranks seeded alike
+    # draw the same one), combined with the global frame index below
+    run_seed = _philox_seed(seed) if not sample_on_cpu else None
     loader = DataLoader(eval_dataset, batch_size=batch_size, shuffle=False, drop_last=False, num_workers=num_workers,
                         pin_memory=pin_memory)
     tracker = EvalMetricsTracker(metrics, save_path=save_path, save_per_frame_metrics=save_per_frame_metrics)
@@ -47,6 +63,17 @@ def evaluate_pose_MF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mo
     flip = torch.diag(torch.tensor([1.0, -1.0, -1.0], device=device))          # rotation by pi about x (:86-91)
     fnames, poses, shapes, cams = [], [], [], []
     pose_shape_model.eval()
+    model_svd_mode, pose_shape_model.svd_mode = pose_shape_model.svd_mode, svd_mode
+    try:
+        return _evaluate_loop(**locals())
+    finally:
+        pose_shape_model.svd_mode = model_svd_mode
+
+
+def _evaluate_loop(pose_shape_model, pose_shape_cfg, smpl_model, smpl_model_male, smpl_model_female, edge_detect_model, device,
+                   loader, tracker, metrics, want_samples, N, flip, fnames, poses, shapes, cams, sample_on_cpu, run_seed, frame0,
+                   reduce_across_ranks, save_per_frame_metrics, save_path, **_unused):
+    frame = frame0
     for batch in loader:
         with torch.no_grad():
             image = batch["image"].to(device)
@@ -93,12 +120,16 @@ def evaluate_pose_MF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mo
 
             if want_samples:                                                                              # :157-179
                 R_s = pose_matrix_fisher_sampling_torch(pose_U, pose_S, pose_V, N, b=1.5, oversampling_ratio=8,
-                                                        sample_on_cpu=sample_on_cpu)                    # (B,N,23,3,3)
+                                                        sample_on_cpu=sample_on_cpu, seed=run_seed,
+                                                        image_offset=frame)                             # (B,N,23,3,3)
                 if sample_on_cpu:      # the reference's CPU route: shape noise from the global CPU generator too
                     cpu_dist = torch.distributions.Normal(shape_dist.loc.cpu(), shape_dist.scale.cpu())
                     shape_s = cpu_dist.rsample([N]).to(device).transpose(0, 1)
-                else:
-                    shape_s = shape_dist.rsample([N]).transpose(0, 1)                                    # (B,N,nb)
+                else:                  # loc + scale * eps (rsample, :166) with eps keyed by the frame's global index
+                    eps = torch.stack([torch.randn(N, shape_dist.loc.shape[1],
+                                                   generator=torch.Generator().manual_seed((run_seed + frame + i) % (2 ** 63)))
+                                       for i in range(B)]).to(device)
+                    shape_s = shape_dist.loc[:, None] + shape_dist.scale[:, None] * eps                  # (B,N,nb)
                 out_s = smpl_model(body_pose=R_s.reshape(B * N, 23, 3, 3),
                                    global_orient=glob_R[:, None, None].expand(B, N, 1, 3, 3).reshape(B * N, 1, 3, 3),
                                    betas=shape_s.reshape(B * N, -1), pose2rot=False)
@@ -120,8 +151,8 @@ def evaluate_pose_MF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mo
                 poses.append(torch.cat([glob_R[:, None], mode], dim=1).cpu().numpy())
                 shapes.append(shape_dist.loc.cpu().numpy())
                 cams.append(cam.cpu().numpy())
-    from .sampling_utils import check_sampling
-    check_sampling()                                           # deferred: a sampling call that never reached N accepts
+            frame += B
+    check_sampling()              # every launch since the last check is recorded (sampling_utils._pending): no batch is missed
     if reduce_across_ranks:
         tracker.reduce_across_ranks()
     final = tracker.compute_final_metrics(verbose=sharding.world_info()[0] == 0)

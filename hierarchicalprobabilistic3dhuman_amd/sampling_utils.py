@@ -19,7 +19,10 @@ import torch
 from . import _capi
 
 _MAX_ROUNDS = 64
-last_accepted = None        # (B*23,) int32 device tensor of the most recent Philox launch: accepted proposals of the final round per call
+last_accepted = None        # ((B*23,) int32 device tensor, N) of the most recent Philox launch: accepted proposals of the final round per call
+_pending = []               # (accepted, N) of every Philox launch since the last check_sampling(): nothing is lost between checks
+_failed = {}                # device -> int64 scalar: failed calls of launches already folded out of _pending
+_PENDING_MAX = 256
 launch_events = None        # bench.py: list collecting (start, end) HIP events around every hps_mf_sample launch
 
 
@@ -142,15 +145,29 @@ def pose_matrix_fisher_sampling_torch(pose_U, pose_S, pose_V, num_samples, b=1.5
         # check_sampling() is the deferred test the harnesses run per batch.
         global last_accepted
         last_accepted = (accepted, num_samples)
+        _pending.append(last_accepted)
+        if len(_pending) > _PENDING_MAX:
+            _fold_pending()
     return R
 
 
+def _fold_pending():
+    """Reduce the recorded accept counts to one failure counter per device (stream-ordered, no synchronisation)."""
+    while _pending:
+        accepted, n = _pending.pop()
+        c = (accepted < n).sum()
+        _failed[accepted.device] = c if accepted.device not in _failed else _failed[accepted.device] + c
+
+
 def check_sampling():
-    """Raise if the most recent Philox sampling launch had a call that never reached N accepted proposals (synchronises)."""
-    if last_accepted is None:
+    """Raise if ANY Philox sampling launch since the previous check had a call that never reached N accepted proposals
+    (synchronises).  Launches are recorded as they are made -- several batches may be in flight (InferencePipeline) or a whole
+    data-loader loop may run between two checks without a failure going unnoticed."""
+    if not _pending and not _failed:
         return
-    accepted, n = last_accepted
-    bad = int((accepted < n).sum().item())
+    _fold_pending()
+    bad = sum(int(c.item()) for c in _failed.values())
+    _failed.clear()
     if bad:
         raise _capi.HpsError("matrix-Fisher sampling failed for %d (image, joint) calls within %d rounds "
                              "(the reference prints 'Failed sampling' and loops, utils/sampling_utils.py:68-69); "

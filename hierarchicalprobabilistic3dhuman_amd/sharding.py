@@ -28,10 +28,44 @@ def init_distributed(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_device(local_rank))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+def local_device(local_rank):
+    """HIP device index of a local rank: ``local_rank`` modulo the visible device count, so that more ranks than GPUs (the
+    world-size-2 functional runs on a one-GPU box over gloo) share devices instead of failing in set_device.  RCCL itself
+    refuses two ranks on one device, so the wrap-around is only ever exercised with the gloo backend."""
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    return local_rank % n if n else 0
+
+
+def _host_staged():
+    """True when the process group cannot carry device tensors (gloo): collectives then go through host copies.  The
+    payloads are O(100) bytes, so the staging copy is irrelevant."""
+    return dist.get_backend() != "nccl"
+
+
+def barrier():
+    """Process-group barrier (no-op without a group).  Under nccl (= RCCL) it runs on this rank's current device."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    if dist.get_backend() == "nccl":
+        dist.barrier(device_ids=[torch.cuda.current_device()])
+    else:
+        dist.barrier()
+
+
+def all_reduce_max(value):
+    """MAX over ranks of one Python float (bench.py: the slowest rank's wall time)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    dev = torch.device("cpu") if _host_staged() else torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def shard_range(total, rank, world):
@@ -49,9 +83,12 @@ def gather_metric_sums(local_sums):
     if not (dist.is_available() and dist.is_initialized()):
         per_rank = local_sums[None].clone()
     else:
-        bufs = [torch.empty_like(local_sums) for _ in range(dist.get_world_size())]
-        dist.all_gather(bufs, local_sums.contiguous())
-        per_rank = torch.stack(bufs)
+        send = local_sums.contiguous()
+        if send.is_cuda and _host_staged():
+            send = send.cpu()                       # gloo: host copy of a few doubles
+        bufs = [torch.empty_like(send) for _ in range(dist.get_world_size())]
+        dist.all_gather(bufs, send)
+        per_rank = torch.stack(bufs).to(local_sums.device)
     total = torch.zeros_like(local_sums)
     for r in range(per_rank.shape[0]):
         total = total + per_rank[r]

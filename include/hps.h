@@ -29,6 +29,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The libraries are built with -fvisibility=hidden: what is declared between this push and the pop at the end of the header is
+ * the complete dynamic symbol table of the shared object (tests/test_capi_symbols.py compares it with `nm -D`). */
+#pragma GCC visibility push(default)
 
 typedef void* hps_stream_t; /* hipStream_t */
 
@@ -377,6 +380,7 @@ int hps_pointset_errors(const float* pred, const float* target, int S, int group
 int hps_sums_f64(const float* const* xs, const int64_t* ns, const int32_t* take_abs, int count, double first,
                  double* partial_ws, double* out, hps_stream_t stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

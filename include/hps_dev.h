@@ -16,6 +16,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The libraries are built with -fvisibility=hidden: what is declared between this push and the pop at the end of the header is
+ * the complete dynamic symbol table of the shared object (tests/test_capi_symbols.py compares it with `nm -D`). */
+#pragma GCC visibility push(default)
 
 /* Development / tuning entry: hps_smpl_lbs with an explicit kernel variant (0..4: meshes per barrier G and
  * vertices per lane VPT = (4,1) (8,1) (4,2) (2,2) (2,1)) and resident-workgroup target. Same results. */
@@ -86,6 +89,7 @@ int hps_dev_conv3x3_winograd(const float* x, const float* u, const float* scale,
                              const float* residual, float* y, int B, int H, int W, int ipad, int Cin, int Cout,
                              int opad, int relu, float* splitk_ws, int ablate, hps_stream_t stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

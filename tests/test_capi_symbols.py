@@ -19,9 +19,11 @@ def _declared_symbols(header="hps.h"):
 
 
 def _exported(path):
+    """EVERY defined dynamic symbol of the shared object (not only the hps_ prefix): the libraries are built with
+    -fvisibility=hidden and a linker version script, so kernel stubs, kernel handles and C++ helpers must not appear."""
     import subprocess
     out = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
-    return {line.split()[-1] for line in out.splitlines() if line.split()[-1].startswith("hps_")}
+    return {line.split()[-1] for line in out.splitlines() if line.strip()}
 
 
 def test_library_builds_and_exports_all_declared_symbols():

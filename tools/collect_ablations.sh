@@ -3,12 +3,16 @@
 # ablation tables of the Winograd and fused mesh kernels, head / SVD / uncertainty timings alone, the pipelined loop's device-side
 # schedule from HIP events, the cost of the overlapped work, the small-batch A/B of the Winograd layers.  Plain text, one file:
 # gpurun_out/ablations_$TAG.txt (copied to profiles/${TAG}_ablations.txt).
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/ablations_$TAG.txt
 mkdir -p $R/gpurun_out; : > $OUT
 sec() { echo; echo "==== $* ====" ; }
 {
+sec "tools/bin/mfma_peak (v_mfma_f32_32x32x2_f32, no memory traffic: constant vs random operands; 3 repetitions)"
+for i in 1 2 3; do $R/tools/bin/mfma_peak 2>&1; done
+sec "tools/bin/mfma_valu_overlap (does fp32 VALU overlap fp32 MFMA: same wave, and MFMA waves beside VALU waves; 2 repetitions)"
+for i in 1 2; do $R/tools/bin/mfma_valu_overlap 2>&1; done
 sec "tests/dev/gpu_bringup.py wino (B = 64; dev library: compile-time ablations of conv_wino_kernel)"
 python $R/tests/dev/gpu_bringup.py wino 2>&1 | grep -E "^wino|^layer4|direct kernel|max \|"
 sec "tests/dev/stem_ablate.py (stem convolution alone: 0 = product, 1 = no epilogue)"
