@@ -225,7 +225,8 @@ def compute_vertex_uncertainties_by_poseMF_shapeGaussian_sampling(pose_U, pose_S
 def joints2D_error_sorted_verts_sampling(pred_vertices_samples, pred_joints_samples, input_joints2D_heatmaps, pred_cam_wp):
     """utils/sampling_utils.py:195-233: order the (N,6890,3) vertex samples by the consistency of their projected COCO
     joints with the input 2D joints (largest per-joint pixel error, ascending).  The 180 degree flip about x the
-    reference does through pytorch3d is the exact diag(1,-1,-1)."""
+    reference does through pytorch3d is the exact diag(1,-1,-1).  Pinned by the reference function's own ordering
+    (tests/golden rank_order; tests/test_frontend.py)."""
     from .label_conversions import convert_heatmaps_to_2Djoints_coordinates_torch, ALL_JOINTS_TO_COCO_MAP
     _capi.require_device(pred_joints_samples, "pred_joints_samples")
     joints = _capi.f32c(pred_joints_samples)
@@ -238,5 +239,5 @@ def joints2D_error_sorted_verts_sampling(pred_vertices_samples, pred_joints_samp
     _capi.call("hps_sample_joints2d_error", _capi.ptr(joints), _capi.iptr(coco), n_all, _capi.ptr(in_j2d[0].contiguous()),
                _capi.ptr(in_vis[0].float().contiguous()), _capi.ptr(cam), float(input_joints2D_heatmaps.shape[-1]),
                _capi.ptr(err), N, len(ALL_JOINTS_TO_COCO_MAP), _capi.stream())
-    order = torch.sort(err, descending=False)[1]
+    order = torch.sort(err, descending=False, stable=True)[1]      # ties keep sample order, like the reference's CPU sort
     return pred_vertices_samples[order]

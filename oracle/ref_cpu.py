@@ -585,13 +585,16 @@ def heatmaps_to_joints2d(heat, eps=1e-6):
 
 
 def joints2d_error_sorted(verts_samples, joints_samples, heat, cam_wp, coco_map):
-    """utils/sampling_utils.py:195-233 with the pytorch3d flip written as diag(1,-1,-1); returns (sorted verts, order)."""
+    """utils/sampling_utils.py:195-233 with the pytorch3d flip written as diag(1,-1,-1); returns (sorted verts, order).
+    Pinned by the reference function's own output (tests/golden: rank_order, produced with pytorch3d's Rodrigues closed form
+    injected -- its pi rotation differs from diag(1,-1,-1) by sin(pi) = -8.7e-8 in two entries, i.e. 1e-5 pixels).  Equal
+    errors keep their sample order (torch's CPU sort is stable; made explicit here)."""
     jc = joints_samples[:, coco_map, :] * torch.tensor([1.0, -1.0, -1.0])
     proj = cam_wp[:, None, [0]] * (jc[:, :, :2] + cam_wp[:, None, 1:])                 # utils/cam_utils.py:9-16
     proj = (proj + 1) * (heat.shape[-1] / 2.0)                                       # utils/joints2d_utils.py:5-10
     in_j, in_vis = heatmaps_to_joints2d(heat)
     l2 = torch.norm(proj[:, in_vis[0], :] - in_j[:, in_vis[0], :], dim=-1)
-    order = torch.sort(l2.max(dim=-1)[0], descending=False)[1]
+    order = torch.sort(l2.max(dim=-1)[0], descending=False, stable=True)[1]
     return verts_samples[order], order
 
 

@@ -146,6 +146,39 @@ def main():
     hh[:, [7, 9]] = 0.0
     hh[:, 3, 10, 10] = hh[:, 3].max()
     out["argmax_joints"] = convert_heatmaps_to_2Djoints_coordinates_torch(hh)[0]
+    # ---- sample ranking: the reference's joints2D_error_sorted_verts_sampling
+    #      (utils/sampling_utils.py:195-233) itself, on the same generator stream (seed 4, continued): N = 12 samples, the two
+    #      invisible joints and the arg-max tie of the heat-maps above, and one TIE between samples (2 and 7 share their joints
+    #      but not their vertices).  pytorch3d is absent, so utils.rigid_transform_utils.so3_exponential_map (guarded import,
+    #      :5-8) is set to the Rodrigues closed form pytorch3d publishes (fac1 = sin(t)/t, fac2 = (1 - cos t)/t^2,
+    #      R = I + fac1 K + fac2 K^2, t = sqrt(clamp(|r|^2, 1e-4))) -- the same accommodation A9 uses for SMPL ----
+    from utils.sampling_utils import joints2D_error_sorted_verts_sampling as ref_rank
+
+    def so3_exponential_map(log_rot, eps=0.0001):
+        nrms = (log_rot * log_rot).sum(1)
+        ang = torch.clamp(nrms, eps).sqrt()
+        inv = 1.0 / ang
+        fac1 = inv * ang.sin()
+        fac2 = inv * inv * (1.0 - ang.cos())
+        K = torch.zeros(log_rot.shape[0], 3, 3, dtype=log_rot.dtype)
+        x, y, z = log_rot.unbind(1)
+        K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -z, y, z, -x, -y, x
+        return fac1[:, None, None] * K + fac2[:, None, None] * torch.bmm(K, K) + torch.eye(3, dtype=log_rot.dtype)[None]
+
+    ref_rtu.so3_exponential_map = so3_exponential_map
+    assert torch.equal(hh, O.joints2d_to_gaussian_heatmaps(jj.round(), 256, 4.0).index_put_(
+        (torch.tensor([0, 0]), torch.tensor([7, 9])), torch.tensor(0.0)).index_put_(
+        (torch.tensor([0]), torch.tensor([3]), torch.tensor([10]), torch.tensor([10])), hh[0, 3].max())), "heat-map recipe"
+    Nr = 12
+    rj = torch.randn(Nr, 90, 3, generator=g4) * 0.4
+    rv = torch.randn(Nr, 6890, 3, generator=g4)
+    rj[7] = rj[2]
+    rcam = torch.tensor([[0.9, 0.05, -0.1]])
+    with torch.no_grad():
+        rsorted = ref_rank(rv, rj, hh, rcam)
+    order = torch.tensor([int((rv == rsorted[i]).all(dim=-1).all(dim=-1).nonzero()[0, 0]) for i in range(Nr)])
+    assert sorted(order.tolist()) == list(range(Nr)) and torch.equal(rv[order], rsorted)
+    out["rank_order"], out["rank_sorted_verts_sub"] = order, rsorted[:, ::53].contiguous()
     # ---- evaluation metrics: the reference tracker on a seeded synthetic scenario ----
     from metrics.eval_metrics_tracker import EvalMetricsTracker
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -111,14 +111,39 @@ def test_heatmap_argmax_and_sample_ranking(dev, golden):
     j, v = convert_heatmaps_to_2Djoints_coordinates_torch(heat.to(dev))
     assert torch.equal(j.cpu(), j_ref) and torch.equal(v.cpu(), v_ref)
     assert torch.equal(golden["argmax_joints"], j_ref)                         # the reference's own arg-max on this case (make_golden.py)
-    # ranking
-    N = 12
+    # ranking: the reference function's own ordering on this case (tests/golden/make_golden.py ran
+    # utils/sampling_utils.py:195-233 with pytorch3d's so3_exponential_map restated): two invisible joints, and samples 2
+    # and 7 tie (same joints, different vertices) -- the earlier sample must come first, as in the reference's CPU sort
+    verts, joints, cam = _ranking_case(g)
+    got = joints2D_error_sorted_verts_sampling(verts.to(dev), joints.to(dev), heat.to(dev), cam.to(dev))
+    order = golden["rank_order"]
+    assert torch.equal(got.cpu(), verts[order])
+    assert torch.equal(got.cpu()[:, ::53], golden["rank_sorted_verts_sub"])
+    want, o_order = O.joints2d_error_sorted(verts, joints, heat, cam, ALL_JOINTS_TO_COCO_MAP)
+    assert torch.equal(got.cpu(), want)
+
+
+def _ranking_case(g, N=12):
+    """Continues the generator stream of the arg-max case (seed 4, after rand(1,17,2)), exactly like make_golden.py."""
     joints = torch.randn(N, 90, 3, generator=g) * 0.4
     verts = torch.randn(N, 6890, 3, generator=g)
-    cam = torch.tensor([[0.9, 0.05, -0.1]])
+    joints[7] = joints[2]
+    return verts, joints, torch.tensor([[0.9, 0.05, -0.1]])
+
+
+def test_oracle_sample_ranking_matches_reference(golden):
+    """SURVEY 8(f)4 pinned: the oracle's restatement (the 180 degree flip as the exact diag(1,-1,-1)) orders the samples like the
+    reference function did (golden rank_order), the tie included."""
+    from hierarchicalprobabilistic3dhuman_amd.label_conversions import ALL_JOINTS_TO_COCO_MAP
+    g = torch.Generator().manual_seed(4)
+    j2d = torch.rand(1, 17, 2, generator=g) * 200 + 20
+    heat = O.joints2d_to_gaussian_heatmaps(j2d.round(), 256, 4.0)
+    heat[:, [7, 9]] = 0.0
+    heat[:, 3, 10, 10] = heat[:, 3].max()
+    verts, joints, cam = _ranking_case(g)
     want, order = O.joints2d_error_sorted(verts, joints, heat, cam, ALL_JOINTS_TO_COCO_MAP)
-    got = joints2D_error_sorted_verts_sampling(verts.to(dev), joints.to(dev), heat.to(dev), cam.to(dev))
-    assert torch.equal(got.cpu(), want)
+    assert order.tolist() == golden["rank_order"].tolist()
+    assert torch.equal(want[:, ::53], golden["rank_sorted_verts_sub"])
 
 
 # ---------------------------------------------------------------------------------------------
