@@ -86,6 +86,10 @@ def main():
     ap.add_argument("--num-samples", type=int, default=100)
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after another on one stream")
     ap.add_argument("--early-relayout", action="store_true", help="A/B: enqueue the input relayout beside the previous batch's mesh kernels")
+    ap.add_argument("--mesh-overlap", choices=("auto", "on", "off"), default="auto",
+                    help="let the mesh kernel run beside the neighbouring batches' encoders (auto: for batches below 32 images, whose "
+                         "encoder cannot fill the chip)")
+    ap.add_argument("--encoder-cus", type=int, default=None, help="CUs per XCD of the encoder's partition when the mesh kernel overlaps (0 = shared CUs)")
     ap.add_argument("--unfused-mesh", action="store_true", help="blend GEMM + LBS as two kernels (the unfused definition) instead of the fused mesh kernel")
     ap.add_argument("--trace-steps", action="store_true", help="print host-side per-step times to stderr (debugging)")
     ap.add_argument("--cpu-images", type=int, default=64, help="images in the CPU-baseline sample (0 = skip); 64 = one full batch, SURVEY 8(d)")
@@ -128,6 +132,9 @@ def main():
     # submitted and finished inside the timed region.
     pipe = InferencePipeline(net, smpl, num_samples=N, use_mean_shape=True)
     pipe.early_relayout = args.early_relayout
+    pipe.exclusive_mesh = {"auto": None, "on": False, "off": True}[args.mesh_overlap]
+    if args.encoder_cus is not None:
+        pipe.encoder_cus = args.encoder_cus
 
     step_marks = []
 
@@ -147,6 +154,10 @@ def main():
     distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
     barrier = sharding.barrier
 
+    # the loop runs on the stream the pipeline asks for (small batches: the mesh partition's stream, see InferencePipeline)
+    loop_stream = pipe.caller_stream(B) if not args.no_pipeline else torch.cuda.current_stream()
+    torch.cuda.current_stream().synchronize()
+    torch.cuda.set_stream(loop_stream)
     # warm-up runs everything the timed region runs (including the metric accumulation and the collective), so
     # no kernel is loaded for the first time inside the timed region
     warm_sums = torch.zeros(4, dtype=torch.float64, device=dev)

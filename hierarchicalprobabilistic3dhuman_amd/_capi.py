@@ -25,6 +25,8 @@ _I = _c.c_int
 _PROTOTYPES = {
     "hps_version": [],
     "hps_last_error": [],
+    "hps_stream_create_cu_partition": [_I, _I, _c.POINTER(_P)],
+    "hps_stream_destroy": [_P],
     "hps_smpl_pose_prep": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
     "hps_smpl_blend": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hps_smpl_lbs": [_P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
@@ -175,6 +177,14 @@ def iptr(t, what="index tensor"):
 
 def stream():
     return _P(torch.cuda.current_stream().cuda_stream)
+
+
+def cu_partition_stream(first_cu, num_cus):
+    """torch stream restricted to CUs [first_cu, first_cu + num_cus) of every XCD (include/hps.h: hps_stream_create_cu_partition).
+    The stream lives as long as the process (a handful are ever created: one pair per InferencePipeline)."""
+    s = _P()
+    call("hps_stream_create_cu_partition", int(first_cu), int(num_cus), _c.byref(s))
+    return torch.cuda.ExternalStream(s.value)
 
 
 def call(name, *args):

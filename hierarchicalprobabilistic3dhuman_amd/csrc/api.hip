@@ -14,7 +14,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace hps
 
-extern "C" int hps_version(void) { return 201; }  // 0.2.1: hps_conv3x3_winograd takes splitk_ws
+extern "C" int hps_version(void) { return 300; }  // 0.3.0: hps_stream_create_cu_partition, one-sweep uncertainty
 
 extern "C" int64_t hps_query_workspace(int what, int64_t d0, int64_t d1, int64_t d2) {
     if (d0 < 0 || d1 < 0 || d2 < 0) { hps::set_error("hps_query_workspace: negative dimension"); return -1; }
@@ -32,3 +32,37 @@ extern "C" int64_t hps_query_workspace(int what, int64_t d0, int64_t d1, int64_t
     }
 }
 extern "C" const char* hps_last_error(void) { return hps::g_err; }
+
+// A HIP stream whose kernels may only run on CUs [first_cu, first_cu + num_cus) OF EVERY XCD (hipExtStreamCreateWithCUMask).
+// Mask bit i addresses CU i / n_xcd of XCD i % n_xcd (probed on MI355X: a mask that leaves an XCD without CUs is ignored by the
+// runtime), so a partition is always "the same CU subset on each of the 8 XCDs": both sides keep the block -> XCD round robin and
+// their own share of every L2.
+extern "C" int hps_stream_create_cu_partition(int first_cu, int num_cus, hps_stream_t* stream_out) {
+    if (!stream_out) return hps::bad_arg("hps_stream_create_cu_partition: null pointer");
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) { hps::set_error("hps_stream_create_cu_partition: %s", hipGetErrorString(e)); return (int)e; }
+    const int total = prop.multiProcessorCount, n_xcd = 8;
+    const int per_xcd = total / n_xcd;
+    if (total % n_xcd != 0 || first_cu < 0 || num_cus < 1 || first_cu + num_cus > per_xcd)
+        return hps::bad_arg("hps_stream_create_cu_partition: CU range outside [0, CUs per XCD)");
+    uint32_t mask[16] = {0};
+    for (int c = first_cu; c < first_cu + num_cus; ++c)
+        for (int x = 0; x < n_xcd; ++x) {
+            const int bit = c * n_xcd + x;
+            mask[bit / 32] |= 1u << (bit % 32);
+        }
+    hipStream_t s = nullptr;
+    e = hipExtStreamCreateWithCUMask(&s, (uint32_t)((total + 31) / 32), mask);
+    if (e != hipSuccess) { hps::set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e)); return (int)e; }
+    *stream_out = (hps_stream_t)s;
+    return HPS_OK;
+}
+
+extern "C" int hps_stream_destroy(hps_stream_t stream) {
+    const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) { hps::set_error("hipStreamDestroy: %s", hipGetErrorString(e)); return (int)e; }
+    return HPS_OK;
+}

@@ -418,6 +418,112 @@ static int launch_unc_reg(const float* verts, float* unc, int B, int N, int V, h
     return check_launch("hps_vertex_uncertainty");
 }
 
+
+// One-sweep form for 128 < N <= 1024 samples (BASELINE configs[4]: N = 1000): a workgroup is VW = 16 vertices x G = 32 sample
+// groups (512 lanes, two workgroups per CU so that one's arithmetic runs under the other's loads); lane (v, g) keeps rows
+// s = i G + g, i < SPT <= 32 (96 registers), in registers: the image's samples are read from HBM ONCE -- the two-sweep kernel
+// above reads them twice (measured 2.0 x the algorithmic traffic, 0.31 of the HBM roofline at N = 1000).
+// Addressing: row i of a lane is (uniform base of row block i) + one per-lane 32-bit offset, i.e. the scalar-base form of
+// global_load -- per-lane 64-bit addresses for every load would not fit beside the data registers.  A row block that would reach
+// beyond row N - 1 is shifted back to end there (uniformly), and the rows it then repeats are masked by ONE compare of the
+// lane's group against a uniform threshold: every address is in bounds, no load is guarded (a guarded load is a basic block of
+// its own ending in s_waitcnt vmcnt(0)).
+// A sample row of a workgroup is VW * 12 contiguous bytes; the neighbouring vertex chunks, which touch the other parts of the
+// same 128-byte lines, are mapped onto the SAME XCD (blockIdx -> chunk below) so that the shared lines are L2 hits.
+// Summation order (fixed, independent of B and of the launch geometry): per lane i ascending; then the 64 / VW groups of a
+// wave by xor butterflies (commutative: every lane holds the same bits); then the waves in wave order.
+// Register budget: two 512-lane workgroups per CU leave 128 registers per lane; 32 rows are 96 of them and hipcc needs ~34
+// beside the data, so with SPT > 24 the first LR = SPT - 23 row blocks of a lane do not pass through registers at all: they are
+// DMA'd straight into LDS (global_load_lds_dwordx3: 12 bytes per lane, which the hardware places at a 16-BYTE lane pitch --
+// tools/ldsdma_probe.hip; 1 KiB per wave instruction, 72 KiB per workgroup at LR = 9, so two workgroups still share the
+// 160 KiB) and read back by the lane that requested them -- no barrier, only the wave's own vmcnt.
+template <int VW, int G, int SPT>
+__global__ __launch_bounds__(VW * G, (VW * G / 256) * (VW * G <= 512 ? 2 : 1)) void uncertainty_sweep1_kernel(
+    const f3* __restrict__ verts, float* __restrict__ unc, int N, int V, int chunks_per_xcd) {
+    constexpr int GW = 64 / VW, NW = VW * G / 64;              // groups per wave, waves
+    constexpr int LR = SPT > 24 ? SPT - 23 : 0;                // row blocks parked in LDS
+    constexpr int RR = SPT - LR;                               // row blocks in registers
+    __shared__ float sRed[NW * 3 * VW];
+    __shared__ __attribute__((aligned(16))) float sRows[LR > 0 ? LR * NW * 64 * 4 : 4];     // [row block][wave][lane][xyz_]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = lane & (VW - 1);
+    int g = wave * GW + lane / VW;
+    const int chunk = (blockIdx.x & 7) * chunks_per_xcd + (blockIdx.x >> 3);     // blocks of one XCD own adjacent vertex chunks
+    const int vg = chunk * VW + v, b = blockIdx.y;
+    if (chunk * VW >= V) return;                                                  // padding block of the last XCD (whole workgroup)
+    const bool live = vg < V;
+    typedef const char __attribute__((address_space(1))) * gbytes;                // GLOBAL pointers (generic ones become flat_load)
+    typedef const float __attribute__((address_space(1))) * gfloats;
+    auto ld3 = [](gbytes at) { const gfloats q = (gfloats)at; f3 r; r.x = q[0]; r.y = q[1]; r.z = q[2]; return r; };   // one global_load_dwordx3
+    const gbytes img = (gbytes)(verts + (size_t)b * N * V);
+    const size_t pitch = (size_t)V * 12;
+    const unsigned lane_off = ((unsigned)g * (unsigned)V + (unsigned)(live ? vg : V - 1)) * 12u;   // < 32 rows * 82,680 bytes
+    f3 p[RR];
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) {
+        const int row0 = min(i * G, N - G);                                      // uniform (N > G): scalar registers
+        if (i < LR)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + (size_t)row0 * pitch + lane_off),
+                                             (__attribute__((address_space(3))) void*)(sRows + (size_t)(i * NW + wave) * 256), 12, 0, 0);
+        else
+            p[i - LR] = ld3(img + (size_t)row0 * pitch + lane_off);
+    }
+    // row block i holds this lane's row i G + g iff g >= lo_i, lo_i = (i + 1) G - N (uniform; <= 0 for the full blocks)
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    const float* mine = sRows + (size_t)wave * 256 + lane * 4;                    // + i * NW * 256: what this lane's DMAs wrote
+#pragma unroll
+    for (int i = 0; i < LR; ++i) {                                                // (hipcc waits vmcnt(0) before the first read)
+        const bool ok = g >= (i + 1) * G - N;
+        const float* q = mine + (size_t)i * NW * 256;
+        sx += ok ? q[0] : 0.0f; sy += ok ? q[1] : 0.0f; sz += ok ? q[2] : 0.0f;
+    }
+#pragma unroll
+    for (int i = LR; i < SPT; ++i) {
+        const bool ok = g >= (i + 1) * G - N;
+        sx += ok ? p[i - LR].x : 0.0f; sy += ok ? p[i - LR].y : 0.0f; sz += ok ? p[i - LR].z : 0.0f;
+    }
+    asm volatile("" : "+v"(g));                        // the second pass recomputes its masks (32 kept lane masks = 64 SGPRs)
+#pragma unroll
+    for (int d = VW; d < 64; d <<= 1) { sx += __shfl_xor(sx, d); sy += __shfl_xor(sy, d); sz += __shfl_xor(sz, d); }
+    if (lane < VW) { sRed[(wave * 3 + 0) * VW + v] = sx; sRed[(wave * 3 + 1) * VW + v] = sy; sRed[(wave * 3 + 2) * VW + v] = sz; }
+    __syncthreads();
+    float mx = 0.f, my = 0.f, mz = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) { mx += sRed[(q * 3 + 0) * VW + v]; my += sRed[(q * 3 + 1) * VW + v]; mz += sRed[(q * 3 + 2) * VW + v]; }
+    mx /= N; my /= N; mz /= N;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < LR; ++i) {
+        const float* q = mine + (size_t)i * NW * 256;
+        const float dist = dist3(q[0] - mx, q[1] - my, q[2] - mz);
+        acc += (g >= (i + 1) * G - N) ? dist : 0.0f;
+    }
+#pragma unroll
+    for (int i = LR; i < SPT; ++i) {
+        const float dist = dist3(p[i - LR].x - mx, p[i - LR].y - my, p[i - LR].z - mz);
+        acc += (g >= (i + 1) * G - N) ? dist : 0.0f;
+    }
+#pragma unroll
+    for (int d = VW; d < 64; d <<= 1) acc += __shfl_xor(acc, d);
+    __syncthreads();                                    // every lane has read the partial sums before the buffer is reused
+    if (lane < VW) sRed[wave * VW + v] = acc;
+    __syncthreads();
+    if (wave == 0 && lane < VW && live) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) t += sRed[q * VW + v];
+        unc[(size_t)b * V + vg] = t / N;
+    }
+}
+
+template <int VW, int G, int SPT>
+static int launch_unc_sweep1(const float* verts, float* unc, int B, int N, int V, hipStream_t s) {
+    const int chunks = ceil_div(V, VW), cpx = ceil_div(chunks, 8);
+    hipLaunchKernelGGL((uncertainty_sweep1_kernel<VW, G, SPT>), dim3(cpx * 8, B), dim3(VW * G), 0, s, reinterpret_cast<const f3*>(verts),
+                       unc, N, V, cpx);
+    return check_launch("hps_vertex_uncertainty");
+}
+
 }  // namespace hps
 
 using namespace hps;
@@ -536,6 +642,17 @@ extern "C" int hps_vertex_uncertainty(const float* verts, float* unc, int B, int
         if (spt <= 8) return launch_unc_reg<8>(verts, unc, B, N, V, st);
         if (spt <= 13) return launch_unc_reg<13>(verts, unc, B, N, V, st);
         return launch_unc_reg<16>(verts, unc, B, N, V, st);
+    }
+    // 128 < N <= 1024: one sweep, 16 vertices x 32 sample groups per workgroup (mode 1: the two-sweep kernel; mode 5: 32 vertices)
+    if ((g_unc_mode == 0 || g_unc_mode >= 5) && N > 16 * UG && N <= 32 * 32) {
+        hipStream_t st = (hipStream_t)stream;
+#ifdef HPS_DEV_BUILD
+        if (g_unc_mode == 5) return launch_unc_sweep1<32, 32, 32>(verts, unc, B, N, V, st);
+#endif
+        if (N <= 32 * 8) return launch_unc_sweep1<16, 32, 8>(verts, unc, B, N, V, st);
+        if (N <= 32 * 16) return launch_unc_sweep1<16, 32, 16>(verts, unc, B, N, V, st);
+        if (N <= 32 * 24) return launch_unc_sweep1<16, 32, 24>(verts, unc, B, N, V, st);
+        return launch_unc_sweep1<16, 32, 32>(verts, unc, B, N, V, st);
     }
 #ifdef HPS_DEV_BUILD
     int uv = 0;

@@ -113,15 +113,47 @@ class InferencePipeline:
     def __init__(self, pose_shape_model, smpl_model, num_samples=50, use_mean_shape=True, sample_on_cpu=False):
         self.net, self.smpl = pose_shape_model, smpl_model
         self.num_samples, self.use_mean_shape, self.sample_on_cpu = num_samples, use_mean_shape, sample_on_cpu
-        self.enc_stream = torch.cuda.Stream()
         # The head is a chain of small dependent kernels; next to kernels that keep every CU's LDS / registers full each of
         # them would otherwise queue behind the pending workgroups.  A high-priority stream lets its few (small: 256 threads,
         # 18 KiB) workgroups take the next free slots.
         self.head_stream = torch.cuda.Stream(priority=-1)
+        self.enc_stream = None        # created by the first submit (its kind depends on the batch size)
+        self.mesh_stream = None
         self._smpl_done = None
+        self._first = True
+        self._exclusive = True
         self.enc_events = None
         self.trace = None             # bench.py --trace-steps: list of per-batch dicts of timing events (head / mesh phases)
         self.early_relayout = False   # A/B on one box: +0.9 % images/s, but the mesh kernel it overlaps runs 12 % slower (0.657 vs 0.586 ms)
+        # exclusive_mesh: the mesh kernel and the neighbouring encoders take turns (right when each fills the chip on its own:
+        # B = 64: 17.9 k images/s either way, the encoder stretched from 2.9 to 3.5 ms when they share).  False: no ordering
+        # between them -- a small batch's encoder cannot fill the chip (its persistent Winograd workgroups are few: 64-256 items
+        # per layer at B = 16) and the mesh kernel's workgroups take the idle CUs: B = 16, N = 1000 4 680 -> 4 925 images/s
+        # (profiles/r03_ablations.txt).  None = decide from the batch size (overlap below 32 images).
+        self.exclusive_mesh = None
+        # encoder_cus > 0: when not exclusive, encoder and mesh phases run on DISJOINT CU subsets (encoder_cus of the 32 CUs of
+        # every XCD for the encoder, hps_stream_create_cu_partition).  Measured at B = 16, N = 1000: 8 / 12 / 16 CUs per XCD ->
+        # 4 860 / 4 550 / 3 930 images/s against 4 925 shared -- the mesh kernel loses CUs in proportion and is the longer chain, so
+        # sharing all CUs is the default; the partition stays available for workloads whose encoder must not be stretched.
+        self.encoder_cus = 0
+
+    def caller_stream(self, batch):
+        """The stream a caller should make current around its submit / finish loop for batches of ``batch`` images: the mesh
+        partition's stream when the pipeline runs encoder and mesh kernels side by side on CU subsets, otherwise the stream
+        that is current now.  (finish() also works from any other stream -- it then hops to the partition's stream and back,
+        which makes every result tensor cross streams: correct, but the caching allocator cannot recycle such blocks promptly.)"""
+        if self.enc_stream is None:
+            self._setup_streams(batch)
+        return self.mesh_stream if self.mesh_stream is not None else torch.cuda.current_stream()
+
+    def _setup_streams(self, batch):
+        self._exclusive = self.exclusive_mesh if self.exclusive_mesh is not None else batch >= 32
+        if not self._exclusive and self.encoder_cus:
+            k = int(self.encoder_cus)
+            self.enc_stream = _capi.cu_partition_stream(0, k)
+            self.mesh_stream = _capi.cu_partition_stream(k, 32 - k)
+        else:
+            self.enc_stream = torch.cuda.Stream()
 
     @torch.no_grad()
     def submit(self, proxy_rep_input, input_ready=None):
@@ -131,11 +163,15 @@ class InferencePipeline:
         that point need ``input_ready``)."""
         _capi.require_device(proxy_rep_input, "proxy_rep_input")
         main = torch.cuda.current_stream()
+        if self.enc_stream is None:
+            self._setup_streams(proxy_rep_input.shape[0])
         if input_ready is not None:
             self.enc_stream.wait_event(input_ready)
         gate = None
-        if self._smpl_done is None:
-            self.enc_stream.wait_stream(main)
+        if self._smpl_done is None or not self._exclusive:
+            if self._first:
+                self.enc_stream.wait_stream(main)
+                self._first = False
         elif self.early_relayout:
             # the input relayout (HBM-bound) is enqueued at once and may run beside the previous batch's fused mesh kernel
             # (MFMA-bound); the convolutions wait for that batch's SMPL kernels
@@ -159,12 +195,27 @@ class InferencePipeline:
 
     @torch.no_grad()
     def finish(self, ticket, seed=None, image_offset=0, after=None):
+        if self.mesh_stream is None or torch.cuda.current_stream() == self.mesh_stream:
+            return self._finish(ticket, seed, image_offset, after)
+        # partitioned: everything after the encoder runs on the mesh partition's stream, ordered after what the caller has
+        # queued; the caller's stream then waits for the results
+        caller = torch.cuda.current_stream()
+        self.mesh_stream.wait_stream(caller)
+        with torch.cuda.stream(self.mesh_stream):
+            res = self._finish(ticket, seed, image_offset, after)
+        caller.wait_stream(self.mesh_stream)
+        for v in res.values():
+            if torch.is_tensor(v):
+                v.record_stream(caller)
+        return res
+
+    def _finish(self, ticket, seed, image_offset, after):
         feats, done = ticket
         main = torch.cuda.current_stream()
         main.wait_event(done)
         feats.record_stream(main)
         def hook():
-            if after is not None:
+            if after is not None and self._exclusive:
                 main.wait_event(after[1])
             if tr is not None:
                 tr["mesh0"].record(main)

@@ -49,6 +49,15 @@ typedef void* hps_stream_t; /* hipStream_t */
 int hps_version(void);
 const char* hps_last_error(void);
 
+/* Spatial partition of the chip for kernels that cannot usefully time-share it (no reference counterpart: the reference runs
+ * one kernel at a time).  Creates a HIP stream restricted to CUs [first_cu, first_cu + num_cus) of EVERY XCD (0 <= first_cu,
+ * first_cu + num_cus <= 32 on MI355X: 8 XCDs x 32 CUs); destroy it with hps_stream_destroy.  Used by the step pipeline for
+ * small batches: the encoder's persistent 512-register Winograd workgroups need a CU to themselves and starve beside a kernel
+ * whose small workgroups keep refilling every CU; on a CU subset of their own they do not.
+ * Host call; allocates a stream (the one exception to "the library never allocates"). */
+int hps_stream_create_cu_partition(int first_cu, int num_cus, hps_stream_t* stream_out);
+int hps_stream_destroy(hps_stream_t stream);
+
 /* Scratch / workspace sizes in BYTES for the buffers the caller hands to the entry points below (the library never allocates):
  *   HPS_WS_CONV_SPLITK (d0 = ksplit, d1 = B*Ho*Wo, d2 = Cout)  splitk_ws of hps_conv2d_bn_act_pad (0 when ksplit <= 1)
  *   HPS_WS_SMPL_MP     (d0 = M)                                 NOT bytes: the padded mesh count mp (M rounded up to 128)

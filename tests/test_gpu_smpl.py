@@ -212,6 +212,36 @@ def test_vertex_uncertainty_kernel(dev):
                     _capi.call("hps_dev_unc_mode", 0)
 
 
+def test_vertex_uncertainty_one_sweep_kernel(dev):
+    """128 < N <= 1024 (BASELINE configs[4]: N = 1000): the one-sweep kernel (rows in registers, the first row blocks DMA'd into
+    LDS) against the oracle and against the two-sweep kernel it replaces (dev library, mode 1; another summation order, so
+    rounding-level agreement, not bits).  Sizes around every dispatch and masking boundary: full and partial last row blocks,
+    rows-per-lane 8 / 16 / 24 / 32, a vertex count that is not a multiple of the 16-vertex chunk, several images per launch."""
+    g = torch.Generator().manual_seed(5)
+    for n, nv, b in ((129, 6890, 2), (160, 6890, 1), (255, 200, 3), (256, 6890, 1), (257, 77, 2), (511, 100, 2), (513, 6890, 1),
+                     (768, 33, 2), (769, 50, 1), (1000, 6890, 2), (1023, 40, 2), (1024, 16, 3)):
+        vv = torch.randn(b, n, nv, 3, generator=g) * 0.3 + torch.randn(b, 1, nv, 3, generator=g)
+        want = torch.stack([O.vertex_uncertainty(vv[i]) for i in range(b)])
+        x = vv.to(dev)
+        got = su.vertex_uncertainty(x)
+        assert maxerr(got, want) <= 1e-5, (n, nv)
+        assert torch.equal(su.vertex_uncertainty(x), got)                       # deterministic
+        # per-image results do not depend on what else is in the launch
+        assert torch.equal(su.vertex_uncertainty(x[b - 1:].contiguous())[0], got[b - 1])
+        with _capi.dev_library():
+            try:
+                _capi.call("hps_dev_unc_mode", 1)
+                two = su.vertex_uncertainty(x)
+                if n in (1000, 1024):
+                    _capi.call("hps_dev_unc_mode", 5)                            # 32-vertex chunks (another reduction tree)
+                    assert maxerr(su.vertex_uncertainty(x), got) <= 2e-6, n
+            finally:
+                _capi.call("hps_dev_unc_mode", 0)
+        assert maxerr(two, got) <= 2e-6, (n, nv)
+    big = torch.randn(1, 1025, 64, 3, generator=g)                              # beyond the register-resident range: two sweeps
+    assert maxerr(su.vertex_uncertainty(big.to(dev)), O.vertex_uncertainty(big[0])[None]) <= 1e-5
+
+
 def test_c_abi_rejects_unsupported_k(dev, smpl_gpu):
     z = torch.zeros(16, device=dev)
     zi = torch.zeros(16, device=dev, dtype=torch.int32)
