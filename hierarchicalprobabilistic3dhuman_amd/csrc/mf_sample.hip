@@ -1,5 +1,5 @@
 // Matrix-Fisher rotation sampling by Bingham / angular-central-Gaussian rejection sampling, one
-// wavefront per (image, joint) call.  Replaces utils/sampling_utils.py:10-143:
+// workgroup of 1-8 wavefronts per (image, joint) call.  Replaces utils/sampling_utils.py:10-143:
 // the per-call Python loop (:128-137), the boolean-mask compaction (:64-65) and the host
 // synchronisation per round (:62) become ballot + prefix-popcount inside one wave.
 #include "hps_common.h"
@@ -37,16 +37,27 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
     n1 = r * sinf(t);
 }
 
-__global__ __launch_bounds__(64) void mf_sample_kernel(
+// Workgroup = one (image, joint) call = W wavefronts (W = blockDim.x / 64, chosen by the launcher from num_samples only).
+// Proposals are taken in order in super-blocks of 64 W: wave w evaluates proposals [64 (it W + w), +64) of iteration it, the
+// waves exchange their accept counts through LDS (one barrier per iteration, two alternating slots), and every accepted proposal
+// gets its rank in PROPOSAL ORDER (accepts of earlier iterations + of lower waves + of lower lanes: ballot and popcount) -- the
+// ordered compaction of the reference's boolean mask (:64-65), identical for every W.
+// The round is decided as soon as N proposals have been accepted (the reference evaluates all 8N and then keeps the first N
+// accepted, :61-66 -- the same N proposals), so with the usual acceptance of 0.4-0.7 about 2N of the 8N proposals are ever
+// evaluated and nothing is evaluated twice.  A round that ends below N accepts (all n_prop evaluated) is discarded like the
+// reference's (:68-69): whatever it wrote is overwritten by the round that succeeds.  count_all (the Bingham entry point, whose
+// accept_ratio :67 needs the total): keeps counting after the N-th accept without emitting.
+__global__ __launch_bounds__(512) void mf_sample_kernel(
     const float* __restrict__ pose_u, const float* __restrict__ pose_s, const float* __restrict__ pose_v,
     const float* __restrict__ bingham_a, const float* __restrict__ acg_override, int nj, int N, int n_prop, float b, float m_star, const float* __restrict__ eps, const float* __restrict__ wun,
-    const int32_t* __restrict__ draw_idx, uint64_t seed, int64_t call_offset, int max_rounds,
+    const int32_t* __restrict__ draw_idx, uint64_t seed, int64_t call_offset, int max_rounds, int count_all,
     float* __restrict__ r_out, float* __restrict__ quat_out, int32_t* __restrict__ accepted) {
+    __shared__ int sCnt[2][8];
     const int c = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
     const int img = c / nj, joint = c % nj;
 
-    // ---- per-call parameters (wave-uniform; every lane computes them redundantly) ----
+    // ---- per-call parameters (uniform over the workgroup; every lane computes them redundantly) ----
     float U[9], V[9], S[3];
 #pragma unroll
     for (int e = 0; e < 9; ++e) { U[e] = pose_u[(size_t)c * 9 + e]; V[e] = pose_v[(size_t)c * 9 + e]; }
@@ -87,78 +98,82 @@ __global__ __launch_bounds__(64) void mf_sample_kernel(
     const uint64_t gcall = (uint64_t)(call_offset + c);
 
     int total = 0;
+    int slot = 0;
     for (int round = 0; round < max_rounds; ++round) {
-        // pass 1 counts the accepted proposals of this round; pass 2 (only if >= N) regenerates the
-        // same proposals and emits the first N accepted in proposal order (:63-65).  A failed round
-        // writes nothing, exactly like the reference's discard-and-redraw (:68-69).
-        for (int pass = 0; pass < 2; ++pass) {
-            int base = 0;
-            for (int p0 = 0; p0 < n_prop; p0 += 64) {
-                const int p = p0 + lane;
-                const bool in_range = p < n_prop;
-                float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 1.f, wu = 2.0f;
-                if (in_range) {
-                    if (host_noise) {
-                        const float4 e4 = *reinterpret_cast<const float4*>(eps_c + (size_t)p * 4);
-                        e0 = e4.x; e1 = e4.y; e2 = e4.z; e3 = e4.w;
-                        wu = w_c[p];
-                    } else {
-                        u4 ctr;
-                        ctr.x = (uint32_t)p; ctr.y = (uint32_t)round;
-                        ctr.z = (uint32_t)gcall; ctr.w = (uint32_t)(gcall >> 32) & 0x7fffffffu;
-                        const u4 r0 = philox4x32_10(ctr, k0, k1);
-                        ctr.w |= 0x80000000u;
-                        const u4 r1 = philox4x32_10(ctr, k0, k1);
-                        box_muller(r0.x, r0.y, e0, e1);
-                        box_muller(r0.z, r0.w, e2, e3);
-                        wu = u01(r1.x);
-                    }
+        int base = 0;                                            // accepts of the proposals before this iteration's super-block
+        for (int p0 = 0; p0 < n_prop; p0 += 64 * W) {
+            const int p = p0 + 64 * wave + lane;
+            const bool in_range = p < n_prop;
+            float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 1.f, wu = 2.0f;
+            if (in_range) {
+                if (host_noise) {
+                    const float4 e4 = *reinterpret_cast<const float4*>(eps_c + (size_t)p * 4);
+                    e0 = e4.x; e1 = e4.y; e2 = e4.z; e3 = e4.w;
+                    wu = w_c[p];
+                } else {
+                    u4 ctr;
+                    ctr.x = (uint32_t)p; ctr.y = (uint32_t)round;
+                    ctr.z = (uint32_t)gcall; ctr.w = (uint32_t)(gcall >> 32) & 0x7fffffffu;
+                    const u4 r0 = philox4x32_10(ctr, k0, k1);
+                    ctr.w |= 0x80000000u;
+                    const u4 r1 = philox4x32_10(ctr, k0, k1);
+                    box_muller(r0.x, r0.y, e0, e1);
+                    box_muller(r0.z, r0.w, e2, e3);
+                    wu = u01(r1.x);
                 }
-                // y = std * eps ; x = y / ||y||                       (:52-53)
-                const float y0 = sd[0] * e0, y1 = sd[1] * e1, y2 = sd[2] * e2, y3 = sd[3] * e3;
-                const float nrm = sqrtf(y0 * y0 + y1 * y1 + y2 * y2 + y3 * y3);
-                const float x0 = y0 / nrm, x1 = y1 / nrm, x2 = y2 / nrm, x3 = y3 / nrm;
-                // p_Bing* = exp(-x^T A x); p_ACG* = (x^T Omega x)^-2   (:56-57)
-                const float qa = x0 * A[0] * x0 + x1 * A[1] * x1 + x2 * A[2] * x2 + x3 * A[3] * x3;
-                const float qo = x0 * Om[0] * x0 + x1 * Om[1] * x1 + x2 * Om[2] * x2 + x3 * Om[3] * x3;
-                const float p_bing = expf(-qa);
-                const float p_acg = 1.0f / (qo * qo);
-                const bool acc = in_range && (wu < p_bing / (m_star * p_acg));          // :61
-                const unsigned long long mask = __ballot(acc);
-                if (pass == 1) {
-                    const int rank = base + __popcll(mask & ((1ull << lane) - 1ull));
-                    if (acc && rank < N) {
-                        float Rq[9], T[9], Ro[9];
-                        quat_to_rotmat_dev(x0, x1, x2, x3, Rq);                          // :139
-                        mat3_mul_bt(Rq, V, T);                                           // R V_p^T
-                        mat3_mul(U, T, Ro);                                              // U_p (R V_p^T)   :140-141
-                        const size_t o = ((size_t)img * N + rank) * nj + joint;
+            }
+            // y = std * eps ; x = y / ||y||                       (:52-53)
+            const float y0 = sd[0] * e0, y1 = sd[1] * e1, y2 = sd[2] * e2, y3 = sd[3] * e3;
+            const float nrm = sqrtf(y0 * y0 + y1 * y1 + y2 * y2 + y3 * y3);
+            const float x0 = y0 / nrm, x1 = y1 / nrm, x2 = y2 / nrm, x3 = y3 / nrm;
+            // p_Bing* = exp(-x^T A x); p_ACG* = (x^T Omega x)^-2   (:56-57)
+            const float qa = x0 * A[0] * x0 + x1 * A[1] * x1 + x2 * A[2] * x2 + x3 * A[3] * x3;
+            const float qo = x0 * Om[0] * x0 + x1 * Om[1] * x1 + x2 * Om[2] * x2 + x3 * Om[3] * x3;
+            const float p_bing = expf(-qa);
+            const float p_acg = 1.0f / (qo * qo);
+            const bool acc = in_range && (wu < p_bing / (m_star * p_acg));          // :61
+            const unsigned long long mask = __ballot(acc);
+            const int mine = __popcll(mask);
+            int before = 0, all = mine;                                              // accepts of the lower waves / of the super-block
+            if (W > 1) {
+                if (lane == 0) sCnt[slot][wave] = mine;
+                __syncthreads();
+                all = 0;
+                for (int j = 0; j < W; ++j) {
+                    const int cj = sCnt[slot][j];
+                    before += j < wave ? cj : 0;
+                    all += cj;
+                }
+                slot ^= 1;
+            }
+            const int rank = base + before + __popcll(mask & ((1ull << lane) - 1ull));
+            if (acc && rank < N) {
+                float Rq[9], T[9], Ro[9];
+                quat_to_rotmat_dev(x0, x1, x2, x3, Rq);                          // :139
+                mat3_mul_bt(Rq, V, T);                                           // R V_p^T
+                mat3_mul(U, T, Ro);                                              // U_p (R V_p^T)   :140-141
+                const size_t o = ((size_t)img * N + rank) * nj + joint;
 #pragma unroll
-                        for (int e = 0; e < 9; ++e) r_out[o * 9 + e] = Ro[e];
-                        if (quat_out) {
-                            quat_out[o * 4 + 0] = x0; quat_out[o * 4 + 1] = x1;
-                            quat_out[o * 4 + 2] = x2; quat_out[o * 4 + 3] = x3;
-                        }
-                    }
+                for (int e = 0; e < 9; ++e) r_out[o * 9 + e] = Ro[e];
+                if (quat_out) {
+                    quat_out[o * 4 + 0] = x0; quat_out[o * 4 + 1] = x1;
+                    quat_out[o * 4 + 2] = x2; quat_out[o * 4 + 3] = x3;
                 }
-                base += __popcll(mask);
-                if (pass == 1 && base >= N) break;   // every kept proposal has been written
             }
-            if (pass == 0) {
-                total = base;
-                if (total < N) break;                // round failed: no emit pass
-            }
+            base += all;
+            if (base >= N && !count_all) break;      // decided (uniform over the workgroup: every wave holds the same base)
         }
+        total = base;
         if (total >= N || host_noise) break;         // host noise: the caller supplies the next draw
     }
-    if (lane == 0) accepted[c] = total;
+    if (threadIdx.x == 0) accepted[c] = total;
     if (total < N && !host_noise) {
         // max_rounds exhausted (NaN / Inf concentrations make every accept test false): the reference would loop for ever
         // printing 'Failed sampling' (:68-69).  Make the failure loud instead of leaving the outputs uninitialised.
         const float nan = __builtin_nanf("");
-        for (int i = lane; i < N * 9; i += 64) r_out[(((size_t)img * N + i / 9) * nj + joint) * 9 + i % 9] = nan;
+        for (int i = threadIdx.x; i < N * 9; i += blockDim.x) r_out[(((size_t)img * N + i / 9) * nj + joint) * 9 + i % 9] = nan;
         if (quat_out)
-            for (int i = lane; i < N * 4; i += 64) quat_out[(((size_t)img * N + i / 4) * nj + joint) * 4 + i % 4] = nan;
+            for (int i = threadIdx.x; i < N * 4; i += blockDim.x) quat_out[(((size_t)img * N + i / 4) * nj + joint) * 4 + i % 4] = nan;
     }
 }
 
@@ -259,9 +274,14 @@ extern "C" int hps_mf_sample(const float* pose_u, const float* pose_s, const flo
     if (num_samples <= 0 || n_prop < num_samples || !(b > 0.f)) return bad_arg("hps_mf_sample: num_samples / n_prop / b");
     if (max_rounds < 1) max_rounds = 1;
     if (C == 0) return HPS_OK;
-    hipLaunchKernelGGL(mf_sample_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, pose_u, pose_s, pose_v,
+    // wavefronts per call: a function of num_samples alone (results do not depend on it; this only keeps each wave at about
+    // four 64-proposal blocks until the N-th accept at the usual acceptance of one in two)
+    int waves = (2 * num_samples + 255) / 256;
+    waves = waves < 1 ? 1 : (waves > 8 ? 8 : waves);
+    const int count_all = quat_out != nullptr;      // the Bingham entry point reports the round's total (accept_ratio, :67)
+    hipLaunchKernelGGL(mf_sample_kernel, dim3(C), dim3(64 * waves), 0, (hipStream_t)stream, pose_u, pose_s, pose_v,
                        bingham_a, acg_override, num_joints, num_samples, n_prop, b, m_star, eps, w, draw_idx, seed, call_offset, max_rounds,
-                       r_out, quat_out, accepted);
+                       count_all, r_out, quat_out, accepted);
     return check_launch("hps_mf_sample");
 }
 

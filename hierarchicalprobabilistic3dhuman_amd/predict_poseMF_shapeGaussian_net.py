@@ -136,6 +136,8 @@ class InferencePipeline:
         # 4 860 / 4 550 / 3 930 images/s against 4 925 shared -- the mesh kernel loses CUs in proportion and is the longer chain, so
         # sharing all CUs is the default; the partition stays available for workloads whose encoder must not be stretched.
         self.encoder_cus = 0
+        # (measured and dropped: making the next encoder wait for the uncertainty pass as well -- B = 16, N = 1000: 3.15 -> 3.24 ms
+        # per step; B = 64, N = 100: 3.53 -> 3.51)
 
     def caller_stream(self, batch):
         """The stream a caller should make current around its submit / finish loop for batches of ``batch`` images: the mesh

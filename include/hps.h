@@ -147,12 +147,17 @@ int hps_vertex_uncertainty(const float* verts, float* unc, int B, int N, int V, 
  * Matrix-Fisher sampling  (utils/sampling_utils.py:10-143)
  * ---------------------------------------------------------------------------------------- */
 
-/* One wavefront per (image, joint) call c = image*num_joints + joint, C calls in total.
+/* One workgroup (1-8 wavefronts, chosen from num_samples alone; results do not depend on it) per (image, joint) call
+ * c = image*num_joints + joint, C calls in total.
  * pose_u/pose_v (C,3,3), pose_s (C,3): raw SVD factors; the proper-SVD fix (:104-111), Bingham A,
  * ACG Omega, Gaussian std (:118-124), the 8N-proposal rejection test (:51-61), in-order compaction
  * of the first N accepted proposals (:64-65), quat_to_rotmat (:139) and U_p R V_p^T (:140-141) are
  * all done in the kernel.  r_out is (B, N, num_joints, 3, 3); quat_out optional (B,N,num_joints,4).
- * accepted (C,) int32 receives the number of accepted proposals of the round that was used.
+ * A round is decided once N proposals have been accepted: the proposals behind the N-th accept (the reference evaluates all
+ * 8N, :51-61, and then keeps the first N accepted) are not evaluated -- the same N samples.
+ * accepted (C,) int32 receives the number of accepted proposals of the round that was used, counted up to the iteration
+ * that reached N (>= N on success); with quat_out != NULL (the Bingham entry point, whose accept_ratio :67 needs it) the
+ * round's total over all n_prop proposals.
  * bingham_a: optional (C,4) Bingham parameter used instead of the one derived from pose_s -- the
  * entry point of bingham_sampling_for_matrix_fisher_torch (:10-71), which takes A directly.
  * acg_override: optional (C,8) = [Omega (4) | Gaussian_std (4)] used instead of the values derived from A and b
@@ -162,7 +167,7 @@ int hps_vertex_uncertainty(const float* verts, float* unc, int B, int N, int V, 
  *   eps/w != NULL : proposals come from host-drawn noise, eps (D, n_prop, 4) standard normals and
  *                   w (D, n_prop) uniforms (the reference's torch.randn / torch.rand stream, :51/:60);
  *                   call c reads draw slot draw_idx[c].  A call with fewer than N accepted proposals
- *                   leaves its outputs untouched and reports accepted[c] < N (the caller retries with
+ *                   reports accepted[c] < N and its outputs are to be discarded (the caller retries with
  *                   the next draw, as the reference does at :68-69).
  *   eps == NULL   : counter-based Philox4x32-10 in the kernel, keyed by (seed, call_offset + c,
  *                   round, proposal) so results do not depend on how images are sharded over GPUs;
