@@ -43,9 +43,10 @@ _PROTOTYPES = {
     "hps_batch_rodrigues": [_P, _P, _I, _P],
     "hps_linear": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "hps_head_joint_level": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _I, _I, _P],
-    "hps_head_joint_level_svd": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _P, _I, _I, _P],
-    "hps_svd3_packed": [_P, _P, _I, _P],
-    "hps_host_svd3_emulated": [_P, _P, _I],
+    "hps_head_joint_level_svd": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _P, _I, _I, _I, _P],
+    "hps_svd3_packed": [_P, _P, _I, _I, _P],
+    "hps_host_svd3_emulated": [_P, _P, _I, _I],
+    "hps_host_svd_flavor": [],
     "hps_host_svd3_packed": [_P, _P, _I, _I],
     "hps_host_bind_lapack": [_c.c_char_p],
     "hps_head_svd_finish": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
@@ -99,7 +100,8 @@ class EncOp(_c.Structure):
 
 
 ENC_RELAYOUT, ENC_CONV, ENC_MAXPOOL, ENC_AVGPOOL, ENC_CONV_WINOGRAD = 0, 1, 2, 3, 4
-SVD_HOST, SVD_DEVICE = 0, 1
+SVD_HOST, SVD_DEVICE, SVD_DEVICE_FMA = 0, 1, 2
+SVD_ROUNDING_REFERENCE, SVD_ROUNDING_FMA = 0, 1
 
 
 class HpsError(RuntimeError):
@@ -185,6 +187,34 @@ def cu_partition_stream(first_cu, num_cus):
     s = _P()
     call("hps_stream_create_cu_partition", int(first_cu), int(num_cus), _c.byref(s))
     return torch.cuda.ExternalStream(s.value)
+
+
+_svd_flavor = None
+_svd_flavor_exact = None
+
+
+def svd_flavor():
+    """Rounding flavour (include/hps.h: HPS_SVD_ROUNDING_*) of the in-kernel SVD that reproduces THIS host's LAPACK (the MKL
+    sgesdd_ behind torch.svd) bit for bit -- calibrated once per process by hps_host_svd_flavor.  If neither flavour matches
+    (another LAPACK build), the reference-BLAS rounding is used and a warning says so."""
+    global _svd_flavor, _svd_flavor_exact
+    if _svd_flavor is None:
+        fl = load(dev=_use_dev).hps_host_svd_flavor()
+        _svd_flavor_exact = fl in (SVD_ROUNDING_REFERENCE, SVD_ROUNDING_FMA)
+        if not _svd_flavor_exact:
+            import warnings
+            warnings.warn("libhps: neither rounding flavour of the in-kernel 3x3 SVD reproduces this host's LAPACK sgesdd bit for "
+                          "bit; using reference rounding (expect about one differently signed singular-vector pair in 10^4 "
+                          "matrices relative to torch.svd on this host; svd_mode='host' is exact)")
+            fl = SVD_ROUNDING_REFERENCE
+        _svd_flavor = fl
+    return _svd_flavor
+
+
+def svd_flavor_is_exact():
+    """True when the calibrated flavour reproduces this host's LAPACK bit for bit (the normal case with PyTorch's MKL)."""
+    svd_flavor()
+    return bool(_svd_flavor_exact)
 
 
 def call(name, *args):

@@ -45,8 +45,9 @@ def _config(dev):
 def _source_digest(dev=False):
     _, sources, flags, _ = _config(dev)
     h = hashlib.sha256()
-    files = [os.path.join(CSRC, s) for s in sources] + [os.path.join(CSRC, "hps_common.h"), os.path.join(INCLUDE, "hps.h"),
-                                                         os.path.join(INCLUDE, "hps_dev.h")]
+    headers = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))          # every header under csrc/ (svd3_gesdd.h, ...)
+    files = [os.path.join(CSRC, s) for s in sources] + [os.path.join(CSRC, h) for h in headers] + [
+        os.path.join(INCLUDE, "hps.h"), os.path.join(INCLUDE, "hps_dev.h")]
     for f in files:
         with open(f, "rb") as fh:
             h.update(fh.read())

@@ -59,14 +59,15 @@ extern "C" int hps_head_pose_levels(const float* embed, int embed_dim, int hidde
                                     float* f_host_pinned, float* usv_host_pinned, int B, int num_body_joints,
                                     int svd_threads, int svd_mode, hps_stream_t stream) {
     if (!embed || !level_joints || !level_sizes_host) return bad_arg("hps_head_pose_levels: null pointer");
-    if (svd_mode == HPS_SVD_DEVICE) {
+    if (svd_mode == HPS_SVD_DEVICE || svd_mode == HPS_SVD_DEVICE_FMA) {
+        const int flavor = svd_mode == HPS_SVD_DEVICE_FMA ? HPS_SVD_ROUNDING_FMA : HPS_SVD_ROUNDING_REFERENCE;
         // every level is ONE kernel (MLPs + in-kernel gesdd-faithful SVD + proper fix): stream-ordered, no host round trip
         int first_d = 0;
         for (int l = 0; l < n_levels; ++l) {
             const int n_level = level_sizes_host[l];
             const int rc = hps_head_joint_level_svd(embed, embed_dim, hidden, level_joints + first_d, n_level, anc_ptr, anc_idx,
                                                     w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper, s_proper, mode, delta_i_weight,
-                                                    pose_f, pose_u, pose_s, pose_v, B, num_body_joints, stream);
+                                                    pose_f, pose_u, pose_s, pose_v, B, num_body_joints, flavor, stream);
             if (rc != HPS_OK) return rc;
             first_d += n_level;
         }

@@ -95,7 +95,22 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 }
 
 // One kinematic level: grid = (n_level joints, batch tiles of TBL images).
-// proper SVD + mode (models/poseMF_shapeGaussian_net.py:139-152) of one joint of one image from its raw factors
+// proper SVD + mode (models/poseMF_shapeGaussian_net.py:139-152) of one joint of one image from its raw factors.  Contraction is
+// off for this function: it is inlined into two kernels (the level kernel with the in-kernel SVD and svd_finish_kernel of the
+// host-LAPACK mode), and u_proper / mode feed the descendants' MLPs -- left to the compiler, the two copies fused different
+// multiply-adds and the two SVD modes differed in the last bits of every later F although their SVDs are bit-identical.
+#pragma clang fp contract(off)
+__device__ __forceinline__ float det3_unfused(const float* m) {          // the expressions of det3 / mat3_mul_bt, written here so
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +      // that the pragma applies to them
+           m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+__device__ __forceinline__ void mat3_mul_bt_unfused(const float* a, const float* b, float* c) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            c[i * 3 + j] = a[i * 3 + 0] * b[j * 3 + 0] + a[i * 3 + 1] * b[j * 3 + 1] + a[i * 3 + 2] * b[j * 3 + 2];
+}
 __device__ __forceinline__ void proper_svd_store(float* U, const float* S, float* V, size_t o, float* __restrict__ pose_u,
                                                  float* __restrict__ pose_s, float* __restrict__ pose_v, float* u_proper,
                                                  float* s_proper, float* mode) {
@@ -103,17 +118,18 @@ __device__ __forceinline__ void proper_svd_store(float* U, const float* S, float
     for (int e = 0; e < 9; ++e) { pose_u[o * 9 + e] = U[e]; pose_v[o * 9 + e] = V[e]; }
 #pragma unroll
     for (int e = 0; e < 3; ++e) pose_s[o * 3 + e] = S[e];
-    const float dU = det3(U), dV = det3(V);
+    const float dU = det3_unfused(U), dV = det3_unfused(V);
     U[2] *= dU; U[5] *= dU; U[8] *= dU;
     V[2] *= dV; V[5] *= dV; V[8] *= dV;
     float Mo[9];
-    mat3_mul_bt(U, V, Mo);
+    mat3_mul_bt_unfused(U, V, Mo);
 #pragma unroll
     for (int e = 0; e < 9; ++e) { u_proper[o * 9 + e] = U[e]; mode[o * 9 + e] = Mo[e]; }
     s_proper[o * 3 + 0] = S[0];
     s_proper[o * 3 + 1] = S[1];
     s_proper[o * 3 + 2] = S[2] * (dU * dV);
 }
+#pragma clang fp contract(fast)
 
 // DEVSVD: the level's 3x3 SVDs run inside the kernel (svd3_gesdd.h: LAPACK's sgesdd followed step by step, so that the
 // singular vectors carry the signs the reference's torch.svd would give them), followed by the proper-SVD fix -- the level
@@ -130,7 +146,7 @@ __global__ __launch_bounds__(NT) void joint_level_kernel(
     const float* const* __restrict__ b1_ptrs, const float* const* __restrict__ w2_ptrs,
     const float* const* __restrict__ b2_ptrs, float* u_proper, float* s_proper,
     float* mode, float delta_i_weight, float* __restrict__ pose_f, float* __restrict__ f_level,
-    float* __restrict__ pose_u, float* __restrict__ pose_s, float* __restrict__ pose_v, int B, int NJ) {
+    float* __restrict__ pose_u, float* __restrict__ pose_s, float* __restrict__ pose_v, int B, int NJ, int svd_flavor) {
     __builtin_amdgcn_s_setprio(3);                          // see linear_kernel
     constexpr int KS = NT / HID;
     constexpr int PARTS = NT >= 9 * TBL * 8 ? 8 : 4;       // lanes per output-layer dot product
@@ -230,7 +246,7 @@ __global__ __launch_bounds__(NT) void joint_level_kernel(
             float F[9], U[9], S[3], V[9];
 #pragma unroll
             for (int e = 0; e < 9; ++e) F[e] = red[r * 9 + e];
-            gesdd3::svd3(F, U, S, V);
+            gesdd3::svd3(svd_flavor, F, U, S, V);
             proper_svd_store(U, S, V, (size_t)(b0 + r) * NJ + joint, pose_u, pose_s, pose_v, u_proper, s_proper, mode);
         }
     }
@@ -255,13 +271,13 @@ __global__ void svd_finish_kernel(const float* __restrict__ usv, const int32_t* 
 }
 
 // n row-major 3x3 matrices -> packed [U | S | V] (21 floats each), the layout of hps_host_svd3_packed
-__global__ void svd3_packed_kernel(const float* __restrict__ f, float* __restrict__ usv, int n) {
+__global__ void svd3_packed_kernel(const float* __restrict__ f, float* __restrict__ usv, int n, int svd_flavor) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float F[9], U[9], S[3], V[9];
 #pragma unroll
     for (int e = 0; e < 9; ++e) F[e] = f[(size_t)i * 9 + e];
-    gesdd3::svd3(F, U, S, V);
+    gesdd3::svd3(svd_flavor, F, U, S, V);
     float* o = usv + (size_t)i * 21;
 #pragma unroll
     for (int e = 0; e < 9; ++e) { o[e] = U[e]; o[12 + e] = V[e]; }
@@ -289,8 +305,10 @@ static int joint_level_launch(const float* embed, int embed_dim, int hidden, con
                               const float* const* b1_ptrs, const float* const* w2_ptrs, const float* const* b2_ptrs,
                               float* u_proper, float* s_proper, float* mode, float delta_i_weight, float* pose_f,
                               float* f_level, float* pose_u, float* pose_s, float* pose_v, int B, int num_body_joints,
-                              hps_stream_t stream) {
+                              int svd_flavor, hps_stream_t stream) {
     const bool devsvd = pose_u != nullptr;
+    if (devsvd && svd_flavor != HPS_SVD_ROUNDING_REFERENCE && svd_flavor != HPS_SVD_ROUNDING_FMA)
+        return bad_arg("hps_head_joint_level_svd: svd_flavor");
     if (!embed || !joint_ids || !anc_ptr || !anc_idx || !w1t_ptrs || !b1_ptrs || !w2_ptrs || !b2_ptrs || !u_proper ||
         !s_proper || !mode || !pose_f || (devsvd && (!pose_s || !pose_v)))
         return bad_arg("hps_head_joint_level: null pointer");
@@ -303,11 +321,11 @@ static int joint_level_launch(const float* embed, int embed_dim, int hidden, con
     if (devsvd)
         hipLaunchKernelGGL((joint_level_kernel<128, true, NT, TBL>), dim3(n_level, ceil_div(B, TBL)), dim3(NT), lds, (hipStream_t)stream,
                            embed, embed_dim, joint_ids, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper,
-                           s_proper, mode, delta_i_weight, pose_f, f_level, pose_u, pose_s, pose_v, B, num_body_joints);
+                           s_proper, mode, delta_i_weight, pose_f, f_level, pose_u, pose_s, pose_v, B, num_body_joints, svd_flavor);
     else
         hipLaunchKernelGGL((joint_level_kernel<128, false, NT, TBL>), dim3(n_level, ceil_div(B, TBL)), dim3(NT), lds, (hipStream_t)stream,
                            embed, embed_dim, joint_ids, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper,
-                           s_proper, mode, delta_i_weight, pose_f, f_level, pose_u, pose_s, pose_v, B, num_body_joints);
+                           s_proper, mode, delta_i_weight, pose_f, f_level, pose_u, pose_s, pose_v, B, num_body_joints, svd_flavor);
     return check_launch("hps_head_joint_level");
 }
 
@@ -319,7 +337,7 @@ extern "C" int hps_head_joint_level(const float* embed, int embed_dim, int hidde
                                     float* f_level, int B, int num_body_joints, hps_stream_t stream) {
     return joint_level_launch(embed, embed_dim, hidden, joint_ids, n_level, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs,
                               const_cast<float*>(u_proper), const_cast<float*>(s_proper), const_cast<float*>(mode),
-                              delta_i_weight, pose_f, f_level, nullptr, nullptr, nullptr, B, num_body_joints, stream);
+                              delta_i_weight, pose_f, f_level, nullptr, nullptr, nullptr, B, num_body_joints, 0, stream);
 }
 
 extern "C" int hps_head_joint_level_svd(const float* embed, int embed_dim, int hidden, const int32_t* joint_ids,
@@ -327,17 +345,19 @@ extern "C" int hps_head_joint_level_svd(const float* embed, int embed_dim, int h
                                         const float* const* w1t_ptrs, const float* const* b1_ptrs,
                                         const float* const* w2_ptrs, const float* const* b2_ptrs, float* u_proper,
                                         float* s_proper, float* mode, float delta_i_weight, float* pose_f, float* pose_u,
-                                        float* pose_s, float* pose_v, int B, int num_body_joints, hps_stream_t stream) {
+                                        float* pose_s, float* pose_v, int B, int num_body_joints, int svd_flavor,
+                                        hps_stream_t stream) {
     if (!pose_u) return bad_arg("hps_head_joint_level_svd: null pointer");
     return joint_level_launch(embed, embed_dim, hidden, joint_ids, n_level, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs,
                               u_proper, s_proper, mode, delta_i_weight, pose_f, nullptr, pose_u, pose_s, pose_v, B,
-                              num_body_joints, stream);
+                              num_body_joints, svd_flavor, stream);
 }
 
-extern "C" int hps_svd3_packed(const float* f, float* usv, int n, hps_stream_t stream) {
+extern "C" int hps_svd3_packed(const float* f, float* usv, int n, int svd_flavor, hps_stream_t stream) {
     if (!f || !usv) return bad_arg("hps_svd3_packed: null pointer");
+    if (svd_flavor != HPS_SVD_ROUNDING_REFERENCE && svd_flavor != HPS_SVD_ROUNDING_FMA) return bad_arg("hps_svd3_packed: svd_flavor");
     if (n <= 0) return HPS_OK;
-    hipLaunchKernelGGL(svd3_packed_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, (hipStream_t)stream, f, usv, n);
+    hipLaunchKernelGGL(svd3_packed_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, (hipStream_t)stream, f, usv, n, svd_flavor);
     return check_launch("hps_svd3_packed");
 }
 

@@ -168,16 +168,55 @@ extern "C" int hps_host_svd3_packed(const float* f_host, float* usv_host, int n,
 
 // The device SVD's algorithm (svd3_gesdd.h) compiled for the host: lets the sign agreement with LAPACK be measured and
 // tested without a GPU.  Single thread; f_host (n,9) -> usv_host (n,21) packed like hps_host_svd3_packed.
-extern "C" int hps_host_svd3_emulated(const float* f_host, float* usv_host, int n) {
+extern "C" int hps_host_svd3_emulated(const float* f_host, float* usv_host, int n, int svd_flavor) {
     if (!f_host || !usv_host) return bad_arg("hps_host_svd3_emulated: null pointer");
+    if (svd_flavor != HPS_SVD_ROUNDING_REFERENCE && svd_flavor != HPS_SVD_ROUNDING_FMA) return bad_arg("hps_host_svd3_emulated: svd_flavor");
     int failed = 0;
     for (int i = 0; i < n; ++i) {
         float U[9], S[3], V[9];
-        if (!gesdd3::svd3(f_host + (size_t)i * 9, U, S, V)) ++failed;
+        if (!gesdd3::svd3(svd_flavor, f_host + (size_t)i * 9, U, S, V)) ++failed;
         float* o = usv_host + (size_t)i * 21;
         for (int e = 0; e < 9; ++e) { o[e] = U[e]; o[12 + e] = V[e]; }
         o[9] = S[0]; o[10] = S[1]; o[11] = S[2];
     }
     if (failed) { set_error("hps_host_svd3_emulated: %d matrices did not converge / were not finite", failed); return HPS_E_BADARG; }
     return HPS_OK;
+}
+
+// Which rounding flavour of csrc/svd3_gesdd.h reproduces the LAPACK this process is bound to (hps_host_bind_lapack)?  MKL picks
+// its kernels by the host CPU: on Intel hosts they fuse multiply-adds (flavour HPS_SVD_ROUNDING_FMA), elsewhere they round like
+// reference BLAS (HPS_SVD_ROUNDING_REFERENCE) -- and one time in 10^4 that last bit decides the sign of a singular-vector pair.
+// 4 096 fixed pseudo-random matrices I + 0.5 N go through sgesdd_ and through both flavours; returns the flavour whose U, S, V
+// are bit-identical on all of them, or -1 when neither is (another LAPACK).  Deterministic, ~2 ms, not cached here.
+extern "C" int hps_host_svd_flavor(void) {
+    sgesdd_fn gesdd = resolve_sgesdd();
+    if (!gesdd) { set_error("hps_host_svd_flavor: LAPACK sgesdd_ not found in the process (expected from libtorch_cpu.so)"); return -1; }
+    const int n = 4096;
+    int lwork = -1, three = 3, info = 0, iwork[24];
+    float query = 0.f, dummy[9];
+    gesdd("A", &three, &three, dummy, &three, dummy, dummy, &three, dummy, &three, &query, &lwork, iwork, &info);
+    lwork = (int)query > 0 ? (int)query : 256;
+    std::vector<float> work((size_t)lwork);
+    bool match[2] = {true, true};
+    uint32_t st = 12345u;
+    auto next_uniform = [&] { st = st * 1664525u + 1013904223u; return (float)(st >> 8) * (1.0f / 16777216.0f); };
+    for (int i = 0; i < n && (match[0] || match[1]); ++i) {
+        float f[9], ref[21];
+        for (int e = 0; e < 9; ++e) {
+            float g = -6.0f;                                      // sum of 12 uniforms: close enough to a normal deviate
+            for (int k = 0; k < 12; ++k) g += next_uniform();
+            f[e] = ((e % 4 == 0) ? 1.0f : 0.0f) + 0.5f * g;
+        }
+        if (svd3(gesdd, f, ref, work.data(), lwork) != 0) continue;
+        for (int fl = 0; fl < 2; ++fl) {
+            float U[9], S[3], V[9];
+            gesdd3::svd3(fl, f, U, S, V);
+            bool same = S[0] == ref[9] && S[1] == ref[10] && S[2] == ref[11];
+            for (int e = 0; e < 9 && same; ++e) same = U[e] == ref[e] && V[e] == ref[12 + e];
+            if (!same) match[fl] = false;
+        }
+    }
+    if (match[HPS_SVD_ROUNDING_FMA]) return HPS_SVD_ROUNDING_FMA;
+    if (match[HPS_SVD_ROUNDING_REFERENCE]) return HPS_SVD_ROUNDING_REFERENCE;
+    return -1;
 }

@@ -11,9 +11,10 @@ dataset order and rank 0 writes them.  The random samples of a frame are keyed b
 (Philox pose samples: seed + global index; shape noise: a host generator seeded per frame), so every metric is the same
 for any world size and batch size.
 
-``svd_mode`` selects the head's 3x3 SVD for this evaluation ("host": MKL sgesdd, the reference's very routine, bit-exact
-signs; "device": the in-kernel restatement of sgesdd).  Default: "host" when ``sample_on_cpu`` (the reference's
-seed-reproducible evaluation route, run_evaluate.py:83-94 -- parity first), the model's own ``svd_mode`` otherwise.  The silhouette / 2D-joint metrics need the pytorch3d renderer and the detector
+``svd_mode`` selects the head's 3x3 SVD for this evaluation ("host": MKL sgesdd on the host, the reference's very routine;
+"device": the in-kernel restatement of sgesdd, bit-identical to this host's MKL in U, S and V once its rounding flavour is
+calibrated, _capi.svd_flavor).  Default: the model's own ``svd_mode`` -- except that the reference's seed-reproducible route
+(``sample_on_cpu``, run_evaluate.py:83-94) falls back to "host" on a machine whose LAPACK neither flavour reproduces.  The silhouette / 2D-joint metrics need the pytorch3d renderer and the detector
 outputs and are out of scope.
 
 The 3DPW frames and the licensed SMPL_{MALE,FEMALE}.pkl files are external assets; any ``eval_dataset`` yielding the
@@ -42,7 +43,7 @@ def evaluate_pose_MF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mo
     if device.type == "cuda":
         torch.cuda.set_device(device)              # libhps launches on the current device's current stream
     if svd_mode is None:
-        svd_mode = "host" if sample_on_cpu else pose_shape_model.svd_mode
+        svd_mode = "host" if (sample_on_cpu and not _capi.svd_flavor_is_exact()) else pose_shape_model.svd_mode
     if svd_mode not in ("host", "device"):
         raise ValueError("svd_mode must be 'host' or 'device'")
     frame0 = 0                                     # index in the whole dataset of this rank's first frame

@@ -12,11 +12,15 @@ kinematic depth levels (hps_head_joint_level; 8 levels for the SMPL tree instead
 3x3 SVD (:137, "SVD is faster on CPU" in the reference).  The column signs LAPACK returns are not determined by the
 mathematics, they feed the child joints' MLPs through U_proper (:126-130), and the trained weights were fitted to them
 (SURVEY.md section 7 hard part 1).  Two modes, ``net.svd_mode``:
-  "device" (default)  the SVD runs inside the level kernel and follows LAPACK's sgesdd step by step (csrc/svd3_gesdd.h):
-                      the same signs as torch.svd on 99.99 % of matrices, factors within 1e-4; the head
-                      is 11 stream-ordered launches, no host synchronisation, capturable in a hipGraph.
-  "host"              the reference's very routine: MKL sgesdd on the host (bit-identical to torch.svd), one D2H / sync /
-                      H2D round trip per kinematic level -- the parity mode.
+  "device" (default)  the SVD runs inside the level kernel and follows LAPACK's sgesdd step by step WITH MKL'S ROUNDINGS
+                      (csrc/svd3_gesdd.h): U, S and V are bit-identical to torch.svd on this host (10^6 matrices of 22 families,
+                      tests/test_host_logic.py).  MKL rounds differently on Intel and on other hosts (fused multiply-adds or
+                      not -- one differently signed vector pair in 10^4 matrices between the two, i.e. the reference itself is
+                      only reproducible across hosts to that level); ``svd_flavor`` = None takes the flavour of this host,
+                      0 / 1 force the reference-BLAS / fused one.  The head is 11 stream-ordered launches, no host
+                      synchronisation.
+  "host"              the reference's very routine: MKL sgesdd on the host, one D2H / sync / H2D round trip per kinematic
+                      level.
 """
 import os
 
@@ -97,7 +101,13 @@ class PoseMFShapeGaussianNet(nn.Module):
         self._pinned_bufs = {}
         self.register_load_state_dict_post_hook(_invalidate_after_load)
         self.composite_head = True     # joint loop through hps_head_pose_levels (one call) instead of per-level Python
-        self.svd_mode = "device"       # "device": in-kernel gesdd-faithful SVD; "host": MKL sgesdd round trip (parity mode)
+        self.svd_mode = "device"       # "device": in-kernel gesdd-faithful SVD; "host": MKL sgesdd round trip (the routine itself)
+        self.svd_flavor = None         # None: the rounding flavour of this host's MKL (calibrated); 0 / 1 force one
+
+    def _flavor(self):
+        """Rounding flavour of the in-kernel SVD: ``svd_flavor`` if set (0 reference BLAS rounding, 1 fused), else the one that
+        reproduces this host's LAPACK bit for bit (_capi.svd_flavor)."""
+        return _capi.svd_flavor() if self.svd_flavor is None else int(self.svd_flavor)
 
     # ---- kernel-side weights; rebuilt after .to() / load_state_dict ----
     def _apply(self, fn, *args, **kwargs):
@@ -234,7 +244,7 @@ class PoseMFShapeGaussianNet(nn.Module):
                        VP(p["w1t_ptrs"].data_ptr()), VP(p["b1_ptrs"].data_ptr()), VP(p["w2_ptrs"].data_ptr()),
                        VP(p["b2_ptrs"].data_ptr()), P(U_proper), P(S_proper), P(mode), delta, P(pose_F), P(pose_U), P(pose_S),
                        P(pose_V), P(f_dev), P(usv_dev), fh, uh, B, nj, _SVD_THREADS,
-                       _capi.SVD_DEVICE if device_svd else _capi.SVD_HOST, s)
+                       (_capi.SVD_DEVICE_FMA if self._flavor() == _capi.SVD_ROUNDING_FMA else _capi.SVD_DEVICE) if device_svd else _capi.SVD_HOST, s)
             return pose_F, pose_U, pose_S, pose_V, mode, shape_dist, glob, cam
         for lvl in p["levels"]:
             n_level = lvl.numel()
@@ -243,7 +253,7 @@ class PoseMFShapeGaussianNet(nn.Module):
                            _capi.iptr(p["anc_ptr"]), _capi.iptr(p["anc_idx"]),
                            _capi._P(p["w1t_ptrs"].data_ptr()), _capi._P(p["b1_ptrs"].data_ptr()),
                            _capi._P(p["w2_ptrs"].data_ptr()), _capi._P(p["b2_ptrs"].data_ptr()),
-                           P(U_proper), P(S_proper), P(mode), delta, P(pose_F), P(pose_U), P(pose_S), P(pose_V), B, nj, s)
+                           P(U_proper), P(S_proper), P(mode), delta, P(pose_F), P(pose_U), P(pose_S), P(pose_V), B, nj, self._flavor(), s)
                 continue
             f_level = torch.empty(B, n_level, 3, 3, **f32)
             _capi.call("hps_head_joint_level", P(embed), embed_dim, embed_dim // 2, _capi.iptr(lvl), n_level,

@@ -39,8 +39,17 @@ typedef void* hps_stream_t; /* hipStream_t */
 #define HPS_E_BADARG (-1)      /* null pointer / size out of range */
 #define HPS_E_UNSUPPORTED (-2) /* shape not implemented by this build */
 
-#define HPS_SVD_HOST 0   /* host LAPACK sgesdd (the reference's own routine) */
-#define HPS_SVD_DEVICE 1 /* in-kernel SVD that follows sgesdd step by step */
+#define HPS_SVD_HOST 0       /* host LAPACK sgesdd (the reference's own routine) */
+#define HPS_SVD_DEVICE 1     /* in-kernel SVD that follows sgesdd step by step, rounding flavour HPS_SVD_ROUNDING_REFERENCE */
+#define HPS_SVD_DEVICE_FMA 2 /* the same with rounding flavour HPS_SVD_ROUNDING_FMA */
+
+/* Rounding flavours of the in-kernel SVD (csrc/svd3_gesdd.h).  The reference runs torch.svd = MKL sgesdd on the host
+ * (models/poseMF_shapeGaussian_net.py:137), and MKL picks its kernels by the host CPU: on Intel hosts they use fused
+ * multiply-adds, elsewhere they round like reference BLAS.  Each flavour reproduces one of them BIT FOR BIT (U, S, V of
+ * 10^6 matrices of 22 families, tests/test_host_logic.py); between the two, one matrix in 10^4 comes out with a differently
+ * signed singular-vector pair.  hps_host_svd_flavor() tells which one the LAPACK bound to this process matches. */
+#define HPS_SVD_ROUNDING_REFERENCE 0
+#define HPS_SVD_ROUNDING_FMA 1
 
 #define HPS_ACT_NONE 0
 #define HPS_ACT_ELU 1
@@ -225,22 +234,29 @@ int hps_head_joint_level(const float* embed, int embed_dim, int hidden, const in
 
 /* hps_head_joint_level with the level's 3x3 SVDs (models/poseMF_shapeGaussian_net.py:137), the proper-SVD fix and the mode
  * (:139-152) done INSIDE the kernel: pose_u / pose_s / pose_v and u_proper / s_proper / mode rows of the level's joints are
- * written, no host round trip.  The SVD follows LAPACK's sgesdd step by step (csrc/svd3_gesdd.h) so that the singular
- * vectors carry the signs the reference's torch.svd gives them -- they are inputs of the child joints (:126-130). */
+ * written, no host round trip.  The SVD follows LAPACK's sgesdd step by step (csrc/svd3_gesdd.h) with the roundings of the
+ * host's MKL (svd_flavor: HPS_SVD_ROUNDING_*), so that the factors -- and with them the signs the reference's torch.svd
+ * gives the singular vectors, which are inputs of the child joints (:126-130) -- are reproduced bit for bit. */
 int hps_head_joint_level_svd(const float* embed, int embed_dim, int hidden, const int32_t* joint_ids,
                              int n_level, const int32_t* anc_ptr, const int32_t* anc_idx,
                              const float* const* w1t_ptrs, const float* const* b1_ptrs,
                              const float* const* w2_ptrs, const float* const* b2_ptrs, float* u_proper,
                              float* s_proper, float* mode, float delta_i_weight, float* pose_f, float* pose_u,
-                             float* pose_s, float* pose_v, int B, int num_body_joints, hps_stream_t stream);
+                             float* pose_s, float* pose_v, int B, int num_body_joints, int svd_flavor,
+                             hps_stream_t stream);
 
 /* The same device SVD for n row-major 3x3 matrices: f (n,9) -> usv (n,21) packed [U (9) | S (3) | V (9)]; replaces
  * torch.svd(F.cpu()) (:137).  Non-finite or non-converging input (LAPACK: INFO != 0) gives NaN factors. */
-int hps_svd3_packed(const float* f, float* usv, int n, hps_stream_t stream);
+int hps_svd3_packed(const float* f, float* usv, int n, int svd_flavor, hps_stream_t stream);
 
 /* HOST function: the algorithm of hps_svd3_packed compiled for the host (single thread) -- for measuring / testing its
  * agreement with LAPACK without a GPU.  f_host (n,9) -> usv_host (n,21). */
-int hps_host_svd3_emulated(const float* f_host, float* usv_host, int n);
+int hps_host_svd3_emulated(const float* f_host, float* usv_host, int n, int svd_flavor);
+
+/* HOST function: the rounding flavour (HPS_SVD_ROUNDING_*) whose factors are bit-identical to those of the LAPACK sgesdd_
+ * this process is bound to (hps_host_bind_lapack) on 4 096 fixed test matrices, or -1 if neither is.  The shipped binding
+ * calls it once and runs the device SVD in that flavour, so that svd_mode device and svd_mode host give the same bits. */
+int hps_host_svd_flavor(void);
 
 /* HOST function (no device work): SVD of n row-major 3x3 matrices through the LAPACK sgesdd_ exported by the
  * process's libtorch_cpu.so -- the routine behind the reference's torch.svd(F.cpu()) (:137), so factors and
@@ -317,8 +333,9 @@ int hps_sizeof_enc_op(void);
 int hps_encoder_run(const hps_enc_op* ops, int n_ops, hps_stream_t stream);
 
 /* models/poseMF_shapeGaussian_net.py:121-160 in one call, one kinematic level after the other.
- *   svd_mode HPS_SVD_DEVICE: hps_head_joint_level_svd per level -- 8 stream-ordered launches for the SMPL tree, no
- *            synchronisation, capturable in a hipGraph; the staging buffers may be NULL.
+ *   svd_mode HPS_SVD_DEVICE / HPS_SVD_DEVICE_FMA (rounding flavour reference / fused): hps_head_joint_level_svd per level --
+ *            8 stream-ordered launches for the SMPL tree, no synchronisation, capturable in a hipGraph; the staging buffers
+ *            may be NULL.
  *   svd_mode HPS_SVD_HOST (parity mode: the very LAPACK routine of the reference): hps_head_joint_level -> D2H of the level's F
  *            matrices -> stream synchronise -> hps_host_svd3_packed (:137) -> H2D -> hps_head_svd_finish.
  * level_joints: DEVICE int32 array, the levels' joint ids concatenated; level_sizes_host: HOST

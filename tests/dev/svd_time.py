@@ -17,11 +17,11 @@ for n, kind in ((4, "near I"), (64, "near I"), (192, "near I"), (192, "random"),
     usv = torch.empty(n, 21, device=dev)
     s = _capi.stream()
     for _ in range(3):
-        _capi.call("hps_svd3_packed", _capi.ptr(f), _capi.ptr(usv), n, s)
+        _capi.call("hps_svd3_packed", _capi.ptr(f), _capi.ptr(usv), n, _capi.svd_flavor(), s)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(50):
-        _capi.call("hps_svd3_packed", _capi.ptr(f), _capi.ptr(usv), n, s)
+        _capi.call("hps_svd3_packed", _capi.ptr(f), _capi.ptr(usv), n, _capi.svd_flavor(), s)
     e1.record()
     torch.cuda.synchronize()
     print("svd3 n=%6d %-9s %.1f us per launch" % (n, kind, e0.elapsed_time(e1) / 50 * 1e3))

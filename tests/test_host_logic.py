@@ -3,6 +3,7 @@ synthetic-model determinism, sharding arithmetic."""
 import hashlib
 
 import numpy as np
+import pytest
 import torch
 
 from hierarchicalprobabilistic3dhuman_amd import configs, smpl_data, sharding
@@ -78,56 +79,82 @@ def test_shard_ranges_partition_the_batch():
     assert sharding.shard_range(512, 3, 8) == (192, 256)                      # BASELINE configs[2]: 64 images per GPU
 
 
-def _emulated_svd(F):
+def _emulated_svd(F, flavor=None):
     import ctypes
     from hierarchicalprobabilistic3dhuman_amd import _capi
     F = F.contiguous().float()
     out = torch.empty(F.shape[0], 21)
-    rc = _capi.load().hps_host_svd3_emulated(ctypes.c_void_p(F.data_ptr()), ctypes.c_void_p(out.data_ptr()), F.shape[0])
+    rc = _capi.load().hps_host_svd3_emulated(ctypes.c_void_p(F.data_ptr()), ctypes.c_void_p(out.data_ptr()), F.shape[0],
+                                             _capi.svd_flavor() if flavor is None else flavor)
     return out[:, :9].reshape(-1, 3, 3), out[:, 9:12], out[:, 12:].reshape(-1, 3, 3), rc
 
 
+def _svd_families(n):
+    """Matrix families the bit-level agreement is asserted on: the head's regime (I + noise), generic, ill-conditioned,
+    rank-deficient, exact ties (orthogonal matrices: sigma = 1, 1, 1), exact and signed zeros, structured, tiny / huge
+    (sgesdd's rescaling path)."""
+    g = torch.Generator().manual_seed(0)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    eye = torch.eye(3)[None]
+    fam = [("I + 0.05 N", eye + 0.05 * rn(n, 3, 3)), ("I + 0.5 N", eye + 0.5 * rn(n, 3, 3)), ("I + 2 N", eye + 2.0 * rn(n, 3, 3)),
+           ("30 N", 30.0 * rn(n, 3, 3)), ("100 I + 20 N", 100.0 * eye + 20.0 * rn(n, 3, 3)), ("I + 1e-3 N", eye + 1e-3 * rn(n, 3, 3)),
+           ("diag(500,400,300) + N", torch.diag(torch.tensor([500.0, 400.0, 300.0]))[None] + rn(n, 3, 3)),
+           ("columns scaled 1e3, 1, 1e-3", rn(n, 3, 3) * torch.tensor([1e3, 1.0, 1e-3]))]
+    q = torch.linalg.qr(rn(n // 4, 3, 3))[0]
+    fam += [("orthogonal (exact ties)", q), ("orthogonal + 1e-6 N", q + 1e-6 * rn(n // 4, 3, 3)),
+            ("rank 2", rn(n // 4, 3, 2) @ rn(n // 4, 2, 3)), ("rank 1", rn(n // 4, 3, 1) @ rn(n // 4, 1, 3)),
+            ("integers", torch.randint(-3, 4, (n // 4, 3, 3), generator=g).float()),
+            ("half zeros (signed)", rn(n // 4, 3, 3) * (torch.rand(n // 4, 3, 3, generator=g) > 0.5)),
+            ("half zeros (+0)", rn(n // 4, 3, 3) * (torch.rand(n // 4, 3, 3, generator=g) > 0.5) + 0.0),
+            ("diagonal", torch.diag_embed(rn(n // 4, 3))), ("upper triangular", torch.triu(rn(n // 4, 3, 3))),
+            ("lower triangular", torch.tril(rn(n // 4, 3, 3))), ("symmetric", (lambda a: a + a.transpose(1, 2))(rn(n // 4, 3, 3))),
+            ("1e-20 N", 1e-20 * rn(n // 4, 3, 3)), ("1e20 N", 1e20 * rn(n // 4, 3, 3)),
+            ("1e-30 I + 1e-31 N", 1e-30 * eye + 1e-31 * rn(n // 4, 3, 3))]
+    return [(name, f.contiguous().float()) for name, f in fam]
+
+
 def test_gesdd_faithful_svd_agrees_with_lapack(golden):
-    """the device SVD's algorithm (csrc/svd3_gesdd.h: LAPACK sgesdd followed step by step), compiled for the
-    host, against torch.svd = MKL sgesdd, the reference's routine (models/poseMF_shapeGaussian_net.py:137).  Measured here on
-    every run: singular-vector SIGN agreement (the load-bearing part, :126-130) and the factors themselves.
-    Observed mismatch rate 0.7-1.4e-4 per matrix (always columns 2 and 3 of U and V negated together: mode and S are
-    unaffected); asserted <= 5e-4.  Golden F matrices: no mismatch."""
-    torch.manual_seed(0)
-    cases = [("golden", golden["net_F"].reshape(-1, 3, 3))]
-    for sigma in (0.05, 0.5, 2.0):
-        cases.append(("I + %.2f N" % sigma, torch.eye(3)[None] + sigma * torch.randn(100000, 3, 3)))
-    cases.append(("100 I + 20 N", torch.eye(3)[None] * 100 + 20 * torch.randn(100000, 3, 3)))
+    """the device SVD's algorithm (csrc/svd3_gesdd.h: LAPACK sgesdd followed step by step with MKL's roundings),
+    compiled for the host, against torch.svd = MKL sgesdd, the reference's routine (models/poseMF_shapeGaussian_net.py:137).
+    The singular-vector SIGNS are load-bearing (:126-130).  MKL picks its kernels by the host CPU (fused multiply-adds on Intel
+    hosts, reference-BLAS rounding elsewhere); hps_host_svd_flavor calibrates which flavour of the header matches this host's,
+    and with it U, S and V must be BIT-IDENTICAL to torch.svd on every matrix of 22 families (1.15 x 10^6 matrices).  The other
+    flavour is the same algorithm with other last bits: no factor further than 1e-3 / 2e-6 away, and a differently signed
+    singular-vector pair in about one matrix of 10^4 -- which is how far the reference itself is reproducible between an Intel
+    and an AMD host."""
+    from hierarchicalprobabilistic3dhuman_amd import _capi
+    native = _capi.load().hps_host_svd_flavor()
+    assert native in (0, 1), "neither rounding flavour reproduces this host's LAPACK sgesdd (another MKL build?)"
+    assert _capi.svd_flavor() == native
+    cases = [("golden net_F", golden["net_F"].reshape(-1, 3, 3).contiguous())] + _svd_families(100000)
+    total = other_flips = well_total = 0
     for name, F in cases:
         U, S, V = torch.svd(F)
-        u, s, v, rc = _emulated_svd(F)
-        assert rc == 0
-        flipped = (((U * u).sum(1) < 0) | ((V * v).sum(1) < 0))              # per column: singular vector with the other sign
-        bad = flipped.any(1)
-        rate = float(bad.float().mean())
-        assert rate <= (0.0 if name == "golden" else 5e-4), (name, rate)
-        # when a matrix with well separated singular values disagrees, it is the (2, 3) pair, jointly in U and V (a half turn
-        # about the first singular direction): U diag(s) V^T is the same matrix
-        gap = torch.minimum(S[:, 0] - S[:, 1], S[:, 1] - S[:, 2]) / S[:, 0]
-        sep = bad & (gap > 0.02)
-        assert bool((flipped[sep] == torch.tensor([False, True, True])).all()), name
-        ok = ~bad & (gap > 1e-3)                # vectors of (nearly) equal singular values are not comparable entry by entry
-        assert float((S - s).abs().max() / S.max()) <= 2e-6, name
-        assert float(torch.maximum((U - u)[ok].abs().amax(), (V - v)[ok].abs().amax())) <= 1e-3, name
-        # both are SVDs of F to fp32 accuracy, mismatching ones included
-        rec = torch.matmul(u * s[:, None, :], v.transpose(1, 2))
-        assert float((rec - F).abs().max() / F.abs().max()) <= 1e-5, name
-        eye = torch.eye(3).expand_as(u)
-        assert float((torch.matmul(u.transpose(1, 2), u) - eye).abs().max()) <= 1e-5, name
-    # the mode U_p V_p^T and the proper singular values do not depend on the sign choice at all
-    F = cases[2][1][:20000]
-    U, S, V = torch.svd(F)
-    u, s, v, _ = _emulated_svd(F)
-    Up, Vp = U.clone(), V.clone()
-    Up[:, :, 2] *= torch.det(U)[:, None]; Vp[:, :, 2] *= torch.det(V)[:, None]
-    up, vp = u.clone(), v.clone()
-    up[:, :, 2] *= torch.det(u)[:, None]; vp[:, :, 2] *= torch.det(v)[:, None]
-    assert float((torch.matmul(Up, Vp.transpose(1, 2)) - torch.matmul(up, vp.transpose(1, 2))).abs().max()) <= 2e-4
+        u, s, v, rc = _emulated_svd(F, native)
+        assert rc == 0, name
+        assert torch.equal(s, S) and torch.equal(u, U) and torch.equal(v, V), name          # bit for bit (as values: -0 == +0)
+        total += F.shape[0]
+        # the other flavour
+        u2, s2, v2, rc = _emulated_svd(F, 1 - native)
+        assert rc == 0, name
+        scale = S.abs().max(1, keepdim=True)[0].clamp_min(1e-30)
+        assert float(((S - s2).abs() / scale).max()) <= 2e-6, name
+        # singular vectors are comparable where the values are well separated and none is (numerically) zero
+        well = (torch.minimum(S[:, 0] - S[:, 1], S[:, 1] - S[:, 2]) / scale[:, 0] > 1e-3) & (S[:, 2] / scale[:, 0] > 1e-4)
+        flipped = (((U * u2).sum(1) < 0) | ((V * v2).sum(1) < 0)).any(1) & well
+        other_flips += int(flipped.sum())
+        well_total += int(well.sum())
+        gap_ok = well & ~flipped
+        if gap_ok.any():
+            assert float(torch.maximum((U - u2)[gap_ok].abs().amax(), (V - v2)[gap_ok].abs().amax())) <= 1e-3, name
+        rec = torch.matmul(u2 * s2[:, None, :], v2.transpose(1, 2))
+        assert float(((rec - F).abs().amax((1, 2)) / F.abs().amax((1, 2)).clamp_min(1e-30)).max()) <= 1e-5, name
+        if name == "golden net_F":
+            assert int(flipped.sum()) == 0                       # the golden matrices come out alike in both flavours
+    print("svd3_gesdd flavour %d vs torch.svd: %d of %d matrices bit-identical in U, S, V; the other flavour: %d of %d "
+          "well-conditioned matrices with a differently signed vector pair (%.1e)"
+          % (native, total, total, other_flips, well_total, other_flips / max(1, well_total)))
+    assert other_flips <= 5e-4 * well_total
 
 
 def test_gesdd_faithful_svd_edge_cases():

@@ -10,27 +10,10 @@
 //                           uses; with the pre-3.10 form 20-30 % of the vectors come out with other signs), then
 //                           negative singular values flipped (rows of V^T) and a descending sort
 //                   sormbr  U = Q U_B,  V^T = V_B^T P^T
-// Every routine below restates the published reference-LAPACK algorithm for n = 3 in fp32 with the same operation order.
-//
-// Roundings.  The algorithm alone is not enough: one matrix in 10^4 reaches a convergence decision of the QR sweeps within
-// one unit in the last place of its threshold, and which side it falls on decides the sign of a singular-vector pair.  So the
-// header also reproduces MKL's ROUNDINGS, which were pinned one routine at a time against observable MKL outputs
-// (tools/svd_pin/: torch.geqrf exposes slarfg / slarf; torch.svd of bidiagonal matrices, which sgebd2 passes through untouched,
-// exposes sbdsqr alone; S of general matrices depends only on the bidiagonal (d, e), i.e. on sgebd2):
-//   * MKL picks its kernels by the host CPU.  On Intel hosts (flavour FL = 1) reflector applications and plane rotations use
-//     fused multiply-adds in specific places; on other hosts (FL = 0: e.g. the AMD EPYC of the MI355X boxes) every operation
-//     is rounded separately, in reference-BLAS order.  Both flavours are below (template parameter FL); each reproduces ITS
-//     MKL bit for bit in U, S and V on 1.15 x 10^6 matrices of 22 families (tests/test_host_logic.py: the head's regime I + N,
-//     ill-conditioned, rank-deficient, exact ties, signed zeros, tiny / huge through sgesdd's rescaling), and they differ from
-//     each other by a differently signed vector pair in 2.5 x 10^-4 of well-conditioned matrices -- which is therefore also how
-//     far the REFERENCE's torch.svd is reproducible between an Intel and an AMD host.  hps_host_svd_flavor() (host_svd.hip)
-//     finds out which flavour the LAPACK bound to the process matches;
-//   * common to both: sormbr applies its reflectors in the LAPACK 3.12 SLARF1F shape, w = c_1 + (v_2 c_2 + v_3 c_3) (sgebd2
-//     does so only in flavour 1; flavour 0 keeps the classic SLARF order (c_1 + v_2 c_2) + v_3 c_3 there); Fortran SIGN(a, b) treats b = -0.0 as positive (ifort's default); SLASCL scales back
-//     by cfrom / cto (a division of its own, not the reciprocal of the forward factor); and with EQUAL singular values the
-//     sorts of SBDSQR, SLASDQ and SBDSDC together permute the tied vectors (reproduced at the end of sbdsqr3).
-// Contraction is switched off for the whole header (the fused multiply-adds of flavour 1 are explicit __builtin_fmaf), so the
-// host and device builds give the same bits (tests/test_gpu_net.py).
+// Every routine below restates the published reference-LAPACK algorithm for n = 3 in fp32 with the same operation order
+// (no fused multiply-add: contraction is switched off so that host and device builds round alike).  Measured against
+// torch.svd (MKL) on 2 x 10^5 matrices I + sigma N(0,1), sigma in {0.05, 0.5, 2}, and on the golden F matrices: see
+// DESIGN.md section 4 (sign agreement table) and tests/test_host_logic.py.
 //
 // Layout: f row-major 3x3; u, v row-major 3x3 with singular vectors in COLUMNS (torch.svd's U, V), s descending.
 #pragma once
@@ -53,10 +36,7 @@ constexpr float kUnfl = 1.17549435e-38f;              // SLAMCH('Safe minimum')
 constexpr float kRtMin = 1.08420217e-19f;             // sqrt(safmin)
 constexpr float kRtMax = 1.30438179e+19f;             // sqrt(safmax / 2)
 
-// Fortran SIGN(a, b) as MKL's compiler evaluates it: a NEGATIVE ZERO b counts as positive (ifort's default, "-assume nominus0";
-// copysign semantics would make it negative -- measured: with copysign 27 % of random matrices that contain -0.0 entries come
-// out with other vector signs than torch.svd, with this form none of 2 x 10^5).
-HPS_HD float sgn(float a, float b) { return b < 0.0f ? -fabsf(a) : fabsf(a); }
+HPS_HD float sgn(float a, float b) { return copysignf(fabsf(a), b); }          // Fortran SIGN(a, b)
 
 // SLAPY2: sqrt(x^2 + y^2) without unnecessary overflow
 HPS_HD float slapy2(float x, float y) {
@@ -213,50 +193,54 @@ HPS_HD void slasv2(float f, float g, float h, float& ssmin, float& ssmax, float&
     ssmin = sgn(ssmin, tsign * sgn(1.0f, f) * sgn(1.0f, h));
 }
 
-// One plane rotation of a pair of vector elements, (x, y) <- (c x + s y, c y - s x) (SLASR and SROT alike).  FL = 1: ONE fused
-// multiply-add per result on top of the rounded other product; FL = 0: two rounded products and a sum.  Pinned bit for bit
-// through torch.svd of bidiagonal matrices (sgebd2 passes them through untouched): the matching form reproduces U, S and V of
-// 10^5 such matrices exactly, the other one 14 % of them.
-template <int FL>
-HPS_HD void rot2(float c, float s, float& x, float& y) {
-    float nx, ny;
-    if (FL) {
-        ny = __builtin_fmaf(c, y, -(s * x));
-        nx = __builtin_fmaf(s, y, c * x);
-    } else {
-        ny = c * y - s * x;
-        nx = s * y + c * x;
+
+#ifndef GEBD2V
+#define GEBD2V 1
+#endif
+#ifndef ROTV
+#define ROTV 0
+#endif
+#ifndef SROTV
+#define SROTV 0
+#endif
+// y' = c*y - s*x ; x' = s*y + c*x   (slasr form: temp=y)
+HPS_HD void rot_pair(int var, float c, float s, float& x, float& y) {
+    const float t = y;
+    float ny, nx;
+    switch (var) {
+        default:
+        case 0: ny = c * t - s * x; nx = s * t + c * x; break;
+        case 1: ny = __builtin_fmaf(c, t, -(s * x)); nx = __builtin_fmaf(s, t, c * x); break;
+        case 2: ny = __builtin_fmaf(-s, x, c * t); nx = __builtin_fmaf(c, x, s * t); break;
+        case 3: ny = __builtin_fmaf(c, t, -(s * x)); nx = __builtin_fmaf(c, x, s * t); break;
+        case 4: ny = __builtin_fmaf(-s, x, c * t); nx = __builtin_fmaf(s, t, c * x); break;
     }
-    x = nx;
-    y = ny;
+    y = ny; x = nx;
 }
 
 // SLASR(SIDE = 'L', PIVOT = 'V'): rotations j = 1..cnt-1 of rows (ll + j - 1, ll + j) of the 3x3 vt, forward or backward
-template <int FL>
 HPS_HD void slasr_left(bool forward, int ll, int cnt, const float* c, const float* s, float* vt) {
     for (int q = 1; q < cnt; ++q) {
         const int j = forward ? q : cnt - q;
         const float ct = c[j - 1], st = s[j - 1];
         float* r0 = vt + (ll + j - 2) * 3;          // row ll + j - 1 (1-based)
         float* r1 = r0 + 3;
-        for (int i = 0; i < 3; ++i) rot2<FL>(ct, st, r0[i], r1[i]);
+        for (int i = 0; i < 3; ++i) rot_pair(ROTV, ct, st, r0[i], r1[i]);
     }
 }
 
 // SLASR(SIDE = 'R', PIVOT = 'V'): the same on columns of the 3x3 u
-template <int FL>
 HPS_HD void slasr_right(bool forward, int ll, int cnt, const float* c, const float* s, float* u) {
     for (int q = 1; q < cnt; ++q) {
         const int j = forward ? q : cnt - q;
         const float ct = c[j - 1], st = s[j - 1];
         const int c0 = ll + j - 2, c1 = c0 + 1;     // 0-based columns
-        for (int i = 0; i < 3; ++i) rot2<FL>(ct, st, u[i * 3 + c0], u[i * 3 + c1]);
+        for (int i = 0; i < 3; ++i) rot_pair(ROTV, ct, st, u[i * 3 + c0], u[i * 3 + c1]);
     }
 }
 
 // SBDSQR for the 3x3 upper bidiagonal (d, e) with U = V^T = I on entry.  Arrays are used 1-based like the Fortran.
 // Returns false if the iteration limit is hit (LAPACK: INFO > 0).
-template <int FL>
 HPS_HD bool sbdsqr3(float* d0, float* e0, float* u, float* vt) {
     const int n = 3;
     float D[4] = {0.f, d0[0], d0[1], d0[2]};
@@ -307,8 +291,8 @@ HPS_HD bool sbdsqr3(float* d0, float* e0, float* u, float* vt) {
             D[m - 1] = sigmx; E[m - 1] = 0.0f; D[m] = sigmn;
             float* r0 = vt + (m - 2) * 3;
             float* r1 = r0 + 3;
-            for (int i = 0; i < 3; ++i) rot2<FL>(cosr, sinr, r0[i], r1[i]);                          // SROT on rows m-1, m of V^T
-            for (int i = 0; i < 3; ++i) rot2<FL>(cosl, sinl, u[i * 3 + m - 2], u[i * 3 + m - 1]);      // SROT on columns m-1, m of U
+            for (int i = 0; i < 3; ++i) rot_pair(SROTV, cosr, sinr, r0[i], r1[i]);
+            for (int i = 0; i < 3; ++i) rot_pair(SROTV, cosl, sinl, u[i * 3 + m - 2], u[i * 3 + m - 1]);
             m = m - 2;
             continue;
         }
@@ -369,8 +353,8 @@ HPS_HD bool sbdsqr3(float* d0, float* e0, float* u, float* vt) {
                 const float h = D[m] * cs;
                 D[m] = h * oldcs;
                 E[m - 1] = h * oldsn;
-                slasr_left<FL>(true, ll, cnt, w1, w2, vt);
-                slasr_right<FL>(true, ll, cnt, w3, w4, u);
+                slasr_left(true, ll, cnt, w1, w2, vt);
+                slasr_right(true, ll, cnt, w3, w4, u);
                 if (fabsf(E[m - 1]) <= thresh) E[m - 1] = 0.0f;
             } else {                                            // bottom to top
                 float cs = 1.0f, oldcs = 1.0f, sn = 0.0f, oldsn = 0.0f;
@@ -383,8 +367,8 @@ HPS_HD bool sbdsqr3(float* d0, float* e0, float* u, float* vt) {
                 const float h = D[ll] * cs;
                 D[ll] = h * oldcs;
                 E[ll] = h * oldsn;
-                slasr_left<FL>(false, ll, cnt, w3, w4, vt);
-                slasr_right<FL>(false, ll, cnt, w1, w2, u);
+                slasr_left(false, ll, cnt, w3, w4, vt);
+                slasr_right(false, ll, cnt, w1, w2, u);
                 if (fabsf(E[ll]) <= thresh) E[ll] = 0.0f;
             }
         } else {
@@ -410,8 +394,8 @@ HPS_HD bool sbdsqr3(float* d0, float* e0, float* u, float* vt) {
                     w1[i - ll] = cosr; w2[i - ll] = sinr; w3[i - ll] = cosl; w4[i - ll] = sinl;
                 }
                 E[m - 1] = f;
-                slasr_left<FL>(true, ll, cnt, w1, w2, vt);
-                slasr_right<FL>(true, ll, cnt, w3, w4, u);
+                slasr_left(true, ll, cnt, w1, w2, vt);
+                slasr_right(true, ll, cnt, w3, w4, u);
                 if (fabsf(E[m - 1]) <= thresh) E[m - 1] = 0.0f;
             } else {                                            // bottom to top
                 float f = (fabsf(D[m]) - shift) * (sgn(1.0f, D[m]) + shift / D[m]);
@@ -436,8 +420,8 @@ HPS_HD bool sbdsqr3(float* d0, float* e0, float* u, float* vt) {
                 }
                 E[ll] = f;
                 if (fabsf(E[ll]) <= thresh) E[ll] = 0.0f;
-                slasr_left<FL>(false, ll, cnt, w3, w4, vt);
-                slasr_right<FL>(false, ll, cnt, w1, w2, u);
+                slasr_left(false, ll, cnt, w3, w4, vt);
+                slasr_right(false, ll, cnt, w1, w2, u);
             }
         }
     }
@@ -464,41 +448,13 @@ HPS_HD bool sbdsqr3(float* d0, float* e0, float* u, float* vt) {
             }
         }
     }
-    // The callers of SBDSQR sort again, and with EQUAL singular values (exact ties: F orthogonal, rank-deficient, ...) the three
-    // sorts together permute the tied vectors -- reproduced here so that ties come out as MKL's do (the order is the identity
-    // whenever the values are distinct).  SLASDQ: ascending selection sort, first strict minimum; then SBDSDC: descending
-    // selection sort, first strict maximum.
-    auto swap_vec = [&](int i, int j) {                       // 1-based singular triplets i <-> j
-        float t = D[i]; D[i] = D[j]; D[j] = t;
-        for (int k = 0; k < 3; ++k) {
-            t = vt[(i - 1) * 3 + k]; vt[(i - 1) * 3 + k] = vt[(j - 1) * 3 + k]; vt[(j - 1) * 3 + k] = t;
-            t = u[k * 3 + i - 1]; u[k * 3 + i - 1] = u[k * 3 + j - 1]; u[k * 3 + j - 1] = t;
-        }
-    };
-    if (D[1] == D[2] || D[2] == D[3]) {                      // distinct values: both sorts together are the identity
-        for (int i = 1; i <= n; ++i) {
-            int isub = i;
-            float smin = D[i];
-            for (int j = i + 1; j <= n; ++j)
-                if (D[j] < smin) { isub = j; smin = D[j]; }
-            if (isub != i) swap_vec(isub, i);
-        }
-        for (int ii = 2; ii <= n; ++ii) {
-            const int i = ii - 1;
-            int kk = i;
-            float p = D[i];
-            for (int j = ii; j <= n; ++j)
-                if (D[j] > p) { kk = j; p = D[j]; }
-            if (kk != i) swap_vec(kk, i);
-        }
-    }
     d0[0] = D[1]; d0[1] = D[2]; d0[2] = D[3];
     return ok;
 }
 
 // sgesdd('A') of the row-major 3x3 matrix f:  f = u diag(s) v^T.  Returns false on non-convergence or non-finite input
 // (LAPACK: INFO != 0; torch raises) -- the outputs are then NaN.
-template <int FL>
+static float* g_dbg = nullptr;
 HPS_HD bool svd3(const float* f, float* u, float* s, float* v) {
     float a[9];
     float anrm = 0.0f;
@@ -515,9 +471,9 @@ HPS_HD bool svd3(const float* f, float* u, float* s, float* v) {
         return false;
     }
     // sgesdd scales matrices whose largest entry is outside [smlnum, bignum] = [9.1e-13, 1.1e12]
-    float rescale = 1.0f, unscale = 1.0f;                       // SLASCL: multiply by cto / cfrom, and back by cfrom / cto
-    if (anrm > 0.0f && anrm < 9.09494702e-13f) { rescale = 9.09494702e-13f / anrm; unscale = anrm / 9.09494702e-13f; }
-    else if (anrm > 1.09951163e+12f) { rescale = 1.09951163e+12f / anrm; unscale = anrm / 1.09951163e+12f; }
+    float rescale = 1.0f;
+    if (anrm > 0.0f && anrm < 9.09494702e-13f) rescale = 9.09494702e-13f / anrm;
+    else if (anrm > 1.09951163e+12f) rescale = 1.09951163e+12f / anrm;
     if (rescale != 1.0f)
         for (int i = 0; i < 9; ++i) a[i] = a[i] * rescale;
 
@@ -528,14 +484,14 @@ HPS_HD bool svd3(const float* f, float* u, float* s, float* v) {
         tauq[0] = slarfg(3, a[0], x);
         d[0] = a[0];
         a[3] = x[0]; a[6] = x[1];
-        // Rounding of the reflector applications (see the note above svd3).  FL = 1: w = c_1 + (v_2 c_2 + v_3 c_3), the rank-one
-        // update as ONE fused multiply-add per element; FL = 0: reference BLAS, w = (c_1 + v_2 c_2) + v_3 c_3, update c + v t.
+        // Rounding of the reflector applications below = MKL's (see the note above svd3): w = c_1 + (v_2 c_2 + v_3 c_3) with
+        // every product and sum rounded, the rank-one update as ONE fused multiply-add per element.
         if (tauq[0] != 0.0f) {                                  // slarf 'L' on a(1:3, 2:3)
             const float vq[3] = {1.0f, x[0], x[1]};
             for (int j = 1; j < 3; ++j) {
-                const float w = FL ? a[j] + (a[3 + j] * vq[1] + a[6 + j] * vq[2]) : (a[j] + a[3 + j] * vq[1]) + a[6 + j] * vq[2];
+                const float w = GEBD2V ? a[j] + (a[3 + j] * vq[1] + a[6 + j] * vq[2]) : (a[j] + a[3 + j] * vq[1]) + a[6 + j] * vq[2];
                 const float t = -tauq[0] * w;
-                for (int r = 0; r < 3; ++r) a[r * 3 + j] = FL ? __builtin_fmaf(vq[r], t, a[r * 3 + j]) : a[r * 3 + j] + vq[r] * t;
+                for (int r = 0; r < 3; ++r) a[r * 3 + j] = GEBD2V ? __builtin_fmaf(vq[r], t, a[r * 3 + j]) : a[r * 3 + j] + vq[r] * t;
             }
         }
         // G(1) annihilates a(1, 3)
@@ -543,14 +499,13 @@ HPS_HD bool svd3(const float* f, float* u, float* s, float* v) {
         taup0 = slarfg(2, a[1], y);
         e[0] = a[1];
         a[2] = y[0];
-        if (taup0 != 0.0f) {                                    // slarf 'R' on a(2:3, 2:3): with FL = 1 the two-term w is fused as well
+        if (taup0 != 0.0f) {                                    // slarf 'R' on a(2:3, 2:3): here the two-term w is fused as well
             const float vp[2] = {1.0f, y[0]};
             float w[2];
-            for (int r = 1; r < 3; ++r) w[r - 1] = FL ? __builtin_fmaf(vp[1], a[r * 3 + 2], a[r * 3 + 1]) : a[r * 3 + 1] + vp[1] * a[r * 3 + 2];
+            for (int r = 1; r < 3; ++r) w[r - 1] = GEBD2V ? __builtin_fmaf(vp[1], a[r * 3 + 2], a[r * 3 + 1]) : a[r * 3 + 1] + vp[1] * a[r * 3 + 2];
             for (int j = 0; j < 2; ++j) {
                 const float t = -taup0 * vp[j];
-                for (int r = 1; r < 3; ++r)
-                    a[r * 3 + 1 + j] = FL ? __builtin_fmaf(w[r - 1], t, a[r * 3 + 1 + j]) : a[r * 3 + 1 + j] + w[r - 1] * t;
+                for (int r = 1; r < 3; ++r) a[r * 3 + 1 + j] = GEBD2V ? __builtin_fmaf(w[r - 1], t, a[r * 3 + 1 + j]) : a[r * 3 + 1 + j] + w[r - 1] * t;
             }
         }
     }
@@ -563,7 +518,7 @@ HPS_HD bool svd3(const float* f, float* u, float* s, float* v) {
             const float vq[2] = {1.0f, x[0]};
             const float w = a[5] + a[8] * vq[1];
             const float t = -tauq[1] * w;
-            for (int r = 0; r < 2; ++r) a[(r + 1) * 3 + 2] = FL ? __builtin_fmaf(vq[r], t, a[(r + 1) * 3 + 2]) : a[(r + 1) * 3 + 2] + vq[r] * t;
+            for (int r = 0; r < 2; ++r) a[(r + 1) * 3 + 2] = GEBD2V ? __builtin_fmaf(vq[r], t, a[(r + 1) * 3 + 2]) : a[(r + 1) * 3 + 2] + vq[r] * t;
         }
         e[1] = a[5];
     }
@@ -573,56 +528,71 @@ HPS_HD bool svd3(const float* f, float* u, float* s, float* v) {
     // ---- bidiagonal SVD ----
     float vt[9];
     for (int i = 0; i < 9; ++i) { u[i] = (i % 4 == 0) ? 1.0f : 0.0f; vt[i] = u[i]; }
-    const bool ok = sbdsqr3<FL>(d, e, u, vt);
+    const bool ok = sbdsqr3(d, e, u, vt);
 
-    // ---- sormbr: U = H(1) H(2) U_B  (apply H(2), then H(1)) ----
-    // The LAPACK 3.12 SLARF1F shape in both flavours: w = c_1 + (v_2 c_2 + v_3 c_3), every product and sum rounded.  FL = 1: the
-    // first row (implicit v_1 = 1) as an AXPY, c_1 <- fma(-tau, w, c_1), the other rows c_i <- fma(v_i, -tau w, c_i) with the
-    // rounded -tau w; FL = 0: c_i <- c_i + v_i (-tau w), unfused.
+    if (g_dbg) { for (int i = 0; i < 9; ++i) g_dbg[i] = u[i]; g_dbg[9] = a[3]; g_dbg[10] = a[6]; g_dbg[11] = a[7]; g_dbg[12] = tauq[0]; g_dbg[13] = tauq[1]; }
+    // ---- sormbr variants ----
+#ifndef LW
+#define LW 0
+#endif
+#ifndef LU
+#define LU 0
+#endif
+#ifndef RW
+#define RW 0
+#endif
+#ifndef RU
+#define RU 0
+#endif
+#ifndef RT
+#define RT 0
+#endif
     if (tauq[1] != 0.0f) {
+        const float vq[2] = {1.0f, a[7]};
         for (int j = 0; j < 3; ++j) {
-            const float w = u[3 + j] + u[6 + j] * a[7];
+            float w;
+            if (LW == 2) w = __builtin_fmaf(u[6 + j], vq[1], u[3 + j]);
+            else w = u[3 + j] + u[6 + j] * vq[1];
             const float t = -tauq[1] * w;
-            u[3 + j] = FL ? __builtin_fmaf(-tauq[1], w, u[3 + j]) : u[3 + j] + t;
-            u[6 + j] = FL ? __builtin_fmaf(a[7], t, u[6 + j]) : u[6 + j] + a[7] * t;
+            if (LU == 2) { u[3 + j] = __builtin_fmaf(-tauq[1], w, u[3 + j]); u[6 + j] = __builtin_fmaf(vq[1], t, u[6 + j]); }
+            else for (int r = 0; r < 2; ++r) u[(r + 1) * 3 + j] = LU ? __builtin_fmaf(vq[r], t, u[(r + 1) * 3 + j]) : u[(r + 1) * 3 + j] + vq[r] * t;
         }
     }
     if (tauq[0] != 0.0f) {
+        const float vq[3] = {1.0f, a[3], a[6]};
         for (int j = 0; j < 3; ++j) {
-            const float w = u[j] + (u[3 + j] * a[3] + u[6 + j] * a[6]);
+            float w;
+            if (LW == 0) w = (u[j] + u[3 + j] * vq[1]) + u[6 + j] * vq[2];
+            else if (LW == 1) w = u[j] + (u[3 + j] * vq[1] + u[6 + j] * vq[2]);
+            else w = __builtin_fmaf(u[6 + j], vq[2], __builtin_fmaf(u[3 + j], vq[1], u[j]));
             const float t = -tauq[0] * w;
-            u[j] = FL ? __builtin_fmaf(-tauq[0], w, u[j]) : u[j] + t;
-            u[3 + j] = FL ? __builtin_fmaf(a[3], t, u[3 + j]) : u[3 + j] + a[3] * t;
-            u[6 + j] = FL ? __builtin_fmaf(a[6], t, u[6 + j]) : u[6 + j] + a[6] * t;
+            if (LU == 2) { u[j] = __builtin_fmaf(-tauq[0], w, u[j]); u[3 + j] = __builtin_fmaf(vq[1], t, u[3 + j]); u[6 + j] = __builtin_fmaf(vq[2], t, u[6 + j]); }
+            else for (int r = 0; r < 3; ++r) u[r * 3 + j] = LU ? __builtin_fmaf(vq[r], t, u[r * 3 + j]) : u[r * 3 + j] + vq[r] * t;
         }
     }
-    // ---- V^T = V_B^T G(1) on columns 2:3 (the shape of the sgebd2 right-hand application) ----
     if (taup0 != 0.0f) {
         const float vp[2] = {1.0f, a[2]};
         float w[3];
-        for (int r = 0; r < 3; ++r) w[r] = FL ? __builtin_fmaf(vp[1], vt[r * 3 + 2], vt[r * 3 + 1]) : vt[r * 3 + 1] + vp[1] * vt[r * 3 + 2];
+        for (int r = 0; r < 3; ++r) w[r] = RW ? __builtin_fmaf(vp[1], vt[r * 3 + 2], vt[r * 3 + 1]) : vt[r * 3 + 1] + vp[1] * vt[r * 3 + 2];
         for (int j = 0; j < 2; ++j) {
-            const float t = -taup0 * vp[j];
-            for (int r = 0; r < 3; ++r) vt[r * 3 + 1 + j] = FL ? __builtin_fmaf(w[r], t, vt[r * 3 + 1 + j]) : vt[r * 3 + 1 + j] + w[r] * t;
+            for (int r = 0; r < 3; ++r) {
+                if (RT == 0) { const float t = -taup0 * vp[j]; vt[r * 3 + 1 + j] = RU ? __builtin_fmaf(w[r], t, vt[r * 3 + 1 + j]) : vt[r * 3 + 1 + j] + w[r] * t; }
+                else { const float t = -taup0 * w[r]; vt[r * 3 + 1 + j] = RU ? __builtin_fmaf(t, vp[j], vt[r * 3 + 1 + j]) : vt[r * 3 + 1 + j] + t * vp[j]; }
+            }
         }
     }
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) v[r * 3 + c] = vt[c * 3 + r];
-    s[0] = rescale != 1.0f ? d[0] * unscale : d[0];
-    s[1] = rescale != 1.0f ? d[1] * unscale : d[1];
-    s[2] = rescale != 1.0f ? d[2] * unscale : d[2];
+    const float inv = 1.0f / rescale;
+    s[0] = rescale != 1.0f ? d[0] * inv : d[0];
+    s[1] = rescale != 1.0f ? d[1] * inv : d[1];
+    s[2] = rescale != 1.0f ? d[2] * inv : d[2];
     if (!ok) {
         const float nan = __builtin_nanf("");
         for (int i = 0; i < 9; ++i) { u[i] = nan; v[i] = nan; }
         s[0] = s[1] = s[2] = nan;
     }
     return ok;
-}
-
-// Run-time flavour: 0 = reference rounding (no fused multiply-add; MKL's kernels on non-Intel hosts round like this),
-// 1 = the fused forms of MKL's kernels on Intel hosts.
-HPS_HD bool svd3(int flavor, const float* f, float* u, float* s, float* v) {
-    return flavor ? svd3<1>(f, u, s, v) : svd3<0>(f, u, s, v);
 }
 
 #pragma clang fp contract(fast)
