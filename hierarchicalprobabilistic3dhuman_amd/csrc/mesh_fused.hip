@@ -153,7 +153,8 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
     // Skinning, two passes of 32 meshes: pass p stages A of meshes [16 p, 16 p + 16) and [32 + 16 p, 32 + 16 p + 16) of the
     // tile -- the meshes of accumulator registers r = 8 p .. 8 p + 7 of both mesh groups -- as LDS slots 0..15 and 16..31.
     const int a_stride = JC ? JC * 12 : J * 12;
-    const int half_bytes = 16 * a_stride * 4;              // one contiguous source range; a multiple of 1 KiB (J * 768)
+    const int half_bytes = 16 * a_stride * 4;              // one contiguous source range of J * 768 bytes (whole 1 KiB pieces iff J % 4 == 0;
+                                                           // the last piece is cut by the off < valid mask otherwise: tested with J = 22)
     const int slot0 = wm * 16 + 4 * kl;                    // the lane's first slot
     int aoff[K];                                           // float offset of A[slot0][joint_k] in LDS
 #pragma unroll
@@ -226,8 +227,13 @@ static int launch_fused(const float* xt, const float* bmat_p, const float* v_tem
                         hipStream_t s) {
     if (J == 24 && !transl) return launch_fused_cfg<K, ABL, 24, false>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s);
     if (J == 24) return launch_fused_cfg<K, ABL, 24, true>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s);
-    if (!transl) return launch_fused_cfg<K, ABL, 0, false>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s);
-    return launch_fused_cfg<K, ABL, 0, true>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s);
+    if constexpr (K == 4) {          // a run-time joint count costs registers: only the K = 4 instantiation stays free of scratch
+        if (!transl) return launch_fused_cfg<K, ABL, 0, false>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s);
+        return launch_fused_cfg<K, ABL, 0, true>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s);
+    } else {
+        set_error("hps_smpl_mesh_fused: K = %d is fused only for num_joints = 24 (use hps_smpl_blend + hps_smpl_lbs)", K);
+        return HPS_E_UNSUPPORTED;
+    }
 }
 
 }  // namespace hps
@@ -257,8 +263,10 @@ extern "C" int hps_smpl_mesh_fused(const float* xt, const float* bmat_p, const f
         case 4: return launch_fused<4>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, s);
         case 8: return launch_fused<8>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, s);
         case 12: return launch_fused<12>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, s);
-        case 24: return launch_fused<24>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, s);
-        default: set_error("hps_smpl_mesh_fused: K=%d unsupported (4, 8, 12, 24)", K); return HPS_E_UNSUPPORTED;
+        // K = 24 (dense skinning weights) does not fit the register budget of four workgroups per CU beside the accumulators
+        // (104-708 bytes of scratch per lane when instantiated): such models take the unfused pair
+        default: set_error("hps_smpl_mesh_fused: K=%d unsupported (4 with any joint count; 8, 12 with 24 joints); use "
+                           "hps_smpl_blend + hps_smpl_lbs", K); return HPS_E_UNSUPPORTED;
     }
 }
 

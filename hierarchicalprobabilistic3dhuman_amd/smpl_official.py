@@ -115,6 +115,9 @@ class SMPL(nn.Module):
         w_val = np.take_along_axis(weights, order, axis=1)
         w_idx = np.where(w_val != 0, order, 0)
         self._lbs_k = K
+        # the fused mesh kernel exists for K = 4 (any joint count) and K = 8, 12 (24 joints): include/hps.h hps_smpl_mesh_fused;
+        # denser skinning weights take the unfused pair (same bits)
+        self._fused_ok = K == 4 or (K in (8, 12) and J == 24)
         self.register_buffer("_w_idx", torch.tensor(w_idx, dtype=torch.int32).contiguous(), persistent=False)
         self.register_buffer("_w_val", f32(w_val).contiguous(), persistent=False)
         # joint rows after the 24 kinematic joints: 21 vertex picks (smplx VertexJointSelector), then the
@@ -188,7 +191,7 @@ class SMPL(nn.Module):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         trp = P(tr) if tr is not None else None
         v_posed = None
-        if self.fused_mesh:
+        if self.fused_mesh and self._fused_ok:
             if ev is not None:
                 ev[0].record()
             _capi.call("hps_smpl_mesh_fused", P(xt), P(self._bmat_p), P(self._v_template_flat), P(a),

@@ -133,6 +133,9 @@ int hps_smpl_lbs(const float* v_posed, int ld_vposed, const float* a, const int3
  *   unused columns zero.  xt, a: from hps_smpl_pose_prep (mp a multiple of 64 covering M).  w_idx / w_val / K / transl /
  *   verts as for hps_smpl_lbs.  Bit-identical to hps_smpl_blend followed by hps_smpl_lbs (same MFMA k order, same
  *   skinning arithmetic).  Bound: fp32 MFMA, 2 * kp * 3 V FLOP per mesh; HBM traffic = the 12 V bytes of verts per mesh.
+ * Instantiated where it needs no scratch memory beside four workgroups per CU: K = 4 with any num_joints in 1..32, K = 8 and
+ * 12 with num_joints = 24; other combinations (e.g. K = 24, dense skinning weights) return HPS_E_UNSUPPORTED -- take the
+ * unfused pair, which gives the same bits.
  * Replaces smplx 0.1.26 lbs (reached from models/smpl_official.py:29) steps blend_shapes, pose_feature @ posedirs,
  * W @ A and T @ v_posed. */
 int hps_smpl_mesh_fused(const float* xt, const float* bmat_p, const float* v_template, const float* a,

@@ -242,6 +242,46 @@ def test_vertex_uncertainty_one_sweep_kernel(dev):
     assert maxerr(su.vertex_uncertainty(big.to(dev)), O.vertex_uncertainty(big[0])[None]) <= 1e-5
 
 
+@pytest.mark.parametrize("J", [22, 24, 7, 32])
+def test_fused_mesh_kernel_with_other_joint_counts(J, dev, smpl_gpu):
+    """hps_smpl_mesh_fused through the C ABI with a run-time joint count -- J = 22 and 7 are not multiples of 4, so
+    the 768 J byte halves of the skinning transforms are not whole 1 KiB DMA pieces and the last piece is cut by the
+    per-lane mask -- against hps_smpl_blend + hps_smpl_lbs on the same operands, bit for bit, with and without translation,
+    for mesh counts that leave ragged tiles."""
+    g = torch.Generator().manual_seed(J)
+    V, kp, K = smpl_gpu.num_verts, smpl_gpu._kp, 4
+    P = _capi.ptr
+    w_idx = (torch.randint(0, J, (V, K), generator=g, dtype=torch.int32)).to(dev)
+    w_val = torch.rand(V, K, generator=g)
+    w_val = (w_val / w_val.sum(1, keepdim=True)).to(dev)
+    for M in (1, 33, 64, 200):
+        mp = _capi.query_workspace(_capi.WS_SMPL_MP, M)
+        xt = (torch.randn(kp, mp, generator=g) * 0.1).to(dev)
+        a = torch.randn(M, J, 12, generator=g).to(dev)
+        transl = torch.randn(M, 3, generator=g).to(dev)
+        for tr in (None, transl):
+            fused = torch.zeros(M, V, 3, device=dev)
+            _capi.call("hps_smpl_mesh_fused", P(xt), P(smpl_gpu._bmat_p), P(smpl_gpu._v_template_flat), P(a), _capi.iptr(w_idx), P(w_val),
+                       K, J, P(tr) if tr is not None else None, P(fused), M, V, kp, mp, smpl_gpu._np_fused, _capi.stream())
+            ldv = smpl_gpu._np
+            v_posed = torch.empty(M, ldv, device=dev)
+            _capi.call("hps_smpl_blend", P(xt), P(smpl_gpu._bmat), P(smpl_gpu._v_template_flat), P(v_posed), M, smpl_gpu._N, kp, mp,
+                       smpl_gpu._np, ldv, _capi.stream())
+            want = torch.zeros(M, V, 3, device=dev)
+            _capi.call("hps_smpl_lbs", P(v_posed), ldv, P(a), _capi.iptr(w_idx), P(w_val), K, J, P(tr) if tr is not None else None,
+                       P(want), M, V, _capi.stream())
+            assert torch.isfinite(fused).all()
+            assert torch.equal(fused, want), (J, M, tr is not None, float((fused - want).abs().max()))
+    # combinations that are not instantiated (they would need scratch memory) are refused, not silently slow
+    with pytest.raises(_capi.HpsError):
+        _capi.call("hps_smpl_mesh_fused", P(xt), P(smpl_gpu._bmat_p), P(smpl_gpu._v_template_flat), P(a), _capi.iptr(w_idx), P(w_val),
+                   24, 24, None, P(fused), M, V, kp, mp, smpl_gpu._np_fused, _capi.stream())
+    if J != 24:
+        with pytest.raises(_capi.HpsError):
+            _capi.call("hps_smpl_mesh_fused", P(xt), P(smpl_gpu._bmat_p), P(smpl_gpu._v_template_flat), P(a), _capi.iptr(w_idx), P(w_val),
+                       8, J, None, P(fused), M, V, kp, mp, smpl_gpu._np_fused, _capi.stream())
+
+
 def test_c_abi_rejects_unsupported_k(dev, smpl_gpu):
     z = torch.zeros(16, device=dev)
     zi = torch.zeros(16, device=dev, dtype=torch.int32)
