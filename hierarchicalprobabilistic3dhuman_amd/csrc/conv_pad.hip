@@ -150,6 +150,12 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
     };
 
     const int fsw = (il >> 1) & 7;                       // f(row) of the fragment rows this lane reads
+#ifdef HPS_DEV_BUILD
+    if (g.ablate >= 2) {       // experiment: de-phase the workgroups that share a CU (ablate - 1 sleeps of 3.4 us for the second slot)
+        if (((blockIdx.x >> 8) & 1) && blockIdx.x < 512)
+            for (int i = 0; i < (g.ablate - 1) * 1; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     dma_chunk(0);
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (c - c_begin) & 1;

@@ -208,11 +208,18 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
     }
 }
 
+#ifdef HPS_DEV_BUILD
+static size_t g_mesh_lds_floor = 0;        // hps_dev_mesh_lds_floor
+#endif
+
 template <int K, int ABL, int JC, bool HAS_T>
 static int launch_fused_cfg(const float* xt, const float* bmat_p, const float* v_template, const float* a, const int32_t* w_idx,
                         const float* w_val, int J, const float* transl, float* verts, int M, int V, int kp, int mp, int np,
                         hipStream_t s) {
-    const size_t lds = (size_t)4 * max(2 * F_CHUNK_FLOATS, 32 * J * 12);
+    size_t lds = (size_t)4 * max(2 * F_CHUNK_FLOATS, 32 * J * 12);
+#ifdef HPS_DEV_BUILD
+    if (g_mesh_lds_floor > lds) lds = g_mesh_lds_floor;     // experiment: fewer workgroups per CU (a larger LDS request, unused)
+#endif
     if (int rc = grant_lds<&mesh_fused_kernel<K, ABL, JC, HAS_T>>(160 * 1024, "hps_smpl_mesh_fused")) return rc;
     const int tiles_m = ceil_div(M, FM), n_panels = ceil_div(V, FV);
     const int tiles_m_per_xcd = ceil_div(tiles_m, 8);
@@ -271,6 +278,11 @@ extern "C" int hps_smpl_mesh_fused(const float* xt, const float* bmat_p, const f
 }
 
 #ifdef HPS_DEV_BUILD
+extern "C" int hps_dev_mesh_lds_floor(int bytes) {
+    g_mesh_lds_floor = bytes > 0 ? (size_t)bytes : 0;
+    return HPS_OK;
+}
+
 extern "C" int hps_dev_mesh_fused(const float* xt, const float* bmat_p, const float* v_template, const float* a,
                                   const int32_t* w_idx, const float* w_val, int K, int num_joints, const float* transl,
                                   float* verts, int M, int V, int kp, int mp, int np, int ablate, hps_stream_t stream) {

@@ -66,6 +66,10 @@ int hps_dev_blend_mode(int mode);
  * with 128 vertices per workgroup in LDS, 3 = with 64. */
 int hps_dev_unc_mode(int mode);
 
+/* Experiment: request at least `bytes` of dynamic LDS for the fused mesh kernel (unused space), i.e. cap its workgroups per CU
+ * (36 KiB -> 4, 52 KiB -> 3, 72 KiB -> 2, 150 KiB -> 1).  0 restores the product value. */
+int hps_dev_mesh_lds_floor(int bytes);
+
 /* Tuning hook (tests/dev only): 1 = hps_conv2d_bn_act_pad skips its epilogue (results are garbage), 0 = normal. */
 int hps_dev_conv_pad_ablate(int mode);
 

@@ -14,12 +14,22 @@ with torch.no_grad(), _capi.dev_library():
     ops = fs["ops"]
     one = (_capi.EncOp * 1)(ops[1])
     s = _capi.stream()
-    for ab in (0, 1, 0, 1):
-        _capi.call("hps_dev_conv_pad_ablate", ab)
-        for _ in range(3): _capi.call("hps_encoder_run", one, 1, s)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20): _capi.call("hps_encoder_run", one, 1, s)
-        e1.record(); torch.cuda.synchronize()
-        print("stem ablate %d: %.4f ms" % (ab, e0.elapsed_time(e1) / 20))
+    import sys as _s
+    modes = [int(a) for a in _s.argv[1:]] or [0, 1]
+    # clocks drift by a few per cent over seconds: interleave the modes over several rounds and compare medians
+    times = {m: [] for m in modes}
+    for _ in range(3):
+        for _ in range(5): _capi.call("hps_encoder_run", one, 1, s)
+    for rnd in range(9):
+        for ab in modes:
+            _capi.call("hps_dev_conv_pad_ablate", ab)
+            for _ in range(2): _capi.call("hps_encoder_run", one, 1, s)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10): _capi.call("hps_encoder_run", one, 1, s)
+            e1.record(); torch.cuda.synchronize()
+            times[ab].append(e0.elapsed_time(e1) / 10)
+    for ab in modes:
+        t = sorted(times[ab])
+        print("stem ablate %d: median %.4f ms (min %.4f max %.4f, 9 rounds of 10 launches, modes interleaved)" % (ab, t[4], t[0], t[-1]))
     _capi.call("hps_dev_conv_pad_ablate", 0)

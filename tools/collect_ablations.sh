@@ -15,12 +15,18 @@ sec "tools/bin/mfma_valu_overlap (does fp32 VALU overlap fp32 MFMA: same wave, a
 for i in 1 2; do $R/tools/bin/mfma_valu_overlap 2>&1; done
 sec "tests/dev/gpu_bringup.py wino (B = 64; dev library: compile-time ablations of conv_wino_kernel)"
 python $R/tests/dev/gpu_bringup.py wino 2>&1 | grep -E "^wino|^layer4|direct kernel|max \|"
-sec "tests/dev/stem_ablate.py (stem convolution alone: 0 = product, 1 = no epilogue)"
-python $R/tests/dev/stem_ablate.py 2>&1 | grep "^stem"
+sec "tests/dev/stem_ablate.py (stem convolution alone, modes interleaved over 9 rounds: 0 = product, 1 = no epilogue, 5 / 13 = second CU slot de-phased by 14 / 41 us)"
+python $R/tests/dev/stem_ablate.py 0 1 5 13 2>&1 | grep "^stem"
 sec "tests/dev/gpu_bringup.py mesh_fused (ablations of mesh_fused_kernel)"
 python $R/tests/dev/gpu_bringup.py mesh_fused 2>&1 | grep -E "mesh_fused M=|alone|ablate"
 sec "tests/dev/gpu_bringup.py unc_modes"
 python $R/tests/dev/gpu_bringup.py unc_modes 2>&1 | grep -E "^unc|registers =="
+sec "tests/dev/unc_time.py (hps_vertex_uncertainty alone: one-sweep product kernel vs the two-sweep kernel, median of 10)"
+python $R/tests/dev/unc_time.py 2>&1 | grep "^unc"
+sec "tests/dev/svd_vs_mkl.py (host build of csrc/svd3_gesdd.h, both rounding flavours, against this host's torch.svd)"
+python $R/tests/dev/svd_vs_mkl.py 2>&1 | grep -E "hps_host_svd_flavor|total"
+sec "tools/bin/ldsdma_probe (LDS placement of global_load_lds of 4 / 12 / 16 bytes per lane: first 20 dwords)"
+$R/tools/bin/ldsdma_probe 2>&1 | cut -d" " -f1-22
 sec "tests/dev/head_time.py 64 (head alone, device SVD)"
 python $R/tests/dev/head_time.py 64 2>&1 | grep "head alone"
 sec "tests/dev/svd_time.py (hps_svd3_packed: one lane per matrix -- divergence)"
@@ -35,6 +41,12 @@ d=json.loads(sys.stdin.read()); print('drop %-9s %6d images/s  %.3f ms/step  enc
 done
 sec "tools/encoder_layers.py time B [direct] (encoder alone, Winograd vs all-direct)"
 for b in 64 16 1; do for m in wino direct; do echo "B=$b $m: $(python $R/tools/encoder_layers.py time $b $m 2>&1 | grep whole)"; done; done
+sec "BASELINE configs[4] (B = 16, N = 1000): mesh kernel exclusive (off) or beside the encoder (on), shared CUs (0) or a CU partition of k CUs per XCD for the encoder"
+for a in "off 0" "on 0" "on 8" "on 12"; do set -- $a
+  python $R/bench.py --batch 16 --num-samples 1000 --steps 12 --warmup 3 --cpu-images 0 --lbs-unfused-reps 0 --mesh-overlap $1 --encoder-cus $2 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('mesh-overlap %-3s encoder-cus %-2s %6d images/s  %.3f ms/step  encoder %.3f ms  mesh kernel %.3f ms' % ('$1', '$2', d['value'], d['ms_per_step'], d['secondary']['encoder']['avg_ms'], d['roofline']['avg_launch_ms']))"
+done
 sec "BASELINE configs[4] (B = 16, N = 1000), Winograd vs all-direct"
 for t in bench.py tests/dev/bench_direct.py; do
   python $R/$t --batch 16 --num-samples 1000 --steps 10 --warmup 3 --cpu-images 0 2>&1 | tail -1 | python -c "

@@ -6,7 +6,7 @@
 #   4. the BASELINE configs[4] stress configuration (B = 16, N = 1000) bench line and its kernel stats
 # Raw output under gpurun_out/prof_$TAG/; tools/summarize_profiles.py $TAG reduces it to profiles/.
 # usage: tools/collect_profiles.sh r02
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
