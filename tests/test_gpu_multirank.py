@@ -72,6 +72,25 @@ def test_two_rank_gloo_bench_is_the_two_disjoint_shards(dev, single_rank_shards)
     assert two["value"] > 0 and abs(two["value"] - 2 * 64 * 2 / (two["ms_per_step"] * 2e-3)) <= 1e-6 * two["value"]
 
 
+def test_eight_rank_gloo_bench_is_baseline_config_2(dev):
+    """BASELINE configs[2] -- 512 images sharded over 8 ranks, 64 per rank -- executed with all 8 ranks on ONE device over gloo
+    (what the 8-GPU node runs over RCCL, minus the xGMI transport): rank r owns images [64 r, 64 r + 64), the first and the last
+    rank's accumulators equal what `--as-rank r 8` computes alone bit for bit, the total is the rank-ordered sum of the eight."""
+    eight = _bench(["--gpus", "8", "--backend", "gloo"], ranks=8, timeout=1500)
+    assert eight["n_gpus"] == 8 and eight["config"]["global_batch"] == 512 and eight["image_range_rank0"] == [0, 64]
+    per_rank = eight["metric_checksums_per_rank"]
+    assert len(per_rank) == 8 and len({tuple(r) for r in per_rank}) == 8          # eight different shards
+    for r in (0, 7):
+        alone = _bench(["--gpus", "1", "--as-rank", str(r), "8"])
+        assert alone["image_range_rank0"] == [64 * r, 64 * r + 64]
+        assert per_rank[r] == alone["metric_checksums_per_rank"][0], r
+    want = [0.0] * 4
+    for row in per_rank:                                                             # rank order, float64
+        want = [a + b for a, b in zip(want, row)]
+    got = [eight["metric_checksums"][k] for k in ("images", "sum_unc", "sum_abs_verts_mode", "sum_abs_joints_samples")]
+    assert got == want and got[0] == 8 * 64 * 2
+
+
 def test_one_rank_nccl_bench_under_torchrun(dev, single_rank_shards):
     """RCCL initialisation, barrier, all_gather of the float64 accumulator and all_reduce(MAX) with one rank: the nccl code
     path of the driver's N > 1 launches, and the same numbers as the run without a process group."""
