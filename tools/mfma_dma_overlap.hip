@@ -1,0 +1,97 @@
+// Dev microbenchmark 3: a whole double-buffered K-loop skeleton beside the MFMAs -- per chunk and wave 64 MFMAs (4 accumulators, 4
+// groups of 16 fed by 4 ds_read_b128 each, next group's reads issued before the current group's MFMAs), NP LDS-DMA pieces
+// (global_load_lds_dwordx4, 1 KiB per wave instruction, from an L2-resident buffer) for the NEXT chunk, s_waitcnt vmcnt(0) + s_barrier
+// at the chunk boundary: the direct convolution kernel's loop without its address arithmetic.
+//   MODE 0: the NP pieces in a burst right after the barrier (the product kernels)
+//   MODE 1: the pieces spread over the chunk, one after every (64 / NP)-th MFMA
+//   MODE 2: burst, but only AFTER the first group's MFMAs have been issued
+//   MODE 3: no DMA at all (barrier + LDS reads only)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void dma16(unsigned voff, const float* sbase, unsigned lds_addr) {
+    unsigned keep;
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+
+template <int MODE, int NP>
+__global__ __launch_bounds__(256) void k(const float* __restrict__ src, float* out, int chunks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // 2 buffers x 4 waves x NP KiB
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 2 * 4 * NP * 256; i += 256) lds[i] = 0.001f * (i % 97) - 0.05f;
+    __syncthreads();
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
+    const float* s = src + (size_t)(blockIdx.x & 63) * 4096;        // 16 KiB per block slot, 1 MiB in all: L2 resident
+    const unsigned voff = lane * 16;
+    auto issue_piece = [&](int buf, int p) { dma16(voff + (unsigned)((p * 1024 + wave * 256) & 16383), s, lds0 + (unsigned)(((buf * 4 + wave) * NP + p) * 1024)); };
+    for (int c = 0; c < chunks; ++c) {
+        const int buf = c & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (MODE == 0)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) issue_piece(buf ^ 1, p);
+        const float4* base = reinterpret_cast<const float4*>(lds + (size_t)((buf * 4 + wave) * NP) * 256) + lane;
+        float4 f[2][4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) f[0][l] = base[(l * 64) % (NP * 64)];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            if (gq + 1 < 4)
+#pragma unroll
+                for (int l = 0; l < 4; ++l) f[(gq + 1) & 1][l] = base[((gq + 1) * 16 + l * 64) % (NP * 64)];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const float4 v = f[gq & 1][m & 3];
+                const float a = (m & 4) ? v.y : v.x, b = (m & 8) ? v.w : v.z;
+                acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m & 3], 0, 0, 0);
+                if (MODE == 1 && ((gq * 16 + m + 1) % (64 / NP)) == 0) issue_piece(buf ^ 1, (gq * 16 + m) / (64 / NP));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (MODE == 2 && gq == 0)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) issue_piece(buf ^ 1, p);
+        }
+    }
+    float t = 0.f;
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) t += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = t;
+}
+
+template <int MODE, int NP>
+void run(int wg_per_cu, const float* src, const char* what) {
+    const int blocks = 256 * wg_per_cu, chunks = 600;
+    float* out; hipMalloc(&out, blocks * 256 * sizeof(float));
+    const size_t lds = (size_t)2 * 4 * NP * 1024;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k<MODE, NP>), dim3(blocks), dim3(256), lds, 0, src, out, chunks);
+    hipEventRecord(e0);
+    for (int w = 0; w < 5; ++w) hipLaunchKernelGGL((k<MODE, NP>), dim3(blocks), dim3(256), lds, 0, src, out, chunks);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    const double flops = (double)blocks * 4 * chunks * 64 * 2.0 * 32 * 32 * 2;
+    printf("%-46s %d WG/CU  %2d pieces per 64 MFMAs : %.3f ms  %.1f TFLOP/s\n", what, wg_per_cu, NP, ms, flops / ms / 1e9);
+    hipFree(out);
+}
+int main() {
+    float* src; hipMalloc(&src, 1 << 20); hipMemset(src, 0, 1 << 20);
+    for (int wg : {1, 2}) {
+        run<3, 8>(wg, src, "no DMA (barrier + LDS reads)");
+        run<0, 8>(wg, src, "burst after the barrier");
+        run<1, 8>(wg, src, "spread over the chunk");
+        run<2, 8>(wg, src, "burst after the first MFMA group");
+        run<0, 4>(wg, src, "burst after the barrier");
+        run<1, 4>(wg, src, "spread over the chunk");
+        run<0, 16>(wg, src, "burst after the barrier");
+        run<1, 16>(wg, src, "spread over the chunk");
+    }
+    return 0;
+}
