@@ -132,14 +132,7 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
 
     const unsigned lds_a = (unsigned)(size_t)(lptr_t)(sA + wave * 8 * PBK);
     const unsigned lds_b = (unsigned)(size_t)(lptr_t)(sB + wave * 8 * PBK);
-    auto dma_chunk = [&](int buf) {
-        const unsigned la = __builtin_amdgcn_readfirstlane(lds_a + buf * BM * PBK * 4);
-        const unsigned lb = __builtin_amdgcn_readfirstlane(lds_b + buf * BN * PBK * 4);
-#pragma unroll
-        for (int r = 0; r < A_LD; ++r) lds_dma16_sv(a_off[r], a_src, la + r * 32 * PBK * 4);
-#pragma unroll
-        for (int r = 0; r < B_LD; ++r) lds_dma16_sv(b_off[r], b_src, lb + r * 32 * PBK * 4);
-        // advance to the next chunk
+    auto advance = [&]() {                               // source pointers of the next chunk (scalar code)
         b_src += PBK;
         if (++ci < cpt) a_src += PBK;
         else {
@@ -147,6 +140,20 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
             if (++kw < g.kw) a_src += tap_jump;
             else { kw = 0; a_src += row_jump; }
         }
+    };
+    auto dma_chunk = [&](int buf) {
+        const unsigned la = __builtin_amdgcn_readfirstlane(lds_a + buf * BM * PBK * 4);
+        const unsigned lb = __builtin_amdgcn_readfirstlane(lds_b + buf * BN * PBK * 4);
+#pragma unroll
+        for (int r = 0; r < A_LD; ++r) lds_dma16_sv(a_off[r], a_src, la + r * 32 * PBK * 4);
+#pragma unroll
+        for (int r = 0; r < B_LD; ++r) lds_dma16_sv(b_off[r], b_src, lb + r * 32 * PBK * 4);
+        advance();
+    };
+    // one piece of the chunk whose sources are (pa_src, pb_src): piece p < A_LD is an A piece, the rest B pieces
+    auto dma_piece = [&](int p, const float* pa_src, const float* pb_src, unsigned la, unsigned lb) {
+        if (p < A_LD) lds_dma16_sv(a_off[p < A_LD ? p : 0], pa_src, la + p * 32 * PBK * 4);
+        else if (p < A_LD + B_LD) lds_dma16_sv(b_off[p >= A_LD && p < A_LD + B_LD ? p - A_LD : 0], pb_src, lb + (p - A_LD) * 32 * PBK * 4);
     };
 
     const int fsw = (il >> 1) & 7;                       // f(row) of the fragment rows this lane reads
@@ -161,7 +168,24 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
         const int buf = (c - c_begin) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of chunk c have landed
         __syncthreads();                                     // ... everyone's have, and buf^1 is no longer being read
-        if (c + 1 < c_end) dma_chunk(buf ^ 1);
+        // The next chunk's DMA pieces are issued ONE PER FOUR MFMAs, not in a burst after the barrier: every 1 KiB piece costs the
+        // SIMD 36-57 cycles that no other wave's MFMAs cover (tools/mfma_dma_overlap.hip: the loop skeleton runs at 139.4 TF/s with
+        // the burst and 143.0 spread); on the stem 0.906 -> 0.888 ms (tests/dev/stem_ablate.py, mode 3 = burst).
+        static_assert(A_LD + B_LD <= (PBK / 8) * TM * TN, "one DMA piece per accumulator block of a chunk at most");
+#ifdef HPS_DEV_BUILD
+        const bool spread = g.ablate != 3;               // hps_dev_conv_pad_ablate(3): the earlier burst
+#else
+        constexpr bool spread = true;
+#endif
+        const bool more = c + 1 < c_end;
+        const float* na_src = a_src;
+        const float* nb_src = b_src;
+        const unsigned nla = __builtin_amdgcn_readfirstlane(lds_a + (buf ^ 1) * BM * PBK * 4);
+        const unsigned nlb = __builtin_amdgcn_readfirstlane(lds_b + (buf ^ 1) * BN * PBK * 4);
+        if (more) {
+            if (spread) advance();
+            else dma_chunk(buf ^ 1);
+        }
         const float* pa = sA + (size_t)buf * BM * PBK + (wm0 + il) * PBK;
         const float* pb = sB + (size_t)buf * BN * PBK + (wn0 + il) * PBK;
         // Fragments are double-buffered by hand: group gq + 1 is requested before the MFMAs of group gq are issued (the
@@ -189,6 +213,11 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[gq & 1][j].y, a4[gq & 1][i].y, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[gq & 1][j].z, a4[gq & 1][i].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[gq & 1][j].w, a4[gq & 1][i].w, acc[i][j], 0, 0, 0);
+                    if (spread && more) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        dma_piece((gq * TM + i) * TN + j, na_src, nb_src, nla, nlb);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -15,8 +15,8 @@ sec "tools/bin/mfma_valu_overlap (does fp32 VALU overlap fp32 MFMA: same wave, a
 for i in 1 2; do $R/tools/bin/mfma_valu_overlap 2>&1; done
 sec "tests/dev/gpu_bringup.py wino (B = 64; dev library: compile-time ablations of conv_wino_kernel)"
 python $R/tests/dev/gpu_bringup.py wino 2>&1 | grep -E "^wino|^layer4|direct kernel|max \|"
-sec "tests/dev/stem_ablate.py (stem convolution alone, modes interleaved over 9 rounds: 0 = product, 1 = no epilogue, 5 / 13 = second CU slot de-phased by 14 / 41 us)"
-python $R/tests/dev/stem_ablate.py 0 1 5 13 2>&1 | grep "^stem"
+sec "tests/dev/stem_ablate.py (stem convolution alone, modes interleaved over 9 rounds: 0 = product, 1 = no epilogue, 3 = DMA pieces in a burst (the earlier form), 5 / 13 = second CU slot de-phased by 14 / 41 us)"
+python $R/tests/dev/stem_ablate.py 0 1 3 5 13 2>&1 | grep "^stem"
 sec "tests/dev/gpu_bringup.py mesh_fused (ablations of mesh_fused_kernel)"
 python $R/tests/dev/gpu_bringup.py mesh_fused 2>&1 | grep -E "mesh_fused M=|alone|ablate"
 sec "tests/dev/gpu_bringup.py unc_modes"

@@ -6,6 +6,9 @@
 //   MODE 1: the pieces spread over the chunk, one after every (64 / NP)-th MFMA
 //   MODE 2: burst, but only AFTER the first group's MFMAs have been issued
 //   MODE 3: no DMA at all (barrier + LDS reads only)
+//   MODE 4: the same bytes by plain global_load_dwordx4 into registers (never written to LDS: what does the VMEM side alone cost?)
+//   MODE 5: register staging: global_load_dwordx4 for the next chunk after the barrier, ds_write_b128 into the other buffer after the
+//           chunk's last MFMA group (the loads have had the whole chunk to arrive)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -37,6 +40,10 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ src, float* o
         if (MODE == 0)
 #pragma unroll
             for (int p = 0; p < NP; ++p) issue_piece(buf ^ 1, p);
+        float4 stage[NP];
+        if (MODE == 4 || MODE == 5)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) stage[p] = *reinterpret_cast<const float4*>(s + ((p * 256 + wave * 64 + (c & 3) * 1024) & 4095) + lane * 4);
         const float4* base = reinterpret_cast<const float4*>(lds + (size_t)((buf * 4 + wave) * NP) * 256) + lane;
         float4 f[2][4];
 #pragma unroll
@@ -58,6 +65,17 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ src, float* o
             if (MODE == 2 && gq == 0)
 #pragma unroll
                 for (int p = 0; p < NP; ++p) issue_piece(buf ^ 1, p);
+        }
+        if (MODE == 5) {
+            float4* dst = reinterpret_cast<float4*>(lds + (size_t)(((buf ^ 1) * 4 + wave) * NP) * 256) + lane;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) dst[p * 64] = stage[p];
+        }
+        if (MODE == 4) {
+            float t4 = 0.f;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) t4 += stage[p].x;
+            if (t4 == 12345.678f) out[0] = t4;
         }
     }
     float t = 0.f;
@@ -88,6 +106,8 @@ int main() {
         run<0, 8>(wg, src, "burst after the barrier");
         run<1, 8>(wg, src, "spread over the chunk");
         run<2, 8>(wg, src, "burst after the first MFMA group");
+        run<4, 8>(wg, src, "plain global loads into registers only");
+        run<5, 8>(wg, src, "register staging (global_load + ds_write_b128)");
         run<0, 4>(wg, src, "burst after the barrier");
         run<1, 4>(wg, src, "spread over the chunk");
         run<0, 16>(wg, src, "burst after the barrier");
