@@ -106,6 +106,12 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
         b_src += (size_t)FBK * np;
         x_src += (size_t)FBK * mp;
     };
+    // piece p of the wave's four pieces of a chunk (0: mesh operand, 1..3: blend matrix), for the spread issue in the K loop
+    auto dma_piece = [&](int p, int buf, const float* xs, const float* bs) {
+        const unsigned base = lds0 + (unsigned)buf * F_CHUNK_FLOATS * 4;
+        if (p == 0) lds_dma16(x_off, xs, base + (unsigned)wave * 1024);
+        else lds_dma16(b_off[p - 1], bs, base + FBK * FM * 4 + (unsigned)(wave + FW * (p - 1)) * 1024);
+    };
 
     f32x16 acc[3];
 #pragma unroll
@@ -115,10 +121,18 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
 
     const int nchunks = kp / FBK;
     if (ABL != 4) dma_chunk(0);
+    static_assert(1 + F_BP / FW == FBK / 4, "four DMA pieces per wave and chunk, one per two k-steps");
     for (int c = 0; c < nchunks; ++c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                   // chunk c has landed; everyone is done with the other buffer
-        if (ABL != 4 && c + 1 < nchunks) dma_chunk((c + 1) & 1);
+        // the next chunk's four DMA pieces go out one per two k-steps of this chunk's MFMAs, not in a burst (csrc/conv_pad.hip,
+        // tools/mfma_dma_overlap.hip: a piece costs the SIMD 36-57 cycles that are better paid between MFMAs than before them)
+        const bool more = ABL != 4 && c + 1 < nchunks;
+        constexpr bool burst = ABL == 5;                  // dev ablation: the earlier burst after the barrier
+        const float* nx_src = x_src;
+        const float* nb_src = b_src;
+        if (more && burst) dma_chunk((c + 1) & 1);
+        else if (more) { b_src += (size_t)FBK * np; x_src += (size_t)FBK * mp; }
         const float* sX = smem + (c & 1) * F_CHUNK_FLOATS;
         const float* sB = sX + FBK * FM;
         // all fragments of the chunk first (32 independent LDS reads in flight), then 24 back-to-back MFMAs
@@ -139,6 +153,11 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k], bx[k], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k], by[k], acc[1], 0, 0, 0);
             acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k], bz[k], acc[2], 0, 0, 0);
+            if (more && !burst && (k & 1) == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                dma_piece(k / 2, (c + 1) & 1, nx_src, nb_src);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 
@@ -296,7 +315,8 @@ extern "C" int hps_dev_mesh_fused(const float* xt, const float* bmat_p, const fl
         case 2: return launch_fused<4, 2>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, s);
         case 3: return launch_fused<4, 3>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, s);
         case 4: return launch_fused<4, 4>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, s);
-        default: return bad_arg("hps_dev_mesh_fused: ablate 0..4");
+        case 5: return launch_fused<4, 5>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, s);
+        default: return bad_arg("hps_dev_mesh_fused: ablate 0..5");
     }
 }
 #endif

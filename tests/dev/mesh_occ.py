@@ -18,7 +18,7 @@ verts = torch.empty(M, 6890, 3, device=dev)
 mp = L["xt"].shape[1]
 flop = 2.0 * 224 * 3 * 6890 * M
 with _capi.dev_library():
-    cfgs = [(lds, ab) for lds in (0, 52 * 1024, 72 * 1024, 150 * 1024) for ab in (0, 3)]
+    cfgs = [(0, 0), (0, 5), (0, 3), (52 * 1024, 0), (52 * 1024, 5)]
     times = {c: [] for c in cfgs}
     def fn(ab):
         _capi.call("hps_dev_mesh_fused", P(L["xt"]), P(smpl._bmat_p), P(smpl._v_template_flat), P(L["a"]), _capi.iptr(smpl._w_idx),
@@ -35,4 +35,4 @@ with _capi.dev_library():
     _capi.call("hps_dev_mesh_lds_floor", 0)
     for (lds, ab) in cfgs:
         t = sorted(times[(lds, ab)])[3]
-        print("mesh M=%d lds floor %3d KiB (%s) %-12s median %.4f ms = %.1f TF/s" % (M, lds // 1024, {0: "4 WG/CU", 52: "3 WG/CU", 72: "2 WG/CU", 150: "1 WG/CU"}[lds // 1024], "product" if ab == 0 else "K loop only", t, flop / t / 1e9))
+        print("mesh M=%d lds floor %3d KiB (%s) %-12s median %.4f ms = %.1f TF/s" % (M, lds // 1024, {0: "4 WG/CU", 52: "3 WG/CU", 72: "2 WG/CU", 150: "1 WG/CU"}[lds // 1024], {0: "product", 3: "K loop only", 5: "DMA burst"}[ab], t, flop / t / 1e9))
