@@ -58,6 +58,9 @@ _PROTOTYPES = {
     "hps_conv2d_bn_act_pad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "hps_conv3x3_winograd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "hps_conv3x3_winograd_workspace": [_I, _I, _I, _I, _I],
+    "hps_stem_phase_frames_bytes": [_I, _I, _I],
+    "hps_stem_phase_split": [_P, _P, _I, _I, _I, _I, _P],
+    "hps_stem_winograd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "hps_sums_f64": [_P, _P, _P, _I, _c.c_double, _P, _P, _P],
     "hps_sizeof_enc_op": [],
     "hps_encoder_run": [_P, _I, _P],
@@ -83,7 +86,8 @@ _DEV_PROTOTYPES = {
     "hps_dev_conv3x3_winograd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "hps_dev_mesh_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
 }
-_RESTYPES = {"hps_last_error": _c.c_char_p, "hps_query_workspace": _c.c_int64, "hps_conv3x3_winograd_workspace": _c.c_size_t}
+_RESTYPES = {"hps_last_error": _c.c_char_p, "hps_query_workspace": _c.c_int64, "hps_conv3x3_winograd_workspace": _c.c_size_t,
+             "hps_stem_phase_frames_bytes": _c.c_size_t}
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
 DEV_EXPORTED_SYMBOLS = tuple(_DEV_PROTOTYPES)
@@ -100,7 +104,7 @@ class EncOp(_c.Structure):
                                                        "relu", "row_mode", "variant", "ksplit")]
 
 
-ENC_RELAYOUT, ENC_CONV, ENC_MAXPOOL, ENC_AVGPOOL, ENC_CONV_WINOGRAD = 0, 1, 2, 3, 4
+ENC_RELAYOUT, ENC_CONV, ENC_MAXPOOL, ENC_AVGPOOL, ENC_CONV_WINOGRAD, ENC_STEM_SPLIT, ENC_STEM_WINOGRAD = 0, 1, 2, 3, 4, 5, 6
 SVD_HOST, SVD_DEVICE, SVD_DEVICE_FMA = 0, 1, 2
 SVD_ROUNDING_REFERENCE, SVD_ROUNDING_FMA = 0, 1
 

@@ -18,7 +18,7 @@ INCLUDE = os.path.join(REPO_ROOT, "include")
 LIB_PATH = os.path.join(PKG_DIR, "libhps.so")
 DEV_LIB_PATH = os.path.join(PKG_DIR, "libhps_dev.so")
 
-SOURCES = ["api.hip", "smpl.hip", "blend_gemm.hip", "mesh_fused.hip", "mf_sample.hip", "head.hip", "conv_pad.hip", "conv_wino.hip", "composite.hip",
+SOURCES = ["api.hip", "smpl.hip", "blend_gemm.hip", "mesh_fused.hip", "mf_sample.hip", "head.hip", "conv_pad.hip", "conv_wino.hip", "stem_wino.hip", "composite.hip",
            "host_svd.hip", "frontend.hip", "metrics.hip"]
 DEV_ONLY_SOURCES = ["conv.hip"]
 # per-file flags.  mesh_fused.hip: hipcc's SLP vectoriser turns the skinning epilogue into v_pk_fma_f32 plus one v_mov

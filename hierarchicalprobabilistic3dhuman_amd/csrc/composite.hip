@@ -33,6 +33,12 @@ extern "C" int hps_encoder_run(const hps_enc_op* ops, int n_ops, hps_stream_t st
                 rc = hps_conv3x3_winograd(o.x, o.w, o.scale, o.shift, o.residual, o.y, o.B, o.H, o.W, o.ipad, o.Cin, o.Cout, o.opad,
                                           o.relu, o.splitk_ws, stream);
                 break;
+            case HPS_ENC_STEM_SPLIT:
+                rc = hps_stem_phase_split(o.x, o.y, o.B, o.Cin, o.H, o.W, stream);
+                break;
+            case HPS_ENC_STEM_WINOGRAD:
+                rc = hps_stem_winograd(o.x, o.w, o.scale, o.shift, o.y, o.B, o.H, o.W, o.opad, o.relu, stream);
+                break;
             case HPS_ENC_MAXPOOL:
                 rc = hps_maxpool3x3s2_pad(o.x, o.y, o.B, o.H, o.W, o.Cin, o.opad, stream);
                 break;

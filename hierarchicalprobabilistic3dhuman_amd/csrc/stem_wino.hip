@@ -1,0 +1,423 @@
+// Winograd form of the ResNet stem (models/resnet.py:147-150, :203-206: conv1 7x7 / stride 2 / pad 3 on the 18-channel proxy
+// representation, bn1, relu) on the fp32 MFMA pipe.
+//
+// Why: the stem is a third of the encoder (0.88 of 2.58 ms at B = 64) and its direct implicit GEMM already runs its K loop at
+// 141 of the 153.7 TF/s the pipe sustains (conv_pad.hip, row mode) -- the only lever left is fewer multiplications.
+//
+// A stride-2 correlation splits into four stride-1 correlations on the even / odd sub-lattices of the input ("phases"):
+//   y[oy, ox] = sum_{ry, rx} sum_{a, b} X_{ry,rx}[oy + a, ox + b] * w[2a + ry, 2b + rx],    X_{ry,rx}[i, j] = x[2i + ry - 3, 2j + rx - 3]
+// with 4 taps per axis for the even phase (ky = 0, 2, 4, 6) and 3 for the odd one.  Each phase is computed as Winograd
+// F(2x2, r x s): a 2x2 output tile from (2 + r - 1) x (2 + s - 1) inputs with as many multiplications -- 25 + 20 + 20 + 16 = 81 per
+// tile and (cin, cout) pair instead of 4 * 49 = 196: 2.4 x fewer MFMAs.  F(2, 4) uses the points 0, 1, -1, 2, inf and F(2, 3) the
+// points 0, 1, -1, inf: B^T and A^T hold small integers only, and in fp32 the result is as close to the fp64 sum as the direct
+// fp32 sum is (5e-7 of the output scale, tools/stem_wino/accuracy.py) -- K = 18 per position, so little rounding accumulates.
+//
+//   V_p[tile, c]  = (B_y^T d B_x)_p               input transform of the tile's 9 x 9 input patch (81 pixels -> 81 positions)
+//   M_p[co, tile] = sum_c U_p[c, co] V_p[tile, c]   81 GEMMs with K = 18: nine v_mfma_f32_32x32x2_f32 per 32 x 32 block
+//   Y = sum_phases A_y^T M A_x                     output transform, then bn1 + relu
+//   U = G_y g G_x^T is prepared on the host (resnet.py).
+//
+// The shape of this problem is unusual: K is tiny, so every transformed input value feeds only 64 output channels.  Staging V
+// through LDS (as conv_wino.hip does) would cost more LDS traffic than the MFMAs take; instead the lane that needs V as an MFMA
+// operand computes it: MFMA lane (il, kl) supplies B[k = kl][column il], so lane (il, kl) transforms tile il's channels of
+// parity kl (2m + kl for the m-th MFMA of a position) and holds them in registers -- no LDS round trip for V at all.
+// The positions are processed in 18 "rows" (one row i of one phase: 5 or 4 positions).  Per row a lane
+//   * forms the vertical combinations c[b] = sum_a B_y^T[i][a] d[a][b] of its patch pixels from the raw window in LDS
+//     (coefficients from a constant table: 2-4 pixels per output),
+//   * per position j: a_j = sum_b B_x^T[j][b] c[b] (compile-time coefficients), nine MFMAs into M[j] with the filters of the
+//     position read from LDS,
+//   * folds the row into the four output accumulators: t = M A_x (compile-time), Y[a][.] += A_y^T[a][i] t.
+// Live registers: M (5 x 16), Y (4 x 16), one channel group of c (20) -- two waves per SIMD, which is what hides the LDS reads.
+//
+// Work item = 8 x 8 tiles (16 x 16 output pixels) of one image x 64 output channels; a workgroup is two teams of four waves
+// (2 tile halves x 2 channel halves), each team on its own item, both teams sharing the filters: LDS holds, per team, two raw
+// phase windows (19 rows of 19 pixels, double buffered: the next phase arrives by LDS-DMA while this one is transformed) and, for
+// the workgroup, two filter rows (5 positions x 4.5 KiB, double buffered) -- 150 KiB, one workgroup per CU, persistent.
+// The input comes from hps_stem_phase_split: the four phase images of every input image as separate NHWC frames, so that a
+// window row is one contiguous run and the channels of a pixel sit in the order the lanes read them.
+#include "hps_common.h"
+
+namespace hps {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr int SW_C = 18;                         // input channels
+constexpr int SW_CO = 64;                        // output channels
+constexpr int SW_SLOTS = 86;                     // 16-byte slots per window row: 19 pixels x 72 bytes = 1368 -> 1376
+constexpr int SW_ROWF = SW_SLOTS * 4;            // floats per window row in LDS
+constexpr int SW_RAW_PIECES = 26;                // 1 KiB DMA pieces per window: 19 rows x 86 slots = 1634 slots (the tail over-reads row 19)
+constexpr int SW_RAW_F = SW_RAW_PIECES * 256;    // floats per window buffer
+constexpr int SW_POS_F = 1152;                   // floats of one position's filters: [co half][k 0-7 | k 8-15 | k 16-17] x 32 co
+constexpr int SW_U_PIECES = 23;                  // a row of five positions = 22.5 KiB
+constexpr int SW_U_F = SW_U_PIECES * 256;
+constexpr int SW_ROWS = 18;
+constexpr int SW_LDS_F = 4 * SW_RAW_F + 2 * SW_U_F;      // 153 600 bytes
+
+// one row of positions: phase, number of x points, the vertical combination, the output fold
+struct StemRow {
+    int phase, first, nxp, ne;
+    int upos;                   // index of the row's first position in the filter array
+    int aoff[4];                // window rows of the vertical combination, as float offsets (a * SW_ROWF)
+    float coef[4];
+    float e0, e1;               // A_y^T[0][i], A_y^T[1][i]
+};
+#define R5(ph, fi, nx, up, i)                                                                                                    \
+    {ph, fi, nx, (i) == 3 ? 2 : ((i) == 1 || (i) == 2) ? 3 : 4, up,                                                              \
+     {((i) == 0 ? 0 : 1) * SW_ROWF, ((i) == 0 ? 1 : (i) == 3 ? 3 : 2) * SW_ROWF, ((i) == 0 ? 2 : 3) * SW_ROWF, ((i) == 4 ? 4 : 3) * SW_ROWF}, \
+     {(i) == 0 ? 2.f : (i) == 1 ? -2.f : (i) == 2 ? 2.f : (i) == 3 ? -1.f : 2.f,                                                 \
+      (i) == 0 ? -1.f : (i) == 1 ? -1.f : (i) == 2 ? -3.f : (i) == 3 ? 1.f : -1.f,                                               \
+      (i) == 0 ? -2.f : (i) == 1 ? 1.f : (i) == 2 ? 1.f : (i) == 3 ? 0.f : -2.f, (i) == 0 ? 1.f : (i) == 4 ? 1.f : 0.f},          \
+     (i) < 4 ? 1.f : 0.f, (i) == 0 ? 0.f : (i) == 1 ? 1.f : (i) == 2 ? -1.f : (i) == 3 ? 2.f : 1.f}
+#define R4(ph, fi, nx, up, i)                                                                                                    \
+    {ph, fi, nx, 2, up,                                                                                                          \
+     {((i) == 0 ? 0 : 1) * SW_ROWF, ((i) == 3 ? 3 : 2) * SW_ROWF, 0, 0},                                                          \
+     {((i) == 0 || (i) == 1) ? 1.f : -1.f, (i) == 0 ? -1.f : 1.f, 0.f, 0.f},                                                      \
+     (i) < 3 ? 1.f : 0.f, (i) == 0 ? 0.f : (i) == 2 ? -1.f : 1.f}
+// F(2, 4), points 0, 1, -1, 2, inf:  B^T = [2 -1 -2 1 0; 0 -2 -1 1 0; 0 2 -3 1 0; 0 -1 0 1 0; 0 2 -1 -2 1],  A^T = [1 1 1 1 0; 0 1 -1 2 1]
+// F(2, 3), points 0, 1, -1, inf:     B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 -1 0 1],                          A^T = [1 1 1 0; 0 1 -1 1]
+__constant__ StemRow c_stem_rows[SW_ROWS] = {
+    R5(0, 1, 5, 0, 0),  R5(0, 0, 5, 5, 1),  R5(0, 0, 5, 10, 2), R5(0, 0, 5, 15, 3), R5(0, 0, 5, 20, 4),     // even rows, even columns
+    R5(1, 1, 4, 25, 0), R5(1, 0, 4, 29, 1), R5(1, 0, 4, 33, 2), R5(1, 0, 4, 37, 3), R5(1, 0, 4, 41, 4),     // even rows, odd columns
+    R4(2, 1, 5, 45, 0), R4(2, 0, 5, 50, 1), R4(2, 0, 5, 55, 2), R4(2, 0, 5, 60, 3),                         // odd rows, even columns
+    R4(3, 1, 4, 65, 0), R4(3, 0, 4, 69, 1), R4(3, 0, 4, 73, 2), R4(3, 0, 4, 77, 3)};                        // odd rows, odd columns
+#undef R5
+#undef R4
+
+struct StemGeom {
+    int fr_rowf, fr_phasef, fr_imgf;      // phase frame pitches in floats: row, phase frame, image (4 phase frames)
+    int blocks_x, blocks_img, n_items;
+    int out_row, out_img, opad, relu;     // output frame (B, Ho + 2 opad, Wo + 2 opad, 64)
+    unsigned magic_img, magic_x;
+};
+
+__device__ __forceinline__ unsigned sw_div(unsigned n, unsigned d, unsigned magic) {
+    unsigned q = __umulhi(n, magic);
+    if (n - q * d >= d) ++q;
+    return q;
+}
+static unsigned sw_magic(unsigned d) { return d <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / d); }
+
+// B_x^T applied to the vertical combinations c[0..NXP): position j of the row
+template <int NXP, typename T>
+__device__ __forceinline__ T sw_horiz(int j, const T (&c)[5]) {
+    if (NXP == 5) {
+        switch (j) {
+            case 0: return 2.0f * (c[0] - c[2]) + (c[3] - c[1]);
+            case 1: return (c[3] - c[2]) - 2.0f * c[1];
+            case 2: return (2.0f * c[1] + c[3]) - 3.0f * c[2];
+            case 3: return c[3] - c[1];
+            default: return 2.0f * (c[1] - c[3]) + (c[4] - c[2]);
+        }
+    }
+    switch (j) {
+        case 0: return c[0] - c[2];
+        case 1: return c[1] + c[2];
+        case 2: return c[2] - c[1];
+        default: return c[3] - c[1];
+    }
+}
+
+// One row of positions (see the header).  rawp: this lane's patch origin in the raw window (pair channels), raws: its single
+// channel; ub / ub1: this lane's filter fragment slots of position 0 of the row (k 0-7, and k 16-17).
+template <int NXP>
+__device__ __forceinline__ void sw_row(const float* rawp, const float* raws, const float* ub, const float* ub1, const StemRow& row,
+                                       f32x16 (&Y)[2][2]) {
+    f32x16 M[5];
+    const int ne = row.ne;
+    const int o0 = row.aoff[0], o1 = row.aoff[1], o2 = row.aoff[2], o3 = row.aoff[3];
+    const float k0 = row.coef[0], k1 = row.coef[1], k2 = row.coef[2], k3 = row.coef[3];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {                 // channel groups 8 g .. 8 g + 7 (this lane: four of them, as two pairs)
+        v2f c[2][5];
+#pragma unroll
+        for (int b = 0; b < NXP; ++b)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float* p = rawp + b * SW_C + g * 8 + h * 4;
+                v2f v = k0 * *reinterpret_cast<const v2f*>(p + o0);
+                v = __builtin_elementwise_fma((v2f){k1, k1}, *reinterpret_cast<const v2f*>(p + o1), v);
+                c[h][b] = v;
+            }
+        if (ne > 2) {
+#pragma unroll
+            for (int b = 0; b < NXP; ++b)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float* p = rawp + b * SW_C + g * 8 + h * 4;
+                    c[h][b] = __builtin_elementwise_fma((v2f){k2, k2}, *reinterpret_cast<const v2f*>(p + o2), c[h][b]);
+                }
+        }
+        if (ne > 3) {
+#pragma unroll
+            for (int b = 0; b < NXP; ++b)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float* p = rawp + b * SW_C + g * 8 + h * 4;
+                    c[h][b] = __builtin_elementwise_fma((v2f){k3, k3}, *reinterpret_cast<const v2f*>(p + o3), c[h][b]);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < NXP; ++j) {
+            const v2f a0 = sw_horiz<NXP>(j, c[0]), a1 = sw_horiz<NXP>(j, c[1]);
+            const float4 u = *reinterpret_cast<const float4*>(ub + j * SW_POS_F + g * 256);
+            if (g == 0) {
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                M[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, a0.x, z, 0, 0, 0);
+            } else {
+                M[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, a0.x, M[j], 0, 0, 0);
+            }
+            M[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.y, a0.y, M[j], 0, 0, 0);
+            M[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, a1.x, M[j], 0, 0, 0);
+            M[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.w, a1.y, M[j], 0, 0, 0);
+        }
+    }
+    {                                              // channels 16, 17: one per lane
+        float c1[5];
+#pragma unroll
+        for (int b = 0; b < NXP; ++b) {
+            const float* p = raws + b * SW_C;
+            c1[b] = __builtin_fmaf(k1, p[o1], k0 * p[o0]);
+        }
+        if (ne > 2) {
+#pragma unroll
+            for (int b = 0; b < NXP; ++b) c1[b] = __builtin_fmaf(k2, raws[b * SW_C + o2], c1[b]);
+        }
+        if (ne > 3) {
+#pragma unroll
+            for (int b = 0; b < NXP; ++b) c1[b] = __builtin_fmaf(k3, raws[b * SW_C + o3], c1[b]);
+        }
+#pragma unroll
+        for (int j = 0; j < NXP; ++j) {
+            const float a = sw_horiz<NXP>(j, c1);
+            M[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub1[j * SW_POS_F], a, M[j], 0, 0, 0);
+        }
+    }
+    // output transform of the row: t = M A_x, Y[a][.] += A_y^T[a][i] t
+    f32x16 t0, t1;
+    if (NXP == 5) {
+        t0 = (M[0] + M[1]) + (M[2] + M[3]);
+        t1 = (M[1] - M[2]) + (2.0f * M[3] + M[4]);
+    } else {
+        t0 = (M[0] + M[1]) + M[2];
+        t1 = (M[1] - M[2]) + M[3];
+    }
+    const float e0 = row.e0, e1 = row.e1;
+    Y[0][0] += e0 * t0;
+    Y[0][1] += e0 * t1;
+    Y[1][0] += e1 * t0;
+    Y[1][1] += e1 * t1;
+}
+
+__global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict__ xf, const float* __restrict__ u,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           float* __restrict__ y, const StemGeom g) {
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // raw[team][buf][SW_RAW_F] | filters[buf][SW_U_F]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int team = wave >> 2, w4 = wave & 3, wm = w4 >> 1, wn = w4 & 1;
+    const int kl = lane >> 5, il = lane & 31;
+    const int ty = 4 * wm + (il >> 3), tx = il & 7;                  // this lane's tile in the item's 8 x 8 block
+
+    // raw-window DMA role: piece t = w4 + 4 k of the team's window, slot s = 64 t + lane -> (window row s / 86, 16-byte slot s % 86)
+    unsigned r_voff[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const unsigned s = 64u * (unsigned)(w4 + 4 * k) + (unsigned)lane;
+        const unsigned wr = s / SW_SLOTS, q = s - wr * SW_SLOTS;
+        r_voff[k] = (wr * (unsigned)g.fr_rowf + q * 4u) * 4u;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned lds_raw = lds0 + (unsigned)(team * 2 * SW_RAW_F * 4);
+    const unsigned lds_u = lds0 + (unsigned)(4 * SW_RAW_F * 4);
+
+    auto window_src = [&](int item, int phase) -> const float* {
+        const unsigned b = sw_div((unsigned)item, (unsigned)g.blocks_img, g.magic_img), rem = item - b * g.blocks_img;
+        const unsigned by = sw_div(rem, (unsigned)g.blocks_x, g.magic_x), bx = rem - by * g.blocks_x;
+        return xf + (size_t)b * g.fr_imgf + (size_t)phase * g.fr_phasef + (size_t)(16 * by) * g.fr_rowf + (size_t)(16 * bx) * SW_C;
+    };
+    auto dma_raw = [&](int item, int phase) {                 // phase window of `item` -> the team's buffer phase & 1
+        const float* src = window_src(item, phase);
+        const unsigned dst = lds_raw + (unsigned)((phase & 1) * SW_RAW_F * 4);
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            if (w4 + 4 * k < SW_RAW_PIECES) lds_dma16(r_voff[k], src, dst + (unsigned)((w4 + 4 * k) * 1024));
+    };
+    auto dma_filters = [&](int r) {                           // filters of row r -> buffer r & 1; wave w moves pieces w, w + 8, w + 16
+        const int pieces = c_stem_rows[r].nxp == 5 ? SW_U_PIECES : 18;
+        const float* src = u + (size_t)c_stem_rows[r].upos * SW_POS_F;
+        const unsigned dst = lds_u + (unsigned)((r & 1) * SW_U_F * 4);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (wave + 8 * k < pieces) lds_dma16((unsigned)((wave + 8 * k) * 1024 + lane * 16), src, dst + (unsigned)((wave + 8 * k) * 1024));
+    };
+
+    // LDS read roles
+    const float* raw_team = smem + team * 2 * SW_RAW_F;
+    const int patch0 = (2 * ty) * SW_ROWF + (2 * tx) * SW_C;                       // the tile's patch origin in a window
+    const float* frag0 = smem + 4 * SW_RAW_F + wn * 576 + kl * 128 + il * 4;      // filter fragment (k 0-7) of position 0, buffer 0
+    const float* frag1 = smem + 4 * SW_RAW_F + wn * 576 + 512 + kl * 32 + il;     // ... (k 16-17)
+
+    int pair = blockIdx.x;
+    if (2 * pair >= g.n_items) return;
+    int item = min(2 * pair + team, g.n_items - 1);
+    bool live = 2 * pair + team < g.n_items;
+    dma_raw(item, 0);
+    dma_filters(0);
+
+    for (;;) {
+        f32x16 Y[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[a][b][r] = 0.0f;
+        const int next_pair = pair + gridDim.x;
+        const bool has_next = 2 * next_pair < g.n_items;
+        const int next_item = min(2 * next_pair + team, g.n_items - 1);
+
+        for (int r = 0; r < SW_ROWS; ++r) {
+            const StemRow& row = c_stem_rows[r];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of row r's filters (and of the phase window)
+            __syncthreads();                                     // ... everyone's; the other filter buffer and window buffer are free
+            if (r + 1 < SW_ROWS) dma_filters(r + 1);
+            else if (has_next) dma_filters(0);
+            const int phase = row.phase;
+            if (row.first) {
+                if (phase < 3) dma_raw(item, phase + 1);
+                else if (has_next) dma_raw(next_item, 0);
+            }
+            const float* rawp = raw_team + (phase & 1) * SW_RAW_F + patch0 + 2 * kl;
+            const float* raws = raw_team + (phase & 1) * SW_RAW_F + patch0 + 16 + kl;
+            const float* ub = frag0 + (r & 1) * SW_U_F;
+            const float* ub1 = frag1 + (r & 1) * SW_U_F;
+            if (row.nxp == 5) sw_row<5>(rawp, raws, ub, ub1, row, Y);
+            else sw_row<4>(rawp, raws, ub, ub1, row, Y);
+        }
+
+        // ---- bn1 + relu, stores: lane = one tile (MFMA column), register quad q = channels wn 32 + 8 q + 4 kl .. + 3 ----
+        if (live) {
+            const unsigned b = sw_div((unsigned)item, (unsigned)g.blocks_img, g.magic_img), rem = item - b * g.blocks_img;
+            const unsigned by = sw_div(rem, (unsigned)g.blocks_x, g.magic_x), bx = rem - by * g.blocks_x;
+            const int co = wn * 32 + 4 * kl;
+            float* yp = y + (size_t)b * g.out_img + (size_t)(16 * by + 2 * ty + g.opad) * g.out_row +
+                        (size_t)(16 * bx + 2 * tx + g.opad) * SW_CO + co;
+            float4 sc[4], sh[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sc[q] = *reinterpret_cast<const float4*>(scale + co + 8 * q);
+                sh[q] = *reinterpret_cast<const float4*>(shift + co + 8 * q);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float4 v = make_float4(Y[a][bb][4 * q] * sc[q].x + sh[q].x, Y[a][bb][4 * q + 1] * sc[q].y + sh[q].y,
+                                               Y[a][bb][4 * q + 2] * sc[q].z + sh[q].z, Y[a][bb][4 * q + 3] * sc[q].w + sh[q].w);
+                        if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        *reinterpret_cast<float4*>(yp + (size_t)a * g.out_row + bb * SW_CO + 8 * q) = v;
+                    }
+        }
+        if (!has_next) break;
+        pair = next_pair;
+        item = next_item;
+        live = 2 * pair + team < g.n_items;
+    }
+}
+
+// (B, 18, H, W) -> the four phase frames of every image: frames[b][2 ry + rx][i][j][18] = x[b][:, 2 i + ry - 3, 2 j + rx - 3],
+// frame = (H / 2 + 4) x (W / 2 + 4) pixels (out-of-image pixels stay zero: the owner zeroes the buffer once).  The 18 channels
+// of a pixel are stored in the order 0 2 1 3 | 4 6 5 7 | 8 10 9 11 | 12 14 13 15 | 16 17: the MFMA lane of parity kl reads the
+// pairs (kl, kl + 2), (kl + 4, kl + 6), ... as 8-byte words.  A workgroup moves one run of up to 256 pixels of an input row.
+__global__ __launch_bounds__(256) void stem_phase_split_kernel(const float* __restrict__ x, float* __restrict__ frames, int H, int W,
+                                                               int runs_per_row) {
+    constexpr int C = SW_C;
+    __shared__ float sp[256 * C];
+    const int t = threadIdx.x;
+    const int run = blockIdx.x % runs_per_row;
+    const long row = blockIdx.x / runs_per_row;              // b * H + h
+    const long b = row / H;
+    const int h = (int)(row - b * H);
+    const int w0 = run * 256, n = min(256, W - w0);
+    const long hw = (long)H * W;
+    if (t < n) {
+        const float* src = x + (b * C) * hw + (long)h * W + w0 + t;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int slot = c >= 16 ? c : (c & ~3) + ((c & 1) << 1) + ((c >> 1) & 1);      // 0 2 1 3 within each group of four
+            sp[t * C + slot] = src[c * hw];
+        }
+    }
+    __syncthreads();
+    const int FR = H / 2 + 4, FC = W / 2 + 4;
+    const int ry = (h + 3) & 1, i = (h + 3) >> 1;
+    const v2f* s2 = reinterpret_cast<const v2f*>(sp);
+#pragma unroll
+    for (int rx = 0; rx < 2; ++rx) {
+        // pixels w0 + wl with (w0 + wl + 3) & 1 == rx (w0 is even): wl = 1 - rx, 3 - rx, ...
+        const int first = 1 - rx, count = (n - first + 1) / 2;
+        const int j0 = (w0 + first + 3) >> 1;
+        v2f* dst = reinterpret_cast<v2f*>(frames + (((b * 4 + ry * 2 + rx) * FR + i) * (long)FC + j0) * C);
+        for (int e = t; e < count * (C / 2); e += 256) {
+            const int pi = e / (C / 2), sl = e - pi * (C / 2);
+            dst[e] = s2[(first + 2 * pi) * (C / 2) + sl];
+        }
+    }
+}
+
+}  // namespace hps
+
+using namespace hps;
+
+extern "C" size_t hps_stem_phase_frames_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0 || (H % 32) || (W % 32)) return 0;
+    // + one window of slack: the last DMA piece of a window over-reads into the rows that follow
+    return ((size_t)B * 4 * (H / 2 + 4) * (W / 2 + 4) * SW_C + 20 * (size_t)(W / 2 + 4) * SW_C) * sizeof(float);
+}
+
+extern "C" int hps_stem_phase_split(const float* x, float* frames, int B, int C, int H, int W, hps_stream_t stream) {
+    if (!x || !frames) return bad_arg("hps_stem_phase_split: null pointer");
+    if (C != SW_C) return bad_arg("hps_stem_phase_split: 18 input channels (the proxy representation)");
+    if (H <= 0 || W <= 0 || (H % 32) || (W % 32)) return bad_arg("hps_stem_phase_split: H and W must be multiples of 32");
+    if (B <= 0) return HPS_OK;
+    const int runs = ceil_div(W, 256);
+    const long blocks = (long)B * H * runs;
+    if (blocks > 0x7fffffffL) return bad_arg("hps_stem_phase_split: too many rows");
+    hipLaunchKernelGGL(stem_phase_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, frames, H, W, runs);
+    return check_launch("hps_stem_phase_split");
+}
+
+extern "C" int hps_stem_winograd(const float* frames, const float* u, const float* scale, const float* shift, float* y, int B, int H,
+                                 int W, int opad, int relu, hps_stream_t stream) {
+    if (!frames || !u || !scale || !shift || !y) return bad_arg("hps_stem_winograd: null pointer");
+    if (H <= 0 || W <= 0 || (H % 32) || (W % 32)) return bad_arg("hps_stem_winograd: H and W must be multiples of 32 (8 x 8 blocks of 2 x 2-pixel tiles at stride 2)");
+    if (opad < 0) return bad_arg("hps_stem_winograd: opad");
+    if (B <= 0) return HPS_OK;
+    const int Ho = H / 2, Wo = W / 2;
+    StemGeom g;
+    g.fr_rowf = (Wo + 4) * SW_C;
+    g.fr_phasef = (Ho + 4) * g.fr_rowf;
+    g.fr_imgf = 4 * g.fr_phasef;
+    g.blocks_x = Wo / 16;
+    g.blocks_img = (Ho / 16) * g.blocks_x;
+    g.n_items = B * g.blocks_img;
+    g.out_row = (Wo + 2 * opad) * SW_CO;
+    g.out_img = (Ho + 2 * opad) * g.out_row;
+    g.opad = opad;
+    g.relu = relu;
+    g.magic_img = sw_magic((unsigned)g.blocks_img);
+    g.magic_x = sw_magic((unsigned)g.blocks_x);
+    if ((size_t)B * g.fr_imgf * 4 >= 0xffffffffull || (size_t)B * g.out_img * 4 >= 0xffffffffull)
+        return bad_arg("hps_stem_winograd: tensor exceeds the 32-bit lane offsets");
+    const size_t lds = (size_t)SW_LDS_F * sizeof(float);
+    if (int rc = grant_lds<&stem_wino_kernel>((int)lds, "hps_stem_winograd")) return rc;
+    const int pairs = (g.n_items + 1) / 2;
+    hipLaunchKernelGGL(stem_wino_kernel, dim3((unsigned)(pairs < 256 ? pairs : 256)), dim3(512), lds, (hipStream_t)stream, frames, u,
+                       scale, shift, y, g);
+    return check_launch("hps_stem_winograd");
+}

@@ -52,6 +52,11 @@ class _ConvBN:
             U = torch.einsum("ai,ocij,bj->abco", G, w.double(), G)                       # (4,4,cin,cout)
             U = U.reshape(16, cin // 8, 2, 4, cout // 64, 64)                            # p, chunk, kq, j, ct, n
             self.wino_u = U.permute(1, 4, 0, 2, 5, 3).contiguous().float()              # chunk, ct, p, kq, n, j
+        # Winograd form of the stem (csrc/stem_wino.hip): the 7x7 / 2 correlation as four stride-1 phase correlations, each
+        # F(2x2, r x s); U = G_y g G_x^T per phase in the kernel's layout (include/hps.h: hps_stem_winograd)
+        self.stem_u = None
+        if kh == 7 and kw == 7 and self.stride == 2 and self.pad == 3 and cin == 18 and cout == 64:
+            self.stem_u = _stem_winograd_filters(w).to(w.device).contiguous()
         self.use_winograd = True
         self.kernel = "v3"        # "v3" direct global->LDS (default), "v2" register-staged, "v1" generic (any Cin % 4 == 0)
         self.variant = 0          # tile choice of the v2 / v3 kernels (0 = automatic)
@@ -76,6 +81,11 @@ class _ConvBN:
         feature, must not depend on how images are batched or sharded)."""
         return self.use_winograd and self.wino_u is not None and ipad >= 1 and \
             ((H % 16 == 0 and W % 16 == 0) or (H == 8 and W == 8))
+
+    def stem_winograd_ok(self, C, H, W):
+        """The Winograd form of the stem (csrc/stem_wino.hip) applies: the released model's conv1 (7x7 / 2 / 3, 18 -> 64) on maps
+        that split into 32 x 32-pixel input blocks -- a rule on the layer and the image size only (see winograd_ok)."""
+        return self.use_winograd and self.stem_u is not None and C == 18 and H % 32 == 0 and W % 32 == 0
 
     def wino_workspace_bytes(self, B, H, W, ipad=1):
         """Bytes of the K-slice buffer hps_conv3x3_winograd needs for this layer on (H, W) maps (0: none / not Winograd)."""
@@ -168,6 +178,31 @@ class _ConvBN:
                    P(residual) if residual is not None else None, P(y), B, H, W, C, self.cout, self.kh, self.kw,
                    self.stride, self.pad, 1 if relu else 0, _capi.stream())
         return y
+
+
+_STEM_G4 = [[0.5, 0, 0, 0], [-0.5, -0.5, -0.5, -0.5], [-1 / 6, 1 / 6, -1 / 6, 1 / 6], [1 / 6, 1 / 3, 2 / 3, 4 / 3], [0, 0, 0, 1]]
+_STEM_G3 = [[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]]
+
+
+def _stem_winograd_filters(w):
+    """w (64, 18, 7, 7) -> the 81 transformed filter positions of csrc/stem_wino.hip, fp64 arithmetic rounded once to fp32.
+    Phase (ry, rx) holds the taps w[:, :, ry::2, rx::2] (4 or 3 per axis); positions are ordered phase 2 ry + rx, row i, column j;
+    one position is 1152 floats: [co / 32][k-block (c % 16) / 8][c % 2][co % 32][(c % 8) / 2] for c < 16, then c = 16, 17 as
+    [c - 16][co % 32] behind them.  256 floats of slack follow (the last DMA piece of a row of positions over-reads)."""
+    w = w.detach().double().cpu()
+    pos = []
+    for ry in (0, 1):
+        for rx in (0, 1):
+            gy = torch.tensor(_STEM_G4 if ry == 0 else _STEM_G3, dtype=torch.float64)
+            gx = torch.tensor(_STEM_G4 if rx == 0 else _STEM_G3, dtype=torch.float64)
+            u = torch.einsum("ia,ocab,jb->ijco", gy, w[:, :, ry::2, rx::2], gx)          # (ny, nx, 18, 64)
+            pos.append(u.reshape(-1, 18, 64))
+    u = torch.cat(pos, 0)                                                                # (81, c, co)
+    lo = u[:, :16].reshape(81, 2, 4, 2, 2, 32)                                           # p, kblock, e, parity, co half, co % 32   (c = 8 kb + 2 e + parity)
+    lo = lo.permute(0, 4, 1, 3, 5, 2).reshape(81, 2, 512)                                # p, half, [kb][parity][co % 32][e]
+    hi = u[:, 16:].reshape(81, 2, 2, 32).permute(0, 2, 1, 3).reshape(81, 2, 64)          # p, half, [c - 16][co % 32]
+    packed = torch.cat([lo, hi], 2).reshape(-1)
+    return torch.cat([packed, torch.zeros(256, dtype=torch.float64)]).float()
 
 
 class _FrameCache(dict):
@@ -281,15 +316,20 @@ class ResNet(nn.Module):
 
     # ---- halo-padded activation frames: owned by the module, zeroed once, only interiors are ever written ----
     def _frame_set(self, prep, B, C, H, W, device):
-        key = (B, C, H, W, str(device), _capi.stream().value)
+        stem = prep["stem"]
+        stem_wino = stem.stem_winograd_ok(C, H, W)
+        key = (B, C, H, W, str(device), _capi.stream().value, stem_wino)
         fs = self._frames.get(key)
         if fs is not None:
             return fs
         if len(self._frames) >= 6:                       # a handful of batch shapes / streams at most
             self._frames.pop(next(iter(self._frames)))
         z = lambda *shape: torch.zeros(*shape, device=device, dtype=torch.float32)
-        stem = prep["stem"]
-        fs = {"in": z(B, H + 6, W + 6, C)}
+        if stem_wino:      # four phase frames per image (hps_stem_phase_split), out-of-image pixels zeroed here once
+            fs = {"in": z(int(_capi.load(dev=_capi._use_dev).hps_stem_phase_frames_bytes(B, H, W)) // 4)}
+        else:
+            fs = {"in": z(B, H + 6, W + 6, C)}
+        fs["stem_wino"] = stem_wino
         h, w = stem.out_hw(H, W)
         fs["stem"] = torch.empty(B, h, w, stem.cout, device=device, dtype=torch.float32)
         h, w = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
@@ -307,8 +347,15 @@ class ResNet(nn.Module):
             fs["blocks"].append(ent)
         fs["hw"] = (h, w)
         # the launch list of hps_encoder_run: every pointer but the input image and the feature output is fixed
-        ops = [_capi.EncOp(kind=_capi.ENC_RELAYOUT, x=None, y=fs["in"].data_ptr(), B=B, Cin=C, H=H, W=W, opad=3),
-               stem.enc_op(fs["in"], 3, fs["stem"], 0, relu=True),
+        if stem_wino:
+            first = [_capi.EncOp(kind=_capi.ENC_STEM_SPLIT, x=None, y=fs["in"].data_ptr(), B=B, Cin=C, H=H, W=W),
+                     _capi.EncOp(kind=_capi.ENC_STEM_WINOGRAD, x=fs["in"].data_ptr(), w=stem.stem_u.data_ptr(), scale=stem.scale.data_ptr(),
+                                 shift=stem.shift.data_ptr(), y=fs["stem"].data_ptr(), B=B, H=H, W=W, Cin=C, Cout=stem.cout, KH=7, KW=7,
+                                 stride=2, pad=3, opad=0, relu=1)]
+        else:
+            first = [_capi.EncOp(kind=_capi.ENC_RELAYOUT, x=None, y=fs["in"].data_ptr(), B=B, Cin=C, H=H, W=W, opad=3),
+                     stem.enc_op(fs["in"], 3, fs["stem"], 0, relu=True)]
+        ops = first + [
                _capi.EncOp(kind=_capi.ENC_MAXPOOL, x=fs["stem"].data_ptr(), y=fs["pool"].data_ptr(), B=B, H=fs["stem"].shape[1],
                            W=fs["stem"].shape[2], Cin=stem.cout, opad=1)]
         y = fs["pool"]
@@ -358,11 +405,18 @@ class ResNet(nn.Module):
                 rest = ctypes.cast(ctypes.byref(ops, ctypes.sizeof(_capi.EncOp)), ctypes.POINTER(_capi.EncOp))
                 _capi.call("hps_encoder_run", rest, len(ops) - 1, s)
             return feats
-        _capi.call("hps_nchw_to_padded_nhwc", P(x), P(fs["in"]), B, C, H, W, 3, s)
-        if gate is not None:
-            gate()
         stem = prep["stem"]
-        y = stem.padded(fs["in"], 3, fs["stem"], 0, relu=True)             # conv1 + bn1 + relu
+        if fs["stem_wino"]:
+            _capi.call("hps_stem_phase_split", P(x), P(fs["in"]), B, C, H, W, s)
+            if gate is not None:
+                gate()
+            y = fs["stem"]
+            _capi.call("hps_stem_winograd", P(fs["in"]), P(stem.stem_u), P(stem.scale), P(stem.shift), P(y), B, H, W, 0, 1, s)
+        else:
+            _capi.call("hps_nchw_to_padded_nhwc", P(x), P(fs["in"]), B, C, H, W, 3, s)
+            if gate is not None:
+                gate()
+            y = stem.padded(fs["in"], 3, fs["stem"], 0, relu=True)         # conv1 + bn1 + relu
         _capi.call("hps_maxpool3x3s2_pad", P(y), P(fs["pool"]), B, y.shape[1], y.shape[2], y.shape[3], 1, s)
         y = fs["pool"]
         for (c1, c2, down), ent in zip(prep["blocks"], fs["blocks"]):      # BasicBlock.forward :62-78

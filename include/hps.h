@@ -309,12 +309,35 @@ int hps_conv3x3_winograd(const float* x, const float* u, const float* scale, con
                          int opad, int relu, float* splitk_ws, hps_stream_t stream);
 size_t hps_conv3x3_winograd_workspace(int B, int H, int W, int Cin, int Cout);
 
+/* The stem -- conv1 7x7 / stride 2 / pad 3 on the 18-channel proxy representation + bn1 + relu (models/resnet.py:147-150,
+ * :203-206) -- in Winograd form (csrc/stem_wino.hip): the stride-2 correlation is the sum of four stride-1 correlations on the
+ * even / odd sub-lattices of the input (4x4, 4x3, 3x4 and 3x3 taps), each computed as F(2x2, r x s): 81 multiplications per 2x2
+ * output tile and (cin, cout) pair instead of 196.  Same result as the direct sum up to fp32 rounding (both are within 1e-6 of the
+ * output scale of the fp64 sum).  H and W multiples of 32, Cin = 18, Cout = 64.
+ *   hps_stem_phase_split: x (B,18,H,W) NCHW -> frames[b][2 ry + rx][i][j][18] = x[b][:, 2 i + ry - 3, 2 j + rx - 3], four
+ *     (H/2 + 4) x (W/2 + 4)-pixel frames per image whose out-of-image pixels the OWNER zeroes once (only in-image pixels are ever
+ *     written); the channels of a pixel are stored in the order 0 2 1 3 | 4 6 5 7 | 8 10 9 11 | 12 14 13 15 | 16 17.  The buffer
+ *     holds hps_stem_phase_frames_bytes(B, H, W) bytes (the frames plus the slack the last window's DMA over-reads).
+ *   hps_stem_winograd: frames -> y, the interior of the (B, H/2 + 2 opad, W/2 + 2 opad, 64) NHWC frame.  u: the transformed
+ *     filters of the 81 positions, position-major in the row order (phase 2 ry + rx; row i; column j), 1152 floats each:
+ *       u[position][co / 32][ k-block: (c % 16) / 8 ][ c % 2 ][co % 32][ (c % 8) / 2 ]   for c < 16   (2 x 2 x 32 x 4 floats)
+ *       u[position][co / 32][512 + (c - 16) * 32 + co % 32]                              for c = 16, 17
+ *     U = G_y g_{ry,rx} G_x^T with g_{ry,rx}[a][b] = w[co][c][2a + ry][2b + rx] and
+ *     G (4 taps) = [1/2 0 0 0; -1/2 -1/2 -1/2 -1/2; -1/6 1/6 -1/6 1/6; 1/6 1/3 2/3 4/3; 0 0 0 1],
+ *     G (3 taps) = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]; 81 * 1152 floats plus 256 floats of readable slack. */
+size_t hps_stem_phase_frames_bytes(int B, int H, int W);
+int hps_stem_phase_split(const float* x, float* frames, int B, int C, int H, int W, hps_stream_t stream);
+int hps_stem_winograd(const float* frames, const float* u, const float* scale, const float* shift, float* y, int B, int H,
+                      int W, int opad, int relu, hps_stream_t stream);
+
 /* One launch of the encoder's operation list (hps_encoder_run).  kind: HPS_ENC_RELAYOUT = hps_nchw_to_padded_nhwc
  * (x, y, B, Cin = C, H, W, opad = P), HPS_ENC_CONV = hps_conv2d_bn_act_pad (all fields), HPS_ENC_MAXPOOL =
  * hps_maxpool3x3s2_pad (x, y, B, H, W, Cin = C, opad), HPS_ENC_AVGPOOL = hps_global_avgpool_pad (x, y, B, H, W,
  * Cin = C, ipad = P), HPS_ENC_CONV_WINOGRAD = hps_conv3x3_winograd (x, w = u, scale, shift, residual, y, B, H, W, ipad, Cin,
- * Cout, opad, relu, splitk_ws). */
-enum { HPS_ENC_RELAYOUT = 0, HPS_ENC_CONV = 1, HPS_ENC_MAXPOOL = 2, HPS_ENC_AVGPOOL = 3, HPS_ENC_CONV_WINOGRAD = 4 };
+ * Cout, opad, relu, splitk_ws), HPS_ENC_STEM_SPLIT = hps_stem_phase_split (x, y = frames, B, Cin = C, H, W),
+ * HPS_ENC_STEM_WINOGRAD = hps_stem_winograd (x = frames, w = u, scale, shift, y, B, H, W, opad, relu). */
+enum { HPS_ENC_RELAYOUT = 0, HPS_ENC_CONV = 1, HPS_ENC_MAXPOOL = 2, HPS_ENC_AVGPOOL = 3, HPS_ENC_CONV_WINOGRAD = 4,
+       HPS_ENC_STEM_SPLIT = 5, HPS_ENC_STEM_WINOGRAD = 6 };
 typedef struct hps_enc_op {
     int kind;
     const float* x;
