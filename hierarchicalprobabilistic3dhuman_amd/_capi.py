@@ -83,6 +83,7 @@ _DEV_PROTOTYPES = {
     "hps_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "hps_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P],
     "hps_global_avgpool": [_P, _P, _I, _I, _I, _P],
+    "hps_dev_stem_winograd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hps_dev_conv3x3_winograd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "hps_dev_mesh_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
 }

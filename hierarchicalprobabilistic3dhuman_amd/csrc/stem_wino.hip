@@ -21,13 +21,18 @@
 // through LDS (as conv_wino.hip does) would cost more LDS traffic than the MFMAs take; instead the lane that needs V as an MFMA
 // operand computes it: MFMA lane (il, kl) supplies B[k = kl][column il], so lane (il, kl) transforms tile il's channels of
 // parity kl (2m + kl for the m-th MFMA of a position) and holds them in registers -- no LDS round trip for V at all.
-// The positions are processed in 18 "rows" (one row i of one phase: 5 or 4 positions).  Per row a lane
-//   * forms the vertical combinations c[b] = sum_a B_y^T[i][a] d[a][b] of its patch pixels from the raw window in LDS
-//     (coefficients from a constant table: 2-4 pixels per output),
-//   * per position j: a_j = sum_b B_x^T[j][b] c[b] (compile-time coefficients), nine MFMAs into M[j] with the filters of the
-//     position read from LDS,
+// The positions are processed in 18 "rows" (one row i of one phase: 5 or 4 positions).  Per row a wave
+//   * transforms: per channel pair, the vertical combinations c[b] = sum_a B_y^T[i][a] d[a][b] of its patch pixels from the
+//     raw window in LDS (coefficients from a constant table: 2-4 pixels per output, the next pair's pixels in flight), then
+//     a_j = sum_b B_x^T[j][b] c[b] (compile-time coefficients) -- 45 operand registers;
+//   * after the row's barrier (filters of the row in LDS): 45 MFMAs back to back, filters read from LDS one position ahead;
 //   * folds the row into the four output accumulators: t = M A_x (compile-time), Y[a][.] += A_y^T[a][i] t.
-// Live registers: M (5 x 16), Y (4 x 16), one channel group of c (20) -- two waves per SIMD, which is what hides the LDS reads.
+// One run of VALU work and one run of MFMAs per row, not a fine interleave: on gfx950 VALU instructions and fp32 MFMAs of a SIMD
+// exclude each other, and every switch between the two costs about 25 cycles in each direction (tools/mfma_valu_ops.hip; a
+// version that hid every window read behind two MFMAs of the same wave was slower, 0.62 against 0.59 ms).  The same tool priced
+// the instructions: packed fp32 adds / multiplies are no cheaper than two plain ones, packed FMAs are -- and forcing everything
+// into v_pk_fma_f32 (inline asm) measured slower than what hipcc makes of the v2f expressions below, so they are left to it.
+// Live registers: M (5 x 16), Y (4 x 16), the 45 operands -- two waves per SIMD.
 //
 // Work item = 8 x 8 tiles (16 x 16 output pixels) of one image x 64 output channels; a workgroup is two teams of four waves
 // (2 tile halves x 2 channel halves), each team on its own item, both teams sharing the filters: LDS holds, per team, two raw
@@ -35,6 +40,8 @@
 // the workgroup, two filter rows (5 positions x 4.5 KiB, double buffered) -- 150 KiB, one workgroup per CU, persistent.
 // The input comes from hps_stem_phase_split: the four phase images of every input image as separate NHWC frames, so that a
 // window row is one contiguous run and the channels of a pixel sit in the order the lanes read them.
+#include <type_traits>
+
 #include "hps_common.h"
 
 namespace hps {
@@ -62,27 +69,29 @@ struct StemRow {
     float coef[4];
     float e0, e1;               // A_y^T[0][i], A_y^T[1][i]
 };
-#define R5(ph, fi, nx, up, i)                                                                                                    \
-    {ph, fi, nx, (i) == 3 ? 2 : ((i) == 1 || (i) == 2) ? 3 : 4, up,                                                              \
-     {((i) == 0 ? 0 : 1) * SW_ROWF, ((i) == 0 ? 1 : (i) == 3 ? 3 : 2) * SW_ROWF, ((i) == 0 ? 2 : 3) * SW_ROWF, ((i) == 4 ? 4 : 3) * SW_ROWF}, \
-     {(i) == 0 ? 2.f : (i) == 1 ? -2.f : (i) == 2 ? 2.f : (i) == 3 ? -1.f : 2.f,                                                 \
-      (i) == 0 ? -1.f : (i) == 1 ? -1.f : (i) == 2 ? -3.f : (i) == 3 ? 1.f : -1.f,                                               \
-      (i) == 0 ? -2.f : (i) == 1 ? 1.f : (i) == 2 ? 1.f : (i) == 3 ? 0.f : -2.f, (i) == 0 ? 1.f : (i) == 4 ? 1.f : 0.f},          \
-     (i) < 4 ? 1.f : 0.f, (i) == 0 ? 0.f : (i) == 1 ? 1.f : (i) == 2 ? -1.f : (i) == 3 ? 2.f : 1.f}
-#define R4(ph, fi, nx, up, i)                                                                                                    \
-    {ph, fi, nx, 2, up,                                                                                                          \
-     {((i) == 0 ? 0 : 1) * SW_ROWF, ((i) == 3 ? 3 : 2) * SW_ROWF, 0, 0},                                                          \
-     {((i) == 0 || (i) == 1) ? 1.f : -1.f, (i) == 0 ? -1.f : 1.f, 0.f, 0.f},                                                      \
-     (i) < 3 ? 1.f : 0.f, (i) == 0 ? 0.f : (i) == 2 ? -1.f : 1.f}
 // F(2, 4), points 0, 1, -1, 2, inf:  B^T = [2 -1 -2 1 0; 0 -2 -1 1 0; 0 2 -3 1 0; 0 -1 0 1 0; 0 2 -1 -2 1],  A^T = [1 1 1 1 0; 0 1 -1 2 1]
 // F(2, 3), points 0, 1, -1, inf:     B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 -1 0 1],                          A^T = [1 1 1 0; 0 1 -1 1]
+// Phases in the order (even rows, even columns), (even, odd), (odd, even), (odd, odd); ne = taps of the row's vertical combination
+// (unused entries repeat tap 0 with coefficient 0).
 __constant__ StemRow c_stem_rows[SW_ROWS] = {
-    R5(0, 1, 5, 0, 0),  R5(0, 0, 5, 5, 1),  R5(0, 0, 5, 10, 2), R5(0, 0, 5, 15, 3), R5(0, 0, 5, 20, 4),     // even rows, even columns
-    R5(1, 1, 4, 25, 0), R5(1, 0, 4, 29, 1), R5(1, 0, 4, 33, 2), R5(1, 0, 4, 37, 3), R5(1, 0, 4, 41, 4),     // even rows, odd columns
-    R4(2, 1, 5, 45, 0), R4(2, 0, 5, 50, 1), R4(2, 0, 5, 55, 2), R4(2, 0, 5, 60, 3),                         // odd rows, even columns
-    R4(3, 1, 4, 65, 0), R4(3, 0, 4, 69, 1), R4(3, 0, 4, 73, 2), R4(3, 0, 4, 77, 3)};                        // odd rows, odd columns
-#undef R5
-#undef R4
+    {0, 1, 5, 4,  0, {0 * SW_ROWF, 1 * SW_ROWF, 2 * SW_ROWF, 3 * SW_ROWF}, {2.0f, -1.0f, -2.0f, 1.0f}, 1.0f, 0.0f},
+    {0, 0, 5, 3,  5, {1 * SW_ROWF, 2 * SW_ROWF, 3 * SW_ROWF, 1 * SW_ROWF}, {-2.0f, -1.0f, 1.0f, 0.0f}, 1.0f, 1.0f},
+    {0, 0, 5, 3, 10, {1 * SW_ROWF, 2 * SW_ROWF, 3 * SW_ROWF, 1 * SW_ROWF}, {2.0f, -3.0f, 1.0f, 0.0f}, 1.0f, -1.0f},
+    {0, 0, 5, 2, 15, {1 * SW_ROWF, 3 * SW_ROWF, 1 * SW_ROWF, 1 * SW_ROWF}, {-1.0f, 1.0f, 0.0f, 0.0f}, 1.0f, 2.0f},
+    {0, 0, 5, 4, 20, {1 * SW_ROWF, 2 * SW_ROWF, 3 * SW_ROWF, 4 * SW_ROWF}, {2.0f, -1.0f, -2.0f, 1.0f}, 0.0f, 1.0f},
+    {1, 1, 4, 4, 25, {0 * SW_ROWF, 1 * SW_ROWF, 2 * SW_ROWF, 3 * SW_ROWF}, {2.0f, -1.0f, -2.0f, 1.0f}, 1.0f, 0.0f},
+    {1, 0, 4, 3, 29, {1 * SW_ROWF, 2 * SW_ROWF, 3 * SW_ROWF, 1 * SW_ROWF}, {-2.0f, -1.0f, 1.0f, 0.0f}, 1.0f, 1.0f},
+    {1, 0, 4, 3, 33, {1 * SW_ROWF, 2 * SW_ROWF, 3 * SW_ROWF, 1 * SW_ROWF}, {2.0f, -3.0f, 1.0f, 0.0f}, 1.0f, -1.0f},
+    {1, 0, 4, 2, 37, {1 * SW_ROWF, 3 * SW_ROWF, 1 * SW_ROWF, 1 * SW_ROWF}, {-1.0f, 1.0f, 0.0f, 0.0f}, 1.0f, 2.0f},
+    {1, 0, 4, 4, 41, {1 * SW_ROWF, 2 * SW_ROWF, 3 * SW_ROWF, 4 * SW_ROWF}, {2.0f, -1.0f, -2.0f, 1.0f}, 0.0f, 1.0f},
+    {2, 1, 5, 2, 45, {0 * SW_ROWF, 2 * SW_ROWF, 0 * SW_ROWF, 0 * SW_ROWF}, {1.0f, -1.0f, 0.0f, 0.0f}, 1.0f, 0.0f},
+    {2, 0, 5, 2, 50, {1 * SW_ROWF, 2 * SW_ROWF, 1 * SW_ROWF, 1 * SW_ROWF}, {1.0f, 1.0f, 0.0f, 0.0f}, 1.0f, 1.0f},
+    {2, 0, 5, 2, 55, {1 * SW_ROWF, 2 * SW_ROWF, 1 * SW_ROWF, 1 * SW_ROWF}, {-1.0f, 1.0f, 0.0f, 0.0f}, 1.0f, -1.0f},
+    {2, 0, 5, 2, 60, {1 * SW_ROWF, 3 * SW_ROWF, 1 * SW_ROWF, 1 * SW_ROWF}, {-1.0f, 1.0f, 0.0f, 0.0f}, 0.0f, 1.0f},
+    {3, 1, 4, 2, 65, {0 * SW_ROWF, 2 * SW_ROWF, 0 * SW_ROWF, 0 * SW_ROWF}, {1.0f, -1.0f, 0.0f, 0.0f}, 1.0f, 0.0f},
+    {3, 0, 4, 2, 69, {1 * SW_ROWF, 2 * SW_ROWF, 1 * SW_ROWF, 1 * SW_ROWF}, {1.0f, 1.0f, 0.0f, 0.0f}, 1.0f, 1.0f},
+    {3, 0, 4, 2, 73, {1 * SW_ROWF, 2 * SW_ROWF, 1 * SW_ROWF, 1 * SW_ROWF}, {-1.0f, 1.0f, 0.0f, 0.0f}, 1.0f, -1.0f},
+    {3, 0, 4, 2, 77, {1 * SW_ROWF, 3 * SW_ROWF, 1 * SW_ROWF, 1 * SW_ROWF}, {-1.0f, 1.0f, 0.0f, 0.0f}, 0.0f, 1.0f}};
 
 struct StemGeom {
     int fr_rowf, fr_phasef, fr_imgf;      // phase frame pitches in floats: row, phase frame, image (4 phase frames)
@@ -118,82 +127,103 @@ __device__ __forceinline__ T sw_horiz(int j, const T (&c)[5]) {
     }
 }
 
-// One row of positions (see the header).  rawp: this lane's patch origin in the raw window (pair channels), raws: its single
-// channel; ub / ub1: this lane's filter fragment slots of position 0 of the row (k 0-7, and k 16-17).
-template <int NXP>
-__device__ __forceinline__ void sw_row(const float* rawp, const float* raws, const float* ub, const float* ub1, const StemRow& row,
-                                       f32x16 (&Y)[2][2]) {
-    f32x16 M[5];
-    const int ne = row.ne;
-    const int o0 = row.aoff[0], o1 = row.aoff[1], o2 = row.aoff[2], o3 = row.aoff[3];
-    const float k0 = row.coef[0], k1 = row.coef[1], k2 = row.coef[2], k3 = row.coef[3];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {                 // channel groups 8 g .. 8 g + 7 (this lane: four of them, as two pairs)
-        v2f c[2][5];
+// One 8-byte LDS read per patch pixel and channel pair, as ds_read_b64 (volatile: hipcc would pair two of them into a
+// ds_read2_b64, which the LDS serves at half the rate -- 16-lane groups, banks mod 32 -- and with the tiles' 144-byte pitch at
+// half of that again)
+__device__ __forceinline__ v2f sw_ld2(const float* p) {
+    typedef const volatile __attribute__((address_space(3))) v2f* lds_v2f_t;
+    return *(lds_v2f_t)(const __attribute__((address_space(3))) float*)p;
+}
+
+template <int AB>
+__device__ __forceinline__ f32x16 sw_mfma(float a, float b, f32x16 c) {
+    if (AB == 2) {
+        c[0] += a * b;
+        return c;
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// Input transform of one row of positions (see the header): A[j][m] = the lane's channel 2 m + kl of position j, m = 0..8.
+// rawp: this lane's patch origin in the raw window (its channel pairs), raws: the channels 16, 17 of that pixel (odd: the lane
+// keeps 17).  NXP: positions of the row, NE: window rows in its vertical combination.
+// AB: profiling ablations (dev library only; the product instantiates AB = 0): 1 = patch pixels not read (constants), 2 = no MFMAs,
+// 3 = no output transform, 4 = no barriers (races), 5 = no filter fragment reads
+template <int NXP, int NE, int AB>
+__device__ __forceinline__ void sw_transform(const float* rawp, const float* raws, const StemRow& row, bool odd, float (&A)[5][9]) {
+    const int o[4] = {row.aoff[0], row.aoff[1], row.aoff[2], row.aoff[3]};
+    const float k[4] = {row.coef[0], row.coef[1], row.coef[2], row.coef[3]};
+    v2f ld[2][5][4];               // [group parity][patch column][tap]: the reads of the next group are in flight while one is combined
+    auto issue = [&](int g) {      // group g = channel pair 0..3, 4 = the single channels 16, 17
 #pragma unroll
         for (int b = 0; b < NXP; ++b)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float* p = rawp + b * SW_C + g * 8 + h * 4;
-                v2f v = k0 * *reinterpret_cast<const v2f*>(p + o0);
-                v = __builtin_elementwise_fma((v2f){k1, k1}, *reinterpret_cast<const v2f*>(p + o1), v);
-                c[h][b] = v;
+            for (int e = 0; e < NE; ++e) {
+                const float* p = (g < 4 ? rawp + g * 4 : raws) + b * SW_C + o[e];
+                ld[g & 1][b][e] = AB == 1 ? (v2f){(float)(unsigned)(size_t)p, 1.0f} : sw_ld2(p);
             }
-        if (ne > 2) {
+    };
+    issue(0);
 #pragma unroll
-            for (int b = 0; b < NXP; ++b)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float* p = rawp + b * SW_C + g * 8 + h * 4;
-                    c[h][b] = __builtin_elementwise_fma((v2f){k2, k2}, *reinterpret_cast<const v2f*>(p + o2), c[h][b]);
-                }
-        }
-        if (ne > 3) {
-#pragma unroll
-            for (int b = 0; b < NXP; ++b)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float* p = rawp + b * SW_C + g * 8 + h * 4;
-                    c[h][b] = __builtin_elementwise_fma((v2f){k3, k3}, *reinterpret_cast<const v2f*>(p + o3), c[h][b]);
-                }
-        }
-#pragma unroll
-        for (int j = 0; j < NXP; ++j) {
-            const v2f a0 = sw_horiz<NXP>(j, c[0]), a1 = sw_horiz<NXP>(j, c[1]);
-            const float4 u = *reinterpret_cast<const float4*>(ub + j * SW_POS_F + g * 256);
-            if (g == 0) {
-                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                M[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, a0.x, z, 0, 0, 0);
-            } else {
-                M[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, a0.x, M[j], 0, 0, 0);
-            }
-            M[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.y, a0.y, M[j], 0, 0, 0);
-            M[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, a1.x, M[j], 0, 0, 0);
-            M[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.w, a1.y, M[j], 0, 0, 0);
-        }
-    }
-    {                                              // channels 16, 17: one per lane
-        float c1[5];
+    for (int g = 0; g < 5; ++g) {
+        if (g + 1 < 5) issue(g + 1);
+        v2f c[5];
 #pragma unroll
         for (int b = 0; b < NXP; ++b) {
-            const float* p = raws + b * SW_C;
-            c1[b] = __builtin_fmaf(k1, p[o1], k0 * p[o0]);
-        }
-        if (ne > 2) {
+            v2f v = k[0] * ld[g & 1][b][0];
 #pragma unroll
-            for (int b = 0; b < NXP; ++b) c1[b] = __builtin_fmaf(k2, raws[b * SW_C + o2], c1[b]);
-        }
-        if (ne > 3) {
-#pragma unroll
-            for (int b = 0; b < NXP; ++b) c1[b] = __builtin_fmaf(k3, raws[b * SW_C + o3], c1[b]);
+            for (int e = 1; e < NE; ++e) v = __builtin_elementwise_fma((v2f){k[e], k[e]}, ld[g & 1][b][e], v);
+            c[b] = v;
         }
 #pragma unroll
         for (int j = 0; j < NXP; ++j) {
-            const float a = sw_horiz<NXP>(j, c1);
-            M[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ub1[j * SW_POS_F], a, M[j], 0, 0, 0);
+            const v2f a = sw_horiz<NXP>(j, c);
+            if (g < 4) {
+                A[j][2 * g] = a.x;
+                A[j][2 * g + 1] = a.y;
+            } else {
+                A[j][8] = odd ? a.y : a.x;
+            }
         }
     }
-    // output transform of the row: t = M A_x, Y[a][.] += A_y^T[a][i] t
+}
+
+// The MFMAs of one row (nine per position, filters of the position read from LDS one position ahead) and its output transform
+// t = M A_x, Y[a][.] += A_y^T[a][i] t.  ub / ub1: this lane's filter fragment slots of position 0 of the row (k 0-15, k 16-17).
+template <int NXP, int AB>
+__device__ __forceinline__ void sw_gemm(const float* ub, const float* ub1, const StemRow& row, const float (&A)[5][9], f32x16 (&Y)[2][2]) {
+    f32x16 M[5];
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float4 u0 = AB == 5 ? make_float4(1.f, 2.f, 3.f, 4.f) : *reinterpret_cast<const float4*>(ub);
+    float4 u1 = AB == 5 ? make_float4(1.f, 2.f, 3.f, 4.f) : *reinterpret_cast<const float4*>(ub + 256);
+    float u2 = AB == 5 ? 1.0f : ub1[0];
+#pragma unroll
+    for (int j = 0; j < NXP; ++j) {
+        float4 n0 = u0, n1 = u1;
+        float n2 = u2;
+        if (j + 1 < NXP && AB != 5) {
+            n0 = *reinterpret_cast<const float4*>(ub + (j + 1) * SW_POS_F);
+            n1 = *reinterpret_cast<const float4*>(ub + (j + 1) * SW_POS_F + 256);
+            n2 = ub1[(j + 1) * SW_POS_F];
+        }
+        M[j] = sw_mfma<AB>(u0.x, A[j][0], z);
+        M[j] = sw_mfma<AB>(u0.y, A[j][1], M[j]);
+        M[j] = sw_mfma<AB>(u0.z, A[j][2], M[j]);
+        M[j] = sw_mfma<AB>(u0.w, A[j][3], M[j]);
+        M[j] = sw_mfma<AB>(u1.x, A[j][4], M[j]);
+        M[j] = sw_mfma<AB>(u1.y, A[j][5], M[j]);
+        M[j] = sw_mfma<AB>(u1.z, A[j][6], M[j]);
+        M[j] = sw_mfma<AB>(u1.w, A[j][7], M[j]);
+        M[j] = sw_mfma<AB>(u2, A[j][8], M[j]);
+        u0 = n0;
+        u1 = n1;
+        u2 = n2;
+    }
+    if (AB == 3) {
+#pragma unroll
+        for (int j = 0; j < NXP; ++j) Y[j & 1][(j >> 1) & 1][j] += M[j][j];
+        return;
+    }
     f32x16 t0, t1;
     if (NXP == 5) {
         t0 = (M[0] + M[1]) + (M[2] + M[3]);
@@ -209,6 +239,7 @@ __device__ __forceinline__ void sw_row(const float* rawp, const float* raws, con
     Y[1][1] += e1 * t1;
 }
 
+template <int AB>
 __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict__ xf, const float* __restrict__ u,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            float* __restrict__ y, const StemGeom g) {
@@ -221,14 +252,16 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
     const int kl = lane >> 5, il = lane & 31;
     const int ty = 4 * wm + (il >> 3), tx = il & 7;                  // this lane's tile in the item's 8 x 8 block
 
-    // raw-window DMA role: piece t = w4 + 4 k of the team's window, slot s = 64 t + lane -> (window row s / 86, 16-byte slot s % 86)
-    unsigned r_voff[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const unsigned s = 64u * (unsigned)(w4 + 4 * k) + (unsigned)lane;
-        const unsigned wr = s / SW_SLOTS, q = s - wr * SW_SLOTS;
-        r_voff[k] = (wr * (unsigned)g.fr_rowf + q * 4u) * 4u;
-    }
+    // raw-window DMA role: piece t = w4 + 4 k of the team's window, slot s = 64 t + lane -> (window row s / 86, 16-byte slot s % 86);
+    // the lane offsets are recomputed per piece (seven registers the row loop has no room for)
+    auto raw_voff = [&](int k) {
+        unsigned ln = (unsigned)lane;
+        asm volatile("" : "+v"(ln));                                   // recomputed where it is used: hoisted out of the loops it was spilled
+        const unsigned s = 64u * (unsigned)(w4 + 4 * k) + ln;
+        const unsigned wr = __umulhi(s, 0x2FA0BE9u);                       // s / 86 for s < 2^16 (ceil(2^32 / 86))
+        const unsigned q = s - wr * SW_SLOTS;
+        return (wr * (unsigned)g.fr_rowf + q * 4u) * 4u;
+    };
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
     const unsigned lds_raw = lds0 + (unsigned)(team * 2 * SW_RAW_F * 4);
     const unsigned lds_u = lds0 + (unsigned)(4 * SW_RAW_F * 4);
@@ -243,7 +276,7 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
         const unsigned dst = lds_raw + (unsigned)((phase & 1) * SW_RAW_F * 4);
 #pragma unroll
         for (int k = 0; k < 7; ++k)
-            if (w4 + 4 * k < SW_RAW_PIECES) lds_dma16(r_voff[k], src, dst + (unsigned)((w4 + 4 * k) * 1024));
+            if (w4 + 4 * k < SW_RAW_PIECES) lds_dma16(raw_voff(k), src, dst + (unsigned)((w4 + 4 * k) * 1024));
     };
     auto dma_filters = [&](int r) {                           // filters of row r -> buffer r & 1; wave w moves pieces w, w + 8, w + 16
         const int pieces = c_stem_rows[r].nxp == 5 ? SW_U_PIECES : 18;
@@ -251,7 +284,7 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
         const unsigned dst = lds_u + (unsigned)((r & 1) * SW_U_F * 4);
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            if (wave + 8 * k < pieces) lds_dma16((unsigned)((wave + 8 * k) * 1024 + lane * 16), src, dst + (unsigned)((wave + 8 * k) * 1024));
+            if (wave + 8 * k < pieces) lds_dma16((unsigned)(lane * 16), src + (wave + 8 * k) * 256, dst + (unsigned)((wave + 8 * k) * 1024));
     };
 
     // LDS read roles
@@ -266,9 +299,11 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
     bool live = 2 * pair + team < g.n_items;
     dma_raw(item, 0);
     dma_filters(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first row's transform reads the window in front of the row's barrier
+    __syncthreads();
 
     for (;;) {
-        f32x16 Y[2][2];
+        f32x16 Y[2][2];                // the four output pixels of the lane's tile x its 16 channels
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -281,21 +316,34 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
 
         for (int r = 0; r < SW_ROWS; ++r) {
             const StemRow& row = c_stem_rows[r];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of row r's filters (and of the phase window)
-            __syncthreads();                                     // ... everyone's; the other filter buffer and window buffer are free
+            const int phase = row.phase;
+            // ---- the row's VALU run: input transform (the window of its phase landed at least a row ago) ----
+            const float* rawp = raw_team + (phase & 1) * SW_RAW_F + patch0 + 2 * kl;
+            const float* raws = raw_team + (phase & 1) * SW_RAW_F + patch0 + 16;
+            const bool odd = kl != 0;
+            float A[5][9];
+            if (row.nxp == 5) {
+                if (row.ne == 4) sw_transform<5, 4, AB>(rawp, raws, row, odd, A);
+                else if (row.ne == 3) sw_transform<5, 3, AB>(rawp, raws, row, odd, A);
+                else sw_transform<5, 2, AB>(rawp, raws, row, odd, A);
+            } else {
+                if (row.ne == 4) sw_transform<4, 4, AB>(rawp, raws, row, odd, A);
+                else if (row.ne == 3) sw_transform<4, 3, AB>(rawp, raws, row, odd, A);
+                else sw_transform<4, 2, AB>(rawp, raws, row, odd, A);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of row r's filters (and of the next phase window)
+            if (AB != 4) __syncthreads();                        // ... everyone's; the other filter buffer and window buffer are free
             if (r + 1 < SW_ROWS) dma_filters(r + 1);
             else if (has_next) dma_filters(0);
-            const int phase = row.phase;
             if (row.first) {
                 if (phase < 3) dma_raw(item, phase + 1);
                 else if (has_next) dma_raw(next_item, 0);
             }
-            const float* rawp = raw_team + (phase & 1) * SW_RAW_F + patch0 + 2 * kl;
-            const float* raws = raw_team + (phase & 1) * SW_RAW_F + patch0 + 16 + kl;
+            // ---- the row's MFMA run, then its output transform (the head of the next VALU run) ----
             const float* ub = frag0 + (r & 1) * SW_U_F;
             const float* ub1 = frag1 + (r & 1) * SW_U_F;
-            if (row.nxp == 5) sw_row<5>(rawp, raws, ub, ub1, row, Y);
-            else sw_row<4>(rawp, raws, ub, ub1, row, Y);
+            if (row.nxp == 5) sw_gemm<5, AB>(ub, ub1, row, A, Y);
+            else sw_gemm<4, AB>(ub, ub1, row, A, Y);
         }
 
         // ---- bn1 + relu, stores: lane = one tile (MFMA column), register quad q = channels wn 32 + 8 q + 4 kl .. + 3 ----
@@ -392,8 +440,8 @@ extern "C" int hps_stem_phase_split(const float* x, float* frames, int B, int C,
     return check_launch("hps_stem_phase_split");
 }
 
-extern "C" int hps_stem_winograd(const float* frames, const float* u, const float* scale, const float* shift, float* y, int B, int H,
-                                 int W, int opad, int relu, hps_stream_t stream) {
+static int stem_wino_launch(const float* frames, const float* u, const float* scale, const float* shift, float* y, int B, int H,
+                            int W, int opad, int relu, int ablate, hps_stream_t stream) {
     if (!frames || !u || !scale || !shift || !y) return bad_arg("hps_stem_winograd: null pointer");
     if (H <= 0 || W <= 0 || (H % 32) || (W % 32)) return bad_arg("hps_stem_winograd: H and W must be multiples of 32 (8 x 8 blocks of 2 x 2-pixel tiles at stride 2)");
     if (opad < 0) return bad_arg("hps_stem_winograd: opad");
@@ -415,9 +463,37 @@ extern "C" int hps_stem_winograd(const float* frames, const float* u, const floa
     if ((size_t)B * g.fr_imgf * 4 >= 0xffffffffull || (size_t)B * g.out_img * 4 >= 0xffffffffull)
         return bad_arg("hps_stem_winograd: tensor exceeds the 32-bit lane offsets");
     const size_t lds = (size_t)SW_LDS_F * sizeof(float);
-    if (int rc = grant_lds<&stem_wino_kernel>((int)lds, "hps_stem_winograd")) return rc;
     const int pairs = (g.n_items + 1) / 2;
-    hipLaunchKernelGGL(stem_wino_kernel, dim3((unsigned)(pairs < 256 ? pairs : 256)), dim3(512), lds, (hipStream_t)stream, frames, u,
-                       scale, shift, y, g);
+    int rc = HPS_OK;
+    auto launch = [&](auto AB) {
+        constexpr int ab = decltype(AB)::value;
+        if ((rc = grant_lds<&stem_wino_kernel<ab>>((int)lds, "hps_stem_winograd")) != HPS_OK) return;
+        hipLaunchKernelGGL((stem_wino_kernel<ab>), dim3((unsigned)(pairs < 256 ? pairs : 256)), dim3(512), lds, (hipStream_t)stream,
+                           frames, u, scale, shift, y, g);
+    };
+    switch (ablate) {
+        case 0: launch(std::integral_constant<int, 0>()); break;
+#ifdef HPS_DEV_BUILD
+        case 1: launch(std::integral_constant<int, 1>()); break;
+        case 2: launch(std::integral_constant<int, 2>()); break;
+        case 3: launch(std::integral_constant<int, 3>()); break;
+        case 4: launch(std::integral_constant<int, 4>()); break;
+        case 5: launch(std::integral_constant<int, 5>()); break;
+#endif
+        default: return bad_arg("hps_stem_winograd: ablate");
+    }
+    if (rc != HPS_OK) return rc;
     return check_launch("hps_stem_winograd");
 }
+
+extern "C" int hps_stem_winograd(const float* frames, const float* u, const float* scale, const float* shift, float* y, int B, int H,
+                                 int W, int opad, int relu, hps_stream_t stream) {
+    return stem_wino_launch(frames, u, scale, shift, y, B, H, W, opad, relu, 0, stream);
+}
+
+#ifdef HPS_DEV_BUILD
+extern "C" int hps_dev_stem_winograd(const float* frames, const float* u, const float* scale, const float* shift, float* y, int B,
+                                     int H, int W, int opad, int relu, int ablate, hps_stream_t stream) {
+    return stem_wino_launch(frames, u, scale, shift, y, B, H, W, opad, relu, ablate, stream);
+}
+#endif

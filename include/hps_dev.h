@@ -93,6 +93,11 @@ int hps_dev_conv3x3_winograd(const float* x, const float* u, const float* scale,
                              const float* residual, float* y, int B, int H, int W, int ipad, int Cin, int Cout,
                              int opad, int relu, float* splitk_ws, int ablate, hps_stream_t stream);
 
+/* hps_stem_winograd with a profiling ablation (csrc/stem_wino.hip: 1 = patch pixels not read, 2 = no MFMAs, 3 = no output
+ * transform, 4 = no barriers, 5 = no filter fragment reads; results are wrong by construction). */
+int hps_dev_stem_winograd(const float* frames, const float* u, const float* scale, const float* shift, float* y, int B, int H,
+                          int W, int opad, int relu, int ablate, hps_stream_t stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }
