@@ -443,6 +443,70 @@ def test_winograd_conv_kernel(cfg, dev):
         assert torch.equal(one[0], out2[B - 1])
 
 
+@pytest.mark.parametrize("cfg", [(1, 32, 32), (2, 64, 96), (3, 256, 256), (5, 224, 224), (33, 128, 64)])
+def test_winograd_stem_kernel(cfg, dev):
+    """csrc/stem_wino.hip (the 7x7 / 2 stem as four stride-1 phase correlations, F(2x2, r x s), + bn1 + relu) against an fp64
+    convolution and against the direct row-mode kernel: both within 2e-6 of the output scale of the fp64 result (the Winograd
+    form does 81 instead of 196 multiplications per tile and is at least as close as the direct fp32 sum), for odd item counts
+    (a team of the last workgroup idles), non-square maps, an output halo, and bit-identical per image whatever the batch."""
+    B, H, W = cfg
+    torch.manual_seed(B + H + W)
+    conv = torch.nn.Conv2d(18, 64, 7, 2, 3, bias=False)
+    bn = torch.nn.BatchNorm2d(64).eval()
+    bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_()
+    x = torch.randn(B, 18, H, W)
+    import copy
+    with torch.no_grad():
+        want = F.relu(copy.deepcopy(bn).double()(copy.deepcopy(conv).double()(x.double()))).permute(0, 2, 3, 1).contiguous()
+        want_lin = bn(conv(x)).permute(0, 2, 3, 1).contiguous()
+    scale_ref = max(1.0, float(want.abs().max()))
+    cb = _ConvBN(conv.to(dev), bn.to(dev), cin_pad=20)
+    assert cb.stem_u is not None and cb.stem_winograd_ok(18, H, W) and not cb.stem_winograd_ok(18, H + 2, W) and not cb.stem_winograd_ok(4, H, W)
+    P, s = _capi.ptr, _capi.stream()
+    xd = x.to(dev)
+    frames = torch.zeros(int(_capi.load().hps_stem_phase_frames_bytes(B, H, W)) // 4, device=dev)
+    _capi.call("hps_stem_phase_split", P(xd), P(frames), B, 18, H, W, s)
+    # the phase frames: frames[b][2 ry + rx][i][j][slot] = x[b][order[slot], 2 i + ry - 3, 2 j + rx - 3], zero outside the image
+    FR, FC = H // 2 + 4, W // 2 + 4
+    fr = frames[:B * 4 * FR * FC * 18].view(B, 2, 2, FR, FC, 18).cpu()
+    order = [0, 2, 1, 3, 4, 6, 5, 7, 8, 10, 9, 11, 12, 14, 13, 15, 16, 17]
+    xpad = torch.zeros(B, 18, 2 * FR, 2 * FC)
+    xpad[:, :, 3:3 + H, 3:3 + W] = x
+    for ry in (0, 1):
+        for rx in (0, 1):
+            assert torch.equal(fr[:, ry, rx], xpad[:, order][:, :, ry::2, rx::2].permute(0, 2, 3, 1)), (ry, rx)
+    for opad in (0, 1):
+        out = torch.full((B, H // 2 + 2 * opad, W // 2 + 2 * opad, 64), 7.0, device=dev)
+        _capi.call("hps_stem_winograd", P(frames), P(cb.stem_u), P(cb.scale), P(cb.shift), P(out), B, H, W, opad, 1, s)
+        inner = out[:, opad:opad + H // 2, opad:opad + W // 2]
+        assert float((inner.cpu().double() - want).abs().max()) <= 2e-6 * scale_ref
+        if opad:        # the halo is never written
+            assert float((out[:, 0] - 7).abs().max()) == 0 and float((out[:, :, -1] - 7).abs().max()) == 0
+    lin = torch.empty(B, H // 2, W // 2, 64, device=dev)
+    _capi.call("hps_stem_winograd", P(frames), P(cb.stem_u), P(cb.scale), P(cb.shift), P(lin), B, H, W, 0, 0, s)
+    assert maxerr(lin, want_lin.to(dev)) <= 1e-5 * scale_ref
+    # the direct kernel on the same input
+    xin = torch.zeros(B, H + 6, W + 6, 18, device=dev)
+    _capi.call("hps_nchw_to_padded_nhwc", P(xd), P(xin), B, 18, H, W, 3, s)
+    direct = torch.empty(B, H // 2, W // 2, 64, device=dev)
+    cb.use_winograd = False
+    cb.padded(xin, 3, direct, 0, relu=False)
+    cb.use_winograd = True
+    assert maxerr(lin, direct) <= 2e-6 * scale_ref
+    # one image alone: the same bits as inside the batch (the summation order depends on the layer only)
+    b = B - 1
+    f1 = torch.zeros(int(_capi.load().hps_stem_phase_frames_bytes(1, H, W)) // 4, device=dev)
+    _capi.call("hps_stem_phase_split", P(xd[b:b + 1].contiguous()), P(f1), 1, 18, H, W, s)
+    one = torch.empty(1, H // 2, W // 2, 64, device=dev)
+    _capi.call("hps_stem_winograd", P(f1), P(cb.stem_u), P(cb.scale), P(cb.shift), P(one), 1, H, W, 0, 0, s)
+    assert torch.equal(one[0], lin[b])
+    # argument checks
+    with pytest.raises(_capi.HpsError):
+        _capi.call("hps_stem_winograd", P(frames), P(cb.stem_u), P(cb.scale), P(cb.shift), P(lin), B, H + 8, W, 0, 0, s)
+    with pytest.raises(_capi.HpsError):
+        _capi.call("hps_stem_phase_split", P(xd), P(frames), B, 20, H, W, s)
+
+
 def test_winograd_and_direct_encoders_agree_and_are_batch_invariant(dev, net_gpu, golden, golden_input):
     enc = net_gpu.image_encoder
     x = golden_input.to(dev)

@@ -168,3 +168,53 @@ def test_gesdd_faithful_svd_edge_cases():
     for i in (0, 1, 2, 4, 5):                                          # tiny / huge matrices go through sgesdd's rescaling
         rec = torch.matmul(u[i] * s[i][None], v[i].T)
         assert float((rec - F[i]).abs().max()) <= 1e-5 * max(1e-30, float(F[i].abs().max()))
+
+
+def test_stem_winograd_filters_reproduce_the_convolution():
+    """resnet._stem_winograd_filters (the 81 transformed filter positions of csrc/stem_wino.hip, in the kernel's packed layout)
+    together with the B^T / A^T matrices the kernel hard-codes is the 7x7 / 2 / 3 convolution: evaluated here in fp64."""
+    import numpy as np
+    from hierarchicalprobabilistic3dhuman_amd.resnet import _stem_winograd_filters
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(64, 18, 7, 7, generator=g, dtype=torch.float64)
+    x = torch.randn(2, 18, 32, 64, generator=g, dtype=torch.float64)
+    packed = _stem_winograd_filters(w)
+    assert packed.dtype == torch.float32 and packed.numel() == 81 * 1152 + 256 and float(packed[-256:].abs().max()) == 0
+    # unpack: [position][co half][k-block][c parity][co % 32][(c % 8) / 2] for c < 16, then [c - 16][co % 32]
+    pk = packed[:81 * 1152].double().view(81, 2, 576)
+    lo = pk[:, :, :512].reshape(81, 2, 2, 2, 32, 4)                # p, half, kb, parity, co32, e
+    U = torch.zeros(81, 18, 64, dtype=torch.float64)
+    for kb in range(2):
+        for par in range(2):
+            for e in range(4):
+                U[:, 8 * kb + 2 * e + par, :] = lo[:, :, kb, par, :, e].reshape(81, 64)
+    hi = pk[:, :, 512:].reshape(81, 2, 2, 32)                      # p, half, c - 16, co32
+    for c in range(2):
+        U[:, 16 + c, :] = hi[:, :, c, :].reshape(81, 64)
+    U = U.numpy()
+    BT = {5: np.array([[2, -1, -2, 1, 0], [0, -2, -1, 1, 0], [0, 2, -3, 1, 0], [0, -1, 0, 1, 0], [0, 2, -1, -2, 1]], float),
+          4: np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, -1, 0, 1]], float)}
+    AT = {5: np.array([[1, 1, 1, 1, 0], [0, 1, -1, 2, 1]], float), 4: np.array([[1, 1, 1, 0], [0, 1, -1, 1]], float)}
+    B, C, H, W = x.shape
+    Ho, Wo = H // 2, W // 2
+    xp = np.zeros((B, C, H + 8, W + 8))
+    xp[:, :, 3:3 + H, 3:3 + W] = x.numpy()
+    y = np.zeros((B, 64, Ho, Wo))
+    pos = 0
+    for ry in (0, 1):
+        for rx in (0, 1):
+            ny, nx = 5 - ry, 5 - rx
+            ph = xp[:, :, ry::2, rx::2]
+            iy = (2 * np.arange(Ho // 2))[:, None] + np.arange(ny)[None]
+            ix = (2 * np.arange(Wo // 2))[:, None] + np.arange(nx)[None]
+            d = ph[:, :, iy][:, :, :, :, ix]                       # (B, C, ty, ny, tx, nx)
+            V = np.einsum("ia,jb,ncpaqb->ijnpqc", BT[ny], BT[nx], d)
+            Uph = U[pos:pos + ny * nx].reshape(ny, nx, 18, 64)
+            M = np.einsum("ijnpqc,ijco->ijnpqo", V, Uph)
+            Y = np.einsum("ai,bj,ijnpqo->nopaqb", AT[ny], AT[nx], M)
+            y += Y.reshape(B, 64, Ho, Wo)
+            pos += ny * nx
+    assert pos == 81
+    want = torch.nn.functional.conv2d(x, w, stride=2, padding=3).numpy()
+    # U went through fp32 once (2^-24 relative per entry)
+    assert np.abs(y - want).max() <= 3e-6 * np.abs(want).max()
