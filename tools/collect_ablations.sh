@@ -17,6 +17,14 @@ sec "tests/dev/gpu_bringup.py wino (B = 64; dev library: compile-time ablations 
 python $R/tests/dev/gpu_bringup.py wino 2>&1 | grep -E "^wino|^layer4|direct kernel|max \|"
 sec "tests/dev/stem_ablate.py (stem convolution alone, modes interleaved over 9 rounds: 0 = product, 1 = no epilogue, 3 = DMA pieces in a burst (the earlier form), 5 / 13 = second CU slot de-phased by 14 / 41 us)"
 python $R/tests/dev/stem_ablate.py 0 1 3 5 13 2>&1 | grep "^stem"
+sec "tests/dev/stem_wino_check.py (Winograd stem against an fp64 convolution and the direct kernel; both alone, B = 64 and 16)"
+PYTHONPATH=$R python $R/tests/dev/stem_wino_check.py 2>&1 | grep -E "^B=|median"
+sec "tests/dev/stem_wino_ablate.py (Winograd stem, modes interleaved over 9 rounds: 0 = product, 1 = window pixels not read, 2 = no MFMAs, 3 = no output transform, 4 = no barriers, 5 = no filter fragment reads)"
+PYTHONPATH=$R python $R/tests/dev/stem_wino_ablate.py 2>&1 | grep "^stem"
+sec "tools/bin/mfma_valu_ops (which VALU instructions cost MFMA time, alone / same wave / other wave of the SIMD; cost of alternating MFMA and VALU runs)"
+$R/tools/bin/mfma_valu_ops 2>&1 | grep -E "^v_"
+sec "tools/stem_pmc.sh (SQ counters of stem_wino_kernel, B = 64, per dispatch)"
+bash $R/tools/stem_pmc.sh 0 2>&1 | grep -E "^SQ_|^GRBM"
 sec "tests/dev/gpu_bringup.py mesh_fused (ablations of mesh_fused_kernel)"
 python $R/tests/dev/gpu_bringup.py mesh_fused 2>&1 | grep -E "mesh_fused M=|alone|ablate"
 sec "tests/dev/gpu_bringup.py unc_modes"
