@@ -7,6 +7,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 net = PoseMFShapeGaussianNet(configs.SMPL_PARENTS, configs.get_cfg_defaults()).eval().to(dev)
 enc = net.image_encoder
+enc.set_winograd(False)          # the direct row-mode stem (the product runs the Winograd stem: tests/dev/stem_wino_ablate.py)
 x = torch.rand(64, 18, 256, 256, device=dev)
 with torch.no_grad(), _capi.dev_library():
     enc(x); torch.cuda.synchronize()
