@@ -77,6 +77,11 @@ def cpu_baseline(net_state, parents, num_samples, n_images):
                               "sample": "%d images, num_samples=%d (%.2f s)" % (n1, num_samples, dt1)}}
 
 
+def _capi_mesh_cus(pipe):
+    """CUs per XCD of the mesh partition of a pipeline that runs encoder and mesh kernels on disjoint CU subsets."""
+    return getattr(pipe, "_mesh_cus", 32)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,7 +288,11 @@ def main():
                        "images_per_gpu": B, "global_batch": B * world, "num_samples": N,
                        "meshes_per_step_per_gpu": M, "parallelism": "images sharded over %d GPU(s)" % world,
                        "mesh_kernel": "fused blend GEMM + LBS" if fused else "blend GEMM, then LBS",
-                       "step_pipelining": "none" if args.no_pipeline else "encoder of step i+1 (own stream) overlaps the latency-bound head of step i (high-priority stream); the mesh kernels (pose prep / blend + LBS / joints) of a batch run alone"},
+                       "step_pipelining": "none" if args.no_pipeline else (
+                           "encoder of step i+1 (own stream) overlaps the latency-bound head of step i (high-priority stream); the mesh kernels (pose prep / blend + LBS / joints) of a batch run alone"
+                           if pipe._exclusive else
+                           "encoder of step i+1 beside the head AND the mesh kernels of step i (small batch: neither fills the chip)" +
+                           (", on disjoint CU subsets (encoder: %d of the 32 CUs of every XCD)" % (32 - _capi_mesh_cus(pipe)) if pipe.mesh_stream is not None else ", sharing all CUs"))},
             # The mesh kernel is FUSED (blend GEMM tile skinned in the MFMA epilogue, no v_posed round trip).  SURVEY 8(d):
             # it is still reported against the UNFUSED LBS definition (166,896 B per mesh), over the fused kernel's
             # whole launch time -- which also contains the 8.97 MFLOP/mesh blend GEMM that really bounds it (roofline_mfma).

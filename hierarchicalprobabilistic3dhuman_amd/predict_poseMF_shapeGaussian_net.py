@@ -132,10 +132,13 @@ class InferencePipeline:
         # (profiles/r03_ablations.txt).  None = decide from the batch size (overlap below 32 images).
         self.exclusive_mesh = None
         # encoder_cus > 0: when not exclusive, encoder and mesh phases run on DISJOINT CU subsets (encoder_cus of the 32 CUs of
-        # every XCD for the encoder, hps_stream_create_cu_partition).  Measured at B = 16, N = 1000: 8 / 12 / 16 CUs per XCD ->
-        # 4 860 / 4 550 / 3 930 images/s against 4 925 shared -- the mesh kernel loses CUs in proportion and is the longer chain, so
-        # sharing all CUs is the default; the partition stays available for workloads whose encoder must not be stretched.
-        self.encoder_cus = 0
+        # every XCD for the encoder, hps_stream_create_cu_partition).  Which side wins depends on which chain is longer.  Measured
+        # at B = 16, N = 1000 (16 032 meshes: mesh kernel 1.5 ms against an encoder of 0.97 ms alone) with the round-3 encoder:
+        # shared CUs 5 570-5 580 images/s, 8 CUs per XCD 5 750-5 790, 10 -> 5 200-5 240, 4 or 6 -> 3 200-3 270 (the persistent
+        # Winograd workgroups of 16 images need 64 CUs); with the slower round-2 encoder sharing won (4 925 against 4 860).  At
+        # B = 16, N = 100 the mesh kernel is a tenth of that and a partition would only slow the encoder down.  None = decide from
+        # the work: 8 CUs per XCD when the batch is small enough to overlap at all AND carries at least 12 000 meshes, else 0.
+        self.encoder_cus = None
         # (measured and dropped: making the next encoder wait for the uncertainty pass as well -- B = 16, N = 1000: 3.15 -> 3.24 ms
         # per step; B = 64, N = 100: 3.53 -> 3.51)
 
@@ -150,10 +153,14 @@ class InferencePipeline:
 
     def _setup_streams(self, batch):
         self._exclusive = self.exclusive_mesh if self.exclusive_mesh is not None else batch >= 32
-        if not self._exclusive and self.encoder_cus:
-            k = int(self.encoder_cus)
+        k = self.encoder_cus
+        if k is None:
+            k = 8 if (not self._exclusive and batch * (self.num_samples + 2) >= 12000) else 0
+        if not self._exclusive and k:
+            k = int(k)
             self.enc_stream = _capi.cu_partition_stream(0, k)
             self.mesh_stream = _capi.cu_partition_stream(k, 32 - k)
+            self._mesh_cus = 32 - k
         else:
             self.enc_stream = torch.cuda.Stream()
 
