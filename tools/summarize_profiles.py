@@ -84,13 +84,16 @@ if os.path.exists(stats_p):
     tot = sum(float(r["TotalDurationNs"]) for r in stats)
     V, J = 6890, 24
     enc_flop = 6.279e9 * B
+    stem_flop = 2.0 * B * 128 * 128 * 64 * 49 * 18
     model = [   # (substring, what, bound, algorithmic quantity per launch, unit)
-        ("conv_", "ResNet-18 convolutions, direct + Winograd (all launches of a step together; direct-convolution FLOPs)", "mfma", enc_flop, "flop/step"),
+        ("stem_wino_kernel", "stem 7x7/2 in Winograd form (direct-convolution FLOPs; the MFMA pipe does 81/196 of them)", "mfma", stem_flop, "flop"),
+        ("conv_", "the other 19 ResNet-18 convolutions, direct + Winograd F(2x2,3x3) (all launches of a step together; direct-convolution FLOPs)", "mfma", enc_flop - stem_flop, "flop/step"),
         ("mesh_fused_kernel", "blend GEMM + LBS, fused", "mfma", 2.0 * 217 * 3 * V * M, "flop"),
         ("uncertainty_reg_kernel", "per-vertex sample uncertainty", "hbm", (B * N * V * 12.0 + B * V * 4.0), "bytes"),
         ("joints_kernel", "90 joints per mesh (CSR rows on the vertices)", "hbm", M * (276 * 12.0 + 90 * 12.0), "bytes (gathered)"),
         ("pose_prep_kernel", "Rodrigues / FK / blend operand", "hbm", M * (24 * 9 * 4.0 + 224 * 4.0 + 24 * 12 * 4.0 + 24 * 3 * 4.0 + 40.0), "bytes"),
         ("nchw_to_padded_nhwc", "input relayout", "hbm", 2.0 * B * 18 * 256 * 256 * 4, "bytes"),
+        ("stem_phase_split_kernel", "input -> four phase frames per image", "hbm", 2.0 * B * 18 * 256 * 256 * 4, "bytes"),
         ("maxpool_pad_kernel", "3x3/2 max pool", "hbm", B * 64 * 4.0 * (128 * 128 + 64 * 64), "bytes"),
         ("mf_sample_kernel", "matrix-Fisher rejection sampling", "alu", B * 23 * 8.0 * N, "proposals"),
         ("joint_level_kernel", "head: per-level MLPs + in-kernel SVD (8 launches per step)", "latency", None, ""),
