@@ -99,7 +99,8 @@ if os.path.exists(stats_p):
         ("joint_level_kernel", "head: per-level MLPs + in-kernel SVD (8 launches per step)", "latency", None, ""),
         ("linear_kernel", "head: FC trunk (3 launches per step)", "latency", None, ""),
     ]
-    steps = 12.0
+    # encoder passes in the profiled run (timed steps + warm-up + the unfused-LBS repetitions behind the timed region): one max-pool each
+    steps = float(sum(int(r["Calls"]) for r in stats if "maxpool_pad_kernel" in r["Name"]) or 12)
     for sub, what, bound, qty, unit in model:
         rs = [r for r in stats if sub in r["Name"]]
         if not rs:
