@@ -190,8 +190,9 @@ __device__ __forceinline__ void sw_transform(const float* rawp, const float* raw
 
 // The MFMAs of one row (nine per position, filters of the position read from LDS one position ahead) and its output transform
 // t = M A_x, Y[a][.] += A_y^T[a][i] t.  ub / ub1: this lane's filter fragment slots of position 0 of the row (k 0-15, k 16-17).
-template <int NXP, int AB>
-__device__ __forceinline__ void sw_gemm(const float* ub, const float* ub1, const StemRow& row, const float (&A)[5][9], f32x16 (&Y)[2][2]) {
+template <int NXP, int AB, typename Spread>
+__device__ __forceinline__ void sw_gemm(const float* ub, const float* ub1, const StemRow& row, const float (&A)[5][9], f32x16 (&Y)[2][2],
+                                        Spread spread) {
     f32x16 M[5];
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float4 u0 = AB == 5 ? make_float4(1.f, 2.f, 3.f, 4.f) : *reinterpret_cast<const float4*>(ub);
@@ -215,6 +216,10 @@ __device__ __forceinline__ void sw_gemm(const float* ub, const float* ub1, const
         M[j] = sw_mfma<AB>(u1.z, A[j][6], M[j]);
         M[j] = sw_mfma<AB>(u1.w, A[j][7], M[j]);
         M[j] = sw_mfma<AB>(u2, A[j][8], M[j]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sl = 2 * j; sl < (j + 1 < NXP ? 2 * j + 2 : 10); ++sl) spread(sl);       // DMA pieces of the next row / phase (see the caller)
+        __builtin_amdgcn_sched_barrier(0);
         u0 = n0;
         u1 = n1;
         u2 = n2;
@@ -271,20 +276,26 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
         const unsigned by = sw_div(rem, (unsigned)g.blocks_x, g.magic_x), bx = rem - by * g.blocks_x;
         return xf + (size_t)b * g.fr_imgf + (size_t)phase * g.fr_phasef + (size_t)(16 * by) * g.fr_rowf + (size_t)(16 * bx) * SW_C;
     };
-    auto dma_raw = [&](int item, int phase) {                 // phase window of `item` -> the team's buffer phase & 1
-        const float* src = window_src(item, phase);
-        const unsigned dst = lds_raw + (unsigned)((phase & 1) * SW_RAW_F * 4);
-#pragma unroll
-        for (int k = 0; k < 7; ++k)
-            if (w4 + 4 * k < SW_RAW_PIECES) lds_dma16(raw_voff(k), src, dst + (unsigned)((w4 + 4 * k) * 1024));
+    // piece k (0..6) of the phase window whose origin is src -> the team's buffer phase & 1; this wave moves pieces w4, w4 + 4, ...
+    auto dma_raw_piece = [&](const float* src, int phase, int k) {
+        if (w4 + 4 * k < SW_RAW_PIECES)
+            lds_dma16(raw_voff(k), src, lds_raw + (unsigned)((phase & 1) * SW_RAW_F * 4 + (w4 + 4 * k) * 1024));
     };
-    auto dma_filters = [&](int r) {                           // filters of row r -> buffer r & 1; wave w moves pieces w, w + 8, w + 16
-        const int pieces = c_stem_rows[r].nxp == 5 ? SW_U_PIECES : 18;
-        const float* src = u + (size_t)c_stem_rows[r].upos * SW_POS_F;
-        const unsigned dst = lds_u + (unsigned)((r & 1) * SW_U_F * 4);
+    auto dma_raw = [&](int item, int phase) {
+        const float* src = window_src(item, phase);
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (wave + 8 * k < pieces) lds_dma16((unsigned)(lane * 16), src + (wave + 8 * k) * 256, dst + (unsigned)((wave + 8 * k) * 1024));
+        for (int k = 0; k < 7; ++k) dma_raw_piece(src, phase, k);
+    };
+    // piece k (0..2) of the filters of row r -> buffer r & 1; wave w moves pieces w, w + 8, w + 16
+    auto dma_filter_piece = [&](int r, int k) {
+        const int pieces = c_stem_rows[r].nxp == 5 ? SW_U_PIECES : 18;
+        if (wave + 8 * k < pieces)
+            lds_dma16((unsigned)(lane * 16), u + (size_t)c_stem_rows[r].upos * SW_POS_F + (wave + 8 * k) * 256,
+                      lds_u + (unsigned)((r & 1) * SW_U_F * 4 + (wave + 8 * k) * 1024));
+    };
+    auto dma_filters = [&](int r) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dma_filter_piece(r, k);
     };
 
     // LDS read roles
@@ -333,17 +344,25 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of row r's filters (and of the next phase window)
             if (AB != 4) __syncthreads();                        // ... everyone's; the other filter buffer and window buffer are free
-            if (r + 1 < SW_ROWS) dma_filters(r + 1);
-            else if (has_next) dma_filters(0);
-            if (row.first) {
-                if (phase < 3) dma_raw(item, phase + 1);
-                else if (has_next) dma_raw(next_item, 0);
-            }
+            // The DMAs of the next row's filters (and, in the first row of a phase, of the next phase's window) are issued INSIDE the
+            // MFMA run, two pieces behind each position's MFMAs: in front of the run their issue (about 50 cycles a piece, up to ten
+            // pieces) held the whole SIMD back while the MFMA pipe was idle.
+            const int f_row = r + 1 < SW_ROWS ? r + 1 : (has_next ? 0 : -1);
+            const int w_phase = phase < 3 ? phase + 1 : 0;
+            const bool w_fetch = row.first && (phase < 3 || has_next);
+            const float* w_src = window_src(phase < 3 ? item : next_item, w_phase);
+            auto spread = [&](int slot) {                        // slots 0-2: filter pieces, 3-9: window pieces
+                if (slot < 3) {
+                    if (f_row >= 0) dma_filter_piece(f_row, slot);
+                } else if (w_fetch) {
+                    dma_raw_piece(w_src, w_phase, slot - 3);
+                }
+            };
             // ---- the row's MFMA run, then its output transform (the head of the next VALU run) ----
             const float* ub = frag0 + (r & 1) * SW_U_F;
             const float* ub1 = frag1 + (r & 1) * SW_U_F;
-            if (row.nxp == 5) sw_gemm<5, AB>(ub, ub1, row, A, Y);
-            else sw_gemm<4, AB>(ub, ub1, row, A, Y);
+            if (row.nxp == 5) sw_gemm<5, AB>(ub, ub1, row, A, Y, spread);
+            else sw_gemm<4, AB>(ub, ub1, row, A, Y, spread);
         }
 
         // ---- bn1 + relu, stores: lane = one tile (MFMA column), register quad q = channels wn 32 + 8 q + 4 kl .. + 3 ----
