@@ -443,7 +443,7 @@ def test_winograd_conv_kernel(cfg, dev):
         assert torch.equal(one[0], out2[B - 1])
 
 
-@pytest.mark.parametrize("cfg", [(1, 32, 32), (2, 64, 96), (3, 256, 256), (5, 224, 224), (33, 128, 64)])
+@pytest.mark.parametrize("cfg", [(1, 32, 32), (2, 64, 96), (3, 256, 256), (5, 224, 224), (33, 128, 64), (1, 32, 288)])
 def test_winograd_stem_kernel(cfg, dev):
     """csrc/stem_wino.hip (the 7x7 / 2 stem as four stride-1 phase correlations, F(2x2, r x s), + bn1 + relu) against an fp64
     convolution and against the direct row-mode kernel: both within 2e-6 of the output scale of the fp64 result (the Winograd
