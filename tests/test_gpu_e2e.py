@@ -90,6 +90,40 @@ def test_pipelined_steps_equal_sequential_infer(dev, net_gpu, smpl_gpu, golden_i
             assert torch.equal(w[k], g[k]), k
 
 
+def test_pipeline_on_cu_partitions_equals_sequential_infer(dev, net_gpu, smpl_gpu):
+    """Small batches with a long mesh chain (BASELINE configs[4]: 16 images x 1000 samples = 16 032 meshes) run the encoder and
+    the mesh kernels side by side on disjoint CU subsets (hps_stream_create_cu_partition, chosen automatically); a batch with a
+    tenth of the meshes keeps sharing the CUs.  Same bits as infer() either way; the loop runs on the stream caller_stream names."""
+    from hierarchicalprobabilistic3dhuman_amd.predict_poseMF_shapeGaussian_net import InferencePipeline
+    B, N = 16, 1000
+    xs = [torch.stack([torch.rand(18, 256, 256, generator=torch.Generator().manual_seed(3000 + 16 * j + i)) for i in range(B)]).to(dev)
+          for j in range(2)]
+    want = [infer(net_gpu, smpl_gpu, x, num_samples=N, seed=70 + i) for i, x in enumerate(xs)]
+    want = [{k: w[k].clone() for k in ("pose_F", "R_samples", "unc", "verts_mode")} for w in want]
+    pipe = InferencePipeline(net_gpu, smpl_gpu, num_samples=N)
+    loop = pipe.caller_stream(B)
+    assert pipe.mesh_stream is not None and loop == pipe.mesh_stream and not pipe._exclusive        # the partition is in use
+    torch.cuda.synchronize()
+    got = []
+    with torch.cuda.stream(loop):
+        t = pipe.submit(xs[0])
+        for i in range(len(xs)):
+            nxt = pipe.submit(xs[i + 1]) if i + 1 < len(xs) else None
+            r = pipe.finish(t, seed=70 + i, after=nxt)
+            got.append({k: r[k].clone() for k in ("pose_F", "R_samples", "unc", "verts_mode")})
+            t = nxt
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        for k in w:
+            assert torch.equal(w[k], g[k]), k
+    small = InferencePipeline(net_gpu, smpl_gpu, num_samples=100)
+    small.caller_stream(B)
+    assert small.mesh_stream is None and not small._exclusive                    # shared CUs, mesh kernel beside the encoder
+    big = InferencePipeline(net_gpu, smpl_gpu, num_samples=100)
+    big.caller_stream(64)
+    assert big.mesh_stream is None and big._exclusive                            # B = 64: the mesh kernel takes turns with the encoders
+
+
 def test_stress_config_1000_samples_per_image(dev, net_gpu, smpl_gpu):
     """BASELINE configs[4]: num_samples=1000 on one GPU (B=16 -> 16 032 meshes, 1.3 GB of vertices): properties only."""
     B, N = 16, 1000
