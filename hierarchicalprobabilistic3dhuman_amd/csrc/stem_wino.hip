@@ -51,15 +51,16 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int SW_C = 18;                         // input channels
 constexpr int SW_CO = 64;                        // output channels
-constexpr int SW_SLOTS = 86;                     // 16-byte slots per window row: 19 pixels x 72 bytes = 1368 -> 1376
+constexpr int SW_PAIR = 38;                      // floats per pixel PAIR: 2 x 18 channels + 2 floats of padding (see stem_phase_split_kernel)
+constexpr int SW_SLOTS = 90;                     // 16-byte slots per window row: 19 pixels = 9.5 pairs x 152 bytes = 1440
 constexpr int SW_ROWF = SW_SLOTS * 4;            // floats per window row in LDS
-constexpr int SW_RAW_PIECES = 26;                // 1 KiB DMA pieces per window: 19 rows x 86 slots = 1634 slots (the tail over-reads row 19)
+constexpr int SW_RAW_PIECES = 27;                // 1 KiB DMA pieces per window: 19 rows x 90 slots = 1710 slots (the tail over-reads row 19)
 constexpr int SW_RAW_F = SW_RAW_PIECES * 256;    // floats per window buffer
 constexpr int SW_POS_F = 1152;                   // floats of one position's filters: [co half][k 0-7 | k 8-15 | k 16-17] x 32 co
 constexpr int SW_U_PIECES = 23;                  // a row of five positions = 22.5 KiB
 constexpr int SW_U_F = SW_U_PIECES * 256;
 constexpr int SW_ROWS = 18;
-constexpr int SW_LDS_F = 4 * SW_RAW_F + 2 * SW_U_F;      // 153 600 bytes
+constexpr int SW_LDS_F = 4 * SW_RAW_F + 2 * SW_U_F;      // 157 696 bytes
 
 // one row of positions: phase, number of x points, the vertical combination, the output fold
 struct StemRow {
@@ -159,7 +160,7 @@ __device__ __forceinline__ void sw_transform(const float* rawp, const float* raw
         for (int b = 0; b < NXP; ++b)
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
-                const float* p = (g < 4 ? rawp + g * 4 : raws) + b * SW_C + o[e];
+                const float* p = (g < 4 ? rawp + g * 4 : raws) + (b >> 1) * SW_PAIR + (b & 1) * SW_C + o[e];
                 ld[g & 1][b][e] = AB == 1 ? (v2f){(float)(unsigned)(size_t)p, 1.0f} : sw_ld2(p);
             }
     };
@@ -257,13 +258,13 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
     const int kl = lane >> 5, il = lane & 31;
     const int ty = 4 * wm + (il >> 3), tx = il & 7;                  // this lane's tile in the item's 8 x 8 block
 
-    // raw-window DMA role: piece t = w4 + 4 k of the team's window, slot s = 64 t + lane -> (window row s / 86, 16-byte slot s % 86);
+    // raw-window DMA role: piece t = w4 + 4 k of the team's window, slot s = 64 t + lane -> (window row s / 90, 16-byte slot s % 90);
     // the lane offsets are recomputed per piece (seven registers the row loop has no room for)
     auto raw_voff = [&](int k) {
         unsigned ln = (unsigned)lane;
         asm volatile("" : "+v"(ln));                                   // recomputed where it is used: hoisted out of the loops it was spilled
         const unsigned s = 64u * (unsigned)(w4 + 4 * k) + ln;
-        const unsigned wr = __umulhi(s, 0x2FA0BE9u);                       // s / 86 for s < 2^16 (ceil(2^32 / 86))
+        const unsigned wr = __umulhi(s, 0x2D82D83u);                       // s / 90 for s < 2^16 (ceil(2^32 / 90))
         const unsigned q = s - wr * SW_SLOTS;
         return (wr * (unsigned)g.fr_rowf + q * 4u) * 4u;
     };
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
     auto window_src = [&](int item, int phase) -> const float* {
         const unsigned b = sw_div((unsigned)item, (unsigned)g.blocks_img, g.magic_img), rem = item - b * g.blocks_img;
         const unsigned by = sw_div(rem, (unsigned)g.blocks_x, g.magic_x), bx = rem - by * g.blocks_x;
-        return xf + (size_t)b * g.fr_imgf + (size_t)phase * g.fr_phasef + (size_t)(16 * by) * g.fr_rowf + (size_t)(16 * bx) * SW_C;
+        return xf + (size_t)b * g.fr_imgf + (size_t)phase * g.fr_phasef + (size_t)(16 * by) * g.fr_rowf + (size_t)(8 * bx) * SW_PAIR;
     };
     // piece k (0..6) of the phase window whose origin is src -> the team's buffer phase & 1; this wave moves pieces w4, w4 + 4, ...
     auto dma_raw_piece = [&](const float* src, int phase, int k) {
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
 
     // LDS read roles
     const float* raw_team = smem + team * 2 * SW_RAW_F;
-    const int patch0 = (2 * ty) * SW_ROWF + (2 * tx) * SW_C;                       // the tile's patch origin in a window
+    const int patch0 = (2 * ty) * SW_ROWF + tx * SW_PAIR;                          // the tile's patch origin in a window (pixel 2 tx = pair tx)
     const float* frag0 = smem + 4 * SW_RAW_F + wn * 576 + kl * 128 + il * 4;      // filter fragment (k 0-7) of position 0, buffer 0
     const float* frag1 = smem + 4 * SW_RAW_F + wn * 576 + 512 + kl * 32 + il;     // ... (k 16-17)
 
@@ -409,7 +410,10 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
 // (B, 18, H, W) -> the four phase frames of every image: frames[b][2 ry + rx][i][j][18] = x[b][:, 2 i + ry - 3, 2 j + rx - 3],
 // frame = (H / 2 + 4) x (W / 2 + 4) pixels (out-of-image pixels stay zero: the owner zeroes the buffer once).  The 18 channels
 // of a pixel are stored in the order 0 2 1 3 | 4 6 5 7 | 8 10 9 11 | 12 14 13 15 | 16 17: the MFMA lane of parity kl reads the
-// pairs (kl, kl + 2), (kl + 4, kl + 6), ... as 8-byte words.  A workgroup moves one run of up to 256 pixels of an input row.
+// pairs (kl, kl + 2), (kl + 4, kl + 6), ... as 8-byte words.  Two pixels are followed by two floats of padding (38 floats per
+// pixel pair): the tiles of a wave start at even pixels, and with 36 floats between them every ds_read_b64 of the stem kernel
+// reached only half of the LDS banks (2-way conflicts, SQ_LDS_BANK_CONFLICT = 42 % of the LDS cycles); with 38 the 32 lanes of a
+// read group cover the 64 banks exactly once.  A workgroup moves one run of up to 256 pixels of an input row.
 __global__ __launch_bounds__(256) void stem_phase_split_kernel(const float* __restrict__ x, float* __restrict__ frames, int H, int W,
                                                                int runs_per_row) {
     constexpr int C = SW_C;
@@ -438,10 +442,15 @@ __global__ __launch_bounds__(256) void stem_phase_split_kernel(const float* __re
         // pixels w0 + wl with (w0 + wl + 3) & 1 == rx (w0 is even): wl = 1 - rx, 3 - rx, ...
         const int first = 1 - rx, count = (n - first + 1) / 2;
         const int j0 = (w0 + first + 3) >> 1;
-        v2f* dst = reinterpret_cast<v2f*>(frames + (((b * 4 + ry * 2 + rx) * FR + i) * (long)FC + j0) * C);
-        for (int e = t; e < count * (C / 2); e += 256) {
-            const int pi = e / (C / 2), sl = e - pi * (C / 2);
-            dst[e] = s2[(first + 2 * pi) * (C / 2) + sl];
+        v2f* row = reinterpret_cast<v2f*>(frames + ((b * 4 + ry * 2 + rx) * FR + i) * (long)(FC / 2) * SW_PAIR);
+        // ten 8-byte words per pixel: its nine channel pairs and, behind the second pixel of a pair, the padding (written as zero
+        // although it never changes: a run that leaves 8-byte holes in its 64-byte sectors makes the memory side read-modify-write
+        // them -- 0.17 instead of 0.11 ms)
+        for (int e = t; e < count * 10; e += 256) {
+            const int pi = e / 10, sl = e - pi * 10;
+            const int j = j0 + pi;                                   // pixel of the phase row: pair j / 2, 19 8-byte words per pair
+            if (sl < C / 2) row[(j >> 1) * (SW_PAIR / 2) + (j & 1) * (C / 2) + sl] = s2[(first + 2 * pi) * (C / 2) + sl];
+            else if (j & 1) row[(j >> 1) * (SW_PAIR / 2) + C] = (v2f){0.0f, 0.0f};
         }
     }
 }
@@ -453,7 +462,8 @@ using namespace hps;
 extern "C" size_t hps_stem_phase_frames_bytes(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0 || (H % 32) || (W % 32)) return 0;
     // + one window of slack: the last DMA piece of a window over-reads into the rows that follow
-    return ((size_t)B * 4 * (H / 2 + 4) * (W / 2 + 4) * SW_C + 20 * (size_t)(W / 2 + 4) * SW_C) * sizeof(float);
+    const size_t rowf = (size_t)(W / 2 + 4) / 2 * SW_PAIR;
+    return ((size_t)B * 4 * (H / 2 + 4) * rowf + 20 * rowf) * sizeof(float);
 }
 
 extern "C" int hps_stem_phase_split(const float* x, float* frames, int B, int C, int H, int W, hps_stream_t stream) {
@@ -476,7 +486,7 @@ static int stem_wino_launch(const float* frames, const float* u, const float* sc
     if (B <= 0) return HPS_OK;
     const int Ho = H / 2, Wo = W / 2;
     StemGeom g;
-    g.fr_rowf = (Wo + 4) * SW_C;
+    g.fr_rowf = (Wo + 4) / 2 * SW_PAIR;
     g.fr_phasef = (Ho + 4) * g.fr_rowf;
     g.fr_imgf = 4 * g.fr_phasef;
     g.blocks_x = Wo / 16;

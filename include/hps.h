@@ -316,7 +316,8 @@ size_t hps_conv3x3_winograd_workspace(int B, int H, int W, int Cin, int Cout);
  * output scale of the fp64 sum).  H and W multiples of 32, Cin = 18, Cout = 64.
  *   hps_stem_phase_split: x (B,18,H,W) NCHW -> frames[b][2 ry + rx][i][j][18] = x[b][:, 2 i + ry - 3, 2 j + rx - 3], four
  *     (H/2 + 4) x (W/2 + 4)-pixel frames per image whose out-of-image pixels the OWNER zeroes once (only in-image pixels are ever
- *     written); the channels of a pixel are stored in the order 0 2 1 3 | 4 6 5 7 | 8 10 9 11 | 12 14 13 15 | 16 17.  The buffer
+ *     written); the channels of a pixel are stored in the order 0 2 1 3 | 4 6 5 7 | 8 10 9 11 | 12 14 13 15 | 16 17, and two pixels
+ *     are followed by two floats of padding (a frame row is (W/2 + 4) / 2 pixel pairs of 38 floats: LDS bank spread).  The buffer
  *     holds hps_stem_phase_frames_bytes(B, H, W) bytes (the frames plus the slack the last window's DMA over-reads).
  *   hps_stem_winograd: frames -> y, the interior of the (B, H/2 + 2 opad, W/2 + 2 opad, 64) NHWC frame.  u: the transformed
  *     filters of the 81 positions, position-major in the row order (phase 2 ry + rx; row i; column j), 1152 floats each:

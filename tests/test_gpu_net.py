@@ -467,8 +467,11 @@ def test_winograd_stem_kernel(cfg, dev):
     frames = torch.zeros(int(_capi.load().hps_stem_phase_frames_bytes(B, H, W)) // 4, device=dev)
     _capi.call("hps_stem_phase_split", P(xd), P(frames), B, 18, H, W, s)
     # the phase frames: frames[b][2 ry + rx][i][j][slot] = x[b][order[slot], 2 i + ry - 3, 2 j + rx - 3], zero outside the image
+    # ... and two pixels are followed by two floats of padding (38 floats per pixel pair), which stay zero
     FR, FC = H // 2 + 4, W // 2 + 4
-    fr = frames[:B * 4 * FR * FC * 18].view(B, 2, 2, FR, FC, 18).cpu()
+    pairs = frames[:B * 4 * FR * (FC // 2) * 38].view(B, 2, 2, FR, FC // 2, 38).cpu()
+    assert float(pairs[..., 36:].abs().max()) == 0
+    fr = pairs[..., :36].reshape(B, 2, 2, FR, FC, 18)
     order = [0, 2, 1, 3, 4, 6, 5, 7, 8, 10, 9, 11, 12, 14, 13, 15, 16, 17]
     xpad = torch.zeros(B, 18, 2 * FR, 2 * FC)
     xpad[:, :, 3:3 + H, 3:3 + W] = x
