@@ -30,14 +30,15 @@
 // One run of VALU work and one run of MFMAs per row, not a fine interleave: on gfx950 VALU instructions and fp32 MFMAs of a SIMD
 // exclude each other, and every switch between the two costs about 25 cycles in each direction (tools/mfma_valu_ops.hip; a
 // version that hid every window read behind two MFMAs of the same wave was slower, 0.62 against 0.59 ms).  The same tool priced
-// the instructions: packed fp32 adds / multiplies are no cheaper than two plain ones, packed FMAs are -- and forcing everything
-// into v_pk_fma_f32 (inline asm) measured slower than what hipcc makes of the v2f expressions below, so they are left to it.
+// the instructions: with distinct register operands every VALU instruction, packed or not, costs about 5.7 cycles -- what counts is
+// their number; forcing everything into v_pk_fma_f32 by inline asm cost registers (spills) and measured slower than what hipcc
+// makes of the v2f expressions below, so they are left to it.
 // Live registers: M (5 x 16), Y (4 x 16), the 45 operands -- two waves per SIMD.
 //
 // Work item = 8 x 8 tiles (16 x 16 output pixels) of one image x 64 output channels; a workgroup is two teams of four waves
 // (2 tile halves x 2 channel halves), each team on its own item, both teams sharing the filters: LDS holds, per team, two raw
 // phase windows (19 rows of 19 pixels, double buffered: the next phase arrives by LDS-DMA while this one is transformed) and, for
-// the workgroup, two filter rows (5 positions x 4.5 KiB, double buffered) -- 150 KiB, one workgroup per CU, persistent.
+// the workgroup, two filter rows (5 positions x 4.5 KiB, double buffered) -- 154 KiB, one workgroup per CU, persistent.
 // The input comes from hps_stem_phase_split: the four phase images of every input image as separate NHWC frames, so that a
 // window row is one contiguous run and the channels of a pixel sit in the order the lanes read them.
 #include <type_traits>
@@ -351,10 +352,15 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
             const int f_row = r + 1 < SW_ROWS ? r + 1 : (has_next ? 0 : -1);
             const int w_phase = phase < 3 ? phase + 1 : 0;
             const bool w_fetch = row.first && (phase < 3 || has_next);
-            const float* w_src = window_src(phase < 3 ? item : next_item, w_phase);
+            const float* w_src = xf;
+            if (w_fetch) w_src = window_src(phase < 3 ? item : next_item, w_phase);      // (four rows in eighteen: two divisions)
+            // the filter row's source and piece count once per row, not per piece
+            const float* f_src = u + (size_t)c_stem_rows[f_row >= 0 ? f_row : 0].upos * SW_POS_F + wave * 256;
+            const int f_pieces = f_row < 0 ? 0 : (c_stem_rows[f_row].nxp == 5 ? SW_U_PIECES : 18);
+            const unsigned f_dst = lds_u + (unsigned)(((r + 1) & 1) * SW_U_F * 4 + wave * 1024);
             auto spread = [&](int slot) {                        // slots 0-2: filter pieces, 3-9: window pieces
                 if (slot < 3) {
-                    if (f_row >= 0) dma_filter_piece(f_row, slot);
+                    if (wave + 8 * slot < f_pieces) lds_dma16((unsigned)(lane * 16), f_src + slot * 8 * 256, f_dst + (unsigned)(slot * 8 * 1024));
                 } else if (w_fetch) {
                     dma_raw_piece(w_src, w_phase, slot - 3);
                 }

@@ -19,6 +19,16 @@ __device__ __forceinline__ void valu(v2f& x, v2f a, v2f b) {
     if (OP == 7) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(x) : "v"(a));
     if (OP == 8) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x.x) : "v"(a.x));
 }
+// the same with three DIFFERENT register operands per instruction (x = y op z [+ x]): operand fetch from the register file
+template <int OP>
+__device__ __forceinline__ void valu3(v2f& x, v2f y, v2f z) {
+    if (OP == 10) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(x.x) : "v"(y.x), "v"(z.x));
+    if (OP == 11) asm volatile("v_add_f32 %0, %1, %2" : "=v"(x.x) : "v"(y.x), "v"(z.x));
+    if (OP == 13) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(x) : "v"(y), "v"(z));
+    if (OP == 14) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(x) : "v"(y), "v"(z));
+    if (OP == 15) asm volatile("v_pk_fma_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(x) : "v"(y), "v"(z));       // y + z as a packed FMA
+    if (OP == 17) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(x) : "v"(y), "v"(z));
+}
 
 template <int NM, int NV, int SPLIT, int OP>
 __global__ __launch_bounds__(512) void k(float* out, int iters, float seed) {
@@ -37,7 +47,10 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, float seed) {
         }
         if (do_v) {
 #pragma unroll
-            for (int i = 0; i < NV; ++i) valu<OP>(v[i & 15], a2, b2);
+            for (int i = 0; i < NV; ++i) {
+                if (OP < 10) valu<OP>(v[i & 15], a2, b2);
+                else valu3<OP>(v[i & 15], v[(i + 5) & 15], v[(i + 11) & 15]);
+            }
         }
     }
     float s = 0.f;
@@ -88,5 +101,12 @@ int main() {
     kind<5>("v_xor_b32");
     kind<6>("v_mov_b32");
     kind<8>("v_cndmask_b32");
+    printf("three different register operands per instruction:\n");
+    kind<10>("v_fma_f32");
+    kind<11>("v_add_f32");
+    kind<13>("v_pk_fma_f32");
+    kind<14>("v_pk_add_f32");
+    kind<15>("v_pk_fma(y,1,z)");
+    kind<17>("v_pk_mul_f32");
     return 0;
 }
