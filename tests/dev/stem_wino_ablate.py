@@ -1,5 +1,7 @@
 """Dev: interleaved timing of the Winograd stem's ablations (libhps_dev.so)."""
+import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from hierarchicalprobabilistic3dhuman_amd import _capi
 from hierarchicalprobabilistic3dhuman_amd.resnet import _ConvBN

@@ -1,5 +1,7 @@
 """Dev check: Winograd stem (csrc/stem_wino.hip) against the direct row-mode stem and an fp64 CPU convolution; timing."""
+import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from hierarchicalprobabilistic3dhuman_amd import _capi
 from hierarchicalprobabilistic3dhuman_amd.resnet import _ConvBN
