@@ -403,7 +403,7 @@ int hps_canny_edges(const float* img, const float* gauss_taps_host, int gauss_si
 
 /* predict/predict_poseMF_shapeGaussian_net.py:93-100 with utils/label_conversions.py:105-124: out (B,K+1,H,W),
  * channel 0 = edge (B,1,H,W), channel 1+k = visib[b,k] * exp(-((row - v)/std)^2/2 - ((col - u)/std)^2/2) for
- * joints2d (B,K,2) = (u, v); visib (B,K) float 0/1 or NULL. */
+ * joints2d (B,K,2) = (u, v); visib (B,K) float 0/1 or NULL; K <= 32. */
 int hps_proxy_rep(const float* edge, const float* joints2d, const float* visib, float* out, int B,
                   int K, int H, int W, float std, hps_stream_t stream);
 
