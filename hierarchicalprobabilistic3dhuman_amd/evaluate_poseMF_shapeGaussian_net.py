@@ -35,6 +35,51 @@ def _h36mlsp(joints):
     return joints[:, ALL_JOINTS_TO_H36M_MAP, :][:, H36M_TO_J14, :]
 
 
+class _StagedCollate:
+    """Collate function for the in-process DataLoader (num_workers = 0): stacks the tensor fields of a batch into two alternating
+    sets of REUSED page-locked buffers instead of fresh pageable ones.  A dataset item in the reference's format is 5 MB (crop + 17
+    full-resolution heat-maps); default_collate's torch.stack into new memory ran at 0.9 GB/s (page faults) and was half of the
+    evaluation loop.  The loop copies the fields to the device with non_blocking=True and calls copied() -- a buffer set is reused
+    only after the copies out of it have finished."""
+
+    def __init__(self, pinned):
+        self.pinned = pinned
+        self.sets, self.events, self.slot = [{}, {}], [None, None], 1
+
+    def __call__(self, items):
+        from torch.utils.data import default_collate
+        self.slot ^= 1
+        if self.events[self.slot] is not None:
+            self.events[self.slot].synchronize()
+            self.events[self.slot] = None
+        bufs, out = self.sets[self.slot], {}
+        for k in items[0]:
+            v0 = items[0][k]
+            if torch.is_tensor(v0) and len(items) == 1:
+                # batch size 1 (the reference's): a view, no copy
+                out[k] = v0.unsqueeze(0)
+            elif torch.is_tensor(v0) and v0.device.type == "cpu" and not v0.requires_grad:
+                # numpy's stack (a plain memcpy per item) into the reused buffer: torch.stack costs milliseconds per call -- even
+                # for a 72-float pose -- wherever torch's intra-op thread pool is larger than the cores the process may use
+                # (containers with a CPU quota: 7 ms per call on the GPU boxes, five calls per batch)
+                shape = (len(items),) + tuple(v0.shape)
+                buf = bufs.get(k)
+                if buf is None or tuple(buf.shape) != shape or buf.dtype != v0.dtype:
+                    buf = bufs[k] = torch.empty(shape, dtype=v0.dtype, pin_memory=self.pinned)
+                np.stack([it[k].numpy() for it in items], out=buf.numpy())
+                out[k] = buf
+            else:
+                out[k] = default_collate([it[k] for it in items])
+        return out
+
+    def copied(self):
+        """Call after the batch's host-to-device copies have been enqueued."""
+        if self.pinned:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.events[self.slot] = ev
+
+
 def evaluate_pose_MF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_model, smpl_model_male, smpl_model_female,
                                        edge_detect_model, device, eval_dataset, metrics, save_path, num_workers=4,
                                        pin_memory=True, save_per_frame_metrics=True, num_samples_for_metrics=10,
@@ -54,8 +99,9 @@ def evaluate_pose_MF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mo
     # one seed for the whole evaluation, from torch's global CPU generator (torch.manual_seed controls it; ranks seeded alike
     # draw the same one), combined with the global frame index below
     run_seed = _philox_seed(seed) if not sample_on_cpu else None
+    staged = _StagedCollate(pinned=device.type == "cuda") if num_workers == 0 else None
     loader = DataLoader(eval_dataset, batch_size=batch_size, shuffle=False, drop_last=False, num_workers=num_workers,
-                        pin_memory=pin_memory)
+                        pin_memory=pin_memory and staged is None, collate_fn=staged)
     tracker = EvalMetricsTracker(metrics, save_path=save_path, save_per_frame_metrics=save_per_frame_metrics)
     tracker.initialise_metric_sums()
     tracker.initialise_per_frame_metric_lists()
@@ -72,21 +118,23 @@ def evaluate_pose_MF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mo
 
 
 def _evaluate_loop(pose_shape_model, pose_shape_cfg, smpl_model, smpl_model_male, smpl_model_female, edge_detect_model, device,
-                   loader, tracker, metrics, want_samples, N, flip, fnames, poses, shapes, cams, sample_on_cpu, run_seed, frame0,
+                   loader, staged, tracker, metrics, want_samples, N, flip, fnames, poses, shapes, cams, sample_on_cpu, run_seed, frame0,
                    reduce_across_ranks, save_per_frame_metrics, save_path, **_unused):
     frame = frame0
     for batch in loader:
         with torch.no_grad():
-            image = batch["image"].to(device)
-            heatmaps = batch["heatmaps"].to(device)
+            image = batch["image"].to(device, non_blocking=True)
+            heatmaps = batch["heatmaps"].to(device, non_blocking=True)
             edges = edge_detect_model(image)                                                          # :69-71
             edge = edges["thresholded_thin_edges"] if pose_shape_cfg.DATA.EDGE_NMS else edges["thresholded_grad_magnitude"]
             proxy = torch.cat([edge, heatmaps], dim=1)
             B = proxy.shape[0]
 
             # ------------------ targets (:74-105) ------------------
-            target_pose = batch["pose"].to(device).float()
-            target_shape = batch["shape"].to(device).float()
+            target_pose = batch["pose"].to(device, non_blocking=True).float()
+            target_shape = batch["shape"].to(device, non_blocking=True).float()
+            if staged is not None:
+                staged.copied()
             genders = list(batch["gender"])
             R = batch_rodrigues(target_pose.reshape(-1, 3)).view(B, 24, 3, 3)
             R[:, 0] = torch.matmul(flip, R[:, 0])                                 # 'pre' multiplication
