@@ -27,6 +27,8 @@ sec "tools/stem_pmc.sh (SQ counters of stem_wino_kernel, B = 64, per dispatch)"
 bash $R/tools/stem_pmc.sh 0 2>&1 | grep -E "^SQ_|^GRBM"
 sec "tools/next_rows_time.py (kernels of the widened rows, SURVEY 8(f) items 1 and 2: time alone against their algorithmic HBM bytes)"
 python $R/tools/next_rows_time.py 2>&1 | grep "^hps_"
+sec "tools/evaluate_time.py 512 <batch> 10 (dataset-evaluation harness, synthetic 3DPW-like dataset: frames/s of the whole loop)"
+for b in 32 8 1; do python $R/tools/evaluate_time.py 512 $b 10 0 2>&1 | grep "evaluate harness"; done
 sec "tests/dev/gpu_bringup.py mesh_fused (ablations of mesh_fused_kernel)"
 python $R/tests/dev/gpu_bringup.py mesh_fused 2>&1 | grep -E "mesh_fused M=|alone|ablate"
 sec "tests/dev/gpu_bringup.py unc_modes"
