@@ -31,6 +31,8 @@ BLEND_FLOP_PER_MESH = 2 * (207 + 10) * 3 * 6890   # pose
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8 TB/s
 ENCODER_GFLOP_PER_IMAGE = 6.279      # 3.139 GMAC per 18x256x256 image
 MFMA_FP32_PEAK_TF = 157.3            # MI355X_MICROARCH.md: dense fp32 matrix peak
+INPUT_SETS = 2                       # different input batches rotated through the timed loop
+SET_STRIDE = 1 << 16                 # global image index distance between the input sets (> any global batch)
 
 
 def synthetic_inputs(lo, hi):
@@ -75,6 +77,16 @@ def cpu_baseline(net_state, parents, num_samples, n_images):
             "stage_seconds": {k: round(v, 4) for k, v in stages.items()},
             "single_thread": {"value": n1 / dt1, "unit": "images/s", "cores": 1,
                               "sample": "%d images, num_samples=%d (%.2f s)" % (n1, num_samples, dt1)}}
+
+
+def workload_name(B, N, world):
+    """Which BASELINE.json configuration the arguments select (the label is derived, never hard-coded)."""
+    if B == 64 and N == 100:
+        return "BASELINE configs[1]" if world == 1 else ("BASELINE configs[2]" if world == 8 else
+                                                         "BASELINE configs[1] per GPU, %d GPUs (configs[2] is the 8-GPU case)" % world)
+    if N == 1000:
+        return "BASELINE configs[4] (num_samples=1000 stress)" + ("" if B == 16 else ", batch %d instead of 16" % B)
+    return "custom (not a BASELINE configuration)"
 
 
 def _capi_mesh_cus(pipe):
@@ -130,7 +142,13 @@ def main():
     smpl.fused_mesh = not args.unfused_mesh
 
     lo, hi = sharding.shard_range(B * shard_world, shard_rank, shard_world)   # weak scaling: B images per GPU
-    x = synthetic_inputs(lo, hi).to(dev)
+    # INPUT_SETS different global batches rotate through the steps (step i reads set i % INPUT_SETS: no step re-reads the
+    # tensor the step before it read); set k holds the global images k * SET_STRIDE + [lo, hi) -- still a function of the global
+    # image index only, so a rank's data does not depend on the sharding
+    set_stride = SET_STRIDE
+    xs = [synthetic_inputs(lo + k * set_stride, hi + k * set_stride).to(dev) for k in range(INPUT_SETS)]
+    x = xs[0]
+    offset_of = lambda step: lo + (step % INPUT_SETS) * set_stride          # Philox key: global index of the batch's first image
 
     # Steps are software-pipelined over three HIP streams: the encoder of step i+1 is enqueued before the latency-bound
     # head of step i runs (InferencePipeline).  Every step does the full work; exactly args.steps batches are
@@ -144,11 +162,12 @@ def main():
     step_marks = []
 
     def run_steps(first, count, on_result=None):
-        ticket = pipe.submit(x)
+        # input_ready=False: the inputs are resident and complete before the loop starts (nothing produces them on a stream)
+        ticket = pipe.submit(xs[first % INPUT_SETS], input_ready=False)
         res = None
         for i in range(count):
-            nxt = pipe.submit(x) if i + 1 < count else None
-            res = pipe.finish(ticket, seed=1234 + first + i, image_offset=lo, after=nxt)
+            nxt = pipe.submit(xs[(first + i + 1) % INPUT_SETS], input_ready=False) if i + 1 < count else None
+            res = pipe.finish(ticket, seed=1234 + first + i, image_offset=offset_of(first + i), after=nxt)
             if on_result is not None:
                 on_result(res)
             ticket = nxt
@@ -171,7 +190,7 @@ def main():
     else:
         for i in range(args.warmup):
             warm_sums.add_(sharding.batch_metric_sums(
-                infer(net, smpl, x, num_samples=N, use_mean_shape=True, seed=1234 + i, image_offset=lo)))
+                infer(net, smpl, xs[i % INPUT_SETS], num_samples=N, use_mean_shape=True, seed=1234 + i, image_offset=offset_of(i))))
     sharding.gather_metric_sums(warm_sums)
     torch.cuda.synchronize()
     smpl.lbs_events = []
@@ -190,8 +209,8 @@ def main():
         run_steps(args.warmup, args.steps, accumulate)
     else:
         for i in range(args.steps):
-            accumulate(infer(net, smpl, x, num_samples=N, use_mean_shape=True, seed=1234 + args.warmup + i,
-                             image_offset=lo))
+            accumulate(infer(net, smpl, xs[(args.warmup + i) % INPUT_SETS], num_samples=N, use_mean_shape=True,
+                             seed=1234 + args.warmup + i, image_offset=offset_of(args.warmup + i)))
     per_rank, total = sharding.gather_metric_sums(sums)                 # the one collective of the run
     torch.cuda.synchronize()
     barrier()
@@ -282,9 +301,10 @@ def main():
             "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: batch=%d synthetic 18x256x256 proxy representations per GPU, "
+            "config": {"workload": "%s: batch=%d synthetic 18x256x256 proxy representations per GPU, "
                                    "num_samples=%d, neutral synthetic SMPL (6890 verts), random-init ResNet-18 + "
-                                   "poseMF_shapeGaussian head (seed 0), Philox sampling" % (B, N),
+                                   "poseMF_shapeGaussian head (seed 0), Philox sampling" % (workload_name(B, N, world), B, N),
+                       "input_sets": INPUT_SETS,
                        "images_per_gpu": B, "global_batch": B * world, "num_samples": N,
                        "meshes_per_step_per_gpu": M, "parallelism": "images sharded over %d GPU(s)" % world,
                        "mesh_kernel": "fused blend GEMM + LBS" if fused else "blend GEMM, then LBS",
@@ -299,6 +319,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": mesh_kernel, "fused": fused,
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_imported": True if traffic else None,      # NOT measured in this run: read from the committed PMC summary
                          "traffic_source": traffic_source if traffic else None,
                          "avg_launch_ms": lbs_avg_ms, "launches": len(lbs_ms), "launch_spread": spread(lbs_ms),
                          "algorithmic_bytes_per_launch": LBS_BYTES_PER_MESH * M,

@@ -96,9 +96,12 @@ def evaluate_pose_MF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mo
         rank, world = sharding.world_info()
         frame0 = sharding.shard_range(len(eval_dataset), rank, world)[0]
         eval_dataset = sharding.shard_dataset(eval_dataset)          # this rank's contiguous block of frames
-    # one seed for the whole evaluation, from torch's global CPU generator (torch.manual_seed controls it; ranks seeded alike
-    # draw the same one), combined with the global frame index below
+    # one seed for the whole evaluation, from torch's global CPU generator (torch.manual_seed controls it), combined with the
+    # global frame index below.  With several ranks it is RANK 0's draw that counts (broadcast): ranks whose generators were not
+    # seeded alike would otherwise sample differently and the metrics would depend on the world size without anyone noticing.
     run_seed = _philox_seed(seed) if not sample_on_cpu else None
+    if run_seed is not None and reduce_across_ranks:
+        run_seed = sharding.broadcast_int(run_seed)
     staged = _StagedCollate(pinned=device.type == "cuda") if num_workers == 0 else None
     loader = DataLoader(eval_dataset, batch_size=batch_size, shuffle=False, drop_last=False, num_workers=num_workers,
                         pin_memory=pin_memory and staged is None, collate_fn=staged)

@@ -120,7 +120,6 @@ class InferencePipeline:
         self.enc_stream = None        # created by the first submit (its kind depends on the batch size)
         self.mesh_stream = None
         self._smpl_done = None
-        self._first = True
         self._exclusive = True
         self.enc_events = None
         self.trace = None             # bench.py --trace-steps: list of per-batch dicts of timing events (head / mesh phases)
@@ -156,31 +155,51 @@ class InferencePipeline:
         k = self.encoder_cus
         if k is None:
             k = 8 if (not self._exclusive and batch * (self.num_samples + 2) >= 12000) else 0
+        self.enc_stream = None
         if not self._exclusive and k:
+            # CUs per XCD from the device (MI355X: 256 / 8 = 32); a device or partition mode the mask scheme does not fit (a CU
+            # count that is not a multiple of 8, fewer CUs per XCD than asked for, a runtime without CU masks) falls back to
+            # shared CUs instead of failing the first submit
             k = int(k)
-            self.enc_stream = _capi.cu_partition_stream(0, k)
-            self.mesh_stream = _capi.cu_partition_stream(k, 32 - k)
-            self._mesh_cus = 32 - k
-        else:
+            per_xcd = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count // 8
+            try:
+                if not 0 < k < per_xcd:
+                    raise _capi.HpsError("encoder_cus = %d does not fit %d CUs per XCD" % (k, per_xcd))
+                enc = _capi.cu_partition_stream(0, k)
+                self.mesh_stream = _capi.cu_partition_stream(k, per_xcd - k)
+                self.enc_stream, self._mesh_cus = enc, per_xcd - k
+            except _capi.HpsError as e:
+                import warnings
+                warnings.warn("InferencePipeline: no CU partition on this device (%s); encoder and mesh kernels share the CUs" % e)
+                self.mesh_stream = None
+        if self.enc_stream is None:
             self.enc_stream = torch.cuda.Stream()
 
     @torch.no_grad()
     def submit(self, proxy_rep_input, input_ready=None):
-        """Enqueue the encoder of one batch on the side stream.  ``input_ready``: optional event after which the input
-        tensor is complete; by default the first submit waits for everything already queued on the caller's stream and
-        later ones for the SMPL kernels of the previously finished batch (inputs produced on the caller's stream after
-        that point need ``input_ready``)."""
+        """Enqueue the encoder of one batch on the side stream.
+
+        ``input_ready`` says when ``proxy_rep_input`` is complete:
+          * an event -- the encoder waits for exactly that event (the precise form: record it right behind the kernels / the
+            non-blocking copy that produce the input, on whatever stream they run);
+          * ``None`` (default) -- safe for any producer on the caller's stream: an event recorded on the caller's stream NOW,
+            i.e. the encoder waits for everything queued there so far -- including a previous batch's uncertainty pass, which it
+            would otherwise run beside (measured: 3.15 -> 3.24 ms per step at B = 64);
+          * ``False`` -- no ordering: the caller guarantees the input is already complete (resident data, or its own
+            synchronisation)."""
         _capi.require_device(proxy_rep_input, "proxy_rep_input")
         main = torch.cuda.current_stream()
         if self.enc_stream is None:
             self._setup_streams(proxy_rep_input.shape[0])
-        if input_ready is not None:
+        if input_ready is None:
+            ready = torch.cuda.Event()
+            ready.record(main)
+            self.enc_stream.wait_event(ready)
+        elif input_ready is not False:
             self.enc_stream.wait_event(input_ready)
         gate = None
         if self._smpl_done is None or not self._exclusive:
-            if self._first:
-                self.enc_stream.wait_stream(main)
-                self._first = False
+            pass
         elif self.early_relayout:
             # the input relayout (HBM-bound) is enqueued at once and may run beside the previous batch's fused mesh kernel
             # (MFMA-bound); the convolutions wait for that batch's SMPL kernels

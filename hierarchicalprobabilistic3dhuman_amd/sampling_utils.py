@@ -20,7 +20,7 @@ from . import _capi
 
 _MAX_ROUNDS = 64
 last_accepted = None        # ((B*23,) int32 device tensor, N) of the most recent Philox launch: accepted proposals of the final round per call
-_pending = []               # (accepted, N) of every Philox launch since the last check_sampling(): nothing is lost between checks
+_pending = []               # (accepted, N, event on the launch stream) of every Philox launch since the last check_sampling()
 _failed = {}                # device -> int64 scalar: failed calls of launches already folded out of _pending
 _PENDING_MAX = 256
 launch_events = None        # bench.py: list collecting (start, end) HIP events around every hps_mf_sample launch
@@ -143,26 +143,34 @@ def pose_matrix_fisher_sampling_torch(pose_U, pose_S, pose_V, num_samples, b=1.5
         # A call that does not reach N accepts within _MAX_ROUNDS rounds (NaN / Inf pose_S from a bad checkpoint) gets NaN
         # rotations from the kernel -- loud downstream.  The counts stay on the device (no sync on the hot path);
         # check_sampling() is the deferred test the harnesses run per batch.
+        # Recorded with an event on the LAUNCH stream (several streams may sample: InferencePipeline's partitions); the counts
+        # are reduced by check_sampling() / _fold_pending() on whatever stream is current then, after waiting for the event.
+        # The tensors stay referenced here until then, so the caching allocator cannot hand their blocks to another stream.
         global last_accepted
         last_accepted = (accepted, num_samples)
-        _pending.append(last_accepted)
+        ev = torch.cuda.Event()
+        ev.record()
+        _pending.append((accepted, num_samples, ev))
         if len(_pending) > _PENDING_MAX:
-            _fold_pending()
+            _fold_pending(_PENDING_MAX // 2)
     return R
 
 
-def _fold_pending():
-    """Reduce the recorded accept counts to one failure counter per device (stream-ordered, no synchronisation)."""
-    while _pending:
-        accepted, n = _pending.pop()
+def _fold_pending(keep=0):
+    """Reduce the oldest recorded accept counts to one failure counter per device, ordered after their launches by event
+    (stream-ordered: no host synchronisation)."""
+    cur = torch.cuda.current_stream()
+    while len(_pending) > keep:
+        accepted, n, ev = _pending.pop(0)
+        cur.wait_event(ev)
         c = (accepted < n).sum()
         _failed[accepted.device] = c if accepted.device not in _failed else _failed[accepted.device] + c
 
 
 def check_sampling():
     """Raise if ANY Philox sampling launch since the previous check had a call that never reached N accepted proposals
-    (synchronises).  Launches are recorded as they are made -- several batches may be in flight (InferencePipeline) or a whole
-    data-loader loop may run between two checks without a failure going unnoticed."""
+    (synchronises).  Launches are recorded as they are made -- several batches may be in flight (InferencePipeline, on any of
+    its streams) or a whole data-loader loop may run between two checks without a failure going unnoticed."""
     if not _pending and not _failed:
         return
     _fold_pending()

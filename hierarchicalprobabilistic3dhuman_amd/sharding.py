@@ -68,6 +68,16 @@ def all_reduce_max(value):
     return float(t.item())
 
 
+def broadcast_int(value, src=0):
+    """Rank ``src``'s Python int on every rank (the evaluation's run seed); the value itself without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return int(value)
+    dev = torch.device("cpu") if _host_staged() else torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=src)
+    return int(t.item())
+
+
 def shard_range(total, rank, world):
     """Contiguous block of ``total`` items owned by ``rank``; the first ``total % world`` ranks get one extra."""
     base, rem = divmod(total, world)

@@ -194,6 +194,31 @@ def main():
                                         dtype=torch.float64)
     out["metrics_sums"] = torch.tensor([tracker.metric_sums[m] for m in METRICS], dtype=torch.float64)
     out["metrics_pve_pa_per_frame"] = torch.tensor(np.concatenate(tracker.per_frame_metrics["PVE-PA"]), dtype=torch.float64)
+    # ---- sampler sizes that take SEVERAL wavefronts per (image, joint) call in hps_mf_sample (waves = ceil(2N / 256):
+    #      N = 129 -> 2, 300 -> 3, 1000 -> 8, the BASELINE configs[4] size): "the first N accepted, in proposal order"
+    #      (utils/sampling_utils.py:61-66) across wavefront boundaries.  N = 129 is kept whole; of N = 300 / 1000 every
+    #      3rd / 8th sample and the last one are kept, plus the float64 sum over ALL samples (any ordering or selection
+    #      error moves it).  Then a starved case -- oversampling_ratio = 2, N = 200 (2 wavefronts) on broad concentrations:
+    #      rounds with fewer than N accepts are discarded and redrawn (:68-69), 23 of them here, up to 9 for one call ----
+    for N, step in ((129, 1), (300, 3), (1000, 8)):
+        torch.manual_seed(40 + N)
+        Rn = ref_sampling(U, S, V, N, sample_on_cpu=True)
+        keep = sorted(set(range(0, N, step)) | {N - 1})
+        out["sampler_R_N%d_keep" % N] = torch.tensor(keep)
+        out["sampler_R_N%d_sub" % N] = Rn[:, keep].contiguous()
+        out["sampler_R_N%d_sum" % N] = Rn.double().sum(1)
+    g = torch.Generator().manual_seed(5)
+    Fs = torch.randn(2, 23, 3, 3, generator=g) * 2.0 + torch.eye(3)
+    Us, Ss, Vhs = torch.linalg.svd(Fs)
+    Vs = Vhs.transpose(-1, -2).contiguous()
+    torch.manual_seed(9)
+    _, (_, _, disc) = O.pose_matrix_fisher_sampling(Us, Ss, Vs, 200, oversampling_ratio=2, return_noise=True)
+    assert int(disc.sum()) >= 10 and int(disc.max()) >= 3, "starved case no longer discards rounds"
+    torch.manual_seed(9)
+    out["starved_U"], out["starved_S"], out["starved_V"] = Us, Ss, Vs
+    out["starved_R_N200"] = ref_sampling(Us, Ss, Vs, 200, oversampling_ratio=2, sample_on_cpu=True)
+    out["starved_next_rand"] = torch.rand(1)          # the host generator's state after the reference loop
+    out["starved_discarded"] = disc
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"),
                         **{k: v.detach().numpy() for k, v in out.items()})
     print("wrote", os.path.join(HERE, "reference_vectors.npz"), {k: tuple(v.shape) for k, v in out.items()})

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import ref_cpu as O
-from hierarchicalprobabilistic3dhuman_amd import configs, sharding
+from hierarchicalprobabilistic3dhuman_amd import _capi, configs, sharding
 from hierarchicalprobabilistic3dhuman_amd.predict_poseMF_shapeGaussian_net import infer
 from hierarchicalprobabilistic3dhuman_amd import sampling_utils as su
 from hierarchicalprobabilistic3dhuman_amd import rigid_transform_utils as rtu
@@ -29,6 +29,84 @@ def test_infer_matches_oracle(B, N, dev, net_gpu, net_cpu, smpl_gpu, smpl_assets
     for k in KEYS:
         assert out[k].shape == ref[k].shape, k
         assert maxerr(out[k], ref[k]) <= 1e-4, k
+
+
+def _oracle_infer_chunked(sd, params, x, N, chunk):
+    """O.infer over ``chunk`` images at a time (the oracle materialises smplx's per-vertex 4x4 transforms: 441 KB per mesh).
+    With use_mean_shape the only random draws are the sampler's, image by image, so the chunks continue one stream."""
+    parts = [O.infer(sd, params, configs.SMPL_PARENTS, x[i:i + chunk], N) for i in range(0, x.shape[0], chunk)]
+    return {k: torch.cat([p[k] for p in parts]) for k in KEYS + ("pose_U", "pose_V")}
+
+
+def _assert_matches_oracle(out, ref, B, N, tol=1e-4):
+    """All KEYS <= tol against the oracle, with the two DISCONTINUITIES of the reference's own function handled explicitly
+    (counted and bounded, never silently skipped):
+
+    (1) torch.svd's choice of signs for a singular-vector pair is not continuous in F: F_gpu and F_oracle differ by ~2e-7
+        (accumulation order of the encoder), and for about one matrix in a thousand LAPACK then returns a differently signed
+        pair (observed at configs[1]: image 32, joint 0, max |dF| = 2.4e-7, columns 2 and 3 of U and V negated).  U_proper feeds
+        the children (models/poseMF_shapeGaussian_net.py:126-130), so that image's descendants, samples and meshes differ --
+        exactly as they would between two runs of the reference on hosts whose convolutions round differently.  What IS
+        required of such an image: the device's (U, S, V) equal torch.svd of the device's own F bit for bit (we ARE the
+        reference's function at that input), checked for every matrix; everything that does not depend on the pose chain still
+        matches; and at most max(1, B / 32) images are affected.
+    (2) an accept decision on an fp32 rounding tie may flip (stated bound: <= 1e-6 of the proposals); a flip changes
+        every later sample of that (image, joint) call."""
+    o = {k: out[k].cpu() for k in KEYS + ("pose_U", "pose_V")}
+    if _capi.svd_flavor_is_exact():
+        Uh, Sh, Vh = torch.svd(o["pose_F"].reshape(-1, 3, 3))
+        assert torch.equal(Uh.view_as(o["pose_U"]), o["pose_U"]) and torch.equal(Vh.view_as(o["pose_V"]), o["pose_V"])
+        assert torch.equal(Sh.view_as(o["pose_S"]), o["pose_S"])
+    dF = (o["pose_F"] - ref["pose_F"]).abs().amax(dim=(2, 3))
+    dUV = torch.maximum((o["pose_U"] - ref["pose_U"]).abs().amax(dim=(2, 3)), (o["pose_V"] - ref["pose_V"]).abs().amax(dim=(2, 3)))
+    split = (dF <= tol) & (dUV > 0.5)                  # same F, differently signed vector pair (ill-conditioning gives <= 1e-2)
+    split_imgs = split.any(dim=1)
+    assert int(split_imgs.sum()) <= max(1, B // 32), "LAPACK sign choice differs in %d images" % int(split_imgs.sum())
+    good = (~split_imgs).nonzero().flatten()
+    err = (o["R_samples"] - ref["R_samples"]).abs().amax(dim=(1, 3, 4))[good]            # (good images, 23)
+    flipped = err > tol
+    allowed = int(-(-B * 23 * 8 * N // 1000000))
+    assert int(flipped.sum()) <= allowed, "accept decisions flipped in %d calls (allowed %d)" % (int(flipped.sum()), allowed)
+    good_s = good[~flipped.any(dim=1)]
+    pose_free = ("shape_loc", "shape_scale", "glob", "cam", "glob_rotmats", "verts_tpose")
+    for k in KEYS:
+        assert o[k].shape == ref[k].shape, k
+        sel = slice(None) if k in pose_free else (good_s if k in ("R_samples", "verts_samples", "joints_samples", "unc") else good)
+        assert maxerr(o[k][sel], ref[k][sel]) <= tol, k
+    return int(split_imgs.sum()), int(flipped.sum())
+
+
+def test_infer_matches_oracle_at_1000_samples(dev, net_gpu, net_cpu, smpl_gpu, smpl_assets, golden_input):
+    """N = 1000: eight wavefronts per sampler call, the one-sweep uncertainty kernel, 2 004 meshes -- against the oracle."""
+    torch.manual_seed(12)
+    ref = _oracle_infer_chunked(net_cpu[1], smpl_assets[2], golden_input, 1000, 1)
+    torch.manual_seed(12)
+    out = infer(net_gpu, smpl_gpu, golden_input.to(dev), num_samples=1000, sample_on_cpu=True)
+    _assert_matches_oracle(out, ref, 2, 1000)
+
+
+@pytest.mark.parametrize("B,N,chunk", [(64, 100, 64), (16, 1000, 4)])
+def test_full_size_configs_match_oracle(B, N, chunk, dev, net_gpu, net_cpu, smpl_gpu, smpl_assets):
+    """BASELINE configs[1] (B = 64, N = 100: 6 528 meshes) and configs[4] (B = 16, N = 1000: 16 032 meshes) at their REAL
+    size against the CPU oracle on the reference's seed-reproducible route (sample_on_cpu=True), all fifteen outputs <= 1e-4 --
+    once through infer() and once through InferencePipeline (three streams; for configs[4] the CU-partition schedule)."""
+    from hierarchicalprobabilistic3dhuman_amd.predict_poseMF_shapeGaussian_net import InferencePipeline
+    x = torch.stack([torch.rand(18, 256, 256, generator=torch.Generator().manual_seed(5000 + i)) for i in range(B)])
+    torch.manual_seed(13)
+    ref = _oracle_infer_chunked(net_cpu[1], smpl_assets[2], x, N, chunk)
+    xd = x.to(dev)
+    torch.manual_seed(13)
+    out = infer(net_gpu, smpl_gpu, xd, num_samples=N, sample_on_cpu=True)
+    _assert_matches_oracle(out, ref, B, N)
+    out = {k: out[k].cpu() for k in KEYS}
+    pipe = InferencePipeline(net_gpu, smpl_gpu, num_samples=N, sample_on_cpu=True)
+    with torch.cuda.stream(pipe.caller_stream(B)):
+        torch.manual_seed(13)
+        got = pipe.finish(pipe.submit(xd))
+        got = {k: got[k].cpu() for k in KEYS}
+    torch.cuda.synchronize()
+    for k in KEYS:
+        assert torch.equal(got[k], out[k]), k
 
 
 def test_reference_call_sequence_batch_one(dev, net_gpu, net_cpu, smpl_gpu, smpl_assets, golden_input):

@@ -25,6 +25,37 @@ def test_host_stream_route_reproduces_reference_samples(N, dev, golden):
     assert maxerr(R, golden["sampler_R_N%d" % N]) <= TOL
 
 
+@pytest.mark.parametrize("N", [129, 300, 1000])
+def test_multi_wavefront_sizes_reproduce_reference_samples(N, dev, golden):
+    """hps_mf_sample runs ceil(2N / 256) wavefronts per (image, joint) call: 2, 3 and 8 here (N = 1000 is BASELINE configs[4]).
+    "The first N accepted, in proposal order" (utils/sampling_utils.py:61-66) across wavefront boundaries: the kept samples of the
+    reference's run (tests/golden/make_golden.py) and the float64 sum over ALL of its samples."""
+    U, S, V = (golden[k].to(dev) for k in ("net_U", "net_S", "net_V"))
+    torch.manual_seed(40 + N)
+    R = su.pose_matrix_fisher_sampling_torch(U, S, V, N, sample_on_cpu=True)
+    assert R.shape == (2, N, 23, 3, 3)
+    assert maxerr(R[:, golden["sampler_R_N%d_keep" % N].to(dev)], golden["sampler_R_N%d_sub" % N]) <= TOL
+    assert maxerr(R.double().sum(1), golden["sampler_R_N%d_sum" % N]) <= TOL * N
+
+
+def test_starved_multi_wavefront_rounds_follow_the_reference(dev, golden):
+    """oversampling_ratio = 2, N = 200 (two wavefronts, 400 proposals = three whole super-blocks and a ragged one) on broad
+    concentrations: the reference discards 23 rounds here, up to 9 for one call (utils/sampling_utils.py:68-69); every later call
+    shifts along the host stream.  Samples and the generator's final state must equal the reference's."""
+    U, S, V = (golden[k].to(dev) for k in ("starved_U", "starved_S", "starved_V"))
+    assert int(golden["starved_discarded"].sum()) >= 10
+    torch.manual_seed(9)
+    R = su.pose_matrix_fisher_sampling_torch(U, S, V, 200, oversampling_ratio=2, sample_on_cpu=True)
+    assert maxerr(R, golden["starved_R_N200"]) <= TOL
+    assert torch.equal(torch.rand(1), golden["starved_next_rand"])
+    # the Philox route with the same starved budget: N proper rotations per call, and the same bits whatever the batch split
+    Rp = su.pose_matrix_fisher_sampling_torch(U, S, V, 200, oversampling_ratio=2, seed=3)
+    su.check_sampling()
+    assert float((torch.matmul(Rp.transpose(-1, -2), Rp) - torch.eye(3, device=dev)).abs().max()) <= 1e-5
+    Rq = su.pose_matrix_fisher_sampling_torch(U[1:], S[1:], V[1:], 200, oversampling_ratio=2, seed=3, image_offset=1)
+    assert torch.equal(Rq[0], Rp[1])
+
+
 def test_concentration_sweep_reproduces_reference(dev, golden):
     torch.manual_seed(1)
     R = su.pose_matrix_fisher_sampling_torch(golden["sweep_U"].to(dev), golden["sweep_S"].to(dev),

@@ -30,6 +30,28 @@ def test_sampler_replays_reference_stream(golden):
         assert maxerr(R, golden["sampler_R_N%d" % N]) <= 1e-6, N
 
 
+def test_sampler_sizes_that_take_several_wavefronts(golden):
+    """N = 129 / 300 / 1000 (2 / 3 / 8 wavefronts per call in hps_mf_sample; 1000 = BASELINE configs[4]): the oracle against
+    the reference's samples (kept subset) and the float64 sum over all samples (utils/sampling_utils.py:61-66)."""
+    U, S, V = golden["net_U"], golden["net_S"], golden["net_V"]
+    for N in (129, 300, 1000):
+        torch.manual_seed(40 + N)
+        R = O.pose_matrix_fisher_sampling(U, S, V, N)
+        assert maxerr(R[:, golden["sampler_R_N%d_keep" % N]], golden["sampler_R_N%d_sub" % N]) <= 1e-6, N
+        assert maxerr(R.double().sum(1), golden["sampler_R_N%d_sum" % N]) <= 1e-6 * N, N
+
+
+def test_sampler_starved_rounds_are_discarded_like_the_reference(golden):
+    """oversampling_ratio = 2, N = 200: 23 discarded rounds (up to 9 for one call, utils/sampling_utils.py:68-69); the oracle
+    follows the reference's stream through every one of them and leaves the generator where the reference leaves it."""
+    U, S, V = golden["starved_U"], golden["starved_S"], golden["starved_V"]
+    torch.manual_seed(9)
+    R, (_, _, disc) = O.pose_matrix_fisher_sampling(U, S, V, 200, oversampling_ratio=2, return_noise=True)
+    assert torch.equal(disc, golden["starved_discarded"]) and int(disc.sum()) >= 10
+    assert maxerr(R, golden["starved_R_N200"]) <= 1e-6
+    assert torch.equal(torch.rand(1), golden["starved_next_rand"])
+
+
 def test_sampler_concentration_sweep(golden):
     torch.manual_seed(1)
     R = O.pose_matrix_fisher_sampling(golden["sweep_U"], golden["sweep_S"], golden["sweep_V"], 50)

@@ -26,7 +26,11 @@ def _worker(rank, world, port, total, q):
     per_image = torch.tensor([[1.0, (i * 0.37) % 1.0, float(i)] for i in range(lo, hi)], dtype=torch.float64).reshape(-1, 3)
     local = per_image.sum(0)
     per_rank, total_sums = sharding.gather_metric_sums(local)
-    q.put((r, lo, hi, per_rank.tolist(), total_sums.tolist()))
+    # the evaluation's run seed: ranks whose generators are seeded differently still end up with rank 0's draw
+    torch.manual_seed(100 + r)
+    mine = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    seed = sharding.broadcast_int(mine)
+    q.put((r, lo, hi, per_rank.tolist(), total_sums.tolist(), mine, seed))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -43,7 +47,8 @@ def test_all_gather_metric_reduction_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, lo0, hi0, pr0, tot0), (r1, lo1, hi1, pr1, tot1) = results
+    (r0, lo0, hi0, pr0, tot0, mine0, seed0), (r1, lo1, hi1, pr1, tot1, mine1, seed1) = results
+    assert mine0 != mine1 and seed0 == seed1 == mine0        # broadcast_int: rank 0's value everywhere
     assert (lo0, hi0, lo1, hi1) == (0, 7, 7, 13)
     assert pr0 == pr1 and tot0 == tot1                       # every rank holds the same gathered table and total
     # equals the single-process run that adds the same shard sums in rank order (bit for bit)
