@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--as-rank", type=int, nargs=2, metavar=("R", "W"), default=None,
                     help="single process, no process group: do exactly the work rank R of a W-rank job would do (its image "
                          "shard, its Philox offsets) -- what the multi-rank tests compare the per-rank checksums against")
+    ap.add_argument("--latency-reps", type=int, default=40,
+                    help="after the timed region: batch-1, num_samples=50 calls timed one by one for secondary.latency_b1 (0 = skip)")
     ap.add_argument("--lbs-unfused-reps", type=int, default=12,
                     help="after the timed region: launches of the unfused blend + LBS pair timed for secondary.lbs_unfused (0 = skip)")
     args = ap.parse_args()
@@ -253,7 +255,26 @@ def main():
                                note="hps_smpl_lbs alone (v_posed read + A read + verts write: SURVEY 8(d)'s definition) on the "
                                     "bench workload, launched after the timed region; not part of the product path, which fuses "
                                     "skinning into the blend GEMM")
+    # Latency at the reference's own operating point (run_predict.py -> predict/predict_poseMF_shapeGaussian_net.py:58-59,103-165:
+    # ONE image at a time, num_samples = 50): input resident, infer() issued and waited for, wall clock per image.
+    latency_b1 = None
+    if args.latency_reps > 0 and rank == 0:
+        x1, n1 = xs[0][:1].contiguous(), 50
+        lat = []
+        for i in range(args.latency_reps + 5):
+            torch.cuda.synchronize()
+            t_a = time.perf_counter()
+            infer(net, smpl, x1, num_samples=n1, use_mean_shape=True, seed=99 + i, image_offset=lo)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t_a) * 1e3)
+        st = spread(lat[5:])
+        latency_b1 = {"median_ms": st["median_ms"], "min_ms": st["min_ms"], "max_ms": st["max_ms"], "reps": st["launches"],
+                      "images_per_s": 1e3 / st["median_ms"], "batch": 1, "num_samples": n1,
+                      "note": "one image per call, host wall clock from issue to completion (torch.cuda.synchronize), input resident "
+                              "in HBM; the reference's run_predict operating point"}
     secondary = {}
+    if latency_b1:
+        secondary["latency_b1"] = latency_b1
     if enc_ms:
         t = sum(enc_ms) / len(enc_ms)
         tf = ENCODER_GFLOP_PER_IMAGE * B / t

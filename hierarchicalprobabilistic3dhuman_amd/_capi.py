@@ -51,6 +51,7 @@ _PROTOTYPES = {
     "hps_host_bind_lapack": [_c.c_char_p],
     "hps_head_svd_finish": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "hps_canny_edges": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _I, _P],
+    "hps_canny_edge_map": [_P, _P, _I, _P, _c.c_int64, _I, _I, _I, _I, _c.c_float, _I, _P],
     "hps_proxy_rep": [_P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _P],
     "hps_pointset_errors": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "hps_heatmaps_to_joints2d": [_P, _P, _P, _I, _I, _I, _c.c_float, _P],

@@ -13,13 +13,35 @@ constexpr int BLD = MAGD + 2;          // blurred image on a further 1-pixel hal
 constexpr int HROWS = BLD + 2 * GH;    // rows of the horizontal pass feeding the vertical pass
 constexpr int IND = BLD + 2 * GH;      // input tile edge (40)
 
+// Orientation bin k = round((atan2(gy, gx) * 180 / pi + 180) / 45) in 0..8 (models/canny_edge_detector.py:128-129; the
+// reference's float value is 45 k) WITHOUT evaluating atan2: the bin is the 45-degree sector (gx, gy) lies in, decided by
+// comparing |gy| with tan(22.5) |gx| and tan(67.5) |gx| and by the two sign bits (atan2's conventions for signed zeros
+// included: atan2(+0, -x) = pi -> 8, atan2(-0, -x) = -pi -> 0, atan2(+-0, +0) = 0 -> 4).  A gradient within 1e-4 (relative) of a
+// sector boundary -- where the reference's own answer hangs on atan2f's last bit -- takes the reference's formula.
+__device__ __forceinline__ int orientation_bin(float gx, float gy) {
+    const float ax = fabsf(gx), ay = fabsf(gy);
+    const float T1 = 0.41421356237309503f, T2 = 2.4142135623730951f;      // tan(22.5 deg), tan(67.5 deg)
+    const float b1 = T1 * ax, b2 = T2 * ax;
+    if (__builtin_expect(fabsf(ay - b1) <= 1e-4f * b1 || fabsf(ay - b2) <= 1e-4f * b2, 0)) {
+        if (!(ax == 0.0f && ay == 0.0f)) {
+            const float ori = atan2f(gy, gx) * (180.0f / 3.14159265358979323846f) + 180.0f;
+            return (int)rintf(ori / 45.0f);
+        }
+    }
+    const bool sx = __builtin_signbit(gx), sy = __builtin_signbit(gy);
+    if (ay <= b1) return sx ? (sy ? 0 : 8) : 4;
+    if (ay >= b2) return sy ? 2 : 6;
+    return sy ? (sx ? 1 : 3) : (sx ? 7 : 5);
+}
+
 // One workgroup = one 32x32 tile of one image.  Every stage reproduces the zero padding of the reference's
 // chain of nn.Conv2d calls: each convolution sees zeros outside the IMAGE, not outside the tile.
 __global__ __launch_bounds__(256) void canny_kernel(const float* __restrict__ img, float g0, float g1, float g2,
                                                     float g3, float g4, float* __restrict__ blurred,
                                                     float* __restrict__ grad_mag, float* __restrict__ grad_ori,
                                                     float* __restrict__ thr_mag, float* __restrict__ thin,
-                                                    float* __restrict__ thr_thin, int C, int H, int W,
+                                                    float* __restrict__ thr_thin, float* __restrict__ edge_out,
+                                                    size_t edge_batch_stride, int C, int H, int W,
                                                     float threshold, int nms) {
     __shared__ float sIn[IND][IND + 1];
     __shared__ float sH[HROWS][BLD + 1];
@@ -62,7 +84,7 @@ __global__ __launch_bounds__(256) void canny_kernel(const float* __restrict__ im
             const int y = y0 - 2 + p, x = x0 - 2 + q;
             const bool inside = y >= 0 && y < H && x >= 0 && x < W;
             sBl[p][q] = inside ? acc : 0.f;
-            if (inside && p >= 2 && p < 2 + CT && q >= 2 && q < 2 + CT)
+            if (blurred && inside && p >= 2 && p < 2 + CT && q >= 2 && q < 2 + CT)
                 blurred[((size_t)b * C + c) * plane + (size_t)y * W + x] = acc;                       // :119
         }
         __syncthreads();
@@ -94,22 +116,26 @@ __global__ __launch_bounds__(256) void canny_kernel(const float* __restrict__ im
         if (y >= H || x >= W) continue;
         const size_t o = (size_t)b * plane + (size_t)y * W + x;
         const float m = sMag[p * (MAGD + 1) + q];
-        float ori = atan2f(sGy[p][q], sGx[p][q]) * (180.0f / 3.14159265358979323846f) + 180.0f;    // :128
-        ori = rintf(ori / 45.0f) * 45.0f;                                                       // :129 (half to even)
-        grad_mag[o] = m;
-        grad_ori[o] = ori;
-        thr_mag[o] = (m < threshold) ? 0.f : m;                                                 // :132-133
-        if (!nms) continue;
-        // directional differences centre - neighbour, order 0,45,...,315 degrees (:56-102)
-        auto M = [&](int dy, int dx) { return sMag[(p + dy) * (MAGD + 1) + q + dx]; };
-        const float d[8] = {m - M(0, 1), m - M(1, 1), m - M(1, 0), m - M(1, -1),
-                            m - M(0, -1), m - M(-1, -1), m - M(-1, 0), m - M(-1, 1)};
-        const int idx = (int)fmodf(ori / 45.0f, 8.0f);                                           // :144
-        const int pos = idx & 3;                                                                // pos_i or pos_i + 4
-        const bool is_max = fminf(d[pos], d[pos + 4]) > 0.0f;                                    // :154
-        const float t = is_max ? m : 0.f;                                                       // :158-159
-        thin[o] = t;
-        thr_thin[o] = (t < threshold) ? 0.f : t;                                                // :160-161
+        const int k = orientation_bin(sGx[p][q], sGy[p][q]);                                     // :128-129
+        const float mt = (m < threshold) ? 0.f : m;                                             // :132-133
+        if (grad_mag) grad_mag[o] = m;
+        if (grad_ori) grad_ori[o] = 45.0f * (float)k;
+        if (thr_mag) thr_mag[o] = mt;
+        float e = mt;                                                                           // the edge map without NMS
+        if (nms) {
+            // directional differences centre - neighbour, order 0,45,...,315 degrees (:56-102); positive_idx = k mod 8 (:144),
+            // and the pair (pos_i, pos_i + 4) it selects is k mod 4
+            auto M = [&](int dy, int dx) { return sMag[(p + dy) * (MAGD + 1) + q + dx]; };
+            const float d[8] = {m - M(0, 1), m - M(1, 1), m - M(1, 0), m - M(1, -1),
+                                m - M(0, -1), m - M(-1, -1), m - M(-1, 0), m - M(-1, 1)};
+            const int pos = k & 3;
+            const bool is_max = fminf(d[pos], d[pos + 4]) > 0.0f;                                // :154
+            const float t = is_max ? m : 0.f;                                                   // :158-159
+            e = (t < threshold) ? 0.f : t;                                                      // :160-161
+            if (thin) thin[o] = t;
+            if (thr_thin) thr_thin[o] = e;
+        }
+        if (edge_out) edge_out[(size_t)b * edge_batch_stride + (size_t)y * W + x] = e;
     }
 }
 
@@ -139,7 +165,8 @@ __global__ __launch_bounds__(256) void proxy_rep_kernel(const float* __restrict_
     const int rows = min(PR_ROWS, H - y0);
     float* o = out + (size_t)b * (K + 1) * plane + (size_t)y0 * W + x;
     const float* e = edge + (size_t)b * plane + (size_t)y0 * W + x;
-    for (int r = 0; r < rows; ++r) o[(size_t)r * W] = e[(size_t)r * W];
+    if (edge)
+        for (int r = 0; r < rows; ++r) o[(size_t)r * W] = e[(size_t)r * W];
     for (int k = 0; k < K; ++k) {
         const float u = joints2d[((size_t)b * K + k) * 2 + 0];
         const float c = ((float)x - u) / std;
@@ -228,23 +255,39 @@ extern "C" int hps_sample_joints2d_error(const float* joints, const int32_t* coc
     return check_launch("hps_sample_joints2d_error");
 }
 
+static int launch_canny(const char* who, const float* img, const float* gauss_taps_host, int gauss_size, float* blurred, float* grad_mag,
+                        float* grad_ori, float* thr_mag, float* thin, float* thr_thin, float* edge_out, size_t edge_batch_stride,
+                        int B, int C, int H, int W, float threshold, int nms, hps_stream_t stream) {
+    if (gauss_size != G) { set_error("%s: gaussian size %d unsupported (5)", who, gauss_size); return HPS_E_UNSUPPORTED; }
+    if (B <= 0) return HPS_OK;
+    dim3 grid(ceil_div(W, CT), ceil_div(H, CT), B);
+    hipLaunchKernelGGL(canny_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gauss_taps_host[0], gauss_taps_host[1],
+                       gauss_taps_host[2], gauss_taps_host[3], gauss_taps_host[4], blurred, grad_mag, grad_ori, thr_mag,
+                       thin, thr_thin, edge_out, edge_batch_stride, C, H, W, threshold, nms);
+    return check_launch(who);
+}
+
 extern "C" int hps_canny_edges(const float* img, const float* gauss_taps_host, int gauss_size, float* blurred,
                                float* grad_mag, float* grad_ori, float* thr_mag, float* thin, float* thr_thin, int B,
                                int C, int H, int W, float threshold, int nms, hps_stream_t stream) {
     if (!img || !gauss_taps_host || !blurred || !grad_mag || !grad_ori || !thr_mag) return bad_arg("hps_canny_edges: null pointer");
     if (nms && (!thin || !thr_thin)) return bad_arg("hps_canny_edges: thin / thr_thin needed with nms");
-    if (gauss_size != G) { set_error("hps_canny_edges: gaussian size %d unsupported (5)", gauss_size); return HPS_E_UNSUPPORTED; }
-    if (B <= 0) return HPS_OK;
-    dim3 grid(ceil_div(W, CT), ceil_div(H, CT), B);
-    hipLaunchKernelGGL(canny_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gauss_taps_host[0], gauss_taps_host[1],
-                       gauss_taps_host[2], gauss_taps_host[3], gauss_taps_host[4], blurred, grad_mag, grad_ori, thr_mag,
-                       thin, thr_thin, C, H, W, threshold, nms);
-    return check_launch("hps_canny_edges");
+    return launch_canny("hps_canny_edges", img, gauss_taps_host, gauss_size, blurred, grad_mag, grad_ori, thr_mag, thin, thr_thin,
+                        nullptr, 0, B, C, H, W, threshold, nms, stream);
+}
+
+extern "C" int hps_canny_edge_map(const float* img, const float* gauss_taps_host, int gauss_size, float* edge_out,
+                                  int64_t edge_batch_stride, int B, int C, int H, int W, float threshold, int nms,
+                                  hps_stream_t stream) {
+    if (!img || !gauss_taps_host || !edge_out) return bad_arg("hps_canny_edge_map: null pointer");
+    if (edge_batch_stride < (int64_t)H * W) return bad_arg("hps_canny_edge_map: edge_batch_stride smaller than one plane");
+    return launch_canny("hps_canny_edge_map", img, gauss_taps_host, gauss_size, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        edge_out, (size_t)edge_batch_stride, B, C, H, W, threshold, nms, stream);
 }
 
 extern "C" int hps_proxy_rep(const float* edge, const float* joints2d, const float* visib, float* out, int B, int K, int H,
                              int W, float std, hps_stream_t stream) {
-    if (!edge || !joints2d || !out) return bad_arg("hps_proxy_rep: null pointer");
+    if (!joints2d || !out) return bad_arg("hps_proxy_rep: null pointer");
     if (K < 0 || K > PR_KMAX) return bad_arg("hps_proxy_rep: at most 32 joints");
     if (B <= 0 || H <= 0 || W <= 0) return HPS_OK;
     hipLaunchKernelGGL(proxy_rep_kernel, dim3(ceil_div(W, 256), ceil_div(H, PR_ROWS), B), dim3(256), 0, (hipStream_t)stream, edge,

@@ -17,22 +17,29 @@ def convert_2Djoints_to_gaussian_heatmaps_torch(joints2D, img_wh, std=4):
     return make_proxy_representation(None, joints2D, None, img_wh, std)[:, 1:]
 
 
-def make_proxy_representation(edge, joints2D, joints2D_visib, img_wh, std=4.0):
+def make_proxy_representation(edge, joints2D, joints2D_visib, img_wh, std=4.0, out=None):
     """predict/predict_poseMF_shapeGaussian_net.py:93-100 in one kernel: channel 0 = ``edge`` (B,1,D,D) (zeros if
-    None), channels 1..N = visibility-masked Gaussian heat-maps.  Returns (B, N+1, D, D) fp32."""
+    None), channels 1..N = visibility-masked Gaussian heat-maps.  Returns (B, N+1, D, D) fp32.
+
+    ``out``: an existing (B, N+1, D, D) tensor whose channel 0 already holds the edge map (CannyEdgeDetector.edge_map_into);
+    only the heat-map channels are written then (``edge`` must be None)."""
     _capi.require_device(joints2D, "joints2D")
     j = _capi.f32c(joints2D)
     B, N = j.shape[:2]
     dev = j.device
-    if edge is None:
-        edge = torch.zeros(B, 1, img_wh, img_wh, device=dev, dtype=torch.float32)
-    e = _capi.f32c(edge)
-    assert e.shape == (B, 1, img_wh, img_wh)
+    e = None
+    if out is not None:
+        assert edge is None and out.shape == (B, N + 1, img_wh, img_wh) and out.is_contiguous() and out.dtype == torch.float32
+    else:
+        if edge is None:
+            edge = torch.zeros(B, 1, img_wh, img_wh, device=dev, dtype=torch.float32)
+        e = _capi.f32c(edge)
+        assert e.shape == (B, 1, img_wh, img_wh)
+        out = torch.empty(B, N + 1, img_wh, img_wh, device=dev, dtype=torch.float32)
     vis = None if joints2D_visib is None else _capi.f32c(joints2D_visib.to(dev).float()).reshape(B, N)
-    out = torch.empty(B, N + 1, img_wh, img_wh, device=dev, dtype=torch.float32)
     P = _capi.ptr
-    _capi.call("hps_proxy_rep", P(e), P(j), P(vis) if vis is not None else None, P(out), B, N, img_wh, img_wh,
-               float(std), _capi.stream())
+    _capi.call("hps_proxy_rep", P(e) if e is not None else None, P(j), P(vis) if vis is not None else None, P(out), B, N,
+               img_wh, img_wh, float(std), _capi.stream())
     return out
 
 

@@ -79,13 +79,21 @@ def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mea
                 unc=unc)
 
 
-def proxy_representation(rgb, joints2D, joints2D_visib, edge_detect_model, pose_shape_cfg):
+def proxy_representation(rgb, joints2D, joints2D_visib, edge_detect_model, pose_shape_cfg, out=None):
     """predict/predict_poseMF_shapeGaussian_net.py:88-100: RGB crop (B,3,D,D), 2D joints (B,17,2) in crop pixels and
-    their visibility (B,17) -> the (B,18,D,D) network input.  ``edge_detect_model`` is a CannyEdgeDetector."""
+    their visibility (B,17) -> the (B,18,D,D) network input.  ``edge_detect_model`` is a CannyEdgeDetector: its edge map goes
+    straight into channel 0 (hps_canny_edge_map: the five other outputs of the detector's dict are not materialised), the
+    heat-map kernel fills channels 1..17.  Any other callable with the reference's interface works through its output dict."""
+    D = pose_shape_cfg.DATA.PROXY_REP_SIZE
+    if hasattr(edge_detect_model, "edge_map_into"):
+        B, K = joints2D.shape[:2]
+        if out is None:
+            out = torch.empty(B, K + 1, D, D, device=rgb.device, dtype=torch.float32)
+        edge_detect_model.edge_map_into(rgb, out)
+        return make_proxy_representation(None, joints2D, joints2D_visib, D, pose_shape_cfg.DATA.HEATMAP_GAUSSIAN_STD, out=out)
     edges = edge_detect_model(rgb)
     edge = edges["thresholded_thin_edges"] if pose_shape_cfg.DATA.EDGE_NMS else edges["thresholded_grad_magnitude"]
-    return make_proxy_representation(edge, joints2D, joints2D_visib, pose_shape_cfg.DATA.PROXY_REP_SIZE,
-                                     pose_shape_cfg.DATA.HEATMAP_GAUSSIAN_STD)
+    return make_proxy_representation(edge, joints2D, joints2D_visib, D, pose_shape_cfg.DATA.HEATMAP_GAUSSIAN_STD)
 
 
 class InferencePipeline:

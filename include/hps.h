@@ -401,8 +401,17 @@ int hps_canny_edges(const float* img, const float* gauss_taps_host, int gauss_si
                     float* grad_mag, float* grad_ori, float* thr_mag, float* thin, float* thr_thin,
                     int B, int C, int H, int W, float threshold, int nms, hps_stream_t stream);
 
+/* The edge map ALONE -- what predict/predict_poseMF_shapeGaussian_net.py:92-93 takes out of the detector's dict
+ * ('thresholded_thin_edges' if nms != 0, else 'thresholded_grad_magnitude'): same kernel and arithmetic as hps_canny_edges,
+ * none of the other five outputs written.  Image b's map goes to edge_out + b * edge_batch_stride (floats), so that it can be
+ * channel 0 of a (B, K+1, H, W) proxy representation directly (edge_batch_stride = (K+1) H W; hps_proxy_rep with edge = NULL
+ * then fills channels 1..K only): 4 planes of traffic per image instead of 11 + 2. */
+int hps_canny_edge_map(const float* img, const float* gauss_taps_host, int gauss_size, float* edge_out,
+                       int64_t edge_batch_stride, int B, int C, int H, int W, float threshold, int nms, hps_stream_t stream);
+
 /* predict/predict_poseMF_shapeGaussian_net.py:93-100 with utils/label_conversions.py:105-124: out (B,K+1,H,W),
- * channel 0 = edge (B,1,H,W), channel 1+k = visib[b,k] * exp(-((row - v)/std)^2/2 - ((col - u)/std)^2/2) for
+ * channel 0 = edge (B,1,H,W) -- or left as it is when edge is NULL (hps_canny_edge_map wrote it in place) --,
+ * channel 1+k = visib[b,k] * exp(-((row - v)/std)^2/2 - ((col - u)/std)^2/2) for
  * joints2d (B,K,2) = (u, v); visib (B,K) float 0/1 or NULL; K <= 32. */
 int hps_proxy_rep(const float* edge, const float* joints2d, const float* visib, float* out, int B,
                   int K, int H, int W, float std, hps_stream_t stream);
