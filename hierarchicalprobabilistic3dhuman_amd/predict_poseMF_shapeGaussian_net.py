@@ -184,8 +184,14 @@ class InferencePipeline:
             self.enc_stream = torch.cuda.Stream()
 
     @torch.no_grad()
-    def submit(self, proxy_rep_input, input_ready=None):
+    def submit(self, proxy_rep_input=None, input_ready=None, make_input=None):
         """Enqueue the encoder of one batch on the side stream.
+
+        ``make_input``: instead of a finished tensor, a callable that BUILDS the proxy representation -- it is called on the
+        encoder's stream (after ``input_ready``, in front of the wait for the previous batch's mesh kernel, so the HBM-bound
+        front-end kernels -- proxy_representation(): Canny edge map + heat-maps -- may run beside that MFMA-bound kernel) and
+        returns the (B,18,D,D) tensor.  This is the reference's order (predict/...:88-104: front end, then the net) without a
+        stream hop in between.
 
         ``input_ready`` says when ``proxy_rep_input`` is complete:
           * an event -- the encoder waits for exactly that event (the precise form: record it right behind the kernels / the
@@ -195,9 +201,12 @@ class InferencePipeline:
             would otherwise run beside (measured: 3.15 -> 3.24 ms per step at B = 64);
           * ``False`` -- no ordering: the caller guarantees the input is already complete (resident data, or its own
             synchronisation)."""
-        _capi.require_device(proxy_rep_input, "proxy_rep_input")
+        if make_input is None:
+            _capi.require_device(proxy_rep_input, "proxy_rep_input")
         main = torch.cuda.current_stream()
         if self.enc_stream is None:
+            if proxy_rep_input is None:
+                raise _capi.HpsError("InferencePipeline: call caller_stream(batch) before the first submit(make_input=...)")
             self._setup_streams(proxy_rep_input.shape[0])
         if input_ready is None:
             ready = torch.cuda.Event()
@@ -205,6 +214,10 @@ class InferencePipeline:
             self.enc_stream.wait_event(ready)
         elif input_ready is not False:
             self.enc_stream.wait_event(input_ready)
+        if make_input is not None:
+            with torch.cuda.stream(self.enc_stream):
+                proxy_rep_input = make_input()
+            _capi.require_device(proxy_rep_input, "proxy_rep_input")
         gate = None
         if self._smpl_done is None or not self._exclusive:
             pass
@@ -287,6 +300,41 @@ class InferencePipeline:
         return infer(self.net, self.smpl, None, num_samples=self.num_samples, use_mean_shape=self.use_mean_shape,
                      sample_on_cpu=self.sample_on_cpu, seed=seed, image_offset=image_offset, input_feats=feats,
                      _before_meshes=hook, _after_smpl=smpl_done, _run_net=run_net)
+
+
+class StagedUpload:
+    """Host -> device staging for a loop of batches: page-locked host tensors are copied with non_blocking=True on a copy
+    stream of their own into ``slots`` alternating sets of device buffers (allocated once), so the copy of batch k+1 runs under
+    the kernels of batch k.  ``upload(host_tensors)`` returns (device_tensors, ready_event); hand the event to
+    InferencePipeline.submit(input_ready=...) and give the batch's encoder event back through ``release`` -- a slot is
+    overwritten only after the consumer recorded on it has run.  Pageable host tensors work too (the runtime then stages them
+    itself, synchronously)."""
+
+    def __init__(self, slots=2):
+        self.stream = torch.cuda.Stream()
+        self._bufs = [None] * slots
+        self._consumed = [None] * slots
+        self._k = 0
+
+    def upload(self, host_tensors):
+        slot = self._k % len(self._bufs)
+        self._k += 1
+        if self._bufs[slot] is None or any(b.shape != h.shape or b.dtype != h.dtype for b, h in zip(self._bufs[slot], host_tensors)):
+            with torch.cuda.stream(self.stream):
+                self._bufs[slot] = [torch.empty(h.shape, dtype=h.dtype, device="cuda") for h in host_tensors]
+        if self._consumed[slot] is not None:
+            self.stream.wait_event(self._consumed[slot])
+        with torch.cuda.stream(self.stream):
+            for b, h in zip(self._bufs[slot], host_tensors):
+                b.copy_(h, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        self._last = slot
+        return list(self._bufs[slot]), ready
+
+    def release(self, consumed_event, slot=None):
+        """``consumed_event``: recorded after the last kernel that reads the most recent upload's device buffers."""
+        self._consumed[self._last if slot is None else slot] = consumed_event
 
 
 def predict_poseMF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_model, hrnet_model, hrnet_cfg,

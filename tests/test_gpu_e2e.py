@@ -168,6 +168,50 @@ def test_pipelined_steps_equal_sequential_infer(dev, net_gpu, smpl_gpu, golden_i
             assert torch.equal(w[k], g[k]), k
 
 
+def test_pipeline_from_host_rgb_equals_infer_on_the_proxy_representation(dev, net_gpu, smpl_gpu):
+    """The reference's order of work (predict/...:61-104) as the pipelined loop runs it: page-locked host RGB crops + keypoints ->
+    StagedUpload (copy stream, two device slots) -> submit(make_input=...) builds the proxy representation on the encoder's stream
+    -> finish().  Same bits as infer() on a proxy representation built up front, for every batch and slot reuse."""
+    from hierarchicalprobabilistic3dhuman_amd import configs
+    from hierarchicalprobabilistic3dhuman_amd.canny_edge_detector import CannyEdgeDetector
+    from hierarchicalprobabilistic3dhuman_amd.predict_poseMF_shapeGaussian_net import (InferencePipeline, StagedUpload,
+                                                                                        proxy_representation)
+    cfg = configs.get_cfg_defaults()
+    det = CannyEdgeDetector(cfg.DATA.EDGE_NMS, cfg.DATA.EDGE_GAUSSIAN_STD, cfg.DATA.EDGE_GAUSSIAN_SIZE, cfg.DATA.EDGE_THRESHOLD).to(dev)
+    B, N = 3, 6
+    host = []
+    for k in range(5):
+        g = torch.Generator().manual_seed(900 + k)
+        rgb = torch.nn.functional.interpolate(torch.rand(B, 3, 32, 32, generator=g), size=(256, 256), mode="bilinear", align_corners=False)
+        host.append([t.pin_memory() for t in (rgb, torch.rand(B, 17, 2, generator=g) * 256, (torch.rand(B, 17, generator=g) > 0.2).float())])
+    want = []
+    for k, (rgb, j, v) in enumerate(host):
+        proxy = proxy_representation(rgb.to(dev), j.to(dev), v.to(dev), det, cfg)
+        r = infer(net_gpu, smpl_gpu, proxy, num_samples=N, seed=60 + k)
+        want.append({key: r[key].clone() for key in ("pose_F", "R_samples", "verts_mode", "unc")})
+    pipe = InferencePipeline(net_gpu, smpl_gpu, num_samples=N)
+    pipe.caller_stream(B)
+    stager = StagedUpload(slots=2)
+
+    def step(k):
+        (rgb_d, j_d, v_d), ready = stager.upload(host[k])
+        t = pipe.submit(make_input=lambda: proxy_representation(rgb_d, j_d, v_d, det, cfg), input_ready=ready)
+        stager.release(t[1])
+        return t
+
+    got = []
+    t = step(0)
+    for k in range(len(host)):
+        nxt = step(k + 1) if k + 1 < len(host) else None
+        r = pipe.finish(t, seed=60 + k, after=nxt)
+        got.append({key: r[key].clone() for key in want[k]})
+        t = nxt
+    torch.cuda.synchronize()
+    for w, g_ in zip(want, got):
+        for key in w:
+            assert torch.equal(w[key], g_[key]), key
+
+
 def test_pipeline_on_cu_partitions_equals_sequential_infer(dev, net_gpu, smpl_gpu):
     """Small batches with a long mesh chain (BASELINE configs[4]: 16 images x 1000 samples = 16 032 meshes) run the encoder and
     the mesh kernels side by side on disjoint CU subsets (hps_stream_create_cu_partition, chosen automatically); a batch with a

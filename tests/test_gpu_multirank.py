@@ -22,7 +22,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMON = ["--steps", "2", "--warmup", "1", "--cpu-images", "0", "--lbs-unfused-reps", "0", "--latency-reps", "0"]
+COMMON = ["--steps", "2", "--warmup", "1", "--cpu-images", "0", "--lbs-unfused-reps", "0", "--latency-reps", "0", "--from-rgb-steps", "0"]
 
 
 def _free_port():
