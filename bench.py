@@ -119,6 +119,8 @@ def main():
                          "shard, its Philox offsets) -- what the multi-rank tests compare the per-rank checksums against")
     ap.add_argument("--from-rgb-steps", type=int, default=20,
                     help="after the timed region: steps of the PCIe-inclusive path from host RGB crops + keypoints for secondary.from_rgb (0 = skip)")
+    ap.add_argument("--from-rgb-variant", choices=("default", "no-copy"), default="default",
+                    help="diagnostic: 'no-copy' runs the from-RGB loop on device-resident crops (isolates the cost of the H2D copies)")
     ap.add_argument("--latency-reps", type=int, default=40,
                     help="after the timed region: batch-1, num_samples=50 calls timed one by one for secondary.latency_b1 (0 = skip)")
     ap.add_argument("--lbs-unfused-reps", type=int, default=12,
@@ -294,7 +296,12 @@ def main():
             host_sets.append([t.contiguous().pin_memory() for t in (rgb, j2d, vis)])
         stager = StagedUpload(slots=2)
 
+        resident = [[t.to(dev) for t in hs] for hs in host_sets] if args.from_rgb_variant == "no-copy" else None
+
         def rgb_step(k):
+            if resident is not None:          # diagnostic: the same loop without the H2D copies
+                rgb_d, j_d, v_d = resident[k % INPUT_SETS]
+                return pipe.submit(make_input=lambda: proxy_representation(rgb_d, j_d, v_d, canny, cfg), input_ready=False)
             (rgb_d, j_d, v_d), ready = stager.upload(host_sets[k % INPUT_SETS])
             t = pipe.submit(make_input=lambda: proxy_representation(rgb_d, j_d, v_d, canny, cfg), input_ready=ready)
             stager.release(t[1])
@@ -311,15 +318,21 @@ def main():
         rgb_steps(0, 4, torch.zeros(4, dtype=torch.float64, device=dev))
         torch.cuda.synchronize()
         barrier()
+        pipe.enc_events, smpl.lbs_events = [], []
         t_a = time.perf_counter()
         rgb_steps(4, args.from_rgb_steps, rgb_sums)
         torch.cuda.synchronize()
         barrier()
         dt_rgb = sharding.all_reduce_max(time.perf_counter() - t_a)
+        rgb_enc_ms = [e0.elapsed_time(e1) for (e0, e1) in pipe.enc_events]
+        rgb_mesh_ms = [e0.elapsed_time(e1) for (m, e0, e1) in smpl.lbs_events if m == M]
+        pipe.enc_events, smpl.lbs_events = None, None
         h2d = sum(t.numel() * t.element_size() for t in host_sets[0])
         from_rgb = {"images_per_s": B * world * args.from_rgb_steps / dt_rgb, "ms_per_step": dt_rgb / args.from_rgb_steps * 1e3,
                     "steps": args.from_rgb_steps, "h2d_bytes_per_step_per_gpu": h2d,
                     "checksum_images": float(rgb_sums[0]), "checksum_sum_unc": float(rgb_sums[1]),
+                    "encoder_avg_ms": sum(rgb_enc_ms) / max(1, len(rgb_enc_ms)),
+                    "mesh_kernel_avg_ms": sum(rgb_mesh_ms) / max(1, len(rgb_mesh_ms)),
                     "note": "PCIe-inclusive: page-locked host RGB crops + 17 keypoints + visibility -> non-blocking H2D on a copy "
                             "stream (two device slots) -> hps_canny_edge_map + hps_proxy_rep on the encoder's stream -> the same "
                             "pipelined step as the headline; %d steps after 4 warm-up steps, wall clock" % args.from_rgb_steps}

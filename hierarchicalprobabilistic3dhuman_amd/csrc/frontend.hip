@@ -8,10 +8,19 @@ namespace hps {
 
 constexpr int CT = 32;                 // output tile edge
 constexpr int G = 5, GH = G / 2;       // Gaussian taps (DATA.EDGE_GAUSSIAN_SIZE = 5)
-constexpr int MAGD = CT + 2;           // gradient magnitude is needed on a 1-pixel halo (non-max suppression)
-constexpr int BLD = MAGD + 2;          // blurred image on a further 1-pixel halo (Sobel)
-constexpr int HROWS = BLD + 2 * GH;    // rows of the horizontal pass feeding the vertical pass
-constexpr int IND = BLD + 2 * GH;      // input tile edge (40)
+// Tile frame: logical column c = 0..39 <-> image x = x0 - 4 + c, row r = 0..39 <-> y = y0 - 4 + r (x0, y0: the tile's origin).
+//   input          c, r in [0, 40)
+//   horizontal     c in [2, 38), every row          (Gaussian along x)
+//   blurred        c, r in [2, 38)                  (Gaussian along y)
+//   gradient / mag c, r in [3, 37)                  (Sobel; one pixel of halo for the non-max suppression)
+//   outputs        c, r in [4, 36)
+// Every stage works on aligned GROUPS of four columns (group g = columns 4 g .. 4 g + 3, g = 0..9): one 16-byte LDS word per
+// item, index arithmetic and border tests once per four pixels.  LDS rows are 48 floats: column c at float c + 4, so that the
+// groups g - 1 and g + 1 an item also reads exist for g = 0 and g = 9 (padding, zeroed once; values computed from it are
+// never used by a valid output).
+constexpr int TF = CT + 8;             // 40: frame edge
+constexpr int TG = TF / 4;             // 10 groups per row
+constexpr int TP = TF + 8;             // 48: LDS row pitch in floats
 
 // Orientation bin k = round((atan2(gy, gx) * 180 / pi + 180) / 45) in 0..8 (models/canny_edge_detector.py:128-129; the
 // reference's float value is 45 k) WITHOUT evaluating atan2: the bin is the 45-degree sector (gx, gy) lies in, decided by
@@ -36,6 +45,10 @@ __device__ __forceinline__ int orientation_bin(float gx, float gy) {
 
 // One workgroup = one 32x32 tile of one image.  Every stage reproduces the zero padding of the reference's
 // chain of nn.Conv2d calls: each convolution sees zeros outside the IMAGE, not outside the tile.
+// The earlier version of this kernel worked pixel by pixel (one LDS word, one index decode and one border test per value): about
+// 2 800 instructions per thread and tile, instruction-bound at 0.092 ms for 64 crops; by groups of four it is about a quarter of that.
+__device__ __forceinline__ float4 lds4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
 __global__ __launch_bounds__(256) void canny_kernel(const float* __restrict__ img, float g0, float g1, float g2,
                                                     float g3, float g4, float* __restrict__ blurred,
                                                     float* __restrict__ grad_mag, float* __restrict__ grad_ori,
@@ -43,99 +56,181 @@ __global__ __launch_bounds__(256) void canny_kernel(const float* __restrict__ im
                                                     float* __restrict__ thr_thin, float* __restrict__ edge_out,
                                                     size_t edge_batch_stride, int C, int H, int W,
                                                     float threshold, int nms) {
-    __shared__ float sIn[IND][IND + 1];
-    __shared__ float sH[HROWS][BLD + 1];
-    __shared__ float sBl[BLD][BLD + 1];
-    __shared__ float sGx[MAGD][MAGD + 1];
-    __shared__ float sGy[MAGD][MAGD + 1];
+    __shared__ __attribute__((aligned(16))) float sIn[TF * TP];      // input tile; the magnitudes after the channel loop
+    __shared__ __attribute__((aligned(16))) float sH[TF * TP];
+    __shared__ __attribute__((aligned(16))) float sBl[TF * TP];
     const float gk[G] = {g0, g1, g2, g3, g4};
     const int b = blockIdx.z, y0 = blockIdx.y * CT, x0 = blockIdx.x * CT;
     const int tid = threadIdx.x;
     const size_t plane = (size_t)H * W;
+    const bool vec = (W & 3) == 0;                                    // rows are 16-byte aligned: whole groups move as float4
 
-    for (int i = tid; i < MAGD * MAGD; i += 256) { sGx[i / MAGD][i % MAGD] = 0.f; sGy[i / MAGD][i % MAGD] = 0.f; }
+    for (int i = tid; i < TF * TP; i += 256) { sIn[i] = 0.f; sH[i] = 0.f; sBl[i] = 0.f; }
+
+    // Sobel items (r = 3 + i / 10, g = i % 10), i = tid and tid + 256 (< 340): the gradients of an item's four pixels stay in
+    // this thread's registers over the channel loop and into the last stage
+    float gx[2][4], gy[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gx[k][e] = 0.f; gy[k][e] = 0.f; }
 
     for (int c = 0; c < C; ++c) {
         const float* src = img + ((size_t)b * C + c) * plane;
         __syncthreads();
-        // input tile with halo GH + 2 (rows/cols y0 - 4 .. y0 + 35), zero outside the image
-        for (int i = tid; i < IND * IND; i += 256) {
-            const int r = i / IND, q = i % IND;
-            const int y = y0 - (GH + 2) + r, x = x0 - (GH + 2) + q;
-            sIn[r][q] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(size_t)y * W + x] : 0.f;
+        // ---- input tile, zero outside the image ----
+        for (int i = tid; i < TF * TG; i += 256) {
+            const int r = i / TG, g = i - r * TG;
+            const int y = y0 - 4 + r, x = x0 - 4 + 4 * g;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y >= 0 && y < H) {
+                const float* row = src + (size_t)y * W;
+                if (vec && x >= 0 && x + 3 < W) {
+                    v = *reinterpret_cast<const float4*>(row + x);
+                } else {
+                    if (x >= 0 && x < W) v.x = row[x];
+                    if (x + 1 >= 0 && x + 1 < W) v.y = row[x + 1];
+                    if (x + 2 >= 0 && x + 2 < W) v.z = row[x + 2];
+                    if (x + 3 >= 0 && x + 3 < W) v.w = row[x + 3];
+                }
+            }
+            *reinterpret_cast<float4*>(&sIn[r * TP + 4 * g + 4]) = v;
         }
         __syncthreads();
-        // horizontal Gaussian (:118): columns x0 - 2 .. x0 + 33
-        for (int i = tid; i < HROWS * BLD; i += 256) {
-            const int r = i / BLD, q = i % BLD;
-            float acc = 0.f;
+        // ---- horizontal Gaussian (:118); it only exists inside the image ----
+        for (int i = tid; i < TF * TG; i += 256) {
+            const int r = i / TG, g = i - r * TG;
+            const float* p = &sIn[r * TP + 4 * g];
+            const float4 a = lds4(p), m = lds4(p + 4), z = lds4(p + 8);
+            const float v[12] = {a.x, a.y, a.z, a.w, m.x, m.y, m.z, m.w, z.x, z.y, z.z, z.w};
+            const int x = x0 - 4 + 4 * g;
+            float o[4];
 #pragma unroll
-            for (int t = 0; t < G; ++t) acc += gk[t] * sIn[r][q + t];
-            const int x = x0 - 2 + q;
-            sH[r][q] = (x >= 0 && x < W) ? acc : 0.f;      // the horizontal pass only exists inside the image
-        }
-        __syncthreads();
-        // vertical Gaussian: rows y0 - 2 .. y0 + 33; zero outside the image (that is what the Sobel convs pad with)
-        for (int i = tid; i < BLD * BLD; i += 256) {
-            const int p = i / BLD, q = i % BLD;
-            float acc = 0.f;
+            for (int e = 0; e < 4; ++e) {
+                float acc = 0.f;
 #pragma unroll
-            for (int t = 0; t < G; ++t) acc += gk[t] * sH[p + t][q];
-            const int y = y0 - 2 + p, x = x0 - 2 + q;
-            const bool inside = y >= 0 && y < H && x >= 0 && x < W;
-            sBl[p][q] = inside ? acc : 0.f;
-            if (blurred && inside && p >= 2 && p < 2 + CT && q >= 2 && q < 2 + CT)
-                blurred[((size_t)b * C + c) * plane + (size_t)y * W + x] = acc;                       // :119
+                for (int t = 0; t < G; ++t) acc += gk[t] * v[2 + e + t];
+                o[e] = (x + e >= 0 && x + e < W) ? acc : 0.f;
+            }
+            *reinterpret_cast<float4*>(&sH[r * TP + 4 * g + 4]) = make_float4(o[0], o[1], o[2], o[3]);
         }
         __syncthreads();
-        // Sobel (:122-123) on rows/cols -1 .. 32 of the tile, accumulated over channels
-        for (int i = tid; i < MAGD * MAGD; i += 256) {
-            const int p = i / MAGD, q = i % MAGD;              // blurred index of the centre: (p + 1, q + 1)
-            const float a00 = sBl[p][q], a01 = sBl[p][q + 1], a02 = sBl[p][q + 2];
-            const float a10 = sBl[p + 1][q], a12 = sBl[p + 1][q + 2];
-            const float a20 = sBl[p + 2][q], a21 = sBl[p + 2][q + 1], a22 = sBl[p + 2][q + 2];
-            // cross-correlation with [[1,0,-1],[2,0,-2],[1,0,-1]] and its transpose
-            sGx[p][q] += (a00 - a02) + 2.f * (a10 - a12) + (a20 - a22);
-            sGy[p][q] += (a00 - a20) + 2.f * (a01 - a21) + (a02 - a22);
+        // ---- vertical Gaussian on rows 2..37; zero outside the image (that is what the Sobel convs pad with) ----
+        for (int i = tid; i < (TF - 4) * TG; i += 256) {
+            const int rr = i / TG, g = i - rr * TG, r = rr + 2;
+            const float* p = &sH[(r - 2) * TP + 4 * g + 4];
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < G; ++t) {
+                const float4 h = lds4(p + t * TP);
+                o[0] += gk[t] * h.x; o[1] += gk[t] * h.y; o[2] += gk[t] * h.z; o[3] += gk[t] * h.w;
+            }
+            const int y = y0 - 4 + r, x = x0 - 4 + 4 * g;
+            const bool yin = y >= 0 && y < H;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (yin && x + e >= 0 && x + e < W) ? o[e] : 0.f;
+            *reinterpret_cast<float4*>(&sBl[r * TP + 4 * g + 4]) = make_float4(o[0], o[1], o[2], o[3]);
+            if (blurred && yin && r >= 4 && r < 4 + CT && g >= 1 && g <= 8) {                                    // :119
+                float* dst = blurred + ((size_t)b * C + c) * plane + (size_t)y * W + x;
+                if (vec && x + 3 < W) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (x + e < W) dst[e] = o[e];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- Sobel (:122-123) on rows / columns 3..36, accumulated over channels in this thread's registers ----
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + 256 * k;
+            if (i >= (TF - 6) * TG) break;
+            const int rr = i / TG, g = i - rr * TG, r = rr + 3;
+            float a[3][6];                                            // rows r - 1 .. r + 1, columns 4 g - 1 .. 4 g + 4
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float* p = &sBl[(r - 1 + d) * TP + 4 * g + 4];
+                const float4 m = lds4(p);
+                a[d][0] = p[-1]; a[d][1] = m.x; a[d][2] = m.y; a[d][3] = m.z; a[d][4] = m.w; a[d][5] = p[4];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // cross-correlation with [[1,0,-1],[2,0,-2],[1,0,-1]] and its transpose
+                gx[k][e] += (a[0][e] - a[0][e + 2]) + 2.f * (a[1][e] - a[1][e + 2]) + (a[2][e] - a[2][e + 2]);
+                gy[k][e] += (a[0][e] - a[2][e]) + 2.f * (a[0][e + 1] - a[2][e + 1]) + (a[0][e + 2] - a[2][e + 2]);
+            }
         }
     }
-    __syncthreads();
-    // gradient magnitude (:126-127) on the halo region, zero outside the image (padding of the directional filters)
-    float* sMag = &sIn[0][0];                                   // reuse: [MAGD][MAGD + 1]
-    for (int i = tid; i < MAGD * MAGD; i += 256) {
-        const int p = i / MAGD, q = i % MAGD;
-        const int y = y0 - 1 + p, x = x0 - 1 + q;
-        const float gx = sGx[p][q] / (float)C, gy = sGy[p][q] / (float)C;
-        sGx[p][q] = gx; sGy[p][q] = gy;
-        sMag[p * (MAGD + 1) + q] = (y >= 0 && y < H && x >= 0 && x < W) ? sqrtf(gx * gx + gy * gy) : 0.f;
+    // ---- gradient magnitude (:126-127) on the halo region, zero outside the image (padding of the directional filters) ----
+    float* sMag = sIn;                                                // its last reader was the last horizontal pass
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + 256 * k;
+        if (i >= (TF - 6) * TG) break;
+        const int rr = i / TG, g = i - rr * TG, r = rr + 3;
+        const int y = y0 - 4 + r, x = x0 - 4 + 4 * g;
+        float m[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gx[k][e] = gx[k][e] / (float)C;
+            gy[k][e] = gy[k][e] / (float)C;
+            m[e] = (y >= 0 && y < H && x + e >= 0 && x + e < W) ? sqrtf(gx[k][e] * gx[k][e] + gy[k][e] * gy[k][e]) : 0.f;
+        }
+        *reinterpret_cast<float4*>(&sMag[r * TP + 4 * g + 4]) = make_float4(m[0], m[1], m[2], m[3]);
     }
     __syncthreads();
-    for (int i = tid; i < CT * CT; i += 256) {
-        const int p = i / CT + 1, q = i % CT + 1;
-        const int y = y0 + p - 1, x = x0 + q - 1;
-        if (y >= H || x >= W) continue;
+    // ---- orientation bins, threshold, non-max suppression: the interior items (rows 4..35, groups 1..8) ----
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + 256 * k;
+        if (i >= (TF - 6) * TG) break;
+        const int rr = i / TG, g = i - rr * TG, r = rr + 3;
+        const int y = y0 - 4 + r, x = x0 - 4 + 4 * g;
+        if (r < 4 || r >= 4 + CT || g < 1 || g > 8 || y >= H || x >= W) continue;
+        float nb[3][6];                                               // magnitudes, rows r - 1 .. r + 1, columns 4 g - 1 .. 4 g + 4
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float* p = &sMag[(r - 1 + d) * TP + 4 * g + 4];
+            const float4 m = lds4(p);
+            nb[d][0] = p[-1]; nb[d][1] = m.x; nb[d][2] = m.y; nb[d][3] = m.z; nb[d][4] = m.w; nb[d][5] = p[4];
+        }
+        float o_mag[4], o_ori[4], o_thr[4], o_thin[4], o_edge[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float m = nb[1][e + 1];
+            const int kbin = orientation_bin(gx[k][e], gy[k][e]);                               // :128-129
+            const float mt = (m < threshold) ? 0.f : m;                                         // :132-133
+            o_mag[e] = m; o_ori[e] = 45.0f * (float)kbin; o_thr[e] = mt; o_thin[e] = 0.f; o_edge[e] = mt;
+            if (nms) {
+                // directional differences centre - neighbour, order 0,45,...,315 degrees (:56-102); positive_idx = k mod 8 (:144),
+                // and the pair (pos_i, pos_i + 4) it selects is k mod 4: E/W, SE/NW, S/N, SW/NE
+                const int pos = kbin & 3;
+                const float na = pos == 0 ? nb[1][e + 2] : pos == 1 ? nb[2][e + 2] : pos == 2 ? nb[2][e + 1] : nb[2][e];
+                const float nc = pos == 0 ? nb[1][e] : pos == 1 ? nb[0][e] : pos == 2 ? nb[0][e + 1] : nb[0][e + 2];
+                const bool is_max = fminf(m - na, m - nc) > 0.0f;                                // :154
+                const float t = is_max ? m : 0.f;                                               // :158-159
+                o_thin[e] = t;
+                o_edge[e] = (t < threshold) ? 0.f : t;                                          // :160-161
+            }
+        }
         const size_t o = (size_t)b * plane + (size_t)y * W + x;
-        const float m = sMag[p * (MAGD + 1) + q];
-        const int k = orientation_bin(sGx[p][q], sGy[p][q]);                                     // :128-129
-        const float mt = (m < threshold) ? 0.f : m;                                             // :132-133
-        if (grad_mag) grad_mag[o] = m;
-        if (grad_ori) grad_ori[o] = 45.0f * (float)k;
-        if (thr_mag) thr_mag[o] = mt;
-        float e = mt;                                                                           // the edge map without NMS
-        if (nms) {
-            // directional differences centre - neighbour, order 0,45,...,315 degrees (:56-102); positive_idx = k mod 8 (:144),
-            // and the pair (pos_i, pos_i + 4) it selects is k mod 4
-            auto M = [&](int dy, int dx) { return sMag[(p + dy) * (MAGD + 1) + q + dx]; };
-            const float d[8] = {m - M(0, 1), m - M(1, 1), m - M(1, 0), m - M(1, -1),
-                                m - M(0, -1), m - M(-1, -1), m - M(-1, 0), m - M(-1, 1)};
-            const int pos = k & 3;
-            const bool is_max = fminf(d[pos], d[pos + 4]) > 0.0f;                                // :154
-            const float t = is_max ? m : 0.f;                                                   // :158-159
-            e = (t < threshold) ? 0.f : t;                                                      // :160-161
-            if (thin) thin[o] = t;
-            if (thr_thin) thr_thin[o] = e;
-        }
-        if (edge_out) edge_out[(size_t)b * edge_batch_stride + (size_t)y * W + x] = e;
+        auto put = [&](float* base, size_t off, const float (&v)[4]) {
+            if (!base) return;
+            if (vec && x + 3 < W) {
+                *reinterpret_cast<float4*>(base + off) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (x + e < W) base[off + e] = v[e];
+            }
+        };
+        put(grad_mag, o, o_mag);
+        put(grad_ori, o, o_ori);
+        put(thr_mag, o, o_thr);
+        if (nms) { put(thin, o, o_thin); put(thr_thin, o, o_edge); }
+        put(edge_out, (size_t)b * edge_batch_stride + (size_t)y * W + x, o_edge);
     }
 }
 

@@ -312,6 +312,8 @@ class StagedUpload:
 
     def __init__(self, slots=2):
         self.stream = torch.cuda.Stream()
+        self.stream2 = torch.cuda.Stream()      # upload_rows alternates its per-item copies over two streams (two DMA queues:
+                                                # the set-up gap of one copy, ~20 us per 4.7 MB item, runs under the other's transfer)
         self._bufs = [None] * slots
         self._consumed = [None] * slots
         self._k = 0
@@ -331,6 +333,31 @@ class StagedUpload:
             ready.record(self.stream)
         self._last = slot
         return list(self._bufs[slot]), ready
+
+    def upload_rows(self, host_items):
+        """Like upload() for ONE batched tensor given as its items: ``host_items`` = list of (1, ...) host tensors (what a
+        per-image loader returns); item i is copied straight into row i of the slot's (len, ...) device buffer -- no host-side
+        concatenation (a 4.7 MB proxy representation per image is a memcpy worth avoiding).  Returns (batch, ready_event)."""
+        slot = self._k % len(self._bufs)
+        self._k += 1
+        shape = (len(host_items),) + tuple(host_items[0].shape[1:])
+        buf = self._bufs[slot]
+        if buf is None or buf[0].shape != shape:
+            with torch.cuda.stream(self.stream):
+                buf = self._bufs[slot] = [torch.empty(shape, dtype=torch.float32, device="cuda")]
+        if self._consumed[slot] is not None:
+            self.stream.wait_event(self._consumed[slot])
+            self.stream2.wait_event(self._consumed[slot])
+        self.stream2.wait_stream(self.stream)            # the buffer's allocation (first use) is ordered on the first stream
+        for j, st in enumerate((self.stream, self.stream2)):
+            with torch.cuda.stream(st):
+                for i in range(j, len(host_items), 2):
+                    buf[0][i:i + 1].copy_(host_items[i], non_blocking=True)
+        self.stream.wait_stream(self.stream2)
+        ready = torch.cuda.Event()
+        ready.record(self.stream)
+        self._last = slot
+        return buf[0], ready
 
     def release(self, consumed_event, slot=None):
         """``consumed_event``: recorded after the last kernel that reads the most recent upload's device buffers."""
@@ -360,19 +387,48 @@ def predict_poseMF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mode
         proxy_rep_fn = _reference_front_end(pose_shape_cfg, hrnet_model, hrnet_cfg, edge_detect_model,
                                             object_detect_model, joints2Dvisib_threshold, device)
     os.makedirs(save_dir, exist_ok=True)
-    for i0 in range(0, len(image_fnames), batch_size):
-        names = image_fnames[i0:i0 + batch_size]
-        proxy = torch.cat([proxy_rep_fn(os.path.join(image_dir, n)).to(device).float() for n in names], dim=0)
-        res = infer(pose_shape_model, smpl_model, proxy, num_samples=num_samples, use_mean_shape=True)
+    # The loop is software-pipelined (InferencePipeline): while batch k's head, sampling and meshes run, batch k+1's proxy
+    # representations are already staged (page-locked host tensors go up by non-blocking copies on a copy stream, StagedUpload)
+    # and its encoder is enqueued.  Same results as infer() per batch.
+    groups = [image_fnames[i0:i0 + batch_size] for i0 in range(0, len(image_fnames), batch_size)]
+    if not groups:
+        return
+    # the pipeline (its streams, the encoder's frame buffers bound to them, the upload slots) is kept on the model between calls
+    key = (id(smpl_model), num_samples, batch_size, torch.cuda.current_device())
+    cached = getattr(pose_shape_model, "_hps_predict_pipeline", None)
+    if cached is None or cached[0] != key:
+        cached = (key, InferencePipeline(pose_shape_model, smpl_model, num_samples=num_samples, use_mean_shape=True), StagedUpload(slots=2))
+        pose_shape_model._hps_predict_pipeline = cached
+    _, pipe, stager = cached
+
+    def stage(names):
+        items = [proxy_rep_fn(os.path.join(image_dir, n)) for n in names]
+        if all(t.is_cuda for t in items):                # built on the device (the reference front end): ordered by submit()'s default event
+            return pipe.submit(torch.cat([t.float() for t in items], dim=0) if len(items) > 1 else items[0].float())
+        proxy, ready = stager.upload_rows([t.float() for t in items])
+        ticket = pipe.submit(proxy, input_ready=ready)
+        stager.release(ticket[1])
+        return ticket
+
+    with torch.cuda.stream(pipe.caller_stream(batch_size)):
+        ticket = stage(groups[0])
+        for gi, names in enumerate(groups):
+            nxt = stage(groups[gi + 1]) if gi + 1 < len(groups) else None
+            res = pipe.finish(ticket, after=nxt)
+            ticket = nxt
+            if result_fn is None or gi % 64 == 63:
+                check_sampling()                         # synchronises; with a result_fn the check is deferred (below) so the loop stays pipelined
+            cols = {key: val.unbind(0) for key, val in res.items()}      # per-image views, made once per key (not 17 x B index calls)
+            for k, n in enumerate(names):
+                item = {key: col[k] for key, col in cols.items()}
+                if result_fn is not None:
+                    result_fn(n, item)
+                else:
+                    keep = ("verts_mode", "joints_mode", "verts_tpose", "unc", "cam", "glob_rotmats")
+                    torch.save({key: item[key].cpu() for key in keep},
+                               os.path.join(save_dir, os.path.splitext(n)[0] + ".pt"))
         check_sampling()
-        for k, n in enumerate(names):
-            item = {key: val[k] for key, val in res.items()}
-            if result_fn is not None:
-                result_fn(n, item)
-            else:
-                keep = ("verts_mode", "joints_mode", "verts_tpose", "unc", "cam", "glob_rotmats")
-                torch.save({key: item[key].cpu() for key in keep},
-                           os.path.join(save_dir, os.path.splitext(n)[0] + ".pt"))
+    torch.cuda.current_stream().wait_stream(pipe.caller_stream(batch_size))
 
 
 def load_rgb_image(path):
@@ -401,9 +457,32 @@ def _reference_front_end(pose_shape_cfg, hrnet_model, hrnet_cfg, edge_detect_mod
         object_detect_model.eval()
     D = pose_shape_cfg.DATA.PROXY_REP_SIZE
 
+    staging = {"bufs": [None, None], "events": [None, None], "k": 0}
+
+    def upload_u8(chw):
+        """(3,H,W) uint8 host array -> device, through one of two reused page-locked buffers with a non-blocking copy: a quarter
+        of the bytes of the reference's float upload (:65 converts on the host first), and the host does not wait for it."""
+        import numpy as np
+        k = staging["k"] % 2
+        staging["k"] += 1
+        n = chw.size
+        if staging["bufs"][k] is None or staging["bufs"][k].numel() < n:
+            staging["bufs"][k] = torch.empty(n, dtype=torch.uint8).pin_memory()
+        if staging["events"][k] is not None:
+            staging["events"][k].synchronize()            # the copy that last used this buffer (two images ago) has finished
+        staging["bufs"][k][:n].copy_(torch.from_numpy(np.ascontiguousarray(chw)).reshape(-1))
+        d = staging["bufs"][k][:n].to(device, non_blocking=True)
+        staging["events"][k] = torch.cuda.Event()
+        staging["events"][k].record()
+        return d.view(chw.shape)
+
     @torch.no_grad()
     def front_end(image_path):
-        image = torch.from_numpy(load_rgb_image(image_path).transpose(2, 0, 1).copy()).float().to(device) / 255.0       # :63-65
+        rgb_u8 = load_rgb_image(image_path).transpose(2, 0, 1)
+        if torch.device(device).type == "cuda":
+            image = upload_u8(rgb_u8).float() / 255.0                                                               # :63-65
+        else:
+            image = torch.from_numpy(rgb_u8.copy()).float().to(device) / 255.0
         hr = predict_hrnet(hrnet_model=hrnet_model, hrnet_config=hrnet_cfg, object_detect_model=object_detect_model,
                            image=image, object_detect_threshold=pose_shape_cfg.DATA.BBOX_THRESHOLD,
                            bbox_scale_factor=pose_shape_cfg.DATA.BBOX_SCALE_FACTOR)                                 # :67-72

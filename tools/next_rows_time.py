@@ -48,6 +48,14 @@ def main():
     canny = CannyEdgeDetector(non_max_suppression=True, gaussian_filter_std=1.0, gaussian_filter_size=5, threshold=0.0).to(dev)
     # reads the image once; writes blurred (3 planes) + magnitude, orientation, thresholded magnitude, thin, thresholded thin
     report("hps_canny_edges (64 x 3 x 256 x 256, NMS)", timed(lambda: canny(img)), B * H * H * 4.0 * (3 + 3 + 5))
+    # the predict front end's form: the edge map alone, written into channel 0 of the proxy representation (3 planes in, 1 out),
+    # then the 17 heat-map channels in place
+    proxy = torch.empty(B, 18, H, H, device=dev)
+    report("hps_canny_edge_map (64 x 3 x 256 x 256 -> ch 0)", timed(lambda: canny.edge_map_into(img, proxy)), B * H * H * 4.0 * (3 + 1))
+    j2 = (torch.rand(B, 17, 2, generator=g) * H).to(dev)
+    v2 = (torch.rand(B, 17, generator=g) > 0.2).to(dev)
+    report("hps_proxy_rep in place (64 x 17 x 256 x 256)", timed(lambda: label_conversions.make_proxy_representation(None, j2, v2, H, 4.0, out=proxy)),
+           B * H * H * 4.0 * 17)
     edge = torch.rand(B, 1, H, H, generator=g).to(dev)
     j2d = (torch.rand(B, 17, 2, generator=g) * H).to(dev)
     vis = (torch.rand(B, 17, generator=g) > 0.2).to(dev)

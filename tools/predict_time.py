@@ -2,7 +2,7 @@
 image-dependent front end replaced by stored proxy representations (proxy_rep_fn) and a no-op result_fn: the loop the host layer adds
 around infer().
 
-    python tools/predict_time.py [images] [batch] [samples]
+    python tools/predict_time.py [images] [batch] [samples] [--pageable]
 """
 import os
 import sys
@@ -21,16 +21,20 @@ from hierarchicalprobabilistic3dhuman_amd.smpl_official import SMPL  # noqa: E40
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-    samples = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n = int(pos[0]) if len(pos) > 0 else 128
+    batch = int(pos[1]) if len(pos) > 1 else 16
+    samples = int(pos[2]) if len(pos) > 2 else 50
     dev = torch.device("cuda:0")
     cfg = configs.get_cfg_defaults()
     torch.manual_seed(0)
     net = PoseMFShapeGaussianNet(configs.SMPL_PARENTS, cfg).eval().to(dev)
     smpl = SMPL(smpl_data.synthetic_smpl_model(0)).to(dev)
     g = torch.Generator().manual_seed(1)
+    pinned = "--pageable" not in sys.argv
     proxies = [torch.rand(1, 18, 256, 256, generator=g) for _ in range(8)]
+    if pinned:                               # stored proxy representations in page-locked memory: the H2D copies are asynchronous
+        proxies = [t.pin_memory() for t in proxies]
     with tempfile.TemporaryDirectory() as d:
         for i in range(n):
             open(os.path.join(d, "img_%04d.png" % i), "wb").close()          # names only: proxy_rep_fn supplies the content
@@ -43,7 +47,7 @@ def main():
         predict_poseMF_shapeGaussian_net(net, cfg, smpl, None, None, None, dev, d, os.path.join(d, "out"), **kw)
         torch.cuda.synchronize()
         dt = time.time() - t0
-    print("predict loop: %d images, batch %d, %d samples: %.3f s = %.0f images/s (%.2f ms per image)" % (n, batch, samples, dt, n / dt, 1e3 * dt / n))
+    print("predict loop (%s host tensors): %d images, batch %d, %d samples: %.3f s = %.0f images/s (%.2f ms per image)" % ("page-locked" if pinned else "pageable", n, batch, samples, dt, n / dt, 1e3 * dt / n))
 
 
 if __name__ == "__main__":
