@@ -58,6 +58,7 @@ class _ConvBN:
         if kh == 7 and kw == 7 and self.stride == 2 and self.pad == 3 and cin == 18 and cout == 64:
             self.stem_u = _stem_winograd_filters(w).to(w.device).contiguous()
         self.use_winograd = True
+        self.latency = False      # ResNet.set_latency_mode: direct kernels with many K slices (see _auto_ksplit)
         self.kernel = "v3"        # "v3" direct global->LDS (default), "v2" register-staged, "v1" generic (any Cin % 4 == 0)
         self.variant = 0          # tile choice of the v2 / v3 kernels (0 = automatic)
         self.ksplit = 0           # split-K slices of the v3 kernel (0 = automatic, 1 = off)
@@ -69,6 +70,17 @@ class _ConvBN:
         pixel must not change with B, otherwise per-image results (and, through accept decisions that sit on rounding
         ties, whole sample streams) would depend on how images are batched or sharded over GPUs."""
         chunks = self.kh * self.kw * self.cin_p // 32
+        if self.latency:
+            # latency mode (ResNet.set_latency_mode): a single image leaves the 3x3 layers of layer2-4 with 4-16 output tiles, each a
+            # serial walk over 36-144 K chunks; 12-18 slices of 3-8 chunks put 50-300 workgroups on the chip instead (batch 1,
+            # tools/latency_sweep.py: layer2 27 -> 18 us, layer3 50 -> 20, layer4 97 -> 27 including the slice-sum pass).  Still a
+            # rule on the layer alone.
+            if self.kh * self.kw == 1 or pixels_per_image > 1024 or chunks < 36:
+                return 1
+            for ks in (18, 12, 9, 8, 6, 4, 3, 2):
+                if chunks % ks == 0 and chunks // ks >= 3:
+                    return ks
+            return 1
         if self.variant == 0 and self.cout % 128 == 0 and self.kh * self.kw > 1 and pixels_per_image <= 64 \
                 and chunks % 4 == 0 and chunks // 4 >= 18:
             return 4
@@ -287,6 +299,21 @@ class ResNet(nn.Module):
         for c in [prep["stem"]] + [c for blk in prep["blocks"] for c in blk if c is not None]:
             c.use_winograd = bool(on)
 
+    def set_latency_mode(self, on=True):
+        """Per-model switch for latency-bound deployments (the reference's own operating point is ONE image per call,
+        predict/predict_poseMF_shapeGaussian_net.py:58-104).  The default kernels are built for throughput: a Winograd work item is
+        a serial walk of one workgroup over all input channels, and a single image has 4-64 of them for 256 CUs.  In latency mode
+        every layer runs the direct implicit-GEMM kernel (the stem in row mode) and the 3x3 layers of layer2-4 split K over
+        12-18 workgroups per output tile (+ the slice-sum pass): encoder 0.80 -> 0.42 ms at batch 1; at batch 64 it is ~1.5x
+        SLOWER than the default.  Like set_winograd it is a property of the model, never of the batch: per-image results do not
+        depend on the batch size within a mode; between the modes they differ in the last bits (another summation order, same
+        1e-4 feature tolerance against the reference -- tests/test_gpu_net.py)."""
+        prep = self._prepared or self.prepare()
+        for c in [prep["stem"]] + [c for blk in prep["blocks"] for c in blk if c is not None]:
+            c.latency = bool(on)
+            c.use_winograd = not on
+        self._frames = _FrameCache()          # cached launch lists belong to the other mode
+
     def invalidate(self):
         """Drop the folded BatchNorm / filter copies and the cached launch lists; the next forward rebuilds them from the
         current parameters.  Called automatically by .to() and by any load_state_dict that reaches this module (also through
@@ -376,7 +403,7 @@ class ResNet(nn.Module):
     @staticmethod
     def _variant_state(prep):
         convs = [prep["stem"]] + [c for blk in prep["blocks"] for c in blk if c is not None]
-        return tuple((c.variant, c.ksplit, c.use_winograd) for c in convs)
+        return tuple((c.variant, c.ksplit, c.use_winograd, c.latency) for c in convs)
 
     def _padded_ok(self, C, H, W):
         # row-mode stem (csrc/conv_pad.hip): 16-byte aligned window starts and rows

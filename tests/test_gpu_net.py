@@ -526,3 +526,24 @@ def test_winograd_and_direct_encoders_agree_and_are_batch_invariant(dev, net_gpu
     # per-image features do not depend on the batch they were computed in (bit for bit)
     big = torch.cat([x, torch.rand(5, 18, 256, 256, generator=torch.Generator().manual_seed(9)).to(dev)])
     assert torch.equal(enc(big)[:2], wino) and torch.equal(enc(x[1:2]), wino[1:2])
+
+
+def test_latency_mode_encoder_matches_reference_and_is_batch_invariant(dev, net_gpu, golden, golden_input):
+    """ResNet.set_latency_mode: every layer on the direct kernel, the 3x3 layers of layer2-4 with 12-18 K slices (a rule on
+    the layer, not on the batch).  Same 1e-4 tolerance against the reference's features; bit-identical per image for every
+    batch size within the mode; the default mode's features come back bit for bit when it is switched off."""
+    enc = net_gpu.image_encoder
+    x = golden_input.to(dev)
+    ref = golden["net_feats"]
+    scale_ref = float(ref.abs().max())
+    default = enc(x).clone()
+    try:
+        enc.set_latency_mode(True)
+        lat = enc(x).clone()
+        one = enc(x[1:2]).clone()
+        big = enc(torch.cat([x, torch.rand(3, 18, 256, 256, generator=torch.Generator().manual_seed(9)).to(dev)])).clone()
+    finally:
+        enc.set_latency_mode(False)
+    assert maxerr(lat, ref) <= 1e-4 * scale_ref and maxerr(lat, default) <= 2e-5 * scale_ref
+    assert torch.equal(one, lat[1:2]) and torch.equal(big[:2], lat)
+    assert torch.equal(enc(x), default)
