@@ -42,6 +42,7 @@ _PROTOTYPES = {
     "hps_rot6d_to_rotmat": [_P, _P, _I, _P],
     "hps_batch_rodrigues": [_P, _P, _I, _P],
     "hps_linear": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "hps_head_trunk": [_P] + [_I] + [_P] * 14 + [_I] * 7 + [_P],
     "hps_head_joint_level": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _I, _I, _P],
     "hps_head_joint_level_svd": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _P, _I, _I, _I, _P],
     "hps_svd3_packed": [_P, _P, _I, _I, _P],

@@ -50,10 +50,20 @@ __device__ __forceinline__ void dot_slice(const float* __restrict__ w, size_t ld
     }
 }
 
-// out[b, n] = act(x[b, :] . wt[:, n] + bias[n] + addend[n]);  256 threads = LKS K-slices x LCOLS columns
-__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ wt,
+// Where the fused fc_shape | fc_glob | fc_cam layer (:98-107) delivers its 2 nsh + ng + nc outputs besides the fc_embed input
+// buffer: the Gaussian's mean and exp(log std) (:100-101), glob (+ init_glob), cam (+ init_cam) -- each contiguous.
+struct TrunkSplit {
+    float* loc; float* scale; float* glob; float* cam;
+    int nsh, ng, nc;
+};
+
+// out[b, n] = act(x[b, :] . wt[:, n] + bias[n] + addend[n]);  256 threads = LKS K-slices x LCOLS columns.
+// x2: optional second source -- input column k >= K1 comes from x2[b, k - K1] (fc_embed's input cat[feats, shape, glob, cam], :108,
+// without materialising the concatenation); split.loc != nullptr: the outputs are also scattered as TrunkSplit says.
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ x2, int ldx2, int K1,
+                                                     const float* __restrict__ wt,
                                                      const float* __restrict__ bias, const float* __restrict__ addend,
-                                                     float* __restrict__ out, int ldo, int B, int K, int N, int act) {
+                                                     float* __restrict__ out, int ldo, int B, int K, int N, int act, TrunkSplit split) {
     // The head is a short latency chain that shares SIMDs with MFMA-bound kernels of other streams in the pipelined loop:
     // its few instructions go first in the SIMD's issue arbitration (they cost the neighbours next to nothing).
     __builtin_amdgcn_s_setprio(3);
@@ -66,7 +76,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 
     for (int i = threadIdx.x; i < K * TB; i += 256) {
         const int r = i / K, k = i % K;                      // coalesced along k
-        xs[k * TB + r] = (b0 + r < B) ? x[(size_t)(b0 + r) * ldx + k] : 0.0f;
+        xs[k * TB + r] = (b0 + r < B) ? (k < K1 ? x[(size_t)(b0 + r) * ldx + k] : x2[(size_t)(b0 + r) * ldx2 + (k - K1)]) : 0.0f;
     }
     __syncthreads();
 
@@ -90,6 +100,14 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
             if (act == HPS_ACT_ELU) v = elu1(v);
             else if (act == HPS_ACT_RELU) v = fmaxf(v, 0.0f);
             out[(size_t)(b0 + r) * ldo + nn] = v;
+            if (split.loc) {
+                const size_t b = (size_t)(b0 + r);
+                const int h = split.nsh;                         // shape_params = [mean (nsh) | log std (nsh)]  (:99-100)
+                if (nn < h) split.loc[b * h + nn] = v;
+                else if (nn < 2 * h) split.scale[b * h + (nn - h)] = expf(v);                      // Normal(loc, exp(log_std)) :101
+                else if (nn < 2 * h + split.ng) split.glob[b * split.ng + (nn - 2 * h)] = v;
+                else split.cam[b * split.nc + (nn - 2 * h - split.ng)] = v;
+            }
         }
     }
 }
@@ -288,16 +306,47 @@ __global__ void svd3_packed_kernel(const float* __restrict__ f, float* __restric
 
 using namespace hps;
 
+static int launch_linear(const char* who, const float* x, int ldx, const float* x2, int ldx2, int K1, const float* wt, const float* bias,
+                         const float* addend, float* out, int ldo, int B, int K, int N, int act, TrunkSplit split, hps_stream_t stream) {
+    size_t lds = ((size_t)((K * TB + 3) & ~3) + LKS * TB * LCOLS) * sizeof(float);
+    if (lds > 64 * 1024) { set_error("%s: K=%d too large for the LDS tile", who, K); return HPS_E_UNSUPPORTED; }
+    hipLaunchKernelGGL(linear_kernel, dim3(ceil_div(N, LCOLS), ceil_div(B, TB)), dim3(256), lds, (hipStream_t)stream, x,
+                       ldx, x2, ldx2, K1, wt, bias, addend, out, ldo, B, K, N, act, split);
+    return check_launch(who);
+}
+
 extern "C" int hps_linear(const float* x, int ldx, const float* wt, const float* bias, const float* addend, float* out,
                           int ldo, int B, int K, int N, int act, hps_stream_t stream) {
     if (!x || !wt || !bias || !out) return bad_arg("hps_linear: null pointer");
     if (K <= 0 || N <= 0 || ldx < K || ldo < N) return bad_arg("hps_linear: dims");
     if (B <= 0) return HPS_OK;
-    size_t lds = ((size_t)((K * TB + 3) & ~3) + LKS * TB * LCOLS) * sizeof(float);
-    if (lds > 64 * 1024) { set_error("hps_linear: K=%d too large for the LDS tile", K); return HPS_E_UNSUPPORTED; }
-    hipLaunchKernelGGL(linear_kernel, dim3(ceil_div(N, LCOLS), ceil_div(B, TB)), dim3(256), lds, (hipStream_t)stream, x,
-                       ldx, wt, bias, addend, out, ldo, B, K, N, act);
-    return check_launch("hps_linear");
+    return launch_linear("hps_linear", x, ldx, nullptr, 0, K, wt, bias, addend, out, ldo, B, K, N, act, TrunkSplit{}, stream);
+}
+
+extern "C" int hps_head_trunk(const float* feats, int ldf, const float* fc1_wt, const float* fc1_b, const float* sgc_wt,
+                              const float* sgc_b, const float* sgc_add, const float* embed_wt, const float* embed_b, float* x_ws,
+                              float* sgc_out, float* embed, float* shape_loc, float* shape_scale, float* glob, float* cam, int B,
+                              int num_feats, int hidden, int num_shape, int num_glob, int num_cam, int embed_dim,
+                              hps_stream_t stream) {
+    if (!feats || !fc1_wt || !fc1_b || !sgc_wt || !sgc_b || !embed_wt || !embed_b || !x_ws || !sgc_out || !embed || !shape_loc ||
+        !shape_scale || !glob || !cam)
+        return bad_arg("hps_head_trunk: null pointer");
+    if (num_feats <= 0 || hidden <= 0 || num_shape <= 0 || num_glob <= 0 || num_cam <= 0 || embed_dim <= 0 || ldf < num_feats)
+        return bad_arg("hps_head_trunk: dims");
+    if (B <= 0) return HPS_OK;
+    const int nt = 2 * num_shape + num_glob + num_cam;
+    // x = ELU(fc1(feats))                                                                              (:95-96)
+    int rc = launch_linear("hps_head_trunk", feats, ldf, nullptr, 0, num_feats, fc1_wt, fc1_b, nullptr, x_ws, hidden, B, num_feats,
+                           hidden, HPS_ACT_ELU, TrunkSplit{}, stream);
+    if (rc != HPS_OK) return rc;
+    // [shape_params | glob + init_glob | cam + init_cam] = fc_shape | fc_glob | fc_cam (x)             (:98-107)
+    TrunkSplit sp{shape_loc, shape_scale, glob, cam, num_shape, num_glob, num_cam};
+    rc = launch_linear("hps_head_trunk", x_ws, hidden, nullptr, 0, hidden, sgc_wt, sgc_b, sgc_add, sgc_out, nt, B, hidden, nt,
+                       HPS_ACT_NONE, sp, stream);
+    if (rc != HPS_OK) return rc;
+    // embed = ELU(fc_embed(cat[feats, shape_params, glob, cam]))                                       (:108-110)
+    return launch_linear("hps_head_trunk", feats, ldf, sgc_out, nt, num_feats, embed_wt, embed_b, nullptr, embed, embed_dim, B,
+                         num_feats + nt, embed_dim, HPS_ACT_ELU, TrunkSplit{}, stream);
 }
 
 static int joint_level_launch(const float* embed, int embed_dim, int hidden, const int32_t* joint_ids, int n_level,

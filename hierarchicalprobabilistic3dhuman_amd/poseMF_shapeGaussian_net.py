@@ -189,26 +189,21 @@ class PoseMFShapeGaussianNet(nn.Module):
         P, s = _capi.ptr, _capi.stream()
         f32 = dict(device=dev, dtype=torch.float32)
 
-        # trunk (:95-110).  cat_buf = [feats | shape_params | glob | cam] is fc_embed's input.
+        # trunk (:95-110): three launches (hps_head_trunk); the Gaussian's mean / exp(log std), glob and cam come out contiguous --
+        # no concatenation buffer, no torch.exp, no clones on the head's stream
         nf = feats.shape[1]
-        ld = nf + nsh + ng + nc
-        cat_buf = torch.empty(B, ld, **f32)
-        cat_buf[:, :nf] = feats
-        x = torch.empty(B, p["fc1_wt"].shape[1], **f32)
-        _capi.call("hps_linear", P(feats), nf, P(p["fc1_wt"]), P(p["fc1_b"]), None, P(x), x.shape[1], B, nf,
-                   x.shape[1], 1, s)
-        sgc_view = cat_buf[:, nf:]                         # written in place with row stride ld
-        _capi.call("hps_linear", P(x), x.shape[1], P(p["sgc_wt"]), P(p["sgc_b"]), P(p["sgc_add"]),
-                   _capi._P(sgc_view.data_ptr()), ld, B, x.shape[1], nsh + ng + nc, 0, s)
+        hidden = p["fc1_wt"].shape[1]
+        x = torch.empty(B, hidden, **f32)
+        sgc = torch.empty(B, nsh + ng + nc, **f32)
         embed = torch.empty(B, embed_dim, **f32)
-        _capi.call("hps_linear", P(cat_buf), ld, P(p["embed_wt"]), P(p["embed_b"]), None, P(embed), embed_dim, B,
-                   ld, embed_dim, 1, s)
-        shape_params = cat_buf[:, nf:nf + nsh]
-        shape_mean = shape_params[:, :self.num_shape_params]
-        shape_log_std = shape_params[:, self.num_shape_params:]
-        shape_dist = Normal(loc=shape_mean, scale=torch.exp(shape_log_std), validate_args=False)
-        glob = cat_buf[:, nf + nsh:nf + nsh + ng].clone()
-        cam = cat_buf[:, nf + nsh + ng:].clone()
+        shape_mean = torch.empty(B, self.num_shape_params, **f32)
+        shape_scale = torch.empty(B, self.num_shape_params, **f32)
+        glob = torch.empty(B, ng, **f32)
+        cam = torch.empty(B, nc, **f32)
+        _capi.call("hps_head_trunk", P(feats), nf, P(p["fc1_wt"]), P(p["fc1_b"]), P(p["sgc_wt"]), P(p["sgc_b"]), P(p["sgc_add"]),
+                   P(p["embed_wt"]), P(p["embed_b"]), P(x), P(sgc), P(embed), P(shape_mean), P(shape_scale), P(glob), P(cam), B, nf,
+                   hidden, self.num_shape_params, ng, nc, embed_dim, s)
+        shape_dist = Normal(loc=shape_mean, scale=shape_scale, validate_args=False)
 
         # hierarchical pose prediction (:121-160), one kinematic level at a time
         # every joint is in exactly one level and ancestors come from earlier levels: all entries are written before

@@ -219,6 +219,19 @@ int hps_batch_rodrigues(const float* aa, float* rotmat, int n, hps_stream_t stre
 int hps_linear(const float* x, int ldx, const float* wt, const float* bias, const float* addend,
                float* out, int ldo, int B, int K, int N, int act, hps_stream_t stream);
 
+/* The FC trunk (models/poseMF_shapeGaussian_net.py:95-110) as three launches and nothing else:
+ *   x      = ELU(fc1(feats))                                        x_ws (B, hidden), scratch
+ *   sgc    = [fc_shape | fc_glob | fc_cam](x) + sgc_add             sgc_out (B, 2 num_shape + num_glob + num_cam): shape_params,
+ *            glob + init_glob, cam + init_cam -- the tail of fc_embed's input; the same launch also writes
+ *            shape_loc = mean, shape_scale = exp(log std) (the Normal of :100-101), glob, cam, each contiguous
+ *   embed  = ELU(fc_embed(cat[feats, sgc]))                         the concatenation (:108) is never materialised
+ * Weights pre-transposed (K, N) like hps_linear; sgc_wt / sgc_b / sgc_add = the three layers stacked (sgc_add: zeros, init_glob,
+ * init_cam).  feats rows have stride ldf. */
+int hps_head_trunk(const float* feats, int ldf, const float* fc1_wt, const float* fc1_b, const float* sgc_wt,
+                   const float* sgc_b, const float* sgc_add, const float* embed_wt, const float* embed_b, float* x_ws,
+                   float* sgc_out, float* embed, float* shape_loc, float* shape_scale, float* glob, float* cam, int B,
+                   int num_feats, int hidden, int num_shape, int num_glob, int num_cam, int embed_dim, hps_stream_t stream);
+
 /* One kinematic level of the joint loop (:121-135): for every joint g in the level
  *   in  = cat[embed(b), U_proper[b, anc].flat, S_proper[b, anc].flat, mode[b, anc].flat]
  *   F   = W2 . ELU(W1 . in + b1) + b2 + delta_i_weight * I
