@@ -69,6 +69,7 @@ _PROTOTYPES = {
     "hps_head_pose_levels": [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _P, _P, _P,
                              _P, _P, _I, _I, _I, _I, _P],
     "hps_nchw_to_padded_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "hps_nchw_to_padded_nhwc_generic": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "hps_maxpool3x3s2_pad": [_P, _P, _I, _I, _I, _I, _I, _P],
     "hps_global_avgpool_pad": [_P, _P, _I, _I, _I, _I, _I, _P],
 }
@@ -107,7 +108,7 @@ class EncOp(_c.Structure):
                                                        "relu", "row_mode", "variant", "ksplit")]
 
 
-ENC_RELAYOUT, ENC_CONV, ENC_MAXPOOL, ENC_AVGPOOL, ENC_CONV_WINOGRAD, ENC_STEM_SPLIT, ENC_STEM_WINOGRAD = 0, 1, 2, 3, 4, 5, 6
+ENC_RELAYOUT, ENC_CONV, ENC_MAXPOOL, ENC_AVGPOOL, ENC_CONV_WINOGRAD, ENC_STEM_SPLIT, ENC_STEM_WINOGRAD, ENC_RELAYOUT_GENERIC = 0, 1, 2, 3, 4, 5, 6, 7
 SVD_HOST, SVD_DEVICE, SVD_DEVICE_FMA = 0, 1, 2
 SVD_ROUNDING_REFERENCE, SVD_ROUNDING_FMA = 0, 1
 

@@ -24,6 +24,9 @@ extern "C" int hps_encoder_run(const hps_enc_op* ops, int n_ops, hps_stream_t st
             case HPS_ENC_RELAYOUT:
                 rc = hps_nchw_to_padded_nhwc(o.x, o.y, o.B, o.Cin, o.H, o.W, o.opad, stream);
                 break;
+            case HPS_ENC_RELAYOUT_GENERIC:
+                rc = hps_nchw_to_padded_nhwc_generic(o.x, o.y, o.B, o.Cin, o.Cout, o.H, o.W, o.KW, o.opad, stream);
+                break;
             case HPS_ENC_CONV:
                 rc = hps_conv2d_bn_act_pad(o.x, o.w, o.scale, o.shift, o.residual, o.y, o.B, o.H, o.W, o.ipad, o.Cin, o.Cout,
                                            o.KH, o.KW, o.stride, o.pad, o.opad, o.relu, o.row_mode, o.variant, o.ksplit,

@@ -385,6 +385,22 @@ __global__ __launch_bounds__(256) void nchw_to_padded_nhwc_kernel(const float* _
     for (int i = t; i < n * C / 2; i += 256) dst[i] = s2[i];
 }
 
+// Any channel count and width (the reference's ResNet takes any in_channels and image size, models/resnet.py:127-176): thread per
+// (pixel, channel), channel c < C of pixel (h, w) goes to the interior of a (B, H + 2P, WF + 2P, CP) frame whose other entries
+// (channels C..CP-1, columns W..WF-1, the halo) the owner zeroed once.  Not a hot path: the released model's shapes take the
+// kernels above / the phase split.
+__global__ __launch_bounds__(256) void nchw_to_padded_nhwc_generic_kernel(const float* __restrict__ x, float* __restrict__ y, int C,
+                                                                          int CP, int H, int W, int WF, int P, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int w = (int)(i % W);
+    long r = i / W;
+    const int h = (int)(r % H); r /= H;
+    const int c = (int)(r % C);
+    const long b = r / C;
+    y[((b * (H + 2 * P) + h + P) * (long)(WF + 2 * P) + w + P) * CP + c] = x[i];
+}
+
 // MaxPool2d(3, 2, 1) on NHWC, thread per (output pixel, 4 channels); output written into a frame with halo opad
 __global__ __launch_bounds__(256) void maxpool_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
                                                           int C, int Ho, int Wo, int opad, long total) {
@@ -540,6 +556,18 @@ extern "C" int hps_nchw_to_padded_nhwc(const float* x, float* y, int B, int C, i
     else if (C == 64) hipLaunchKernelGGL(nchw_to_padded_nhwc_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, s, x, y, H, W, P, runs);
     else return bad_arg("hps_nchw_to_padded_nhwc: C must be 4, 18 or 64");
     return check_launch("hps_nchw_to_padded_nhwc");
+}
+
+extern "C" int hps_nchw_to_padded_nhwc_generic(const float* x, float* y, int B, int C, int CP, int H, int W, int WF, int P,
+                                               hps_stream_t stream) {
+    if (!x || !y) return bad_arg("hps_nchw_to_padded_nhwc_generic: null pointer");
+    if (C <= 0 || CP < C || WF < W || P < 0) return bad_arg("hps_nchw_to_padded_nhwc_generic: need CP >= C > 0, WF >= W, P >= 0");
+    if (B <= 0 || H <= 0 || W <= 0) return HPS_OK;
+    const long total = (long)B * C * H * W;
+    if ((total + 255) / 256 > 0x7fffffffL) return bad_arg("hps_nchw_to_padded_nhwc_generic: tensor too large");
+    hipLaunchKernelGGL(nchw_to_padded_nhwc_generic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       C, CP, H, W, WF, P, total);
+    return check_launch("hps_nchw_to_padded_nhwc_generic");
 }
 
 extern "C" int hps_maxpool3x3s2_pad(const float* x, float* y, int B, int H, int W, int C, int opad, hps_stream_t stream) {

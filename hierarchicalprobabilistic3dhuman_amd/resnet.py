@@ -37,13 +37,24 @@ class _ConvBN:
         self.wn = wk.reshape(k_real, cout).t().contiguous() if cin_p % 32 == 0 else None
         # row-mode filter (Cout, KH * ceil32(KW*Cin)) for the halo-padded kernel when Cin % 32 != 0 (the stem): one
         # filter row of a window is KW*Cin contiguous NHWC floats, treated as one tap; the tail of each row is zero
+        # Channels per pixel of a row-mode frame (row_c >= cin, the extra channels are zero = part of the zero padding): the
+        # kernel's LDS-DMA windows start at multiples of stride * row_c floats and a window is ceil32(kw * row_c) floats long, so
+        # row_c must be even (16-byte window starts on frames of even width) and the window's zero-weight tail must fit into
+        # the one pixel of slack an even frame width leaves behind the last window.  18 (the proxy representation) qualifies as
+        # it is; any other count rounds up to a multiple of 4, which always does.
         self.cin = cin
         self.wrow = None
+        self.row_c = cin
         if cin % 32 != 0:
-            ck = (kw * cin + 31) // 32 * 32
-            wr = torch.zeros(cout, kh, ck, device=w.device, dtype=torch.float32)
-            wr[:, :, :kw * cin] = w.permute(0, 2, 3, 1).reshape(cout, kh, kw * cin)
-            self.wrow = wr.reshape(cout, kh * ck).contiguous()
+            fits = lambda c: c % 2 == 0 and (kw * c + 31) // 32 * 32 - kw * c <= c
+            rc = cin if fits(cin) else (cin + 3) // 4 * 4
+            self.row_c = rc
+            ck = (kw * rc + 31) // 32 * 32
+            wr = torch.zeros(cout, kh, kw, rc, device=w.device, dtype=torch.float32)
+            wr[:, :, :, :cin] = w.permute(0, 2, 3, 1)
+            wrow = torch.zeros(cout, kh, ck, device=w.device, dtype=torch.float32)
+            wrow[:, :, :kw * rc] = wr.reshape(cout, kh, kw * rc)
+            self.wrow = wrow.reshape(cout, kh * ck).contiguous()
         # Winograd F(2x2, 3x3) form of a stride-1 3x3 layer (csrc/conv_wino.hip): U = G g G^T in the kernel's layout
         #   [cin / 8][cout / 64][position 4a + b][(cin % 8) / 4][cout % 64][cin % 4]
         self.wino_u = None
@@ -121,7 +132,7 @@ class _ConvBN:
                        P(ws) if need else None, _capi.stream())
             return out
         row_mode = self.wn is None
-        assert C == (self.cin if row_mode else self.cin_p)
+        assert C == (self.row_c if row_mode else self.cin_p)
         Ho = (H + 2 * self.pad - self.kh) // self.stride + 1
         Wo = (W + 2 * self.pad - self.kw) // self.stride + 1
         assert tuple(out.shape) == (B, Ho + 2 * opad, Wo + 2 * opad, self.cout)
@@ -149,7 +160,7 @@ class _ConvBN:
                                Cin=C, Cout=self.cout, KH=3, KW=3, stride=1, pad=1, opad=opad, relu=1 if relu else 0, ksplit=1)
         row_mode = self.wn is None
         Ho, Wo = self.out_hw(H, W)
-        assert tuple(out.shape) == (B, Ho + 2 * opad, Wo + 2 * opad, self.cout) and C == (self.cin if row_mode else self.cin_p)
+        assert tuple(out.shape) == (B, Ho + 2 * opad, Wo + 2 * opad, self.cout) and C == (self.row_c if row_mode else self.cin_p)
         ksplit = 1 if row_mode else (self.ksplit if self.ksplit > 0 else self._auto_ksplit(Ho * Wo))
         assert ksplit == 1 or ws is not None
         return _capi.EncOp(kind=_capi.ENC_CONV, x=dp(xp), w=dp(self.wrow if row_mode else self.wn), scale=dp(self.scale),
@@ -352,11 +363,16 @@ class ResNet(nn.Module):
         if len(self._frames) >= 6:                       # a handful of batch shapes / streams at most
             self._frames.pop(next(iter(self._frames)))
         z = lambda *shape: torch.zeros(*shape, device=device, dtype=torch.float32)
+        # input frame of the direct stem: channels as the stem's filters expect them (row mode: row_c; Cin % 32 == 0: cin_p), an even
+        # number of columns; zero channels / a zero column are part of the convolution's zero padding
+        cf = stem.row_c if stem.wn is None else stem.cin_p
+        wf = W + (W & 1)
+        generic = cf != C or wf != W or C not in (4, 18, 64)
         if stem_wino:      # four phase frames per image (hps_stem_phase_split), out-of-image pixels zeroed here once
             fs = {"in": z(int(_capi.load(dev=_capi._use_dev).hps_stem_phase_frames_bytes(B, H, W)) // 4)}
         else:
-            fs = {"in": z(B, H + 6, W + 6, C)}
-        fs["stem_wino"] = stem_wino
+            fs = {"in": z(B, H + 6, wf + 6, cf)}
+        fs["stem_wino"], fs["generic_in"] = stem_wino, (C, cf, W, wf) if generic else None
         h, w = stem.out_hw(H, W)
         fs["stem"] = torch.empty(B, h, w, stem.cout, device=device, dtype=torch.float32)
         h, w = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
@@ -380,8 +396,9 @@ class ResNet(nn.Module):
                                  shift=stem.shift.data_ptr(), y=fs["stem"].data_ptr(), B=B, H=H, W=W, Cin=C, Cout=stem.cout, KH=7, KW=7,
                                  stride=2, pad=3, opad=0, relu=1)]
         else:
-            first = [_capi.EncOp(kind=_capi.ENC_RELAYOUT, x=None, y=fs["in"].data_ptr(), B=B, Cin=C, H=H, W=W, opad=3),
-                     stem.enc_op(fs["in"], 3, fs["stem"], 0, relu=True)]
+            relayout = (_capi.EncOp(kind=_capi.ENC_RELAYOUT_GENERIC, x=None, y=fs["in"].data_ptr(), B=B, Cin=C, Cout=cf, H=H, W=W, KW=wf, opad=3)
+                        if generic else _capi.EncOp(kind=_capi.ENC_RELAYOUT, x=None, y=fs["in"].data_ptr(), B=B, Cin=C, H=H, W=W, opad=3))
+            first = [relayout, stem.enc_op(fs["in"], 3, fs["stem"], 0, relu=True)]
         ops = first + [
                _capi.EncOp(kind=_capi.ENC_MAXPOOL, x=fs["stem"].data_ptr(), y=fs["pool"].data_ptr(), B=B, H=fs["stem"].shape[1],
                            W=fs["stem"].shape[2], Cin=stem.cout, opad=1)]
@@ -406,8 +423,9 @@ class ResNet(nn.Module):
         return tuple((c.variant, c.ksplit, c.use_winograd, c.latency) for c in convs)
 
     def _padded_ok(self, C, H, W):
-        # row-mode stem (csrc/conv_pad.hip): 16-byte aligned window starts and rows
-        return self.layout == "padded" and (2 * C) % 4 == 0 and ((W + 6) * C) % 4 == 0 and C in (4, 18, 64)
+        # every (C, H, W) runs on the product kernels: shapes the stem's fast paths do not take get a channel-padded, even-width
+        # input frame (hps_nchw_to_padded_nhwc_generic) in front of the row-mode / direct stem
+        return self.layout == "padded"
 
     def _forward_padded(self, prep, x, gate=None):
         """``gate``: optional callable invoked after the input relayout has been enqueued and before the first convolution
@@ -440,7 +458,11 @@ class ResNet(nn.Module):
             y = fs["stem"]
             _capi.call("hps_stem_winograd", P(fs["in"]), P(stem.stem_u), P(stem.scale), P(stem.shift), P(y), B, H, W, 0, 1, s)
         else:
-            _capi.call("hps_nchw_to_padded_nhwc", P(x), P(fs["in"]), B, C, H, W, 3, s)
+            if fs["generic_in"] is not None:
+                _, cf, _, wf = fs["generic_in"]
+                _capi.call("hps_nchw_to_padded_nhwc_generic", P(x), P(fs["in"]), B, C, cf, H, W, wf, 3, s)
+            else:
+                _capi.call("hps_nchw_to_padded_nhwc", P(x), P(fs["in"]), B, C, H, W, 3, s)
             if gate is not None:
                 gate()
             y = stem.padded(fs["in"], 3, fs["stem"], 0, relu=True)         # conv1 + bn1 + relu
@@ -465,13 +487,6 @@ class ResNet(nn.Module):
         B, C, H, W = x.shape
         if self._padded_ok(C, H, W):
             return self._forward_padded(prep, x, gate=_gate)
-        if self.layout != "plain":
-            raise _capi.HpsError("encoder input (C=%d, H=%d, W=%d) is not supported by the product kernels: libhps.so covers the "
-                                 "released model's input family (in_channels 4, 18 or 64; W a multiple of 4 so that rows are "
-                                 "16-byte aligned) -- the reference's resnet accepts any shape.  For other shapes set "
-                                 "`encoder.layout = 'plain'`, which runs the earlier generic convolution kernels of "
-                                 "libhps_dev.so (build it with hierarchicalprobabilistic3dhuman_amd.build.build(dev=True); "
-                                 "correct, about 2x slower, not part of the product library)" % (C, H, W))
         with _capi.dev_library():          # earlier kernel generation: cross-check only, lives in libhps_dev.so
             return self._forward_plain(prep, x)
 

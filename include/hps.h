@@ -351,7 +351,8 @@ int hps_stem_winograd(const float* frames, const float* u, const float* scale, c
  * Cout, opad, relu, splitk_ws), HPS_ENC_STEM_SPLIT = hps_stem_phase_split (x, y = frames, B, Cin = C, H, W),
  * HPS_ENC_STEM_WINOGRAD = hps_stem_winograd (x = frames, w = u, scale, shift, y, B, H, W, opad, relu). */
 enum { HPS_ENC_RELAYOUT = 0, HPS_ENC_CONV = 1, HPS_ENC_MAXPOOL = 2, HPS_ENC_AVGPOOL = 3, HPS_ENC_CONV_WINOGRAD = 4,
-       HPS_ENC_STEM_SPLIT = 5, HPS_ENC_STEM_WINOGRAD = 6 };
+       HPS_ENC_STEM_SPLIT = 5, HPS_ENC_STEM_WINOGRAD = 6,
+       HPS_ENC_RELAYOUT_GENERIC = 7 /* hps_nchw_to_padded_nhwc_generic (x, y, B, Cin = C, Cout = CP, H, W, KW = WF, opad = P) */ };
 typedef struct hps_enc_op {
     int kind;
     const float* x;
@@ -394,6 +395,14 @@ int hps_head_pose_levels(const float* embed, int embed_dim, int hidden, const in
 /* (B,C,H,W) -> interior of the (B, H + 2P, W + 2P, C) NHWC frame; C in {4, 18, 64}
  * (predict/predict_poseMF_shapeGaussian_net.py:103 hands the net an NCHW proxy representation). */
 int hps_nchw_to_padded_nhwc(const float* x, float* y, int B, int C, int H, int W, int P, hps_stream_t stream);
+
+/* The same for ANY channel count and width (models/resnet.py:127-176 accepts any in_channels / image size): channel c < C of
+ * pixel (h, w) -> interior of a (B, H + 2P, WF + 2P, CP) frame, CP >= C, WF >= W; channels C..CP-1, columns W..WF-1 and the
+ * halo are left as the owner zeroed them.  The encoder uses CP = C rounded up to 4 and WF = W rounded up to even, which gives
+ * the row-mode stem of hps_conv2d_bn_act_pad its 16-byte aligned windows for every shape (zero channels / a zero column are
+ * exactly the convolution's zero padding). */
+int hps_nchw_to_padded_nhwc_generic(const float* x, float* y, int B, int C, int CP, int H, int W, int WF, int P,
+                                    hps_stream_t stream);
 
 /* nn.MaxPool2d(3, 2, 1) (models/resnet.py:152, :207): x (B,H,W,C) plain NHWC -> interior of the
  * (B, Ho + 2 opad, Wo + 2 opad, C) frame. */

@@ -547,3 +547,32 @@ def test_latency_mode_encoder_matches_reference_and_is_batch_invariant(dev, net_
     assert maxerr(lat, ref) <= 1e-4 * scale_ref and maxerr(lat, default) <= 2e-5 * scale_ref
     assert torch.equal(one, lat[1:2]) and torch.equal(big[:2], lat)
     assert torch.equal(enc(x), default)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 65, 47), (1, 3, 224, 224), (3, 5, 40, 72), (2, 32, 64, 66), (2, 18, 130, 67)])
+def test_encoder_takes_any_channel_count_and_image_size(shape, dev):
+    """models/resnet.py:127-176: ResNet(in_channels=k) on any image size.  The product library runs them all: a channel-padded,
+    even-width input frame (hps_nchw_to_padded_nhwc_generic) in front of the row-mode / direct stem, direct kernels on maps that
+    do not split into Winograd blocks.  Against torch's convolutions (the oracle's resnet18_forward), 1e-4 relative; results do
+    not depend on the batch; the composite launch list and the per-layer calls agree bit for bit."""
+    from hierarchicalprobabilistic3dhuman_amd.resnet import resnet18
+    B, C, H, W = shape
+    torch.manual_seed(100 + C)
+    enc = resnet18(in_channels=C).eval()
+    for m in enc.modules():                                   # non-trivial BatchNorm statistics
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0.0, 0.1)
+            m.running_var.uniform_(0.6, 1.4)
+            m.weight.data.uniform_(0.7, 1.3)
+            m.bias.data.normal_(0.0, 0.1)
+    sd = {"image_encoder." + k: v.clone() for k, v in enc.state_dict().items()}
+    x = torch.rand(B, C, H, W, generator=torch.Generator().manual_seed(sum(shape)))
+    with torch.no_grad():
+        want = O.resnet18_forward(sd, x)
+    enc = enc.to(dev)
+    got = enc(x.to(dev))
+    assert got.shape == (B, 512)
+    assert maxerr(got, want) <= 1e-4 * float(want.abs().max())
+    assert torch.equal(enc(x[:1].to(dev)), got[:1])
+    enc.composite = False
+    assert torch.equal(enc(x.to(dev)), got)
