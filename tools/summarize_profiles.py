@@ -134,3 +134,9 @@ if os.path.exists(stats_p):
     open(os.path.join(dst, tag + "_kernel_roofline.md"), "w").write("\n".join(md) + "\n")
     print("\n".join(md))
     print("kernel time per profiled run: %.2f ms" % (tot / 1e6))
+
+# ---- round-4 additions: the driver-flag bench line, batch-1 latency (+ kernel timeline), widened rows, predict loop, mesh-kernel SQ / LDS counters
+for a, b in (("bench_driver_flags.json", "_bench_driver_flags.json"), ("latency_b1.txt", "_latency_b1.txt"),
+             ("latency_b1_timeline.txt", "_latency_b1_timeline.txt"), ("next_rows.txt", "_next_rows.txt"),
+             ("predict_time.txt", "_predict_time.txt"), ("mesh_pmc_lds.txt", "_mesh_pmc_lds.txt")):
+    copy(a, tag + b)
