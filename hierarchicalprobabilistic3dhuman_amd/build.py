@@ -24,7 +24,9 @@ DEV_ONLY_SOURCES = ["conv.hip"]
 # per-file flags.  mesh_fused.hip: hipcc's SLP vectoriser turns the skinning epilogue into v_pk_fma_f32 plus one v_mov
 # per packed operand (525 moves, 2 051 instructions); unpacked it is 1 963 instructions with 109 moves, and packed fp32
 # VALU next to MFMAs is slower on gfx950 (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
-FILE_FLAGS = {"mesh_fused.hip": ["-fno-slp-vectorize"]}
+# frontend.hip: the row-marching Canny kernel holds its windows in ~250 registers; SLP-packed pairs add alignment moves and push it
+# into AGPR spills (310 registers, 6 126 VALU instructions per six steps against 260 / 5 864 unpacked).
+FILE_FLAGS = {"mesh_fused.hip": ["-fno-slp-vectorize"], "frontend.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
 
@@ -120,7 +122,7 @@ def build_tools(force=False, verbose=True):
         if not force and os.path.exists(exe) and os.path.getmtime(exe) >= os.path.getmtime(src):
             built.append(exe)
             continue
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-result", src, "-o", exe]
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-result", "-I", INCLUDE, "-I", CSRC, src, "-o", exe]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -2,6 +2,8 @@
 // (models/canny_edge_detector.py:104-166) and 2D-joint Gaussian heat-maps
 // (utils/label_conversions.py:105-124), i.e. what turns an RGB crop + 17 keypoints into the 18-channel network
 // input (predict/predict_poseMF_shapeGaussian_net.py:88-100).  Pure stencil / element-wise work: HBM bound.
+#include <type_traits>
+
 #include "hps_common.h"
 
 namespace hps {
@@ -234,6 +236,223 @@ __global__ __launch_bounds__(256) void canny_kernel(const float* __restrict__ im
     }
 }
 
+// ---- The same detector, marching down the rows: the product form for 1 and 3 channels ---------------------------------------
+// The tile kernel above spends its time on instruction issue (about 2 200 instructions per thread and tile: index arithmetic,
+// border tests and one LDS access per value in every stage, 56 % halo overhead in the early stages, five barriers per channel:
+// 0.090 ms for 64 crops, a quarter of the HBM roofline).  Here one WAVE owns a strip of rows of up to 256 columns -- four
+// adjacent pixels per lane -- and walks down it; every stage's vertical neighbourhood lives in the lane's own registers (a ring
+// of the last five horizontally filtered rows, the last three blurred rows, the last three magnitude rows), the horizontal
+// neighbours come from the adjacent lanes by DPP wavefront shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1; the lane without a
+// neighbour receives 0, which is exactly the zero padding of the reference's convolutions).  No LDS, no barriers, no index
+// decoding; the arithmetic of every pixel is the tile kernel's, in the same order.
+//   step with input row y:  h(y) -> blurred(y - 2) -> gradient, magnitude(y - 3) -> outputs(y - 4)
+// Images wider than 256 are cut into column blocks of 248 valid columns with four columns of overlap on each side.
+__device__ __forceinline__ float dpp_from_left(float v) {      // lane i <- lane i - 1; lane 0 <- 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_right(float v) {     // lane i <- lane i + 1; lane 63 <- 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+// grad / num_channels (:125), correctly rounded (div3_rn: hps_common.h).  One channel: nothing to do.
+template <int C>
+__device__ __forceinline__ float div_by_channels(float v) {
+    if (C == 1) return v;
+    if (C == 3) return div3_rn(v);
+    return v / (float)C;
+}
+
+struct CannyOut {
+    float* blurred; float* grad_mag; float* grad_ori; float* thr_mag; float* thin; float* thr_thin; float* edge;
+    size_t edge_batch_stride;
+};
+
+template <int C, bool FULL, bool VEC>
+__global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict__ img, float g0, float g1, float g2, float g3,
+                                                         float g4, CannyOut out, int H, int W, float threshold, int nms,
+                                                         int rows_per_strip, int strips, int col_blocks, int n_items) {
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_items) return;                                   // whole waves only: every lane of a wave stays active below
+    const int lane = threadIdx.x & 63;
+    const int s = item % strips, cb = (item / strips) % col_blocks, b = item / (strips * col_blocks);
+    const float gk[G] = {g0, g1, g2, g3, g4};
+    const size_t plane = (size_t)H * W;
+    // columns: this lane's four pixels x .. x + 3; outputs are stored for columns [out_lo, out_hi).  VEC: W % 4 == 0 -- rows are
+    // 16-byte aligned and a lane's four pixels are all inside or all outside the image.
+    const int x0 = col_blocks == 1 ? 0 : cb * 248 - 4;
+    const int out_lo = col_blocks == 1 ? 0 : cb * 248, out_hi = col_blocks == 1 ? W : min(W, cb * 248 + 248);
+    const int x = x0 + 4 * lane;
+    bool cin[4], cst[4];                                           // column inside the image / column stored by this lane
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { cin[e] = x + e >= 0 && x + e < W; cst[e] = x + e >= out_lo && x + e < out_hi; }
+    const bool all_in = cin[0] && cin[3], all_st = cst[0] && cst[3];
+    const int Y0 = s * rows_per_strip, Y1 = min(H, Y0 + rows_per_strip);
+    const int steps = (Y1 - Y0) + 8;
+
+    // Branch-free loads (a clamped address is always read, pixels outside the image are then replaced by zero): with a branch per
+    // load hipcc lost track of the loads in flight and waited for all of them (s_waitcnt vmcnt(0)) in front of every use.
+    int xc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xc[e] = cin[e] ? x + e : 0;
+    auto load_row = [&](int c, int y) __attribute__((always_inline)) -> float4 {
+        const bool yin = y >= 0 && y < H;
+        const float* row = img + ((size_t)b * C + c) * plane + (size_t)min(max(y, 0), H - 1) * W;
+        float4 v;
+        if (VEC) {
+            v = *reinterpret_cast<const float4*>(row + (all_in ? x : 0));
+            const bool keep = yin && all_in;
+            v.x = keep ? v.x : 0.f; v.y = keep ? v.y : 0.f; v.z = keep ? v.z : 0.f; v.w = keep ? v.w : 0.f;
+        } else {
+            v.x = row[xc[0]]; v.y = row[xc[1]]; v.z = row[xc[2]]; v.w = row[xc[3]];
+            v.x = (yin && cin[0]) ? v.x : 0.f; v.y = (yin && cin[1]) ? v.y : 0.f;
+            v.z = (yin && cin[2]) ? v.z : 0.f; v.w = (yin && cin[3]) ? v.w : 0.f;
+        }
+        return v;
+    };
+    auto store4 = [&](float* base, size_t off, const float (&v)[4]) __attribute__((always_inline)) {
+        if (!base) return;
+        if (VEC) {
+            if (all_st) *reinterpret_cast<float4*>(base + off) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (cst[e]) base[off + e] = v[e];
+        }
+    };
+
+    // Every vertical window is a ring indexed by the step number modulo its length; the step loop is unrolled six times (a multiple
+    // of every ring length, the five-row Gaussian ring carrying one spare slot), so that every ring index is a compile-time
+    // constant and no window is ever shifted through register moves.
+    float hw[C][6][4];             // horizontally filtered rows: row y_in lands in slot t % 6
+    float ar[C][3][6];             // blurred rows, columns x - 1 .. x + 4: row y_bl lands in slot t % 3
+    float mr[3][6];                // magnitude rows, columns x - 1 .. x + 4: row y_g lands in slot t % 3
+    float gr[2][2][4];             // gradient (x, y) of row y_g in slot t % 2
+    float4 inr[C][3];              // input rows: row y_in sits in slot t % 3, row y_in + 2 is loaded into slot (t + 2) % 3
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hw[c][k][e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < 6; ++e) ar[c][k][e] = 0.f;
+        inr[c][0] = load_row(c, Y0 - 4);
+        inr[c][1] = load_row(c, Y0 - 3);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 6; ++e) mr[k][e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gr[k][0][e] = 0.f; gr[k][1][e] = 0.f; }
+
+    auto step = [&](auto ph, int t) __attribute__((always_inline)) {
+        constexpr int PH = decltype(ph)::value;                    // t % 6
+        constexpr int S3 = PH % 3, S2 = PH % 2;
+        const int y_in = Y0 - 4 + t, y_bl = y_in - 2, y_g = y_in - 3, y_o = y_in - 4;
+        const bool bl_in = y_bl >= 0 && y_bl < H, g_in = y_g >= 0 && y_g < H;
+        float gx[4] = {0.f, 0.f, 0.f, 0.f}, gy[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float4 cur = inr[c][S3];
+            inr[c][(S3 + 2) % 3] = load_row(c, y_in + 2);
+            // ---- horizontal Gaussian (:118) of row y_in: columns x - 2 .. x + 5 ----
+            const float v[8] = {dpp_from_left(cur.z), dpp_from_left(cur.w), cur.x, cur.y, cur.z, cur.w,
+                                dpp_from_right(cur.x), dpp_from_right(cur.y)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < G; ++k) acc += gk[k] * v[e + k];
+                hw[c][PH][e] = cin[e] ? acc : 0.f;                 // the horizontal pass only exists inside the image
+            }
+            // ---- vertical Gaussian: blurred row y_bl from the rows y_in - 4 .. y_in of the ring ----
+            float bl[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < G; ++k) acc += gk[k] * hw[c][(PH + 2 + k) % 6][e];
+                bl[e] = bl_in ? acc : 0.f;                         // zero outside the image: what the Sobel convolutions pad with
+            }
+            if (FULL && bl_in && y_bl >= Y0 && y_bl < Y1)                                                         // :119
+                store4(out.blurred, ((size_t)b * C + c) * plane + (size_t)y_bl * W + x, bl);
+            // ---- Sobel (:122-123) of row y_g from the blurred rows y_g - 1 (a0), y_g (a1), y_g + 1 (a2, new) ----
+            float (&a2)[6] = ar[c][S3];
+            const float (&a1)[6] = ar[c][(S3 + 2) % 3];
+            const float (&a0)[6] = ar[c][(S3 + 1) % 3];
+            a2[0] = dpp_from_left(bl[3]); a2[1] = bl[0]; a2[2] = bl[1]; a2[3] = bl[2]; a2[4] = bl[3]; a2[5] = dpp_from_right(bl[0]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                gx[e] += (a0[e] - a0[e + 2]) + 2.f * (a1[e] - a1[e + 2]) + (a2[e] - a2[e + 2]);
+                gy[e] += (a0[e] - a2[e]) + 2.f * (a0[e + 1] - a2[e + 1]) + (a0[e + 2] - a2[e + 2]);
+            }
+        }
+        // ---- gradient magnitude (:126-127) of row y_g, zero outside the image ----
+        float (&m2)[6] = mr[S3];
+        const float (&m1)[6] = mr[(S3 + 2) % 3];
+        const float (&m0)[6] = mr[(S3 + 1) % 3];
+        float mg[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gx[e] = div_by_channels<C>(gx[e]);
+            gy[e] = div_by_channels<C>(gy[e]);
+            gr[S2][0][e] = gx[e];
+            gr[S2][1][e] = gy[e];
+            mg[e] = (g_in && cin[e]) ? sqrtf(gx[e] * gx[e] + gy[e] * gy[e]) : 0.f;
+        }
+        m2[0] = dpp_from_left(mg[3]); m2[1] = mg[0]; m2[2] = mg[1]; m2[3] = mg[2]; m2[4] = mg[3]; m2[5] = dpp_from_right(mg[0]);
+        // ---- outputs of row y_o = y_g - 1: magnitudes m0 / m1 / m2 = rows y_o - 1, y_o, y_o + 1, gradient of the previous step ----
+        if (y_o >= Y0 && y_o < Y1) {
+            const float (&gxp)[4] = gr[(S2 + 1) % 2][0];
+            const float (&gyp)[4] = gr[(S2 + 1) % 2][1];
+            float o_mag[4], o_ori[4], o_thr[4], o_thin[4], o_edge[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float m = m1[e + 1];
+                const int kbin = orientation_bin(gxp[e], gyp[e]);                               // :128-129
+                const float mt = (m < threshold) ? 0.f : m;                                     // :132-133
+                o_mag[e] = m; o_ori[e] = 45.0f * (float)kbin; o_thr[e] = mt; o_thin[e] = 0.f; o_edge[e] = mt;
+                if (nms) {
+                    // the four direction pairs E/W, SE/NW, S/N, SW/NE (:56-102), all evaluated; positive_idx mod 4 (:144) picks one.
+                    // (Selecting the two NEIGHBOURS by pos instead made hipcc index the magnitude window dynamically -- through
+                    // scratch memory, a vmcnt(0) wait per pixel.)
+                    const int pos = kbin & 3;
+                    const bool im0 = fminf(m - m1[e + 2], m - m1[e]) > 0.0f, im1 = fminf(m - m2[e + 2], m - m0[e]) > 0.0f;
+                    const bool im2 = fminf(m - m2[e + 1], m - m0[e + 1]) > 0.0f, im3 = fminf(m - m2[e], m - m0[e + 2]) > 0.0f;
+                    const bool is_max = pos == 0 ? im0 : pos == 1 ? im1 : pos == 2 ? im2 : im3;   // :154
+                    const float tt = is_max ? m : 0.f;                                          // :158-159
+                    o_thin[e] = tt;
+                    o_edge[e] = (tt < threshold) ? 0.f : tt;                                    // :160-161
+                }
+            }
+            const size_t o = (size_t)b * plane + (size_t)y_o * W + x;
+            if (FULL) {
+                store4(out.grad_mag, o, o_mag);
+                store4(out.grad_ori, o, o_ori);
+                store4(out.thr_mag, o, o_thr);
+                if (nms) { store4(out.thin, o, o_thin); store4(out.thr_thin, o, o_edge); }
+            }
+            store4(out.edge, (size_t)b * out.edge_batch_stride + (size_t)y_o * W + x, o_edge);
+        }
+    };
+    // six steps per iteration, unconditionally (a step beyond the strip loads zeros and stores nothing): one basic block, so that
+    // the waits for the rows loaded two steps earlier count the memory operations issued since (behind a branch per step hipcc fell
+    // back to s_waitcnt vmcnt(0) -- also draining the loads just issued, i.e. no prefetch at all)
+    for (int t = 0; t < steps; t += 6) {
+        step(std::integral_constant<int, 0>(), t);
+        step(std::integral_constant<int, 1>(), t + 1);
+        step(std::integral_constant<int, 2>(), t + 2);
+        step(std::integral_constant<int, 3>(), t + 3);
+        step(std::integral_constant<int, 4>(), t + 4);
+        step(std::integral_constant<int, 5>(), t + 5);
+    }
+}
+
 // proxy representation (predict/...:93-100): channel 0 = edge map, channels 1..K = visibility * Gaussian blob
 // (label_conversions.py:123: exp(-((row - v) / std)^2 / 2 - ((col - u) / std)^2 / 2)).  A workgroup writes PR_ROWS rows of up to 256
 // columns: the row term of a (row, joint) pair is computed once per workgroup (LDS), the column term once per thread and joint --
@@ -355,6 +574,29 @@ static int launch_canny(const char* who, const float* img, const float* gauss_ta
                         int B, int C, int H, int W, float threshold, int nms, hps_stream_t stream) {
     if (gauss_size != G) { set_error("%s: gaussian size %d unsupported (5)", who, gauss_size); return HPS_E_UNSUPPORTED; }
     if (B <= 0) return HPS_OK;
+    if (C == 1 || C == 3) {
+        // one wave per (image, column block, strip of rows); strips as tall as they can be while the chip still gets about one wave
+        // per SIMD (each strip re-reads eight rows of halo).  Results do not depend on the strip height.
+        const int col_blocks = W <= 256 ? 1 : ceil_div(W, 248);
+        int rows = 64;
+        while (rows > 8 && (long)B * col_blocks * ceil_div(H, rows) < 1024) rows /= 2;
+        const int strips = ceil_div(H, rows);
+        const long n_items = (long)B * col_blocks * strips;
+        if (n_items > 0x7fffffffL / 4) return bad_arg("hps_canny_edges: too many strips");
+        const bool full = blurred || grad_mag || grad_ori || thr_mag || thin || thr_thin;
+        CannyOut o{blurred, grad_mag, grad_ori, thr_mag, thin, thr_thin, edge_out, edge_batch_stride};
+        const dim3 grid((unsigned)ceil_div((int)n_items, 4)), block(256);
+        const float* t = gauss_taps_host;
+        hipStream_t st = (hipStream_t)stream;
+#define HPS_CANNY_ROWS(CC, FF, VV) hipLaunchKernelGGL((canny_rows_kernel<CC, FF, VV>), grid, block, 0, st, img, t[0], t[1], t[2], t[3], t[4], o, H, W, threshold, nms, rows, strips, col_blocks, (int)n_items)
+#define HPS_CANNY_ROWS_F(CC, VV) do { if (full) HPS_CANNY_ROWS(CC, true, VV); else HPS_CANNY_ROWS(CC, false, VV); } while (0)
+        const bool vec = (W & 3) == 0;
+        if (C == 3) { if (vec) HPS_CANNY_ROWS_F(3, true); else HPS_CANNY_ROWS_F(3, false); }
+        else { if (vec) HPS_CANNY_ROWS_F(1, true); else HPS_CANNY_ROWS_F(1, false); }
+#undef HPS_CANNY_ROWS_F
+#undef HPS_CANNY_ROWS
+        return check_launch(who);
+    }
     dim3 grid(ceil_div(W, CT), ceil_div(H, CT), B);
     hipLaunchKernelGGL(canny_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, gauss_taps_host[0], gauss_taps_host[1],
                        gauss_taps_host[2], gauss_taps_host[3], gauss_taps_host[4], blurred, grad_mag, grad_ori, thr_mag,

@@ -137,6 +137,17 @@ __device__ __forceinline__ f3 skin_vertex(const float* Am, const int (&idx)[K], 
     return o;
 }
 
+// v / 3, correctly rounded, without the ~12-instruction division expansion: q = v * RN(1/3), then one Newton correction with two
+// fused multiply-adds -- r = v - 3 q is exact, q + r * RN(1/3) rounds to RN(v / 3); r == 0 means q is already the quotient (this
+// also keeps the sign of -0).  Bit-identical to the IEEE quotient for EVERY one of the 4 278 190 080 finite fp32 values
+// (tools/div3_check.hip runs them all on the device; numpy agreed on the host).
+__device__ __forceinline__ float div3_rn(float v) {
+    const float inv = 0.3333333432674407958984375f;              // RN(1/3) = 0x3EAAAAAB
+    const float q = v * inv;
+    const float r = __builtin_fmaf(-3.0f, q, v);
+    return r == 0.0f ? q : __builtin_fmaf(r, inv, q);
+}
+
 // One 1 KiB LDS-DMA piece: every lane moves 16 bytes from sbase + voff (bytes) to LDS[lds_addr + 16 * lane].
 __device__ __forceinline__ void lds_dma16(unsigned voff, const float* sbase, unsigned lds_addr) {
     unsigned keep;
