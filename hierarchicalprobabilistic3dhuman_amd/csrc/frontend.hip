@@ -39,10 +39,11 @@ __device__ __forceinline__ int orientation_bin(float gx, float gy) {
             return (int)rintf(ori / 45.0f);
         }
     }
-    const bool sx = __builtin_signbit(gx), sy = __builtin_signbit(gy);
-    if (ay <= b1) return sx ? (sy ? 0 : 8) : 4;
-    if (ay >= b2) return sy ? 2 : 6;
-    return sy ? (sx ? 1 : 3) : (sx ? 7 : 5);
+    // k = 4 +- d: d = 4 [gx < 0] in the horizontal sector (k = 4, 8, 0), 2 in the vertical one (6, 2), 1 + 2 [gx < 0] on the
+    // diagonals (5, 7 / 3, 1); the sign is that of gy (sign BITS: atan2's conventions for signed zeros)
+    const int sx = (int)(__builtin_bit_cast(unsigned, gx) >> 31), sy = (int)(__builtin_bit_cast(unsigned, gy) >> 31);
+    const int d = ay <= b1 ? 4 * sx : (ay >= b2 ? 2 : 1 + 2 * sx);
+    return 4 + (1 - 2 * sy) * d;
 }
 
 // One workgroup = one 32x32 tile of one image.  Every stage reproduces the zero padding of the reference's
@@ -368,7 +369,8 @@ __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict
                 float acc = 0.f;
 #pragma unroll
                 for (int k = 0; k < G; ++k) acc += gk[k] * v[e + k];
-                hw[c][PH][e] = cin[e] ? acc : 0.f;                 // the horizontal pass only exists inside the image
+                hw[c][PH][e] = acc;    // outside the image's columns this is not zero as the reference's is -- but the vertical pass
+                                       // does not mix columns, and the blurred row is zeroed there below
             }
             // ---- vertical Gaussian: blurred row y_bl from the rows y_in - 4 .. y_in of the ring ----
             float bl[4];
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict
                 float acc = 0.f;
 #pragma unroll
                 for (int k = 0; k < G; ++k) acc += gk[k] * hw[c][(PH + 2 + k) % 6][e];
-                bl[e] = bl_in ? acc : 0.f;                         // zero outside the image: what the Sobel convolutions pad with
+                bl[e] = (bl_in && cin[e]) ? acc : 0.f;             // zero outside the image: what the Sobel convolutions pad with
             }
             if (FULL && bl_in && y_bl >= Y0 && y_bl < Y1)                                                         // :119
                 store4(out.blurred, ((size_t)b * C + c) * plane + (size_t)y_bl * W + x, bl);
