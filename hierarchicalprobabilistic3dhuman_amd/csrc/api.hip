@@ -14,7 +14,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace hps
 
-extern "C" int hps_version(void) { return 310; }  // 0.3.1: hps_stem_phase_split, hps_stem_winograd (HPS_ENC_STEM_* ops)
+extern "C" int hps_version(void) { return 400; }  // 0.4.0: hps_head_trunk, hps_canny_edge_map, hps_nchw_to_padded_nhwc_generic (HPS_ENC_RELAYOUT_GENERIC)
 
 extern "C" int64_t hps_query_workspace(int what, int64_t d0, int64_t d1, int64_t d2) {
     if (d0 < 0 || d1 < 0 || d2 < 0) { hps::set_error("hps_query_workspace: negative dimension"); return -1; }
