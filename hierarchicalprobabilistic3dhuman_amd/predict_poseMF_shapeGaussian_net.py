@@ -9,6 +9,7 @@ and the Canny / heat-map kernels of SURVEY 8(f)1; ``proxy_rep_fn`` may replace i
 writing; :167-333) is out of scope (rows 14, 20): results go to ``result_fn`` or to .pt files.
 """
 import os
+import weakref
 
 import torch
 
@@ -302,6 +303,9 @@ class InferencePipeline:
                      _before_meshes=hook, _after_smpl=smpl_done, _run_net=run_net)
 
 
+_PREDICT_PIPELINES = weakref.WeakKeyDictionary()      # model -> (key, InferencePipeline, StagedUpload) of predict_poseMF_shapeGaussian_net
+
+
 class StagedUpload:
     """Host -> device staging for a loop of batches: page-locked host tensors are copied with non_blocking=True on a copy
     stream of their own into ``slots`` alternating sets of device buffers (allocated once), so the copy of batch k+1 runs under
@@ -393,12 +397,13 @@ def predict_poseMF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mode
     groups = [image_fnames[i0:i0 + batch_size] for i0 in range(0, len(image_fnames), batch_size)]
     if not groups:
         return
-    # the pipeline (its streams, the encoder's frame buffers bound to them, the upload slots) is kept on the model between calls
+    # the pipeline (its streams, the encoder's frame buffers bound to them, the upload slots) is kept between calls, per model (weakly
+    # referenced side table: nothing is attached to the module, so copies / pickles of it are unaffected)
     key = (id(smpl_model), num_samples, batch_size, torch.cuda.current_device())
-    cached = getattr(pose_shape_model, "_hps_predict_pipeline", None)
+    cached = _PREDICT_PIPELINES.get(pose_shape_model)
     if cached is None or cached[0] != key:
         cached = (key, InferencePipeline(pose_shape_model, smpl_model, num_samples=num_samples, use_mean_shape=True), StagedUpload(slots=2))
-        pose_shape_model._hps_predict_pipeline = cached
+        _PREDICT_PIPELINES[pose_shape_model] = cached
     _, pipe, stager = cached
 
     def stage(names):
