@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--as-rank", type=int, nargs=2, metavar=("R", "W"), default=None,
                     help="single process, no process group: do exactly the work rank R of a W-rank job would do (its image "
                          "shard, its Philox offsets) -- what the multi-rank tests compare the per-rank checksums against")
-    ap.add_argument("--from-rgb-steps", type=int, default=20,
+    ap.add_argument("--from-rgb-steps", type=int, default=16,
                     help="after the timed region: steps of the PCIe-inclusive path from host RGB crops + keypoints for secondary.from_rgb (0 = skip)")
     ap.add_argument("--from-rgb-variant", choices=("default", "no-copy"), default="default",
                     help="diagnostic: 'no-copy' runs the from-RGB loop on device-resident crops (isolates the cost of the H2D copies)")
@@ -331,28 +331,36 @@ def main():
                 sink.add_(sharding.batch_metric_sums(pipe.finish(ticket, seed=777 + first + i, image_offset=lo, after=nxt)))
                 ticket = nxt
 
-        rgb_sums = torch.zeros(4, dtype=torch.float64, device=dev)
         rgb_steps(0, 4, torch.zeros(4, dtype=torch.float64, device=dev))
         torch.cuda.synchronize()
         barrier()
-        pipe.enc_events, smpl.lbs_events = [], []
-        t_a = time.perf_counter()
-        rgb_steps(4, args.from_rgb_steps, rgb_sums)
-        torch.cuda.synchronize()
-        barrier()
-        dt_rgb = sharding.all_reduce_max(time.perf_counter() - t_a)
-        rgb_enc_ms = [e0.elapsed_time(e1) for (e0, e1) in pipe.enc_events]
-        rgb_mesh_ms = [e0.elapsed_time(e1) for (m, e0, e1) in smpl.lbs_events if m == M]
+        # three legs of --from-rgb-steps steps each; the median leg is reported and all three are listed (one leg in about six runs
+        # comes out ~0.9 ms per step slower -- the H2D copy of a step not hidden behind the kernels; cause not found)
+        legs = []
+        for leg in range(3):
+            pipe.enc_events, smpl.lbs_events = [], []
+            leg_sums = torch.zeros(4, dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()
+            barrier()
+            t_a = time.perf_counter()
+            rgb_steps(4 + leg * args.from_rgb_steps, args.from_rgb_steps, leg_sums)
+            torch.cuda.synchronize()
+            barrier()
+            dt_leg = sharding.all_reduce_max(time.perf_counter() - t_a)
+            legs.append((dt_leg, [e0.elapsed_time(e1) for (e0, e1) in pipe.enc_events],
+                         [e0.elapsed_time(e1) for (m, e0, e1) in smpl.lbs_events if m == M], leg_sums))
         pipe.enc_events, smpl.lbs_events = None, None
+        leg_rates = [B * world * args.from_rgb_steps / l[0] for l in legs]
+        dt_rgb, rgb_enc_ms, rgb_mesh_ms, rgb_sums = sorted(legs, key=lambda l: l[0])[1]
         h2d = sum(t.numel() * t.element_size() for t in host_sets[0])
         from_rgb = {"images_per_s": B * world * args.from_rgb_steps / dt_rgb, "ms_per_step": dt_rgb / args.from_rgb_steps * 1e3,
-                    "steps": args.from_rgb_steps, "h2d_bytes_per_step_per_gpu": h2d,
+                    "steps": args.from_rgb_steps, "legs_images_per_s": leg_rates, "h2d_bytes_per_step_per_gpu": h2d,
                     "checksum_images": float(rgb_sums[0]), "checksum_sum_unc": float(rgb_sums[1]),
                     "encoder_avg_ms": sum(rgb_enc_ms) / max(1, len(rgb_enc_ms)),
                     "mesh_kernel_avg_ms": sum(rgb_mesh_ms) / max(1, len(rgb_mesh_ms)),
                     "note": "PCIe-inclusive: page-locked host RGB crops + 17 keypoints + visibility -> non-blocking H2D on a copy "
                             "stream (two device slots) -> hps_canny_edge_map + hps_proxy_rep on the encoder's stream -> the same "
-                            "pipelined step as the headline; %d steps after 4 warm-up steps, wall clock" % args.from_rgb_steps}
+                            "pipelined step as the headline; median of three legs of %d steps (all listed) after 4 warm-up steps, wall clock" % args.from_rgb_steps}
     secondary = {}
     if from_rgb:
         secondary["from_rgb"] = from_rgb
