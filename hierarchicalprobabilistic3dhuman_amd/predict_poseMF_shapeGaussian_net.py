@@ -402,7 +402,10 @@ def predict_poseMF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mode
     key = (id(smpl_model), num_samples, batch_size, torch.cuda.current_device())
     cached = _PREDICT_PIPELINES.get(pose_shape_model)
     if cached is None or cached[0] != key:
-        cached = (key, InferencePipeline(pose_shape_model, smpl_model, num_samples=num_samples, use_mean_shape=True), StagedUpload(slots=2))
+        # the cached pipeline refers to the model through a weak proxy: a strong reference from the table's value to its key would
+        # keep the model (and the encoder's frame buffers) alive for ever
+        cached = (key, InferencePipeline(weakref.proxy(pose_shape_model), smpl_model, num_samples=num_samples, use_mean_shape=True),
+                  StagedUpload(slots=2))
         _PREDICT_PIPELINES[pose_shape_model] = cached
     _, pipe, stager = cached
 
