@@ -212,6 +212,70 @@ def test_pipeline_from_host_rgb_equals_infer_on_the_proxy_representation(dev, ne
             assert torch.equal(w[key], g_[key]), key
 
 
+def test_predict_loop_from_host_proxies_equals_infer(dev, net_gpu, smpl_gpu, tmp_path):
+    """predict_poseMF_shapeGaussian_net (reference signature, run_predict.py:77-89) with per-image proxy representations in HOST
+    memory (page-locked and pageable): the loop stages them over two copy streams into alternating device slots and
+    software-pipelines the batches -- every image's outputs must be those of infer() on its batch, bit for bit (7 images in
+    batches of 3: a ragged last batch; slots reused)."""
+    import os
+    from hierarchicalprobabilistic3dhuman_amd import configs
+    from hierarchicalprobabilistic3dhuman_amd.predict_poseMF_shapeGaussian_net import predict_poseMF_shapeGaussian_net
+    cfg = configs.get_cfg_defaults()
+    names = ["img_%02d.png" % i for i in range(7)]
+    image_dir = tmp_path / "images"
+    os.makedirs(image_dir)
+    for n in names:
+        open(image_dir / n, "wb").close()                                  # names only: proxy_rep_fn supplies the content
+    proxies = {n: torch.rand(1, 18, 256, 256, generator=torch.Generator().manual_seed(700 + i)) for i, n in enumerate(names)}
+    for pinned in (True, False):
+        store = {n: (t.pin_memory() if pinned else t) for n, t in proxies.items()}
+        got = {}
+        torch.manual_seed(21)
+        predict_poseMF_shapeGaussian_net(net_gpu, cfg, smpl_gpu, None, None, None, dev, str(image_dir), str(tmp_path / "out"),
+                                         proxy_rep_fn=lambda path: store[os.path.basename(path)], num_samples=5, batch_size=3,
+                                         result_fn=lambda name, item: got.__setitem__(name, {k: item[k].clone() for k in ("pose_F", "R_samples", "verts_mode", "unc")}))
+        torch.cuda.synchronize()
+        assert sorted(got) == names
+        torch.manual_seed(21)                                              # the loop draws one Philox seed per batch from this generator
+        for i0 in range(0, len(names), 3):
+            batch = names[i0:i0 + 3]
+            want = infer(net_gpu, smpl_gpu, torch.cat([proxies[n] for n in batch]).to(dev), num_samples=5)
+            for k, n in enumerate(batch):
+                for key in got[n]:
+                    assert torch.equal(got[n][key], want[key][k]), (pinned, n, key)
+
+
+def test_bench_line_has_every_leg(dev):
+    """The line the driver records: one short run of bench.py with all of its legs on (headline, lbs_unfused, latency_b1,
+    from_rgb), every field the contract names present and consistent."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2", "--cpu-images", "1", "--lbs-unfused-reps", "2",
+           "--latency-reps", "3", "--from-rgb-steps", "3"]
+    p = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["config"]["workload"].startswith("BASELINE configs[1]") and d["config"]["input_sets"] == 2
+    assert abs(d["value"] - 64 * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["fused"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["traffic"] is None or r["traffic_imported"] is True
+    sec = d["secondary"]
+    assert sec["latency_b1"]["median_ms"] > 0 and sec["latency_b1"]["throughput_mode_median_ms"] > 0
+    assert sec["from_rgb"]["images_per_s"] > 0 and len(sec["from_rgb"]["legs_images_per_s"]) == 3
+    assert sec["from_rgb"]["checksum_images"] == 64 * 3
+    assert sec["lbs_unfused"]["frac"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["metric_checksums"]["images"] == 64 * 3
+
+
 def test_pipeline_on_cu_partitions_equals_sequential_infer(dev, net_gpu, smpl_gpu):
     """Small batches with a long mesh chain (BASELINE configs[4]: 16 images x 1000 samples = 16 032 meshes) run the encoder and
     the mesh kernels side by side on disjoint CU subsets (hps_stream_create_cu_partition, chosen automatically); a batch with a
