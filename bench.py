@@ -275,7 +275,7 @@ def main():
         # the same calls with the encoder in latency mode (ResNet.set_latency_mode: direct kernels, many K slices -- a per-model
         # switch for one-image-at-a-time deployments; ~1.5x slower than the default at batch 64, hence not the bench's mode)
         lat2 = []
-        net.image_encoder.set_latency_mode(True)
+        net.set_latency_mode(True)
         try:
             for i in range(args.latency_reps + 5):
                 torch.cuda.synchronize()
@@ -284,11 +284,11 @@ def main():
                 torch.cuda.synchronize()
                 lat2.append((time.perf_counter() - t_a) * 1e3)
         finally:
-            net.image_encoder.set_latency_mode(False)
+            net.set_latency_mode(False)
         st2 = spread(lat2[5:])
         latency_b1 = {"median_ms": st2["median_ms"], "min_ms": st2["min_ms"], "max_ms": st2["max_ms"], "reps": st2["launches"],
                       "images_per_s": 1e3 / st2["median_ms"], "batch": 1, "num_samples": n1,
-                      "encoder_mode": "latency (ResNet.set_latency_mode(True))",
+                      "model_mode": "latency (PoseMFShapeGaussianNet.set_latency_mode(True): direct kernels with many K slices, wide head workgroups)",
                       "throughput_mode_median_ms": st["median_ms"],
                       "note": "one image per call, host wall clock from issue to completion (torch.cuda.synchronize), input resident "
                               "in HBM; the reference's run_predict operating point.  median_ms: encoder in latency mode (what a "

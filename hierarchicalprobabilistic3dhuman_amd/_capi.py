@@ -111,6 +111,7 @@ class EncOp(_c.Structure):
 ENC_RELAYOUT, ENC_CONV, ENC_MAXPOOL, ENC_AVGPOOL, ENC_CONV_WINOGRAD, ENC_STEM_SPLIT, ENC_STEM_WINOGRAD, ENC_RELAYOUT_GENERIC = 0, 1, 2, 3, 4, 5, 6, 7
 SVD_HOST, SVD_DEVICE, SVD_DEVICE_FMA = 0, 1, 2
 SVD_ROUNDING_REFERENCE, SVD_ROUNDING_FMA = 0, 1
+HEAD_WIDE_WORKGROUPS = 0x100
 
 
 class HpsError(RuntimeError):

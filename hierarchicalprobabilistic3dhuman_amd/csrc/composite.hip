@@ -68,8 +68,10 @@ extern "C" int hps_head_pose_levels(const float* embed, int embed_dim, int hidde
                                     float* f_host_pinned, float* usv_host_pinned, int B, int num_body_joints,
                                     int svd_threads, int svd_mode, hps_stream_t stream) {
     if (!embed || !level_joints || !level_sizes_host) return bad_arg("hps_head_pose_levels: null pointer");
+    const int wide = svd_mode & HPS_HEAD_WIDE_WORKGROUPS;
+    svd_mode &= ~HPS_HEAD_WIDE_WORKGROUPS;
     if (svd_mode == HPS_SVD_DEVICE || svd_mode == HPS_SVD_DEVICE_FMA) {
-        const int flavor = svd_mode == HPS_SVD_DEVICE_FMA ? HPS_SVD_ROUNDING_FMA : HPS_SVD_ROUNDING_REFERENCE;
+        const int flavor = (svd_mode == HPS_SVD_DEVICE_FMA ? HPS_SVD_ROUNDING_FMA : HPS_SVD_ROUNDING_REFERENCE) | wide;
         // every level is ONE kernel (MLPs + in-kernel gesdd-faithful SVD + proper fix): stream-ordered, no host round trip
         int first_d = 0;
         for (int l = 0; l < n_levels; ++l) {

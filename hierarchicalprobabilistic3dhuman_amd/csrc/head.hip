@@ -356,6 +356,8 @@ static int joint_level_launch(const float* embed, int embed_dim, int hidden, con
                               float* f_level, float* pose_u, float* pose_s, float* pose_v, int B, int num_body_joints,
                               int svd_flavor, hps_stream_t stream) {
     const bool devsvd = pose_u != nullptr;
+    const bool wide = devsvd && (svd_flavor & HPS_HEAD_WIDE_WORKGROUPS) != 0;
+    svd_flavor &= ~HPS_HEAD_WIDE_WORKGROUPS;
     if (devsvd && svd_flavor != HPS_SVD_ROUNDING_REFERENCE && svd_flavor != HPS_SVD_ROUNDING_FMA)
         return bad_arg("hps_head_joint_level_svd: svd_flavor");
     if (!embed || !joint_ids || !anc_ptr || !anc_idx || !w1t_ptrs || !b1_ptrs || !w2_ptrs || !b2_ptrs || !u_proper ||
@@ -367,7 +369,13 @@ static int joint_level_launch(const float* embed, int embed_dim, int hidden, con
     const int max_in = embed_dim + 21 * num_body_joints;
     size_t lds = ((size_t)((max_in * TBL + 3) & ~3) + 128 * TBL + (NT / 128) * TBL * 128) * sizeof(float);
     if (lds > 64 * 1024) { set_error("hps_head_joint_level: embed_dim=%d too large", embed_dim); return HPS_E_UNSUPPORTED; }
-    if (devsvd)
+    if (wide) {
+        constexpr int NTW = 1024;
+        const size_t ldsw = ((size_t)((max_in * TBL + 3) & ~3) + 128 * TBL + (NTW / 128) * TBL * 128) * sizeof(float);
+        hipLaunchKernelGGL((joint_level_kernel<128, true, NTW, TBL>), dim3(n_level, ceil_div(B, TBL)), dim3(NTW), ldsw, (hipStream_t)stream,
+                           embed, embed_dim, joint_ids, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper,
+                           s_proper, mode, delta_i_weight, pose_f, f_level, pose_u, pose_s, pose_v, B, num_body_joints, svd_flavor);
+    } else if (devsvd)
         hipLaunchKernelGGL((joint_level_kernel<128, true, NT, TBL>), dim3(n_level, ceil_div(B, TBL)), dim3(NT), lds, (hipStream_t)stream,
                            embed, embed_dim, joint_ids, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper,
                            s_proper, mode, delta_i_weight, pose_f, f_level, pose_u, pose_s, pose_v, B, num_body_joints, svd_flavor);

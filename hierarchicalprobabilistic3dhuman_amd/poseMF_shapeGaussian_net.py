@@ -103,6 +103,15 @@ class PoseMFShapeGaussianNet(nn.Module):
         self.composite_head = True     # joint loop through hps_head_pose_levels (one call) instead of per-level Python
         self.svd_mode = "device"       # "device": in-kernel gesdd-faithful SVD; "host": MKL sgesdd round trip (the routine itself)
         self.svd_flavor = None         # None: the rounding flavour of this host's MKL (calibrated); 0 / 1 force one
+        self.latency_mode = False      # set_latency_mode(): encoder on direct kernels with many K slices, joint MLPs on wide workgroups
+
+    def set_latency_mode(self, on=True):
+        """One switch for one-image-at-a-time deployments (the reference's run_predict operating point): the encoder's latency mode
+        (ResNet.set_latency_mode) and 1024-thread / eight-K-slice workgroups for the joint MLPs of the head
+        (HPS_HEAD_WIDE_WORKGROUPS; device SVD mode only).  A property of the model: within a mode results do not depend on the
+        batch size; between the modes they differ in the last bits (other summation orders)."""
+        self.latency_mode = bool(on)
+        self.image_encoder.set_latency_mode(on)
 
     def _flavor(self):
         """Rounding flavour of the in-kernel SVD: ``svd_flavor`` if set (0 reference BLAS rounding, 1 fused), else the one that
@@ -239,7 +248,8 @@ class PoseMFShapeGaussianNet(nn.Module):
                        VP(p["w1t_ptrs"].data_ptr()), VP(p["b1_ptrs"].data_ptr()), VP(p["w2_ptrs"].data_ptr()),
                        VP(p["b2_ptrs"].data_ptr()), P(U_proper), P(S_proper), P(mode), delta, P(pose_F), P(pose_U), P(pose_S),
                        P(pose_V), P(f_dev), P(usv_dev), fh, uh, B, nj, _SVD_THREADS,
-                       (_capi.SVD_DEVICE_FMA if self._flavor() == _capi.SVD_ROUNDING_FMA else _capi.SVD_DEVICE) if device_svd else _capi.SVD_HOST, s)
+                       ((_capi.SVD_DEVICE_FMA if self._flavor() == _capi.SVD_ROUNDING_FMA else _capi.SVD_DEVICE) |
+                        (_capi.HEAD_WIDE_WORKGROUPS if self.latency_mode else 0)) if device_svd else _capi.SVD_HOST, s)
             return pose_F, pose_U, pose_S, pose_V, mode, shape_dist, glob, cam
         for lvl in p["levels"]:
             n_level = lvl.numel()
@@ -248,7 +258,8 @@ class PoseMFShapeGaussianNet(nn.Module):
                            _capi.iptr(p["anc_ptr"]), _capi.iptr(p["anc_idx"]),
                            _capi._P(p["w1t_ptrs"].data_ptr()), _capi._P(p["b1_ptrs"].data_ptr()),
                            _capi._P(p["w2_ptrs"].data_ptr()), _capi._P(p["b2_ptrs"].data_ptr()),
-                           P(U_proper), P(S_proper), P(mode), delta, P(pose_F), P(pose_U), P(pose_S), P(pose_V), B, nj, self._flavor(), s)
+                           P(U_proper), P(S_proper), P(mode), delta, P(pose_F), P(pose_U), P(pose_S), P(pose_V), B, nj,
+                           self._flavor() | (_capi.HEAD_WIDE_WORKGROUPS if self.latency_mode else 0), s)
                 continue
             f_level = torch.empty(B, n_level, 3, 3, **f32)
             _capi.call("hps_head_joint_level", P(embed), embed_dim, embed_dim // 2, _capi.iptr(lvl), n_level,

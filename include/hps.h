@@ -50,6 +50,12 @@ typedef void* hps_stream_t; /* hipStream_t */
  * signed singular-vector pair.  hps_host_svd_flavor() tells which one the LAPACK bound to this process matches. */
 #define HPS_SVD_ROUNDING_REFERENCE 0
 #define HPS_SVD_ROUNDING_FMA 1
+/* OR'ed into the svd_flavor of hps_head_joint_level_svd / the svd_mode of hps_head_pose_levels (device modes): 1024-thread
+ * workgroups with eight K slices for the joint MLPs instead of 256 threads with two -- the latency form for one or a few images
+ * (a level 28 -> 21 us at batch 1), too large a footprint beside the chip-filling kernels of the pipelined loop.  The hidden
+ * layer's partial sums are then added in another order: results differ in the last bits, so this is a property of the model
+ * (PoseMFShapeGaussianNet.set_latency_mode), never of the batch. */
+#define HPS_HEAD_WIDE_WORKGROUPS 0x100
 
 #define HPS_ACT_NONE 0
 #define HPS_ACT_ELU 1

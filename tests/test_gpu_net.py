@@ -576,3 +576,32 @@ def test_encoder_takes_any_channel_count_and_image_size(shape, dev):
     assert torch.equal(enc(x[:1].to(dev)), got[:1])
     enc.composite = False
     assert torch.equal(enc(x.to(dev)), got)
+
+
+def test_latency_mode_of_the_whole_net(dev, net_gpu, net_cpu, golden, golden_input):
+    """PoseMFShapeGaussianNet.set_latency_mode: encoder latency mode + 1024-thread / eight-K-slice workgroups for the joint MLPs
+    (HPS_HEAD_WIDE_WORKGROUPS).  Against the reference's golden outputs with the usual tolerances, against the oracle from
+    features at B = 1, 3, 17, and bit-identical per image for every batch size within the mode; the default mode's outputs come
+    back bit for bit when it is switched off."""
+    x = golden_input.to(dev)
+    default = [t.clone() if torch.is_tensor(t) else t for t in net_gpu(x)]
+    try:
+        net_gpu.set_latency_mode(True)
+        pose_F, pose_U, pose_S, pose_V, mode, shape_dist, glob, cam = net_gpu(x)
+        assert maxerr(pose_F, golden["net_F"]) <= 1e-4 and maxerr(mode, golden["net_mode"]) <= 1e-4
+        assert maxerr(pose_S, golden["net_S"]) <= 1e-5 * max(1.0, float(golden["net_S"].max()))
+        assert maxerr(pose_U, golden["net_U"]) <= 1e-3 and maxerr(pose_V, golden["net_V"]) <= 1e-3
+        assert maxerr(shape_dist.loc, golden["net_shape_loc"]) <= 1e-4 and maxerr(glob, golden["net_glob"]) <= 1e-4
+        one = net_gpu(x[1:2])
+        assert torch.equal(one[0], pose_F[1:2]) and torch.equal(one[1], pose_U[1:2]) and torch.equal(one[4], mode[1:2])
+        for B in (1, 3, 17):
+            feats = torch.rand(B, 512, generator=torch.Generator().manual_seed(B)) * 2
+            ref = O.head_forward(net_cpu[1], feats, configs.SMPL_PARENTS)
+            out = net_gpu(None, input_feats=feats.to(dev))
+            assert maxerr(out[0], ref[0]) <= 1e-4 and maxerr(out[2], ref[2]) <= 1e-4 and maxerr(out[4], ref[4]) <= 1e-4
+    finally:
+        net_gpu.set_latency_mode(False)
+    again = net_gpu(x)
+    for a, b in zip(default, again):
+        if torch.is_tensor(a):
+            assert torch.equal(a, b)

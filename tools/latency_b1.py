@@ -58,7 +58,7 @@ def main():
     if "--direct" in sys.argv:
         net.image_encoder.set_winograd(False)
     if "--latency" in sys.argv:
-        net.image_encoder.set_latency_mode(True)
+        net.set_latency_mode(True)
     smpl = SMPL(smpl_data.synthetic_smpl_model(0)).to(dev)
     x = torch.rand(1, 18, 256, 256, generator=torch.Generator().manual_seed(1)).to(dev)
     lat, host = [], []
