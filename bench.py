@@ -379,7 +379,7 @@ def main():
                                 "unit": "matrix-Fisher proposals/s (8N per image and joint, Philox)"}
 
     fused = bool(getattr(smpl, "fused_mesh", False))
-    mesh_kernel = "hps::mesh_fused_kernel<4,0,24,false>" if fused else "hps::lbs_kernel<4,8,1>"
+    mesh_kernel = "hps::mesh_fused_kernel<4,0,24,false,5>" if fused else "hps::lbs_kernel<4,8,1>"
     # HBM traffic of the same kernel from the PMC counters: collected in separate rocprofv3 passes of this very
     # command (tools/collect_profiles.sh), corrected as MI355X_MICROARCH.md prescribes, committed under profiles/
     traffic = None

@@ -31,6 +31,8 @@
 // panels in order, so an XCD's L2 holds its own xt / A slices plus the few panels in flight; bmat_p streams from the
 // memory-side cache once per XCD.
 
+#include <type_traits>
+
 #include "hps_common.h"
 
 namespace hps {
@@ -51,7 +53,9 @@ static_assert(F_XP == FW && F_BP % FW == 0, "DMA pieces must divide evenly over 
 // ABL: profiling ablations, dev library only (hps_dev_mesh_fused); the product instantiates ABL = 0.
 // JC: joints per mesh as a compile-time constant (24 = SMPL: every LDS offset of the epilogue folds into an immediate), 0 = runtime J;
 // HAS_T: a per-mesh translation is added (smplx SMPL.forward step (7)).
-template <int K, int ABL, int JC, bool HAS_T>
+// TAIL: k-pairs of the LAST chunk that carry data (compile-time: a run-time bound inside the unrolled MFMA run cost 30 % -- the
+// branch per k-step broke the pinned schedule and put an accumulator into scratch); 8 = the whole chunk.
+template <int K, int ABL, int JC, bool HAS_T, int TAIL = FBK / 2>
 __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
     const float* __restrict__ xt, const float* __restrict__ bmat_p, const float* __restrict__ v_template,
     const float* __restrict__ a, const int32_t* __restrict__ w_idx, const float* __restrict__ w_val, int J,
@@ -119,15 +123,18 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
 
-    const int nchunks = kp / FBK;
+    // kp = K rows that carry data (even).  Chunks are 16 rows; the last one runs only its TAIL k-pairs: the rows behind kp are zero
+    // padding (SMPL: K = 217 -> kp = 218, TAIL = 5: nine MFMAs fewer of 336 per wave; adding their zero products changes nothing,
+    // so the bits are those of the padded sum).
+    const int nchunks = (kp + FBK - 1) / FBK;
     if (ABL != 4) dma_chunk(0);
     static_assert(1 + F_BP / FW == FBK / 4, "four DMA pieces per wave and chunk, one per two k-steps");
-    for (int c = 0; c < nchunks; ++c) {
+    auto do_chunk = [&](auto pairs_c, int c, bool more) __attribute__((always_inline)) {
+        constexpr int PAIRS = decltype(pairs_c)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                   // chunk c has landed; everyone is done with the other buffer
         // the next chunk's four DMA pieces go out one per two k-steps of this chunk's MFMAs, not in a burst (csrc/conv_pad.hip,
         // tools/mfma_dma_overlap.hip: a piece costs the SIMD 36-57 cycles that are better paid between MFMAs than before them)
-        const bool more = ABL != 4 && c + 1 < nchunks;
         constexpr bool burst = ABL == 5;                  // dev ablation: the earlier burst after the barrier
         const float* nx_src = x_src;
         const float* nb_src = b_src;
@@ -135,17 +142,17 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
         else if (more) { b_src += (size_t)FBK * np; x_src += (size_t)FBK * mp; }
         const float* sX = smem + (c & 1) * F_CHUNK_FLOATS;
         const float* sB = sX + FBK * FM;
-        // all fragments of the chunk first (32 independent LDS reads in flight), then 24 back-to-back MFMAs
-        float af[FBK / 2], bx[FBK / 2], by[FBK / 2], bz[FBK / 2];
+        // all fragments of the chunk first (independent LDS reads in flight), then the MFMAs back to back
+        float af[PAIRS], bx[PAIRS], by[PAIRS], bz[PAIRS];
 #pragma unroll
-        for (int k = 0; k < FBK; k += 2) {
+        for (int k = 0; k < 2 * PAIRS; k += 2) {
             af[k / 2] = sX[(k + kl) * FM + wm * 32 + il];
             const float* brow = sB + (k + kl) * FN + wn * 32 + il;
             bx[k / 2] = brow[0]; by[k / 2] = brow[FV]; bz[k / 2] = brow[2 * FV];
         }
         __builtin_amdgcn_sched_barrier(0);                 // keep the reads ahead of the MFMAs (hipcc would sink each to its use)
 #pragma unroll
-        for (int k = 0; k < FBK / 2; ++k) {
+        for (int k = 0; k < PAIRS; ++k) {
             if (ABL == 2) {                                // no MFMA: keep the fragment reads alive
                 acc[0][0] += af[k] * bx[k]; acc[1][0] += af[k] * by[k]; acc[2][0] += af[k] * bz[k];
                 continue;
@@ -159,7 +166,9 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-    }
+    };
+    for (int c = 0; c + 1 < nchunks; ++c) do_chunk(std::integral_constant<int, FBK / 2>(), c, ABL != 4);
+    do_chunk(std::integral_constant<int, TAIL>(), nchunks - 1, false);
 
     if (ABL == 3) {                                        // K loop only: one never-taken store keeps the accumulators alive
         float t = 0.f;
@@ -239,11 +248,21 @@ static int launch_fused_cfg(const float* xt, const float* bmat_p, const float* v
 #ifdef HPS_DEV_BUILD
     if (g_mesh_lds_floor > lds) lds = g_mesh_lds_floor;     // experiment: fewer workgroups per CU (a larger LDS request, unused)
 #endif
-    if (int rc = grant_lds<&mesh_fused_kernel<K, ABL, JC, HAS_T>>(160 * 1024, "hps_smpl_mesh_fused")) return rc;
     const int tiles_m = ceil_div(M, FM), n_panels = ceil_div(V, FV);
     const int tiles_m_per_xcd = ceil_div(tiles_m, 8);
-    hipLaunchKernelGGL((mesh_fused_kernel<K, ABL, JC, HAS_T>), dim3(tiles_m_per_xcd * 8 * n_panels), dim3(FT), lds, s, xt, bmat_p, v_template,
-                       a, w_idx, w_val, J, transl, reinterpret_cast<f3*>(verts), M, V, kp, mp, np, tiles_m, tiles_m_per_xcd);
+    const dim3 grid(tiles_m_per_xcd * 8 * n_panels);
+    // the last chunk's data-carrying k-pairs: SMPL (K = 10 + 207 -> kp = 218) has 5 of 8; that case is instantiated for the product
+    // configuration, every other tail runs the whole (zero-padded) chunk
+    const int tail = (kp - FBK * ((kp + FBK - 1) / FBK - 1)) / 2;
+    if (K == 4 && JC == 24 && ABL == 0 && tail == 5) {
+        if (int rc = grant_lds<&mesh_fused_kernel<K, ABL, JC, HAS_T, 5>>(160 * 1024, "hps_smpl_mesh_fused")) return rc;
+        hipLaunchKernelGGL((mesh_fused_kernel<K, ABL, JC, HAS_T, 5>), grid, dim3(FT), lds, s, xt, bmat_p, v_template,
+                           a, w_idx, w_val, J, transl, reinterpret_cast<f3*>(verts), M, V, kp, mp, np, tiles_m, tiles_m_per_xcd);
+    } else {
+        if (int rc = grant_lds<&mesh_fused_kernel<K, ABL, JC, HAS_T>>(160 * 1024, "hps_smpl_mesh_fused")) return rc;
+        hipLaunchKernelGGL((mesh_fused_kernel<K, ABL, JC, HAS_T>), grid, dim3(FT), lds, s, xt, bmat_p, v_template,
+                           a, w_idx, w_val, J, transl, reinterpret_cast<f3*>(verts), M, V, kp, mp, np, tiles_m, tiles_m_per_xcd);
+    }
     return check_launch("hps_smpl_mesh_fused");
 }
 
@@ -271,7 +290,7 @@ extern "C" int hps_smpl_mesh_fused_np(int V) { return V > 0 ? ceil_div(V, FV) * 
 static int fused_check_args(const void* xt, const void* bmat_p, const void* v_template, const void* a, const void* w_idx,
                             const void* w_val, const void* verts, int num_joints, int M, int V, int kp, int mp, int np) {
     if (!xt || !bmat_p || !v_template || !a || !w_idx || !w_val || !verts) return bad_arg("hps_smpl_mesh_fused: null pointer");
-    if (kp <= 0 || kp % FBK != 0) return bad_arg("hps_smpl_mesh_fused: kp must be a positive multiple of 16");
+    if (kp <= 0 || kp % 2 != 0) return bad_arg("hps_smpl_mesh_fused: kp must be positive and even");
     if (num_joints < 1 || num_joints > 32) return bad_arg("hps_smpl_mesh_fused: num_joints must be 1..32");
     if (M <= 0 || V <= 0) return 1;                                     /* nothing to do */
     if (mp % FM != 0 || mp < ceil_div(M, FM) * FM) return bad_arg("hps_smpl_mesh_fused: mp must be a multiple of 64 covering M");

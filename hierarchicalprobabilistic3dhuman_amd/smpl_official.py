@@ -86,6 +86,7 @@ class SMPL(nn.Module):
         n_pose = posedirs_v3k.shape[-1]
         self._N = 3 * V
         self._kp = _round_up(nb + n_pose, 16)
+        self._k_used = _round_up(nb + n_pose, 2)          # rows the fused kernel multiplies (the rest of the 16-row padding is zero)
         self._np = _round_up(self._N, 128)
         bmat = np.zeros((self._kp, self._np), np.float64)
         bmat[:nb, :self._N] = shapedirs.reshape(self._N, nb).T                    # row l: d v[n] / d beta_l
@@ -195,7 +196,7 @@ class SMPL(nn.Module):
             if ev is not None:
                 ev[0].record()
             _capi.call("hps_smpl_mesh_fused", P(xt), P(self._bmat_p), P(self._v_template_flat), P(a),
-                       _capi.iptr(self._w_idx), P(self._w_val), self._lbs_k, J, trp, P(verts), M, V, self._kp, mp,
+                       _capi.iptr(self._w_idx), P(self._w_val), self._lbs_k, J, trp, P(verts), M, V, self._k_used, mp,
                        self._np_fused, s)
         else:
             ldv = self._np if self.pad_v_posed else N          # row pitch of v_posed in floats (128-byte aligned rows)

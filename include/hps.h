@@ -136,9 +136,11 @@ int hps_smpl_lbs(const float* v_posed, int ld_vposed, const float* a, const int3
  *   verts[m,v] = (sum_k w[v,k] A[m, idx[v,k]]) . [v_template[v] + sum_k xt[k,m] bmat_p[k, col(v,c)]; 1] (+ transl[m])
  * bmat_p: the blend matrix of hps_smpl_blend with PANEL-PERMUTED columns, (kp, np) k-major, np = hps_smpl_mesh_fused_np(V):
  *   col(v, c) = (v / 64) * 192 + c * 64 + v % 64  (x, y, z of a 64-vertex panel as three 64-wide column groups),
- *   unused columns zero.  xt, a: from hps_smpl_pose_prep (mp a multiple of 64 covering M).  w_idx / w_val / K / transl /
+ *   unused columns zero.  kp here = the K rows that carry data, rounded up to EVEN (SMPL: 10 + 207 -> 218); both operands must be
+ *   allocated (and zero) up to the next multiple of 16 rows -- what hps_smpl_pose_prep / hps_smpl_blend call kp (224): the rows
+ *   behind kp are not multiplied.  xt, a: from hps_smpl_pose_prep (mp a multiple of 64 covering M).  w_idx / w_val / K / transl /
  *   verts as for hps_smpl_lbs.  Bit-identical to hps_smpl_blend followed by hps_smpl_lbs (same MFMA k order, same
- *   skinning arithmetic).  Bound: fp32 MFMA, 2 * kp * 3 V FLOP per mesh; HBM traffic = the 12 V bytes of verts per mesh.
+ *   skinning arithmetic: the skipped rows are zeros).  Bound: fp32 MFMA, 2 * kp * 3 V FLOP per mesh; HBM traffic = the 12 V bytes of verts per mesh.
  * Instantiated where it needs no scratch memory beside four workgroups per CU: K = 4 with any num_joints in 1..32, K = 8 and
  * 12 with num_joints = 24; other combinations (e.g. K = 24, dense skinning weights) return HPS_E_UNSUPPORTED -- take the
  * unfused pair, which gives the same bits.
