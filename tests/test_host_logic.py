@@ -218,3 +218,39 @@ def test_stem_winograd_filters_reproduce_the_convolution():
     want = torch.nn.functional.conv2d(x, w, stride=2, padding=3).numpy()
     # U went through fp32 once (2^-24 relative per entry)
     assert np.abs(y - want).max() <= 3e-6 * np.abs(want).max()
+
+
+def test_smpl_pkl_loader_reads_the_licensed_file_format(tmp_path):
+    """BASELINE configs[3] needs the licensed SMPL_{NEUTRAL,MALE,FEMALE}.pkl (absent here; the reference reads them at
+    models/smpl_official.py:15-16 through smplx).  The guarded loader is exercised on files WRITTEN in that format from the
+    synthetic model: scipy-sparse J_regressor, 300 shape directions of which the first num_betas are kept, an unsigned
+    kintree_table whose root parent is 2^32 - 1, extra keys ignored; SMPL(model_dir, gender=...) resolves the reference's
+    directory + gender convention and ends with the constants of the in-memory model, bit for bit."""
+    import pickle
+    import numpy as np
+    import scipy.sparse
+    from hierarchicalprobabilistic3dhuman_amd import smpl_data
+    from hierarchicalprobabilistic3dhuman_amd.smpl_official import SMPL
+    for gender, seed in (("neutral", 0), ("male", 1), ("female", 2)):
+        m = smpl_data.synthetic_smpl_model(seed)
+        shapedirs300 = np.concatenate([np.asarray(m["shapedirs"]), np.zeros((6890, 3, 290))], axis=2)
+        kt = np.asarray(m["kintree_table"]).astype(np.int64).copy()
+        kt[0, 0] = 2 ** 32 - 1
+        raw = {"v_template": np.asarray(m["v_template"]), "shapedirs": shapedirs300, "posedirs": np.asarray(m["posedirs"]),
+               "J_regressor": scipy.sparse.csc_matrix(np.asarray(m["J_regressor"])), "weights": np.asarray(m["weights"]),
+               "kintree_table": kt.astype(np.uint32), "f": np.zeros((13776, 3), np.uint32), "bs_style": "lbs", "bs_type": "lrotmin"}
+        with open(tmp_path / ("SMPL_%s.pkl" % gender.upper()), "wb") as f:
+            pickle.dump(raw, f, protocol=2)
+    with pytest.raises(FileNotFoundError):
+        smpl_data.resolve_smpl_model(str(tmp_path / "missing"), gender="neutral")
+    for gender, seed in (("neutral", 0), ("male", 1), ("female", 2)):
+        loaded = smpl_data.resolve_smpl_model(str(tmp_path), gender=gender, num_betas=10)
+        want = smpl_data.synthetic_smpl_model(seed)
+        for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "weights"):
+            assert np.array_equal(np.asarray(loaded[k]), np.asarray(want[k])), (gender, k)
+        assert smpl_data.parents_from_kintree(loaded["kintree_table"]).tolist() == \
+            [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21]
+        from_file, from_dict = SMPL(str(tmp_path), batch_size=1, gender=gender, num_betas=10), SMPL(want, gender=gender)
+        assert from_file.parents.tolist() == from_dict.parents.tolist()
+        a, b = from_file.state_dict(), from_dict.state_dict()
+        assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
