@@ -46,6 +46,28 @@ __device__ __forceinline__ int orientation_bin(float gx, float gy) {
     return 4 + (1 - 2 * sy) * d;
 }
 
+// The same decision for the row-marching kernel, in two straight-line pieces: the sector arithmetic for every pixel (selects only,
+// no divergent control flow -- a wave that owns a whole strip runs one per SIMD, so every exec-mask region costs issue slots nothing
+// hides), and `near`: the pixel must take the reference's formula instead (orientation_bin_slow), which the caller evaluates under ONE
+// branch per group of four pixels.  Same conditions and the same results as orientation_bin.
+__device__ __forceinline__ int orientation_bin_fast(float gx, float gy, bool& near) {
+    const float ax = fabsf(gx), ay = fabsf(gy);
+    const float T1 = 0.41421356237309503f, T2 = 2.4142135623730951f;
+    const float b1 = T1 * ax, b2 = T2 * ax;
+    const bool on1 = fabsf(ay - b1) <= 1e-4f * b1, on2 = fabsf(ay - b2) <= 1e-4f * b2, zero = ax == 0.0f && ay == 0.0f;
+    near = (on1 | on2) & !zero;
+    const int sx = (int)(__builtin_bit_cast(unsigned, gx) >> 31), sy = (int)(__builtin_bit_cast(unsigned, gy) >> 31);
+    const int d_h = 4 * sx, d_d = 1 + 2 * sx;
+    const bool h = ay <= b1, v = ay >= b2;
+    const int d_vd = v ? 2 : d_d;
+    const int d = h ? d_h : d_vd;
+    return 4 + (1 - 2 * sy) * d;
+}
+__device__ __forceinline__ int orientation_bin_slow(float gx, float gy) {
+    const float ori = atan2f(gy, gx) * (180.0f / 3.14159265358979323846f) + 180.0f;
+    return (int)rintf(ori / 45.0f);
+}
+
 // One workgroup = one 32x32 tile of one image.  Every stage reproduces the zero padding of the reference's
 // chain of nn.Conv2d calls: each convolution sees zeros outside the IMAGE, not outside the tile.
 // The earlier version of this kernel worked pixel by pixel (one LDS word, one index decode and one border test per value): about
@@ -268,9 +290,9 @@ struct CannyOut {
     size_t edge_batch_stride;
 };
 
-template <int C, bool FULL, bool VEC>
+template <int C, bool FULL, bool VEC, bool NMS>
 __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict__ img, float g0, float g1, float g2, float g3,
-                                                         float g4, CannyOut out, int H, int W, float threshold, int nms,
+                                                         float g4, CannyOut out, int H, int W, float threshold,
                                                          int rows_per_strip, int strips, int col_blocks, int n_items) {
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= n_items) return;                                   // whole waves only: every lane of a wave stays active below
@@ -413,20 +435,34 @@ __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict
             const float (&gxp)[4] = gr[(S2 + 1) % 2][0];
             const float (&gyp)[4] = gr[(S2 + 1) % 2][1];
             float o_mag[4], o_ori[4], o_thr[4], o_thin[4], o_edge[4];
+            int kbin[4];
+            bool near[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kbin[e] = orientation_bin_fast(gxp[e], gyp[e], near[e]);       // :128-129
+            if (near[0] | near[1] | near[2] | near[3]) {               // rare: a gradient on a sector boundary
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ks = orientation_bin_slow(gxp[e], gyp[e]);
+                    kbin[e] = near[e] ? ks : kbin[e];
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float m = m1[e + 1];
-                const int kbin = orientation_bin(gxp[e], gyp[e]);                               // :128-129
                 const float mt = (m < threshold) ? 0.f : m;                                     // :132-133
-                o_mag[e] = m; o_ori[e] = 45.0f * (float)kbin; o_thr[e] = mt; o_thin[e] = 0.f; o_edge[e] = mt;
-                if (nms) {
-                    // the four direction pairs E/W, SE/NW, S/N, SW/NE (:56-102), all evaluated; positive_idx mod 4 (:144) picks one.
-                    // (Selecting the two NEIGHBOURS by pos instead made hipcc index the magnitude window dynamically -- through
-                    // scratch memory, a vmcnt(0) wait per pixel.)
-                    const int pos = kbin & 3;
-                    const bool im0 = fminf(m - m1[e + 2], m - m1[e]) > 0.0f, im1 = fminf(m - m2[e + 2], m - m0[e]) > 0.0f;
-                    const bool im2 = fminf(m - m2[e + 1], m - m0[e + 1]) > 0.0f, im3 = fminf(m - m2[e], m - m0[e + 2]) > 0.0f;
-                    const bool is_max = pos == 0 ? im0 : pos == 1 ? im1 : pos == 2 ? im2 : im3;   // :154
+                o_mag[e] = m; o_ori[e] = 45.0f * (float)kbin[e]; o_thr[e] = mt; o_thin[e] = 0.f; o_edge[e] = mt;
+                if (NMS) {
+                    // the direction pair E/W, SE/NW, S/N or SW/NE (:56-102) that positive_idx mod 4 (:144) picks.  The eight
+                    // neighbours are named values BEFORE the selects: written as pos == 0 ? m1[e + 2] : ... hipcc merged the
+                    // array reads into one read at a selected ADDRESS -- the window went to scratch memory.
+                    const int pos = kbin[e] & 3;
+                    const float n_e = m1[e + 2], n_w = m1[e], n_se = m2[e + 2], n_nw = m0[e];
+                    const float n_s = m2[e + 1], n_n = m0[e + 1], n_sw = m2[e], n_ne = m0[e + 2];
+                    const bool p0 = pos == 0, p1 = pos == 1, p2 = pos == 2;
+                    const float na2 = p2 ? n_s : n_sw, nc2 = p2 ? n_n : n_ne;
+                    const float na1 = p1 ? n_se : na2, nc1 = p1 ? n_nw : nc2;
+                    const float na = p0 ? n_e : na1, nc = p0 ? n_w : nc1;
+                    const bool is_max = fminf(m - na, m - nc) > 0.0f;                            // :154
                     const float tt = is_max ? m : 0.f;                                          // :158-159
                     o_thin[e] = tt;
                     o_edge[e] = (tt < threshold) ? 0.f : tt;                                    // :160-161
@@ -437,7 +473,7 @@ __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict
                 store4(out.grad_mag, o, o_mag);
                 store4(out.grad_ori, o, o_ori);
                 store4(out.thr_mag, o, o_thr);
-                if (nms) { store4(out.thin, o, o_thin); store4(out.thr_thin, o, o_edge); }
+                if (NMS) { store4(out.thin, o, o_thin); store4(out.thr_thin, o, o_edge); }
             }
             store4(out.edge, (size_t)b * out.edge_batch_stride + (size_t)y_o * W + x, o_edge);
         }
@@ -590,12 +626,14 @@ static int launch_canny(const char* who, const float* img, const float* gauss_ta
         const dim3 grid((unsigned)ceil_div((int)n_items, 4)), block(256);
         const float* t = gauss_taps_host;
         hipStream_t st = (hipStream_t)stream;
-#define HPS_CANNY_ROWS(CC, FF, VV) hipLaunchKernelGGL((canny_rows_kernel<CC, FF, VV>), grid, block, 0, st, img, t[0], t[1], t[2], t[3], t[4], o, H, W, threshold, nms, rows, strips, col_blocks, (int)n_items)
-#define HPS_CANNY_ROWS_F(CC, VV) do { if (full) HPS_CANNY_ROWS(CC, true, VV); else HPS_CANNY_ROWS(CC, false, VV); } while (0)
+#define HPS_CANNY_ROWS(CC, FF, VV, NN) hipLaunchKernelGGL((canny_rows_kernel<CC, FF, VV, NN>), grid, block, 0, st, img, t[0], t[1], t[2], t[3], t[4], o, H, W, threshold, rows, strips, col_blocks, (int)n_items)
+#define HPS_CANNY_ROWS_N(CC, FF, VV) do { if (nms) HPS_CANNY_ROWS(CC, FF, VV, true); else HPS_CANNY_ROWS(CC, FF, VV, false); } while (0)
+#define HPS_CANNY_ROWS_F(CC, VV) do { if (full) HPS_CANNY_ROWS_N(CC, true, VV); else HPS_CANNY_ROWS_N(CC, false, VV); } while (0)
         const bool vec = (W & 3) == 0;
         if (C == 3) { if (vec) HPS_CANNY_ROWS_F(3, true); else HPS_CANNY_ROWS_F(3, false); }
         else { if (vec) HPS_CANNY_ROWS_F(1, true); else HPS_CANNY_ROWS_F(1, false); }
 #undef HPS_CANNY_ROWS_F
+#undef HPS_CANNY_ROWS_N
 #undef HPS_CANNY_ROWS
         return check_launch(who);
     }
