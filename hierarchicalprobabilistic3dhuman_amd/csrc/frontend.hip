@@ -270,11 +270,12 @@ __global__ __launch_bounds__(256) void canny_kernel(const float* __restrict__ im
 // decoding; the arithmetic of every pixel is the tile kernel's, in the same order.
 //   step with input row y:  h(y) -> blurred(y - 2) -> gradient, magnitude(y - 3) -> outputs(y - 4)
 // Images wider than 256 are cut into column blocks of 248 valid columns with four columns of overlap on each side.
+// (bound_ctrl: the lane without a source reads 0 -- no zeroed destination register to set up per shift)
 __device__ __forceinline__ float dpp_from_left(float v) {      // lane i <- lane i - 1; lane 0 <- 0
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float dpp_from_right(float v) {     // lane i <- lane i + 1; lane 63 <- 0
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
 // grad / num_channels (:125), correctly rounded (div3_rn: hps_common.h).  One channel: nothing to do.
@@ -345,7 +346,8 @@ __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict
 
     // Every vertical window is a ring indexed by the step number modulo its length; the step loop is unrolled six times (a multiple
     // of every ring length, the five-row Gaussian ring carrying one spare slot), so that every ring index is a compile-time
-    // constant and no window is ever shifted through register moves.
+    // constant and no window is ever shifted through register moves.  Every slot is written before its first use (the eight
+    // warm-up steps below fill the rings in the order the stages consume them), so nothing is initialised.
     float hw[C][6][4];             // horizontally filtered rows: row y_in lands in slot t % 6
     float ar[C][3][6];             // blurred rows, columns x - 1 .. x + 4: row y_bl lands in slot t % 3
     float mr[3][6];                // magnitude rows, columns x - 1 .. x + 4: row y_g lands in slot t % 3
@@ -353,28 +355,17 @@ __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict
     float4 inr[C][3];              // input rows: row y_in sits in slot t % 3, row y_in + 2 is loaded into slot (t + 2) % 3
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) hw[c][k][e] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int e = 0; e < 6; ++e) ar[c][k][e] = 0.f;
         inr[c][0] = load_row(c, Y0 - 4);
         inr[c][1] = load_row(c, Y0 - 3);
     }
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int e = 0; e < 6; ++e) mr[k][e] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { gr[k][0][e] = 0.f; gr[k][1][e] = 0.f; }
 
-    auto step = [&](auto ph, int t) __attribute__((always_inline)) {
+    // STAGES: how much of the chain a step runs -- 1: horizontal Gaussian only, 2: + vertical Gaussian (a blurred row), 3: + Sobel
+    // and magnitude, 4: + the outputs of a row.  The strip's first output row Y0 needs magnitudes from Y0 - 1, blurred rows from
+    // Y0 - 2, horizontally filtered rows from Y0 - 4: the warm-up steps t = 0..3 run stage 1, t = 4, 5 stages 1-2, t = 6, 7 stages
+    // 1-3 (2.5 instead of 5.5 steps' worth of instructions for the eight rows of halo every strip re-reads).
+    auto step = [&](auto ph, auto stages, int t) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph)::value;                    // t % 6
+        constexpr int STAGES = decltype(stages)::value;
         constexpr int S3 = PH % 3, S2 = PH % 2;
         const int y_in = Y0 - 4 + t, y_bl = y_in - 2, y_g = y_in - 3, y_o = y_in - 4;
         const bool bl_in = y_bl >= 0 && y_bl < H, g_in = y_g >= 0 && y_g < H;
@@ -394,6 +385,7 @@ __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict
                 hw[c][PH][e] = acc;    // outside the image's columns this is not zero as the reference's is -- but the vertical pass
                                        // does not mix columns, and the blurred row is zeroed there below
             }
+            if (STAGES < 2) continue;
             // ---- vertical Gaussian: blurred row y_bl from the rows y_in - 4 .. y_in of the ring ----
             float bl[4];
 #pragma unroll
@@ -410,12 +402,14 @@ __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict
             const float (&a1)[6] = ar[c][(S3 + 2) % 3];
             const float (&a0)[6] = ar[c][(S3 + 1) % 3];
             a2[0] = dpp_from_left(bl[3]); a2[1] = bl[0]; a2[2] = bl[1]; a2[3] = bl[2]; a2[4] = bl[3]; a2[5] = dpp_from_right(bl[0]);
+            if (STAGES < 3) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 gx[e] += (a0[e] - a0[e + 2]) + 2.f * (a1[e] - a1[e + 2]) + (a2[e] - a2[e + 2]);
                 gy[e] += (a0[e] - a2[e]) + 2.f * (a0[e + 1] - a2[e + 1]) + (a0[e + 2] - a2[e + 2]);
             }
         }
+        if (STAGES < 3) return;
         // ---- gradient magnitude (:126-127) of row y_g, zero outside the image ----
         float (&m2)[6] = mr[S3];
         const float (&m1)[6] = mr[(S3 + 2) % 3];
@@ -430,8 +424,9 @@ __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict
             mg[e] = (g_in && cin[e]) ? sqrtf(gx[e] * gx[e] + gy[e] * gy[e]) : 0.f;
         }
         m2[0] = dpp_from_left(mg[3]); m2[1] = mg[0]; m2[2] = mg[1]; m2[3] = mg[2]; m2[4] = mg[3]; m2[5] = dpp_from_right(mg[0]);
+        if (STAGES < 4) return;
         // ---- outputs of row y_o = y_g - 1: magnitudes m0 / m1 / m2 = rows y_o - 1, y_o, y_o + 1, gradient of the previous step ----
-        if (y_o >= Y0 && y_o < Y1) {
+        {
             const float (&gxp)[4] = gr[(S2 + 1) % 2][0];
             const float (&gyp)[4] = gr[(S2 + 1) % 2][1];
             float o_mag[4], o_ori[4], o_thr[4], o_thin[4], o_edge[4];
@@ -478,16 +473,31 @@ __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict
             store4(out.edge, (size_t)b * out.edge_batch_stride + (size_t)y_o * W + x, o_edge);
         }
     };
-    // six steps per iteration, unconditionally (a step beyond the strip loads zeros and stores nothing): one basic block, so that
-    // the waits for the rows loaded two steps earlier count the memory operations issued since (behind a branch per step hipcc fell
-    // back to s_waitcnt vmcnt(0) -- also draining the loads just issued, i.e. no prefetch at all)
-    for (int t = 0; t < steps; t += 6) {
-        step(std::integral_constant<int, 0>(), t);
-        step(std::integral_constant<int, 1>(), t + 1);
-        step(std::integral_constant<int, 2>(), t + 2);
-        step(std::integral_constant<int, 3>(), t + 3);
-        step(std::integral_constant<int, 4>(), t + 4);
-        step(std::integral_constant<int, 5>(), t + 5);
+    using std::integral_constant;
+    step(integral_constant<int, 0>(), integral_constant<int, 1>(), 0);
+    step(integral_constant<int, 1>(), integral_constant<int, 1>(), 1);
+    step(integral_constant<int, 2>(), integral_constant<int, 1>(), 2);
+    step(integral_constant<int, 3>(), integral_constant<int, 1>(), 3);
+    step(integral_constant<int, 4>(), integral_constant<int, 2>(), 4);
+    step(integral_constant<int, 5>(), integral_constant<int, 2>(), 5);
+    step(integral_constant<int, 0>(), integral_constant<int, 3>(), 6);
+    step(integral_constant<int, 1>(), integral_constant<int, 3>(), 7);
+    // The rows of the strip: step t = 8 + i writes row Y0 + i.  The only branches are the exits (nothing joins the straight line
+    // again, so the waits for the rows loaded two steps earlier still count the memory operations issued since: behind a branch
+    // AROUND every step hipcc fell back to s_waitcnt vmcnt(0) -- also draining the loads just issued, i.e. no prefetch at all).
+    for (int t = 8;; t += 6) {
+        step(integral_constant<int, 2>(), integral_constant<int, 4>(), t);
+        if (t + 1 >= steps) return;
+        step(integral_constant<int, 3>(), integral_constant<int, 4>(), t + 1);
+        if (t + 2 >= steps) return;
+        step(integral_constant<int, 4>(), integral_constant<int, 4>(), t + 2);
+        if (t + 3 >= steps) return;
+        step(integral_constant<int, 5>(), integral_constant<int, 4>(), t + 3);
+        if (t + 4 >= steps) return;
+        step(integral_constant<int, 0>(), integral_constant<int, 4>(), t + 4);
+        if (t + 5 >= steps) return;
+        step(integral_constant<int, 1>(), integral_constant<int, 4>(), t + 5);
+        if (t + 6 >= steps) return;
     }
 }
 
