@@ -295,7 +295,9 @@ template <int C, bool FULL, bool VEC, bool NMS>
 __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict__ img, float g0, float g1, float g2, float g3,
                                                          float g4, CannyOut out, int H, int W, float threshold,
                                                          int rows_per_strip, int strips, int col_blocks, int n_items) {
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the wave's number as a SCALAR (readfirstlane: hipcc cannot know that threadIdx.x >> 6 is the same in all 64 lanes): the strip,
+    // its rows and every row test below then live in scalar registers, row addresses are scalar bases + one per-lane column offset
+    const int item = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (item >= n_items) return;                                   // whole waves only: every lane of a wave stays active below
     const int lane = threadIdx.x & 63;
     const int s = item % strips, cb = (item / strips) % col_blocks, b = item / (strips * col_blocks);
@@ -315,32 +317,38 @@ __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict
 
     // Branch-free loads (a clamped address is always read, pixels outside the image are then replaced by zero): with a branch per
     // load hipcc lost track of the loads in flight and waited for all of them (s_waitcnt vmcnt(0)) in front of every use.
-    int xc[4];
+    unsigned xc[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) xc[e] = cin[e] ? x + e : 0;
+    for (int e = 0; e < 4; ++e) xc[e] = cin[e] ? 4u * (unsigned)(x + e) : 0u;
+    // BYTE offsets of the lane's columns in a row, 32 bits wide (vector load / stores): "scalar row address + zero-extended 32-bit
+    // lane offset" is the form hipcc turns into global_load/store ... s[base:base+1] -- no 64-bit address per lane and access
+    const unsigned xv = all_in ? 4u * (unsigned)x : 0u, xs = 4u * (unsigned)max(x, 0);
     auto load_row = [&](int c, int y) __attribute__((always_inline)) -> float4 {
         const bool yin = y >= 0 && y < H;
         const float* row = img + ((size_t)b * C + c) * plane + (size_t)min(max(y, 0), H - 1) * W;
         float4 v;
         if (VEC) {
-            v = *reinterpret_cast<const float4*>(row + (all_in ? x : 0));
+            v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(row) + xv);
             const bool keep = yin && all_in;
             v.x = keep ? v.x : 0.f; v.y = keep ? v.y : 0.f; v.z = keep ? v.z : 0.f; v.w = keep ? v.w : 0.f;
         } else {
-            v.x = row[xc[0]]; v.y = row[xc[1]]; v.z = row[xc[2]]; v.w = row[xc[3]];
+            const char* rb = reinterpret_cast<const char*>(row);
+            v.x = *reinterpret_cast<const float*>(rb + xc[0]); v.y = *reinterpret_cast<const float*>(rb + xc[1]);
+            v.z = *reinterpret_cast<const float*>(rb + xc[2]); v.w = *reinterpret_cast<const float*>(rb + xc[3]);
             v.x = (yin && cin[0]) ? v.x : 0.f; v.y = (yin && cin[1]) ? v.y : 0.f;
             v.z = (yin && cin[2]) ? v.z : 0.f; v.w = (yin && cin[3]) ? v.w : 0.f;
         }
         return v;
     };
-    auto store4 = [&](float* base, size_t off, const float (&v)[4]) __attribute__((always_inline)) {
+    auto store4 = [&](float* base, size_t row_off, const float (&v)[4]) __attribute__((always_inline)) {   // row_off: scalar
         if (!base) return;
+        char* row = reinterpret_cast<char*>(base + row_off);
         if (VEC) {
-            if (all_st) *reinterpret_cast<float4*>(base + off) = make_float4(v[0], v[1], v[2], v[3]);
+            if (all_st) *reinterpret_cast<float4*>(row + xs) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (cst[e]) base[off + e] = v[e];
+                if (cst[e]) *reinterpret_cast<float*>(row + (xs + 4u * e)) = v[e];
         }
     };
 
@@ -396,7 +404,7 @@ __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict
                 bl[e] = (bl_in && cin[e]) ? acc : 0.f;             // zero outside the image: what the Sobel convolutions pad with
             }
             if (FULL && bl_in && y_bl >= Y0 && y_bl < Y1)                                                         // :119
-                store4(out.blurred, ((size_t)b * C + c) * plane + (size_t)y_bl * W + x, bl);
+                store4(out.blurred, ((size_t)b * C + c) * plane + (size_t)y_bl * W, bl);
             // ---- Sobel (:122-123) of row y_g from the blurred rows y_g - 1 (a0), y_g (a1), y_g + 1 (a2, new) ----
             float (&a2)[6] = ar[c][S3];
             const float (&a1)[6] = ar[c][(S3 + 2) % 3];
@@ -463,14 +471,14 @@ __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict
                     o_edge[e] = (tt < threshold) ? 0.f : tt;                                    // :160-161
                 }
             }
-            const size_t o = (size_t)b * plane + (size_t)y_o * W + x;
+            const size_t o = (size_t)b * plane + (size_t)y_o * W;
             if (FULL) {
                 store4(out.grad_mag, o, o_mag);
                 store4(out.grad_ori, o, o_ori);
                 store4(out.thr_mag, o, o_thr);
                 if (NMS) { store4(out.thin, o, o_thin); store4(out.thr_thin, o, o_edge); }
             }
-            store4(out.edge, (size_t)b * out.edge_batch_stride + (size_t)y_o * W + x, o_edge);
+            store4(out.edge, (size_t)b * out.edge_batch_stride + (size_t)y_o * W, o_edge);
         }
     };
     using std::integral_constant;
