@@ -401,36 +401,48 @@ __global__ __launch_bounds__(256) void nchw_to_padded_nhwc_generic_kernel(const 
     y[((b * (H + 2 * P) + h + P) * (long)(WF + 2 * P) + w + P) * CP + c] = x[i];
 }
 
-// MaxPool2d(3, 2, 1) on NHWC, thread per (output pixel, 4 channels); output written into a frame with halo opad
+// MaxPool2d(3, 2, 1) on NHWC, thread per (2 x 2 output pixels, 4 channels); output written into a frame with halo opad.
+// The four windows of a 2 x 2 output block share a 5 x 5 input patch: 25 loads for four outputs instead of 36 (the kernel is
+// bound by the requests its loads put to the vector cache, not by HBM: every input pixel used to be fetched 2.25 times), and
+// the row maxima are formed once per patch row and column triple.
 __global__ __launch_bounds__(256) void maxpool_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
                                                           int C, int Ho, int Wo, int opad, long total) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int c4 = C / 4;
+    const int c4 = C / 4, Ho2 = (Ho + 1) / 2, Wo2 = (Wo + 1) / 2;
     const int cq = (int)(i % c4);
     long p = i / c4;
-    const int wo = (int)(p % Wo); p /= Wo;
-    const int ho = (int)(p % Ho);
-    const long b = p / Ho;
+    const int wo = 2 * (int)(p % Wo2); p /= Wo2;
+    const int ho = 2 * (int)(p % Ho2);
+    const long b = p / Ho2;
     // Guard-free: a tap outside the map is clamped onto the nearest row / column, which belongs to the window anyway (max is
-    // idempotent: exact).  All nine loads go out before the first comparison; with `if (outside) continue` every load sat in a
+    // idempotent: exact).  All loads go out before the first comparison; with `if (outside) continue` every load sat in a
     // block of its own behind s_waitcnt vmcnt(0).
-    float4 v[9];
+    float4 v[5][5];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int hi = min(max(ho * 2 - 1 + kh, 0), H - 1);
+    for (int r = 0; r < 5; ++r) {
+        const int hi = min(max(ho * 2 - 1 + r, 0), H - 1);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int wi = min(max(wo * 2 - 1 + kw, 0), W - 1);
-            v[kh * 3 + kw] = *reinterpret_cast<const float4*>(x + ((b * H + hi) * W + wi) * C + cq * 4);
+        for (int q = 0; q < 5; ++q) {
+            const int wi = min(max(wo * 2 - 1 + q, 0), W - 1);
+            v[r][q] = *reinterpret_cast<const float4*>(x + ((b * H + hi) * W + wi) * C + cq * 4);
         }
     }
-    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    auto max4 = [](const float4& a, const float4& c) { return make_float4(fmaxf(a.x, c.x), fmaxf(a.y, c.y), fmaxf(a.z, c.z), fmaxf(a.w, c.w)); };
+    float4 hm[5][2];               // maxima over the columns 0..2 / 2..4 of every patch row
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        m.x = fmaxf(m.x, v[t].x); m.y = fmaxf(m.y, v[t].y); m.z = fmaxf(m.z, v[t].z); m.w = fmaxf(m.w, v[t].w);
+    for (int r = 0; r < 5; ++r) {
+        hm[r][0] = max4(max4(v[r][0], v[r][1]), v[r][2]);
+        hm[r][1] = max4(max4(v[r][2], v[r][3]), v[r][4]);
     }
-    *reinterpret_cast<float4*>(y + ((b * (Ho + 2 * opad) + ho + opad) * (long)(Wo + 2 * opad) + wo + opad) * C + cq * 4) = m;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (ho + a >= Ho || wo + c >= Wo) continue;
+            const float4 m = max4(max4(hm[2 * a][c], hm[2 * a + 1][c]), hm[2 * a + 2][c]);
+            *reinterpret_cast<float4*>(y + ((b * (Ho + 2 * opad) + ho + a + opad) * (long)(Wo + 2 * opad) + wo + c + opad) * C + cq * 4) = m;
+        }
 }
 
 // global average pool over the interior of a padded frame: thread per (b, c), coalesced over c, pixels in row-major order
@@ -574,7 +586,7 @@ extern "C" int hps_maxpool3x3s2_pad(const float* x, float* y, int B, int H, int 
     if (!x || !y) return bad_arg("hps_maxpool3x3s2_pad: null pointer");
     if (C % 4 != 0) return bad_arg("hps_maxpool3x3s2_pad: C % 4 == 0 required");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    const long total = (long)B * Ho * Wo * (C / 4);
+    const long total = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2) * (C / 4);
     if (total <= 0) return HPS_OK;
     hipLaunchKernelGGL(maxpool_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, H, W,
                        C, Ho, Wo, opad, total);
