@@ -88,10 +88,12 @@ def test_edge_map_entry_point_equals_the_detectors_dict_entry(nms, thr, dev, gol
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1, 3, 256, 256), (3, 3, 70, 45), (2, 1, 33, 32), (1, 3, 40, 300), (2, 1, 21, 522), (1, 2, 37, 50),
-                                   (1, 3, 9, 252)])
+                                   (1, 3, 9, 252), (1, 3, 3, 8), (2, 1, 65, 64), (3, 3, 17, 260), (1, 3, 1, 4)])
 def test_canny_kernel_matches_oracle_at_borders_and_odd_sizes(shape, dev):
     """Shapes wider than 256 run the row-marching kernel in column blocks of 248 valid columns (300 -> 2 blocks, 522 -> 3), W % 4 != 0
-    takes its scalar-load instantiation, two channels the tile kernel, 9 rows a single ragged strip."""
+    takes its scalar-load instantiation, two channels the tile kernel, 9 rows a single ragged strip.  Strips of 1, 3 and 8 + 1 rows
+    (65 rows in strips of 8: the last one has a single row) leave the row loop by each of its early exits; the warm-up steps run
+    above the image there (rows -4 .. -1 of the first strip)."""
     from hierarchicalprobabilistic3dhuman_amd.canny_edge_detector import CannyEdgeDetector
     g = torch.Generator().manual_seed(sum(shape))
     B, C, H, W = shape

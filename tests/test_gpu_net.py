@@ -206,6 +206,15 @@ def test_padded_pooling_and_layout_kernels(dev):
     _capi.call("hps_maxpool3x3s2_pad", P(yh), P(out), 2, 13, 11, 64, 1, _capi.stream())
     assert maxerr(out[:, 1:-1, 1:-1].permute(0, 3, 1, 2), F.max_pool2d(y, 3, 2, 1)) == 0.0
     assert float(out[:, 0].abs().max()) == 0.0 and float(out[:, :, 0].abs().max()) == 0.0
+    # a thread pools a 2 x 2 block of outputs: odd / even output sizes, a single row, a single pixel
+    for (h, w, c) in [(1, 1, 4), (2, 5, 8), (6, 6, 64), (7, 1, 12), (16, 9, 64)]:
+        z = torch.randn(3, c, h, w, generator=torch.Generator().manual_seed(h * 31 + w))
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        zo = torch.zeros(3, ho + 4, wo + 4, c, device=dev)
+        _capi.call("hps_maxpool3x3s2_pad", P(z.to(dev).permute(0, 2, 3, 1).contiguous()), P(zo), 3, h, w, c, 2, _capi.stream())
+        assert maxerr(zo[:, 2:-2, 2:-2].permute(0, 3, 1, 2), F.max_pool2d(z, 3, 2, 1)) == 0.0, (h, w, c)
+        zo[:, 2:-2, 2:-2] = 0
+        assert float(zo.abs().max()) == 0.0, (h, w, c)
     avg = torch.empty(2, 64, device=dev)
     _capi.call("hps_global_avgpool_pad", P(_frame(yh, 1)), P(avg), 2, 13, 11, 64, 1, _capi.stream())
     plain = torch.empty(2, 64, device=dev)
