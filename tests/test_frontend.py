@@ -5,6 +5,7 @@ Stated tolerance: 2e-6 on blurred image / gradient magnitude / heat-maps.  Orien
 suppression decision are discontinuous: a pixel may differ only where the reference's own decision sits on an fp32
 rounding tie (orientation exactly on a 22.5 degree boundary, or equal neighbouring magnitudes); such pixels are
 bounded to <= 0.1 % and must have matching magnitudes."""
+import numpy as np
 import pytest
 import torch
 
@@ -105,6 +106,36 @@ def test_canny_kernel_matches_oracle_at_borders_and_odd_sizes(shape, dev):
     assert maxerr(out["grad_magnitude"], ref["grad_magnitude"]) <= 2e-6
     for k in ("thin_edges", "thresholded_thin_edges", "thresholded_grad_magnitude"):
         assert _fraction_differing(out[k], ref[k], 2e-6) <= 2e-3, k
+
+
+@pytest.mark.gpu
+def test_canny_rows_kernel_on_random_shapes(dev):
+    """Sixteen seeded random shapes (1 or 3 channels, 1-5 images, 1-140 rows, 4-600 columns, with and without NMS): every strip height
+    the launcher can choose, ragged last strips, one to three column blocks, both load forms -- against the oracle, and the edge-map
+    entry point against the full detector bit for bit."""
+    from hierarchicalprobabilistic3dhuman_amd.canny_edge_detector import CannyEdgeDetector
+    rng = np.random.RandomState(4)
+    for _ in range(16):
+        B, C = int(rng.randint(1, 6)), int(rng.choice([1, 3]))
+        H = int(rng.randint(1, 141))
+        W = 4 * int(rng.randint(1, 151)) if rng.randint(0, 2) else int(rng.randint(4, 601))      # half of them with 16-byte rows
+        nms, thr = bool(rng.randint(0, 2)), float(rng.choice([0.0, 0.05, 0.2]))
+        g = torch.Generator().manual_seed(B * 1000003 + H * 1009 + W)
+        img = torch.nn.functional.interpolate(torch.rand(B, C, max(H // 4, 2), max(W // 4, 2), generator=g), size=(H, W),
+                                              mode="bilinear", align_corners=False) + 0.05 * torch.rand(B, C, H, W, generator=g)
+        ref = O.canny_edge_detector(img, nms, 1.0, 5, thr)
+        det = CannyEdgeDetector(nms, 1.0, 5, thr).to(dev)
+        out = det(img.to(dev))
+        tag = (B, C, H, W, nms, thr)
+        assert maxerr(out["blurred_img"], ref["blurred_img"]) <= 2e-6, tag
+        assert maxerr(out["grad_magnitude"], ref["grad_magnitude"]) <= 2e-6, tag
+        keys = ("thin_edges", "thresholded_thin_edges", "thresholded_grad_magnitude") if nms else ("thresholded_grad_magnitude",)
+        for k in keys:
+            assert _fraction_differing(out[k], ref[k], 2e-6) <= max(2e-3, 2.0 / (B * H * W)), (k,) + tag
+        edge = torch.full((B, 2, H, W), -1.0, device=dev)
+        det.edge_map_into(img.to(dev), edge)
+        assert torch.equal(edge[:, 0], out["thresholded_thin_edges" if nms else "thresholded_grad_magnitude"][:, 0]), tag
+        assert float(edge[:, 1].max()) == -1.0 and float(edge[:, 1].min()) == -1.0, tag
 
 
 @pytest.mark.gpu
