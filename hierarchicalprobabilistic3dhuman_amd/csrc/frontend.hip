@@ -315,40 +315,53 @@ __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict
     const int Y0 = s * rows_per_strip, Y1 = min(H, Y0 + rows_per_strip);
     const int steps = (Y1 - Y0) + 8;
 
-    // Branch-free loads (a clamped address is always read, pixels outside the image are then replaced by zero): with a branch per
-    // load hipcc lost track of the loads in flight and waited for all of them (s_waitcnt vmcnt(0)) in front of every use.
-    unsigned xc[4];
+    // Memory accesses are BUFFER instructions on a descriptor of ONE ROW (base = the row's address, a scalar; num_records = its
+    // W * 4 bytes, or 0 when the row does not exist / must not be written): a lane whose byte offset is not below num_records reads
+    // zeros and its stores are dropped -- by the address unit, not by the exec mask.  So every load and store is issued
+    // unconditionally: no clamped addresses and zero-selects, and no branch around any of them.  With `if (lane stores)` regions
+    // around global stores hipcc could not count the stores in flight (vmcnt counts loads AND stores on gfx9; a skipped region
+    // issues none), assumed none, and waited s_waitcnt vmcnt(6) for the row loaded two steps earlier -- i.e. for all but the last
+    // six memory operations, the previous step's nine stores included; now the waits are vmcnt(17..21).  (Measured: 240 fewer
+    // VALU instructions per six steps, no AGPR spills, 0.0416 -> 0.0405 ms; the 30 % of the wave cycles that SQ_WAIT_ANY reports
+    // -- tools/canny_pmc.sh -- did NOT move, so they are not waits for stores.)
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    constexpr int RSRC_FLAGS = 0x00020000;                         // raw buffer, 32-bit data format (gfx90a / gfx94x / gfx950)
+    const unsigned row_bytes = 4u * (unsigned)W;
+    // per-lane byte offsets, constant for the whole kernel.  Loads: 4 x as an unsigned number -- columns left of the image wrap to
+    // 2^32 - 16, columns right of it are >= row_bytes: both out of range.  Stores: out of range unless the lane stores the column.
+    const unsigned ld_off = 4u * (unsigned)x;
+    unsigned st_off[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) xc[e] = cin[e] ? 4u * (unsigned)(x + e) : 0u;
-    // BYTE offsets of the lane's columns in a row, 32 bits wide (vector load / stores): "scalar row address + zero-extended 32-bit
-    // lane offset" is the form hipcc turns into global_load/store ... s[base:base+1] -- no 64-bit address per lane and access
-    const unsigned xv = all_in ? 4u * (unsigned)x : 0u, xs = 4u * (unsigned)max(x, 0);
+    for (int e = 0; e < 4; ++e) st_off[e] = cst[e] ? 4u * (unsigned)(x + e) : 0xffffffffu;
+    const unsigned st_off4 = all_st ? 4u * (unsigned)x : 0xffffffffu;
     auto load_row = [&](int c, int y) __attribute__((always_inline)) -> float4 {
         const bool yin = y >= 0 && y < H;
         const float* row = img + ((size_t)b * C + c) * plane + (size_t)min(max(y, 0), H - 1) * W;
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, yin ? row_bytes : 0u, RSRC_FLAGS);
         float4 v;
         if (VEC) {
-            v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(row) + xv);
-            const bool keep = yin && all_in;
-            v.x = keep ? v.x : 0.f; v.y = keep ? v.y : 0.f; v.z = keep ? v.z : 0.f; v.w = keep ? v.w : 0.f;
+            // (the whole vector is bit-cast: __builtin_bit_cast(float, q.y) on an ELEMENT of the loaded vector is miscompiled by this
+            // hipcc -- it narrows the load to one dword and uses undefined values for y, z, w; tools/buffer_probe.hip)
+            const v4f q = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, ld_off, 0, 0));
+            v = make_float4(q.x, q.y, q.z, q.w);
         } else {
-            const char* rb = reinterpret_cast<const char*>(row);
-            v.x = *reinterpret_cast<const float*>(rb + xc[0]); v.y = *reinterpret_cast<const float*>(rb + xc[1]);
-            v.z = *reinterpret_cast<const float*>(rb + xc[2]); v.w = *reinterpret_cast<const float*>(rb + xc[3]);
-            v.x = (yin && cin[0]) ? v.x : 0.f; v.y = (yin && cin[1]) ? v.y : 0.f;
-            v.z = (yin && cin[2]) ? v.z : 0.f; v.w = (yin && cin[3]) ? v.w : 0.f;
+            v.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, ld_off, 0, 0));
+            v.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, ld_off + 4u, 0, 0));
+            v.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, ld_off + 8u, 0, 0));
+            v.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, ld_off + 12u, 0, 0));
         }
         return v;
     };
-    auto store4 = [&](float* base, size_t row_off, const float (&v)[4]) __attribute__((always_inline)) {   // row_off: scalar
-        if (!base) return;
-        char* row = reinterpret_cast<char*>(base + row_off);
+    // base: never null where this is called; row_off and `wanted` are scalars
+    auto store4 = [&](float* base, size_t row_off, bool wanted, const float (&v)[4]) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base + row_off, 0, wanted ? row_bytes : 0u, RSRC_FLAGS);
         if (VEC) {
-            if (all_st) *reinterpret_cast<float4*>(row + xs) = make_float4(v[0], v[1], v[2], v[3]);
+            const v4f q = {v[0], v[1], v[2], v[3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, q), r, st_off4, 0, 0);
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (cst[e]) *reinterpret_cast<float*>(row + (xs + 4u * e)) = v[e];
+            for (int e = 0; e < 4; ++e) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[e]), r, st_off[e], 0, 0);
         }
     };
 
@@ -361,27 +374,31 @@ __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict
     float mr[3][6];                // magnitude rows, columns x - 1 .. x + 4: row y_g lands in slot t % 3
     float gr[2][2][4];             // gradient (x, y) of row y_g in slot t % 2
     float4 inr[C][3];              // input rows: row y_in sits in slot t % 3, row y_in + 2 is loaded into slot (t + 2) % 3
+    // The first six rows are requested at once, before anything is computed: the warm-up steps are short (a horizontal Gaussian is
+    // a quarter of a microsecond), a row requested two steps ahead arrives after its step began.  (The registers are free: the
+    // other rings are not in use yet.  Worth less than expected: within the noise of the 0.040 ms.)
+    float4 pre[C][6];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        inr[c][0] = load_row(c, Y0 - 4);
-        inr[c][1] = load_row(c, Y0 - 3);
-    }
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < C; ++c) pre[c][r] = load_row(c, Y0 - 4 + r);
 
     // STAGES: how much of the chain a step runs -- 1: horizontal Gaussian only, 2: + vertical Gaussian (a blurred row), 3: + Sobel
     // and magnitude, 4: + the outputs of a row.  The strip's first output row Y0 needs magnitudes from Y0 - 1, blurred rows from
     // Y0 - 2, horizontally filtered rows from Y0 - 4: the warm-up steps t = 0..3 run stage 1, t = 4, 5 stages 1-2, t = 6, 7 stages
     // 1-3 (2.5 instead of 5.5 steps' worth of instructions for the eight rows of halo every strip re-reads).
-    auto step = [&](auto ph, auto stages, int t) __attribute__((always_inline)) {
+    auto step = [&](auto ph, auto stages, auto pre_row, int t) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph)::value;                    // t % 6
         constexpr int STAGES = decltype(stages)::value;
+        constexpr int PRE = decltype(pre_row)::value;              // steps 0..5: their row is pre[.][PRE]; -1: the ring's
         constexpr int S3 = PH % 3, S2 = PH % 2;
         const int y_in = Y0 - 4 + t, y_bl = y_in - 2, y_g = y_in - 3, y_o = y_in - 4;
         const bool bl_in = y_bl >= 0 && y_bl < H, g_in = y_g >= 0 && y_g < H;
         float gx[4] = {0.f, 0.f, 0.f, 0.f}, gy[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const float4 cur = inr[c][S3];
-            inr[c][(S3 + 2) % 3] = load_row(c, y_in + 2);
+            const float4 cur = PRE >= 0 ? pre[c][PRE >= 0 ? PRE : 0] : inr[c][S3];
+            if (PRE < 0 || PRE >= 4) inr[c][(S3 + 2) % 3] = load_row(c, y_in + 2);     // rows 6, 7, ...: two steps ahead
             // ---- horizontal Gaussian (:118) of row y_in: columns x - 2 .. x + 5 ----
             const float v[8] = {dpp_from_left(cur.z), dpp_from_left(cur.w), cur.x, cur.y, cur.z, cur.w,
                                 dpp_from_right(cur.x), dpp_from_right(cur.y)};
@@ -403,8 +420,8 @@ __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict
                 for (int k = 0; k < G; ++k) acc += gk[k] * hw[c][(PH + 2 + k) % 6][e];
                 bl[e] = (bl_in && cin[e]) ? acc : 0.f;             // zero outside the image: what the Sobel convolutions pad with
             }
-            if (FULL && bl_in && y_bl >= Y0 && y_bl < Y1)                                                         // :119
-                store4(out.blurred, ((size_t)b * C + c) * plane + (size_t)y_bl * W, bl);
+            if (FULL && STAGES >= 3)       // :119 (the first blurred row of the strip is formed at step 6; num_records = 0 drops the others)
+                store4(out.blurred, ((size_t)b * C + c) * plane + (size_t)min(max(y_bl, 0), H - 1) * W, bl_in && y_bl >= Y0 && y_bl < Y1, bl);
             // ---- Sobel (:122-123) of row y_g from the blurred rows y_g - 1 (a0), y_g (a1), y_g + 1 (a2, new) ----
             float (&a2)[6] = ar[c][S3];
             const float (&a1)[6] = ar[c][(S3 + 2) % 3];
@@ -472,39 +489,41 @@ __global__ __launch_bounds__(256) void canny_rows_kernel(const float* __restrict
                 }
             }
             const size_t o = (size_t)b * plane + (size_t)y_o * W;
-            if (FULL) {
-                store4(out.grad_mag, o, o_mag);
-                store4(out.grad_ori, o, o_ori);
-                store4(out.thr_mag, o, o_thr);
-                if (NMS) { store4(out.thin, o, o_thin); store4(out.thr_thin, o, o_edge); }
+            if (FULL) {                    // hps_canny_edges: every output of the reference's dict, no edge map
+                store4(out.grad_mag, o, true, o_mag);
+                store4(out.grad_ori, o, true, o_ori);
+                store4(out.thr_mag, o, true, o_thr);
+                if (NMS) { store4(out.thin, o, true, o_thin); store4(out.thr_thin, o, true, o_edge); }
+            } else {                       // hps_canny_edge_map: the edge map alone
+                store4(out.edge, (size_t)b * out.edge_batch_stride + (size_t)y_o * W, true, o_edge);
             }
-            store4(out.edge, (size_t)b * out.edge_batch_stride + (size_t)y_o * W, o_edge);
         }
     };
     using std::integral_constant;
-    step(integral_constant<int, 0>(), integral_constant<int, 1>(), 0);
-    step(integral_constant<int, 1>(), integral_constant<int, 1>(), 1);
-    step(integral_constant<int, 2>(), integral_constant<int, 1>(), 2);
-    step(integral_constant<int, 3>(), integral_constant<int, 1>(), 3);
-    step(integral_constant<int, 4>(), integral_constant<int, 2>(), 4);
-    step(integral_constant<int, 5>(), integral_constant<int, 2>(), 5);
-    step(integral_constant<int, 0>(), integral_constant<int, 3>(), 6);
-    step(integral_constant<int, 1>(), integral_constant<int, 3>(), 7);
+    using none = integral_constant<int, -1>;
+    step(integral_constant<int, 0>(), integral_constant<int, 1>(), integral_constant<int, 0>(), 0);
+    step(integral_constant<int, 1>(), integral_constant<int, 1>(), integral_constant<int, 1>(), 1);
+    step(integral_constant<int, 2>(), integral_constant<int, 1>(), integral_constant<int, 2>(), 2);
+    step(integral_constant<int, 3>(), integral_constant<int, 1>(), integral_constant<int, 3>(), 3);
+    step(integral_constant<int, 4>(), integral_constant<int, 2>(), integral_constant<int, 4>(), 4);
+    step(integral_constant<int, 5>(), integral_constant<int, 2>(), integral_constant<int, 5>(), 5);
+    step(integral_constant<int, 0>(), integral_constant<int, 3>(), none(), 6);
+    step(integral_constant<int, 1>(), integral_constant<int, 3>(), none(), 7);
     // The rows of the strip: step t = 8 + i writes row Y0 + i.  The only branches are the exits (nothing joins the straight line
     // again, so the waits for the rows loaded two steps earlier still count the memory operations issued since: behind a branch
     // AROUND every step hipcc fell back to s_waitcnt vmcnt(0) -- also draining the loads just issued, i.e. no prefetch at all).
     for (int t = 8;; t += 6) {
-        step(integral_constant<int, 2>(), integral_constant<int, 4>(), t);
+        step(integral_constant<int, 2>(), integral_constant<int, 4>(), none(), t);
         if (t + 1 >= steps) return;
-        step(integral_constant<int, 3>(), integral_constant<int, 4>(), t + 1);
+        step(integral_constant<int, 3>(), integral_constant<int, 4>(), none(), t + 1);
         if (t + 2 >= steps) return;
-        step(integral_constant<int, 4>(), integral_constant<int, 4>(), t + 2);
+        step(integral_constant<int, 4>(), integral_constant<int, 4>(), none(), t + 2);
         if (t + 3 >= steps) return;
-        step(integral_constant<int, 5>(), integral_constant<int, 4>(), t + 3);
+        step(integral_constant<int, 5>(), integral_constant<int, 4>(), none(), t + 3);
         if (t + 4 >= steps) return;
-        step(integral_constant<int, 0>(), integral_constant<int, 4>(), t + 4);
+        step(integral_constant<int, 0>(), integral_constant<int, 4>(), none(), t + 4);
         if (t + 5 >= steps) return;
-        step(integral_constant<int, 1>(), integral_constant<int, 4>(), t + 5);
+        step(integral_constant<int, 1>(), integral_constant<int, 4>(), none(), t + 5);
         if (t + 6 >= steps) return;
     }
 }
