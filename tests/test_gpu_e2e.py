@@ -109,6 +109,19 @@ def test_full_size_configs_match_oracle(B, N, chunk, dev, net_gpu, net_cpu, smpl
         assert torch.equal(got[k], out[k]), k
 
 
+@pytest.mark.parametrize("B,N,chunk", [(3, 7, 3), (5, 129, 5), (33, 20, 11)])
+def test_ragged_sizes_match_oracle(B, N, chunk, dev, net_gpu, net_cpu, smpl_gpu, smpl_assets):
+    """Sizes that divide nothing: 3 / 5 / 33 images (head batch tiles of four, odd encoder batches), 27 / 655 / 726 meshes (ragged
+    64-mesh tiles of the fused kernel), 7 / 129 / 20 samples (one wavefront, the first size that takes two, a partial one) --
+    every output against the oracle on the seed-reproducible route."""
+    x = torch.stack([torch.rand(18, 256, 256, generator=torch.Generator().manual_seed(7000 + 31 * B + i)) for i in range(B)])
+    torch.manual_seed(14)
+    ref = _oracle_infer_chunked(net_cpu[1], smpl_assets[2], x, N, chunk)
+    torch.manual_seed(14)
+    out = infer(net_gpu, smpl_gpu, x.to(dev), num_samples=N, sample_on_cpu=True)
+    _assert_matches_oracle(out, ref, B, N)
+
+
 def test_reference_call_sequence_batch_one(dev, net_gpu, net_cpu, smpl_gpu, smpl_assets, golden_input):
     """The calls of predict/predict_poseMF_shapeGaussian_net.py:103-165, written as the reference writes them."""
     x = golden_input[:1].to(dev)
