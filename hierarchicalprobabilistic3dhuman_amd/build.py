@@ -26,7 +26,12 @@ DEV_ONLY_SOURCES = ["conv.hip"]
 # VALU next to MFMAs is slower on gfx950 (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
 # frontend.hip: the row-marching Canny kernel holds its windows in ~250 registers; SLP-packed pairs add alignment moves and push it
 # into AGPR spills (310 registers, 6 126 VALU instructions per six steps against 260 / 5 864 unpacked).
-FILE_FLAGS = {"mesh_fused.hip": ["-fno-slp-vectorize"], "frontend.hip": ["-fno-slp-vectorize"]}
+# frontend.hip, max-ilp scheduling: the default (max-occupancy) strategy at ~250 registers emits the Gaussian / Sobel sums as runs of
+# dependent FMAs into one accumulator; a wave alone on its SIMD issues a dependent v_fma_f32 every 8.25 cycles and an independent
+# one every 5.0 (tools/valu_dep_probe.hip; two waves per SIMD together: one per 2.5).  Interleaved chains: edge map 0.031 -> 0.029 ms.  (Tried on stem_wino.hip and mesh_fused.hip:
+# no change -- 0.603 / 0.574 ms; conv_wino.hip goes to scratch with it.)
+FILE_FLAGS = {"mesh_fused.hip": ["-fno-slp-vectorize"],
+              "frontend.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
 
