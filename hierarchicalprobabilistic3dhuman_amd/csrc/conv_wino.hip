@@ -70,8 +70,15 @@ __device__ __forceinline__ unsigned wino_div(unsigned n, unsigned d, unsigned ma
 // output channels x one slice of K.  The raw ring holds the four 8 x 8 interiors (the halo is not fetched: a patch pixel outside
 // its image reads a zero pixel kept in LDS), wave (wm, kl) of the epilogue owns image 2 wm + kl, and the item writes raw partial
 // sums Y (the output transform is linear: the slices are added, in slice order, by wino_splitk_epilogue_kernel).
-template <int AB, bool QUAD>
-__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restrict__ x, const float* __restrict__ u,
+// W8 (16 x 16-block geometry only): the same item, LDS contents and chunk schedule on EIGHT waves -- two per SIMD.  The sixteen
+// positions are split by their column j (p = 4 i + j): waves 0-3 multiply j = 0, 1, waves 4-7 j = 2, 3, 128 accumulator registers
+// each.  Why: a wave alone on its SIMD issues a VALU instruction every 5 cycles at best (8 when it depends on the previous one), two
+// waves together one per 2.5 (tools/valu_dep_probe.hip) -- and the input transform, the fragment reads and the epilogue are a
+// quarter of a layer's time.  The transform role becomes thread = (tile, ONE channel); the DMA pieces are dealt over eight waves;
+// the output transform needs the other column pair's s[.][2] (resp. s[.][1]): two floats per (tile, channel) cross through the
+// then idle sA buffers; every sum is formed in the four-wave kernel's order (identical bits).
+template <int AB, bool QUAD, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ residual, float* __restrict__ y,
                                                            const WinoGeom g) {
@@ -82,11 +89,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
     float* sR = smem + 4 * W_OPER;
     constexpr int ab = AB;
 
+    static_assert(!(QUAD && W8), "eight waves: 16 x 16-block geometry only");
+    constexpr int NW = W8 ? 8 : 4;                                // waves per workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kl = lane >> 5, il = lane & 31;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int pg = W8 ? wave >> 2 : 0;                            // W8: the wave's column pair of positions (j = 2 pg, 2 pg + 1)
+    const int wm = (wave & 3) >> 1, wn = wave & 1;
     const int nchunks = QUAD ? g.cps : g.Cin / WK;
-    constexpr int RP = QUAD ? 2 : 3;                              // raw DMA pieces per wave and chunk (quad: 8 pieces = 256 pixels)
+    constexpr int RP = (QUAD || W8) ? 2 : 3;                      // raw DMA pieces per wave and chunk (quad: 8 pieces = 256 pixels; W8: 11 over 8 waves)
 
     // ---- raw-window DMA role: piece q = wave + 4 t covers window entries e = 64 q + lane (pixel e >> 1, 16-byte half e & 1) ----
     unsigned r_off[3];             // byte offset of the lane's 16 bytes from the item's origin (quad: without the image term)
@@ -94,14 +104,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
     bool r_ok[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        const int e = 64 * (wave + 4 * t) + lane;
+        const int e = 64 * (wave + NW * t) + lane;
         if (QUAD) {
             const int px = e >> 1;                                // [image][y][x]: 4 x 8 x 8
             r_ok[t] = t < 2;
             r_img[t] = (px >> 6) & 3;
             r_off[t] = (unsigned)((((px >> 3) & 7) * g.in_row + (px & 7) * g.Cin + (e & 1) * 4) * 4);
         } else {
-            r_ok[t] = (wave + 4 * t) < W_RAW_PIECES && e < 2 * W_WIN;
+            r_ok[t] = t < RP && (wave + NW * t) < W_RAW_PIECES && e < 2 * W_WIN;
             const int px = r_ok[t] ? (e >> 1) : 0;
             r_img[t] = 0;
             r_off[t] = (unsigned)(((px / 18) * g.in_row + (px % 18) * g.Cin + (e & 1) * 4) * 4);
@@ -113,12 +123,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
     const unsigned lds_b0 = (unsigned)(size_t)(lptr_t)(sB);
 
     // ---- transform role: thread = (tile (ty, tx) = (tid >> 5, (tid >> 2) & 7), channel pair tid & 3) ----
-    const int ltile = tid >> 2, cp = tid & 3;
+    const int ltile = W8 ? tid >> 3 : tid >> 2, cp = W8 ? (tid & 7) >> 1 : tid & 3;
+    const int ce = W8 ? tid & 1 : 0;                              // W8: the thread's channel of the pair (it transforms ONE channel)
     // float offset of patch pixel (0,0) in a raw window (quad: image (ty >> 2, tx >> 2), pixel (2 ly - 1, 2 lx - 1) of its 8 x 8
     // interior -- outside the interior for edge tiles, whose edge pixels read the zero pixel instead)
     const int t_ly = (ltile >> 3) & 3, t_lx = ltile & 3;
     const int w_slot = QUAD ? (((((ltile >> 5) * 2 + ((ltile >> 2) & 1)) * 64 + (2 * t_ly - 1) * 8 + (2 * t_lx - 1)) * WK) + cp * 2)
-                            : ((2 * (ltile >> 3)) * 18 + 2 * (ltile & 7)) * WK + cp * 2;
+                            : ((2 * (ltile >> 3)) * 18 + 2 * (ltile & 7)) * WK + cp * 2 + ce;
     const bool e_top = t_ly == 0, e_bot = t_ly == 3, e_left = t_lx == 0, e_right = t_lx == 3;
     constexpr int W_ZERO = 4 * 64 * WK;                           // quad: a zero pixel sits behind each slot's 256 pixels
     // quad: float offsets (from the ring's start, slot 0) of the thread's 16 patch pixels, halo pixels redirected to the zero pixel,
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
             pk_off[n >> 1] |= off << (16 * (n & 1));
         }
     }
-    const int a_slot = ((cp >> 1) * 64 + ltile) * 4 + (cp & 1) * 2;                     // ... of the (tile, pair) slot of position 0 in sA
+    const int a_slot = ((cp >> 1) * 64 + ltile) * 4 + (cp & 1) * 2 + ce;                // ... of the (tile, pair) slot of position 0 in sA
 
     const float* fa = sA + (kl * 64 + wm * 32 + il) * 4;          // this lane's fragment slot of position 0, buffer 0
     const float* fb = sB + (kl * 64 + wn * 32 + il) * 4;
@@ -173,12 +184,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
     // the main loop spreads the eleven pieces of an interval over its sixteen positions.
     auto dma_raw_piece = [&](int chunk, int t) {              // window of `chunk` -> ring slot chunk % 3, piece wave + 4 t
         if (ab == 1 || ab == 6) return;
-        if (t < RP && r_ok[t]) lds_dma16(r_cur[t], x_item + chunk * WK, lds_r0 + (unsigned)((chunk % 3) * W_RAW * 4 + (wave + 4 * t) * 1024));
+        if (t < RP && r_ok[t]) lds_dma16(r_cur[t], x_item + chunk * WK, lds_r0 + (unsigned)((chunk % 3) * W_RAW * 4 + (wave + NW * t) * 1024));
     };
-    auto dma_filter_piece = [&](int chunk, int q) {           // filters of `chunk` -> sB[chunk & 1]; wave w moves pieces 8 w .. 8 w + 7
+    constexpr int FP = 32 / NW;                               // filter pieces per wave and chunk
+    auto dma_filter_piece = [&](int chunk, int q) {           // filters of `chunk` -> sB[chunk & 1]; wave w moves pieces FP w .. FP w + FP - 1
         if (ab == 3) return;
-        lds_dma16((unsigned)((wave * 8 + q) * 1024 + lane * 16), u_item + (size_t)chunk * g.n_ct * W_OPER,
-                  lds_b0 + (unsigned)((chunk & 1) * W_OPER * 4 + (wave * 8 + q) * 1024));
+        lds_dma16((unsigned)((wave * FP + q) * 1024 + lane * 16), u_item + (size_t)chunk * g.n_ct * W_OPER,
+                  lds_b0 + (unsigned)((chunk & 1) * W_OPER * 4 + (wave * FP + q) * 1024));
     };
     auto dma_raw = [&](int chunk) {
 #pragma unroll
@@ -186,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
     };
     auto dma_filters = [&](int chunk) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) dma_filter_piece(chunk, q);
+        for (int q = 0; q < FP; ++q) dma_filter_piece(chunk, q);
     };
     // input transform of one chunk, in two parts so that the LDS round trip of the reads hides under MFMAs:
     //   t_read : the thread's 16 patch pixels (one channel pair) from the raw ring slot chunk % 3
@@ -203,6 +215,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
             d[2 * q + 1] = *reinterpret_cast<const float2*>(slot + (pk >> 16));
             return;
         }
+        if (W8) {                                                 // one channel: the .y halves stay unused
+            d[2 * q].x = src[(((2 * q) >> 2) * 18 + ((2 * q) & 3)) * WK];
+            d[2 * q + 1].x = src[(((2 * q + 1) >> 2) * 18 + ((2 * q + 1) & 3)) * WK];
+            return;
+        }
         d[2 * q] = *reinterpret_cast<const float2*>(src + (((2 * q) >> 2) * 18 + ((2 * q) & 3)) * WK);
         d[2 * q + 1] = *reinterpret_cast<const float2*>(src + (((2 * q + 1) >> 2) * 18 + ((2 * q + 1) & 3)) * WK);
     };
@@ -213,6 +230,24 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
     auto t_write = [&](int chunk) {
         if (ab == 1 || ab == 5) return;
         float* dst = sA + (chunk & 1) * W_OPER + a_slot;
+        if (W8) {                                                 // the same sums for the thread's one channel
+            float t1[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t1[0 * 4 + j] = d[0 * 4 + j].x - d[2 * 4 + j].x;
+                t1[1 * 4 + j] = d[1 * 4 + j].x + d[2 * 4 + j].x;
+                t1[2 * 4 + j] = d[2 * 4 + j].x - d[1 * 4 + j].x;
+                t1[3 * 4 + j] = d[1 * 4 + j].x - d[3 * 4 + j].x;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dst[(i * 4 + 0) * 512] = t1[i * 4 + 0] - t1[i * 4 + 2];
+                dst[(i * 4 + 1) * 512] = t1[i * 4 + 1] + t1[i * 4 + 2];
+                dst[(i * 4 + 2) * 512] = t1[i * 4 + 2] - t1[i * 4 + 1];
+                dst[(i * 4 + 3) * 512] = t1[i * 4 + 1] - t1[i * 4 + 3];
+            }
+            return;
+        }
         float2 t[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {          // t = B^T d
@@ -248,9 +283,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
     prologue_dma();
 
     for (;;) {
-        f32x16 acc[16];
+        constexpr int NP = W8 ? 8 : 16;                      // positions per wave (W8: acc[2 i + jj] is position 4 i + 2 pg + jj)
+        f32x16 acc[NP];
 #pragma unroll
-        for (int p = 0; p < 16; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
 
@@ -265,7 +301,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
                 // wave's own pieces of that window (needed one iteration later) must have landed
                 // (waves 0-2 move three pieces of a window, wave 3 two: the count is wave-uniform)
                 if (c + 2 < nchunks && ab != 1 && ab != 6) {
-                    if (!QUAD && wave < 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    if (W8) {                                // eleven window pieces over eight waves: waves 0-2 move two, the others one
+                        if (wave < 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    } else if (!QUAD && wave < 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -274,17 +313,47 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
             // one wave per SIMD: a latency is hidden only by this wave's own MFMAs.  Order of the interval: first fragments, the
             // DMAs, positions 0-8 with two patch pixels of chunk c + 1 requested per position, transform + store chunk c + 1 (VALU:
             // the only part that does not overlap), positions 9-15.
-            const float* pa = fa + buf * W_OPER;
-            const float* pb = fb + buf * W_OPER;
+            const float* pa = fa + buf * W_OPER + (W8 ? pg * 2 * 512 : 0);      // W8: position 2 pg is the wave's first
+            const float* pb = fb + buf * W_OPER + (W8 ? pg * 2 * 512 : 0);
             float4 a4[2], b4[2];
             a4[0] = *reinterpret_cast<const float4*>(pa);
             b4[0] = *reinterpret_cast<const float4*>(pb);
+            if (W8) {
+                // eight positions per wave and interval (the other eight run on the wave that shares the SIMD): four filter pieces,
+                // then the window pieces; four patch pixels per position in positions 0-3, the transform + its stores in position 5
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int poff = (4 * (pp >> 1) + (pp & 1)) * 512, pnext = (4 * ((pp + 1) >> 1) + ((pp + 1) & 1)) * 512;
+                    if (more) {
+                        if (pp < FP) dma_filter_piece(c + 1, pp);
+                        else if (pp >= 5 && pp < 5 + RP && c + 3 < nchunks) dma_raw_piece(c + 3, pp - 5);
+                    }
+                    if (pp < 7) {
+                        a4[(pp + 1) & 1] = *reinterpret_cast<const float4*>(pa + pnext);
+                        b4[(pp + 1) & 1] = *reinterpret_cast<const float4*>(pb + pnext);
+                    }
+                    (void)poff;
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float4 a = a4[pp & 1], b = b4[pp & 1];
+                    acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[pp], 0, 0, 0);
+                    acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[pp], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (pp < 4 && more) { t_read2(c + 1, 2 * pp); t_read2(c + 1, 2 * pp + 1); }
+                    if (pp == 5 && more) t_write(c + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[pp], 0, 0, 0);
+                    acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[pp], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                continue;
+            }
             if (more && ab == 9) {                           // profiling: the burst this kernel used to issue
                 dma_filters(c + 1);
                 if (c + 3 < nchunks) dma_raw(c + 3);
             }
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 if (more && ab != 9) {                       // filters first, then the window: the vmcnt above counts on that order
                     if (p < 8) dma_filter_piece(c + 1, p);
                     else if (p >= 9 && p < 9 + RP && c + 3 < nchunks) dma_raw_piece(c + 3, p - 9);
@@ -332,7 +401,58 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
         // ---- output transform Y = A^T M A, BatchNorm, residual, ReLU.  A lane owns one output channel (MFMA column) and 16 tiles
         //      (MFMA rows dr = (r & 3) + 8 (r >> 2), + 4 kl, of the wave's 32 = tile rows 4 wm + (dr >> 3), columns 4 kl + (dr & 3)):
         //      per output pixel a half-wave stores 128 contiguous bytes ----
-        if (ab != 4) {
+        if (W8) {
+            // Row transform s = A^T M for the wave's two columns jj (identical sums, in the four-wave kernel's order), then the column
+            // transform needs ONE column of the other pair: y(a, 0) = (s_a[0] + s_a[1]) + s_a[2] is formed by the waves of columns
+            // 0-1 with s_a[2] from their partners, y(a, 1) = (s_a[1] - s_a[2]) - s_a[3] by the waves of columns 2-3 with s_a[1].
+            // The exchange runs through sA (idle: the next item's first DMAs fill sB[0] and the raw ring).
+            const int co = cur_ct * WC + wn * 32 + il;
+            const float sc = scale[co], sh = shift[co];
+            const size_t lane_base = cur_out + (size_t)(8 * wm) * g.out_row + (size_t)(8 * kl) * g.Cout + co + (size_t)pg * g.Cout;
+            float2* xch = reinterpret_cast<float2*>(sA);
+            float k0[2][16], k1[2][16];                      // s_0[jj], s_1[jj] of the wave's columns, per tile register r
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    k0[jj][r] = acc[0 + jj][r] + acc[2 + jj][r] + acc[4 + jj][r];
+                    k1[jj][r] = acc[2 + jj][r] - acc[4 + jj][r] - acc[6 + jj][r];
+                }
+            const int w4 = wave & 3;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {                   // columns 0-1 export column 1, columns 2-3 export column 2 (their jj = 0)
+                const float2 e = pg == 0 ? make_float2(k0[1][r], k1[1][r]) : make_float2(k0[0][r], k1[0][r]);
+                xch[((pg * 16 + r) * 4 + w4) * 64 + lane] = e;
+            }
+            float res[16][2];
+            if (residual) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        res[r][a] = residual[lane_base + (size_t)(2 * (r >> 2) + a) * g.out_row + (size_t)(2 * (r & 3)) * g.Cout];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float2 o = xch[(((1 - pg) * 16 + r) * 4 + w4) * 64 + lane];
+                float yv[2];
+                if (pg == 0) {                               // y(a, 0) = (s_a[0] + s_a[1]) + s_a[2]
+                    yv[0] = k0[0][r] + k0[1][r] + o.x;
+                    yv[1] = k1[0][r] + k1[1][r] + o.y;
+                } else {                                     // y(a, 1) = (s_a[1] - s_a[2]) - s_a[3]
+                    yv[0] = o.x - k0[0][r] - k0[1][r];
+                    yv[1] = o.y - k1[0][r] - k1[1][r];
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float v = yv[a] * sc + sh;
+                    if (residual) v += res[r][a];
+                    if (g.relu) v = fmaxf(v, 0.0f);
+                    y[lane_base + (size_t)(2 * (r >> 2) + a) * g.out_row + (size_t)(2 * (r & 3)) * g.Cout] = v;
+                }
+            }
+        } else if (ab != 4) {
             const int co = cur_ct * WC + wn * 32 + il;
             const float sc = scale[co], sh = shift[co];
             // quad: wave (wm, kl)'s 4 x 4 tiles are the whole map of image 2 wm + kl
@@ -352,8 +472,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
                 float s0[4], s1[4];                          // s = A^T M  (2 x 4), A^T = [1 1 1 0; 0 1 -1 -1]
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    s0[j] = acc[0 * 4 + j][r] + acc[1 * 4 + j][r] + acc[2 * 4 + j][r];
-                    s1[j] = acc[1 * 4 + j][r] - acc[2 * 4 + j][r] - acc[3 * 4 + j][r];
+                    constexpr int S = W8 ? 0 : 4;            // (W8 never runs this branch; keeps the indices inside its eight accumulators)
+                    s0[j] = acc[0 * S + j][r] + acc[1 * S + j][r] + acc[2 * S + j][r];
+                    s1[j] = acc[1 * S + j][r] - acc[2 * S + j][r] - acc[3 * S + j][r];
                 }
                 float yv[4];
                 yv[0] = s0[0] + s0[1] + s0[2];
@@ -374,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const float* __restri
         } else {
             float t = 0.f;
 #pragma unroll
-            for (int p = 0; p < 16; ++p)
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) t += acc[p][r];
             if (t == 12345.678f) y[0] = t;
@@ -472,6 +593,10 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
         hipLaunchKernelGGL((conv_wino_kernel<ab, q>), grid, dim3(256), lds, (hipStream_t)stream, x, u, scale, shift, quad ? nullptr : residual,
                            quad ? splitk_ws : y, g);
     };
+    auto launch8 = [&]() {                                    // the eight-wave form of the 16 x 16-block geometry
+        if ((grant_rc = grant_lds<&conv_wino_kernel<0, false, true>>(160 * 1024, "hps_conv3x3_winograd")) != HPS_OK) return;
+        hipLaunchKernelGGL((conv_wino_kernel<0, false, true>), grid, dim3(512), lds, (hipStream_t)stream, x, u, scale, shift, residual, y, g);
+    };
     typedef std::integral_constant<bool, false> F;
     typedef std::integral_constant<bool, true> T;
     if (quad) {
@@ -486,8 +611,9 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
         return check_launch("hps_conv3x3_winograd (slices)");
     }
     switch (ablate) {
-        case 0: launch(std::integral_constant<int, 0>(), F()); break;
+        case 0: launch8(); break;                                               // the product form: eight waves
 #ifdef HPS_DEV_BUILD
+        case 21: launch(std::integral_constant<int, 0>(), F()); break;          // the four-wave form (identical bits; the ablations below are its)
         case 1: launch(std::integral_constant<int, 1>(), F()); break;
         case 2: launch(std::integral_constant<int, 2>(), F()); break;
         case 3: launch(std::integral_constant<int, 3>(), F()); break;
