@@ -89,14 +89,13 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
     float* sR = smem + 4 * W_OPER;
     constexpr int ab = AB;
 
-    static_assert(!(QUAD && W8), "eight waves: 16 x 16-block geometry only");
     constexpr int NW = W8 ? 8 : 4;                                // waves per workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kl = lane >> 5, il = lane & 31;
     const int pg = W8 ? wave >> 2 : 0;                            // W8: the wave's column pair of positions (j = 2 pg, 2 pg + 1)
     const int wm = (wave & 3) >> 1, wn = wave & 1;
     const int nchunks = QUAD ? g.cps : g.Cin / WK;
-    constexpr int RP = (QUAD || W8) ? 2 : 3;                      // raw DMA pieces per wave and chunk (quad: 8 pieces = 256 pixels; W8: 11 over 8 waves)
+    constexpr int RP = QUAD ? (W8 ? 1 : 2) : (W8 ? 2 : 3);        // raw DMA pieces per wave and chunk (quad: 8 pieces = 256 pixels; else 11)
 
     // ---- raw-window DMA role: piece q = wave + 4 t covers window entries e = 64 q + lane (pixel e >> 1, 16-byte half e & 1) ----
     unsigned r_off[3];             // byte offset of the lane's 16 bytes from the item's origin (quad: without the image term)
@@ -107,7 +106,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
         const int e = 64 * (wave + NW * t) + lane;
         if (QUAD) {
             const int px = e >> 1;                                // [image][y][x]: 4 x 8 x 8
-            r_ok[t] = t < 2;
+            r_ok[t] = t < RP;
             r_img[t] = (px >> 6) & 3;
             r_off[t] = (unsigned)((((px >> 3) & 7) * g.in_row + (px & 7) * g.Cin + (e & 1) * 4) * 4);
         } else {
@@ -128,7 +127,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
     // float offset of patch pixel (0,0) in a raw window (quad: image (ty >> 2, tx >> 2), pixel (2 ly - 1, 2 lx - 1) of its 8 x 8
     // interior -- outside the interior for edge tiles, whose edge pixels read the zero pixel instead)
     const int t_ly = (ltile >> 3) & 3, t_lx = ltile & 3;
-    const int w_slot = QUAD ? (((((ltile >> 5) * 2 + ((ltile >> 2) & 1)) * 64 + (2 * t_ly - 1) * 8 + (2 * t_lx - 1)) * WK) + cp * 2)
+    const int w_slot = QUAD ? (((((ltile >> 5) * 2 + ((ltile >> 2) & 1)) * 64 + (2 * t_ly - 1) * 8 + (2 * t_lx - 1)) * WK) + cp * 2 + ce)
                             : ((2 * (ltile >> 3)) * 18 + 2 * (ltile & 7)) * WK + cp * 2 + ce;
     const bool e_top = t_ly == 0, e_bot = t_ly == 3, e_left = t_lx == 0, e_right = t_lx == 3;
     constexpr int W_ZERO = 4 * 64 * WK;                           // quad: a zero pixel sits behind each slot's 256 pixels
@@ -143,7 +142,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
         for (int n = 0; n < 16; ++n) {
             const int i = n >> 2, j = n & 3;
             const bool halo = (i == 0 && e_top) || (i == 3 && e_bot) || (j == 0 && e_left) || (j == 3 && e_right);
-            const unsigned off = (unsigned)(halo ? W_ZERO + cp * 2 : w_slot + (i * 8 + j) * WK);
+            const unsigned off = (unsigned)(halo ? W_ZERO + cp * 2 + ce : w_slot + (i * 8 + j) * WK);
             pk_off[n >> 1] |= off << (16 * (n & 1));
         }
     }
@@ -211,6 +210,11 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
             unsigned pk = pk_off[q];
             asm volatile("" : "+v"(pk));                          // keep the unpacking here (see pk_off)
             const float* slot = sR + (chunk % 3) * W_RAW;
+            if (W8) {
+                d[2 * q].x = slot[pk & 0xffffu];
+                d[2 * q + 1].x = slot[pk >> 16];
+                return;
+            }
             d[2 * q] = *reinterpret_cast<const float2*>(slot + (pk & 0xffffu));
             d[2 * q + 1] = *reinterpret_cast<const float2*>(slot + (pk >> 16));
             return;
@@ -301,8 +305,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
                 // wave's own pieces of that window (needed one iteration later) must have landed
                 // (waves 0-2 move three pieces of a window, wave 3 two: the count is wave-uniform)
                 if (c + 2 < nchunks && ab != 1 && ab != 6) {
-                    if (W8) {                                // eleven window pieces over eight waves: waves 0-2 move two, the others one
-                        if (wave < 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    if (W8) {                                // eleven window pieces over eight waves: waves 0-2 move two, the others one (quad: eight pieces, one each)
+                        if (!QUAD && wave < 3) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                     } else if (!QUAD && wave < 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -408,7 +412,10 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
             // The exchange runs through sA (idle: the next item's first DMAs fill sB[0] and the raw ring).
             const int co = cur_ct * WC + wn * 32 + il;
             const float sc = scale[co], sh = shift[co];
-            const size_t lane_base = cur_out + (size_t)(8 * wm) * g.out_row + (size_t)(8 * kl) * g.Cout + co + (size_t)pg * g.Cout;
+            // quad: wave (wm, kl)'s 4 x 4 tiles are the whole map of image 2 wm + kl
+            const size_t lane_base = (QUAD ? cur_out + (size_t)(2 * wm + kl) * g.out_img + co
+                                           : cur_out + (size_t)(8 * wm) * g.out_row + (size_t)(8 * kl) * g.Cout + co) + (size_t)pg * g.Cout;
+            const bool store_ok = !QUAD || 2 * wm + kl < cur_nimg;
             float2* xch = reinterpret_cast<float2*>(sA);
             float k0[2][16], k1[2][16];                      // s_0[jj], s_1[jj] of the wave's columns, per tile register r
 #pragma unroll
@@ -446,10 +453,13 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
                 }
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
-                    float v = yv[a] * sc + sh;
-                    if (residual) v += res[r][a];
-                    if (g.relu) v = fmaxf(v, 0.0f);
-                    y[lane_base + (size_t)(2 * (r >> 2) + a) * g.out_row + (size_t)(2 * (r & 3)) * g.Cout] = v;
+                    float v = yv[a];
+                    if (!QUAD || !g.raw) {
+                        v = v * sc + sh;
+                        if (residual) v += res[r][a];
+                        if (g.relu) v = fmaxf(v, 0.0f);
+                    }
+                    if (store_ok) y[lane_base + (size_t)(2 * (r >> 2) + a) * g.out_row + (size_t)(2 * (r & 3)) * g.Cout] = v;
                 }
             }
         } else if (ab != 4) {
@@ -593,15 +603,18 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
         hipLaunchKernelGGL((conv_wino_kernel<ab, q>), grid, dim3(256), lds, (hipStream_t)stream, x, u, scale, shift, quad ? nullptr : residual,
                            quad ? splitk_ws : y, g);
     };
-    auto launch8 = [&]() {                                    // the eight-wave form of the 16 x 16-block geometry
-        if ((grant_rc = grant_lds<&conv_wino_kernel<0, false, true>>(160 * 1024, "hps_conv3x3_winograd")) != HPS_OK) return;
-        hipLaunchKernelGGL((conv_wino_kernel<0, false, true>), grid, dim3(512), lds, (hipStream_t)stream, x, u, scale, shift, residual, y, g);
+    auto launch8 = [&](auto Q) {                              // the eight-wave form (the product)
+        constexpr bool q = decltype(Q)::value;
+        if ((grant_rc = grant_lds<&conv_wino_kernel<0, q, true>>(160 * 1024, "hps_conv3x3_winograd")) != HPS_OK) return;
+        hipLaunchKernelGGL((conv_wino_kernel<0, q, true>), grid, dim3(512), lds, (hipStream_t)stream, x, u, scale, shift, quad ? nullptr : residual,
+                           quad ? splitk_ws : y, g);
     };
     typedef std::integral_constant<bool, false> F;
     typedef std::integral_constant<bool, true> T;
     if (quad) {
-        if (ablate != 0) return bad_arg("hps_conv3x3_winograd: ablations exist for the 16 x 16-block geometry only");
-        launch(std::integral_constant<int, 0>(), T());
+        if (ablate != 0 && ablate != 21) return bad_arg("hps_conv3x3_winograd: ablations exist for the 16 x 16-block geometry only");
+        if (ablate == 21) launch(std::integral_constant<int, 0>(), T());      // dev: the four-wave form
+        else launch8(T());
         if (grant_rc != HPS_OK) return grant_rc;
         const int rc = check_launch("hps_conv3x3_winograd");
         if (rc != HPS_OK) return rc;
@@ -611,7 +624,7 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
         return check_launch("hps_conv3x3_winograd (slices)");
     }
     switch (ablate) {
-        case 0: launch8(); break;                                               // the product form: eight waves
+        case 0: launch8(F()); break;                                            // the product form: eight waves
 #ifdef HPS_DEV_BUILD
         case 21: launch(std::integral_constant<int, 0>(), F()); break;          // the four-wave form (identical bits; the ablations below are its)
         case 1: launch(std::integral_constant<int, 1>(), F()); break;
