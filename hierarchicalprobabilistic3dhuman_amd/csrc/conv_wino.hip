@@ -613,8 +613,11 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
     typedef std::integral_constant<bool, true> T;
     if (quad) {
         if (ablate != 0 && ablate != 21) return bad_arg("hps_conv3x3_winograd: ablations exist for the 16 x 16-block geometry only");
-        if (ablate == 21) launch(std::integral_constant<int, 0>(), T());      // dev: the four-wave form
-        else launch8(T());
+#ifdef HPS_DEV_BUILD
+        if (ablate == 21) launch(std::integral_constant<int, 0>(), T());      // the four-wave form
+        else
+#endif
+            launch8(T());
         if (grant_rc != HPS_OK) return grant_rc;
         const int rc = check_launch("hps_conv3x3_winograd");
         if (rc != HPS_OK) return rc;
