@@ -12,8 +12,9 @@
 //   U = G g G^T is precomputed on the host when the weights are prepared (resnet.py).
 //
 // Work item = one 8 x 8 block of tiles of one image (16 x 16 output pixels, an 18 x 18 input window) x 64 output channels.
-// Workgroup = 256 threads = 4 waves as 2 (tile groups of 32) x 2 (cout groups of 32): a wave keeps 16 accumulators of 32x32
-// (256 accumulator registers), one wave per SIMD; the grid is persistent (one workgroup per CU walks its items).
+// Workgroup (the first form, kept in the dev library) = 256 threads = 4 waves as 2 (tile groups of 32) x 2 (cout groups of 32): a
+// wave keeps 16 accumulators of 32x32 (256 accumulator registers), one wave per SIMD; the grid is persistent (one workgroup per CU
+// walks its items).  The product form (W8, described at the kernel) runs the same item on 8 waves, two per SIMD.
 // K = Cin is streamed in chunks of 8 channels through LDS (160 KiB: 2 x 32 KiB of transformed input, 2 x 32 KiB of
 // transformed filters, a ring of three 10 KiB raw input windows):
 //   * the raw 18 x 18 x 8 window of chunk c + 3 arrives by LDS-DMA (each input pixel once per workgroup -- the 4x4 patches of
