@@ -327,9 +327,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
                 // eight positions per wave and interval (the other eight run on the wave that shares the SIMD): four filter pieces,
                 // then the window pieces; four patch pixels per position in positions 0-3, the transform + its stores in position 5
 #pragma unroll
-                for (int pp = 0; pp < 8; ++pp) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int poff = (4 * (pp >> 1) + (pp & 1)) * 512, pnext = (4 * ((pp + 1) >> 1) + ((pp + 1) & 1)) * 512;
+                for (int pp = 0; pp < 8; ++pp) {             // pp = 2 i + jj: position 4 i + 2 pg + jj (pa / pb start at position 2 pg)
+                    const int pnext = (4 * ((pp + 1) >> 1) + ((pp + 1) & 1)) * 512;
                     if (more) {
                         if (pp < FP) dma_filter_piece(c + 1, pp);
                         else if (pp >= 5 && pp < 5 + RP && c + 3 < nchunks) dma_raw_piece(c + 3, pp - 5);
@@ -338,7 +337,6 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
                         a4[(pp + 1) & 1] = *reinterpret_cast<const float4*>(pa + pnext);
                         b4[(pp + 1) & 1] = *reinterpret_cast<const float4*>(pb + pnext);
                     }
-                    (void)poff;
                     __builtin_amdgcn_sched_barrier(0);
                     const float4 a = a4[pp & 1], b = b4[pp & 1];
                     acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[pp], 0, 0, 0);
