@@ -408,6 +408,8 @@ def test_cost_of_a_differently_signed_vector_pair(dev, net_gpu, smpl_gpu):
 @pytest.mark.parametrize("cfg", [
     # B, H, Cin, Cout -- the stride-1 3x3 layers of layer1 / layer2 / layer3 at the 256x256 input, plus an odd batch
     (2, 64, 64, 64), (2, 32, 128, 128), (3, 16, 256, 256), (1, 16, 64, 128), (5, 48, 8, 64), (300, 16, 64, 64),
+    # one, two and three chunks of input channels: the window ring and the DMA waits at the ends of a short K loop
+    (2, 16, 16, 64), (3, 32, 24, 128),
     # layer4's 8 x 8 maps: four images per item (full and partial quads), K in four slices (512, 256) or one (64)
     (4, 8, 512, 512), (5, 8, 512, 512), (1, 8, 256, 128), (7, 8, 64, 64), (70, 8, 256, 64)])
 def test_winograd_conv_kernel(cfg, dev):
