@@ -132,7 +132,7 @@ class InferencePipeline:
         self._exclusive = True
         self.enc_events = None
         self.trace = None             # bench.py --trace-steps: list of per-batch dicts of timing events (head / mesh phases)
-        self.early_relayout = False   # A/B on one box: +0.9 % images/s, but the mesh kernel it overlaps runs 12 % slower (0.657 vs 0.586 ms)
+        self.early_relayout = False   # A/B (bench.py --early-relayout): round 3 +0.9 % images/s with the mesh kernel 12 % slower; round 4's kernels: 21.2 -> 19.6 k
         # exclusive_mesh: the mesh kernel and the neighbouring encoders take turns (right when each fills the chip on its own:
         # B = 64: 17.9 k images/s either way, the encoder stretched from 2.9 to 3.5 ms when they share).  False: no ordering
         # between them -- a small batch's encoder cannot fill the chip (its persistent Winograd workgroups are few: 64-256 items
