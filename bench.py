@@ -68,7 +68,25 @@ def cpu_baseline(net_state, parents, num_samples, n_images):
             dt1 = time.perf_counter() - t1
         finally:
             torch.set_num_threads(default_threads)
-    return {"value": n_images / dt, "unit": "images/s", "cores": cores, "kind": "port",
+        # the reference's OWN operating point: one image per call, num_samples = 50, image after image
+        # (predict/predict_poseMF_shapeGaussian_net.py:58-59 loop, :103-165 per image) -- what secondary.latency_b1 is the GPU side of
+        lat = {}
+        for label, threads, reps in (("all_threads", cores, 6), ("single_thread", 1, 3)):
+            torch.set_num_threads(threads)
+            try:
+                O.infer(net_state, params, parents, x[:1], 50)
+                ts = []
+                for i in range(reps):
+                    t1 = time.perf_counter()
+                    O.infer(net_state, params, parents, x[i % n_images:i % n_images + 1], 50)
+                    ts.append(time.perf_counter() - t1)
+            finally:
+                torch.set_num_threads(default_threads)
+            ts.sort()
+            lat[label] = {"median_ms": ts[len(ts) // 2] * 1e3, "min_ms": ts[0] * 1e3, "images_per_s": 1.0 / ts[len(ts) // 2], "cores": threads, "reps": reps}
+        lat["note"] = ("oracle/ref_cpu.infer on ONE image per call, num_samples=50, calls looped one after another like "
+                       "predict/predict_poseMF_shapeGaussian_net.py:58-59,103-165 (the CPU side of secondary.latency_b1)")
+    return {"value": n_images / dt, "unit": "images/s", "cores": cores, "kind": "port", "latency_b1": lat,
             "sample": "%d images (one batch of the metric's workload), num_samples=%d, oracle/ref_cpu.infer timed once after a 1-image "
                       "warm-up (%.2f s).  The port batches what the reference loops over: it makes ONE flattened SMPL call over all "
                       "B*(N+2) meshes and one batched encoder / head pass, where predict_poseMF_shapeGaussian_net.py handles one image "
@@ -87,6 +105,44 @@ def workload_name(B, N, world):
     if N == 1000:
         return "BASELINE configs[4] (num_samples=1000 stress)" + ("" if B == 16 else ", batch %d instead of 16" % B)
     return "custom (not a BASELINE configuration)"
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no RANK / WORLD_SIZE in the environment: start the N ranks ourselves -- the
+    command the driver would otherwise have to wrap (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...`), on a
+    free port of 127.0.0.1 -- relay rank 0's single JSON line on stdout (everything else the children print goes to stderr) and
+    return their exit status."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if args.backend == "nccl" and have < args.gpus:
+        sys.stderr.write("bench.py --gpus %d: only %d HIP device(s) visible and RCCL (--backend nccl) needs one device per rank; run on a "
+                         "node with %d GPUs, or pass --backend gloo for a functional run whose ranks share devices\n"
+                         % (args.gpus, have, args.gpus))
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")                 # what torchrun would set anyway; the ranks' host side is one thread
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE)
+    lines = 0
+    for raw in p.stdout:
+        text = raw.decode(errors="replace")
+        if text.startswith("{"):
+            sys.stdout.write(text)
+            sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(text)
+    rc = p.wait()
+    if rc == 0 and lines != 1:
+        sys.stderr.write("bench.py: expected ONE JSON line from rank 0, saw %d\n" % lines)
+        return 3
+    return rc
 
 
 def _capi_mesh_cus(pipe):
@@ -123,12 +179,17 @@ def main():
                     help="diagnostic: 'no-copy' runs the from-RGB loop on device-resident crops (isolates the cost of the H2D copies)")
     ap.add_argument("--latency-reps", type=int, default=40,
                     help="after the timed region: batch-1, num_samples=50 calls timed one by one for secondary.latency_b1 (0 = skip)")
+    ap.add_argument("--stress-steps", type=int, default=8,
+                    help="after the timed region (one GPU only): pipelined steps of BASELINE configs[4] (batch 16, num_samples 1000) "
+                         "for secondary.stress_n1000 (0 = skip)")
     ap.add_argument("--lbs-unfused-reps", type=int, default=12,
                     help="after the timed region: launches of the unfused blend + LBS pair timed for secondary.lbs_unfused (0 = skip)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (HIP) device; there is no CPU fallback for the product path")
+    if args.gpus > 1 and args.as_rank is None and not ("RANK" in os.environ and "WORLD_SIZE" in os.environ):
+        raise SystemExit(self_launch(args))                 # bare `python bench.py --gpus N`: one process per GPU, started here
     rank, world, local_rank = sharding.init_distributed(args.backend)
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d must be launched with %d ranks (torch.distributed.run), got WORLD_SIZE=%d"
@@ -331,11 +392,14 @@ def main():
                 sink.add_(sharding.batch_metric_sums(pipe.finish(ticket, seed=777 + first + i, image_offset=lo, after=nxt)))
                 ticket = nxt
 
-        rgb_steps(0, 4, torch.zeros(4, dtype=torch.float64, device=dev))
+        # warm-up = one whole untimed leg (at least 8 steps): both upload slots, both input sets, the page-locked buffers' first
+        # DMA mappings and the front-end kernels' code objects have all been used before the first timed leg (round 4 warmed 4
+        # steps and its first leg read 12.6 k images/s beside 18.9 / 20.1 k in the driver's run)
+        rgb_warm = max(8, args.from_rgb_steps)
+        rgb_steps(0, rgb_warm, torch.zeros(4, dtype=torch.float64, device=dev))
         torch.cuda.synchronize()
         barrier()
-        # three legs of --from-rgb-steps steps each; the median leg is reported and all three are listed (one leg in about six runs
-        # comes out ~0.9 ms per step slower -- the H2D copy of a step not hidden behind the kernels; cause not found)
+        # three legs of --from-rgb-steps steps each; the median leg is reported and all three are listed
         legs = []
         for leg in range(3):
             pipe.enc_events, smpl.lbs_events = [], []
@@ -343,7 +407,7 @@ def main():
             torch.cuda.synchronize()
             barrier()
             t_a = time.perf_counter()
-            rgb_steps(4 + leg * args.from_rgb_steps, args.from_rgb_steps, leg_sums)
+            rgb_steps(rgb_warm + leg * args.from_rgb_steps, args.from_rgb_steps, leg_sums)
             torch.cuda.synchronize()
             barrier()
             dt_leg = sharding.all_reduce_max(time.perf_counter() - t_a)
@@ -360,8 +424,75 @@ def main():
                     "mesh_kernel_avg_ms": sum(rgb_mesh_ms) / max(1, len(rgb_mesh_ms)),
                     "note": "PCIe-inclusive: page-locked host RGB crops + 17 keypoints + visibility -> non-blocking H2D on a copy "
                             "stream (two device slots) -> hps_canny_edge_map + hps_proxy_rep on the encoder's stream -> the same "
-                            "pipelined step as the headline; median of three legs of %d steps (all listed) after 4 warm-up steps, wall clock" % args.from_rgb_steps}
+                            "pipelined step as the headline; median of three legs of %d steps (all listed) after %d warm-up steps, wall clock"
+                            % (args.from_rgb_steps, rgb_warm),
+                    "legs_spread": (max(leg_rates) - min(leg_rates)) / max(leg_rates)}
+    # BASELINE configs[4] under the same clock: batch 16, num_samples 1000 = 16 032 meshes per step, the
+    # pipelined loop with the schedule InferencePipeline picks for it (encoder and mesh kernels on disjoint CU subsets), a few
+    # steps after the timed region.  Reported: images/s, the sampler's proposal rate, the mesh kernel against the blend GEMM's
+    # MFMA roofline, the one-sweep uncertainty kernel and the unfused LBS kernel against the HBM roofline.
+    stress = None
+    if args.stress_steps > 0 and world == 1 and not args.no_pipeline:
+        Bs, Ns = 16, 1000
+        Ms = Bs * (Ns + 2)
+        sx = [xs[k % INPUT_SETS][:Bs].contiguous() for k in range(2)]
+        spipe = InferencePipeline(net, smpl, num_samples=Ns, use_mean_shape=True)
+        s_stream = spipe.caller_stream(Bs)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s_stream):
+            def stress_steps(first, count):
+                ticket = spipe.submit(sx[first % 2], input_ready=False)
+                for i in range(count):
+                    nxt = spipe.submit(sx[(first + i + 1) % 2], input_ready=False) if i + 1 < count else None
+                    r = spipe.finish(ticket, seed=555 + first + i, image_offset=lo, after=nxt)
+                    ticket = nxt
+                return r
+            stress_steps(0, 3)
+            torch.cuda.synchronize()
+            spipe.enc_events, smpl.lbs_events, sampling_utils.launch_events, sampling_utils.unc_events = [], [], [], []
+            t_a = time.perf_counter()
+            r_last = stress_steps(3, args.stress_steps)
+            torch.cuda.synchronize()
+            dt_s = time.perf_counter() - t_a
+            s_mesh = [e0.elapsed_time(e1) for (m, e0, e1) in smpl.lbs_events if m == Ms]
+            s_enc = [e0.elapsed_time(e1) for (e0, e1) in spipe.enc_events]
+            s_smp = [e0.elapsed_time(e1) for (e0, e1) in sampling_utils.launch_events]
+            s_unc = [e0.elapsed_time(e1) for (b_, n_, e0, e1) in sampling_utils.unc_events if (b_, n_) == (Bs, Ns)]
+            spipe.enc_events, smpl.lbs_events, sampling_utils.launch_events, sampling_utils.unc_events = None, None, None, None
+            finite = bool(torch.isfinite(r_last["unc"]).all())
+            # the unfused LBS kernel at this size (SURVEY 8(d)'s definition), a few sequential calls on the same stream
+            smpl.fused_mesh, smpl.lbs_events = False, []
+            for i in range(5):
+                infer(net, smpl, sx[0], num_samples=Ns, use_mean_shape=True, seed=4321 + i, image_offset=lo)
+            torch.cuda.synchronize()
+            s_lbs = [e0.elapsed_time(e1) for (m, e0, e1) in smpl.lbs_events if m == Ms][2:]
+            smpl.fused_mesh, smpl.lbs_events = True, None
+        torch.cuda.set_stream(loop_stream)
+        med = lambda v: spread(v)["median_ms"] if v else None
+        mesh_ms, unc_ms, smp_s_ms, lbs_ms_s = med(s_mesh), med(s_unc), med(s_smp), med(s_lbs)
+        unc_bytes = Bs * Ns * 6890 * 12 + Bs * 6890 * 4          # every sample vertex read once, the uncertainties written
+        stress = {"workload": "BASELINE configs[4]: batch=%d, num_samples=%d (%d meshes per step), 1 GPU" % (Bs, Ns, Ms),
+                  "images_per_s": Bs * args.stress_steps / dt_s, "ms_per_step": dt_s / args.stress_steps * 1e3, "steps": args.stress_steps,
+                  "results_finite": finite,
+                  "schedule": ("encoder on %d of the 32 CUs of every XCD, mesh kernels on the other %d" % (32 - _capi_mesh_cus(spipe), _capi_mesh_cus(spipe))
+                               if spipe.mesh_stream is not None else "shared CUs"),
+                  "encoder_avg_ms": sum(s_enc) / max(1, len(s_enc)),
+                  "sampler": ({"median_ms": smp_s_ms, "proposals_per_s": Bs * 23 * 8 * Ns / (smp_s_ms * 1e-3),
+                               "unit": "matrix-Fisher proposals/s as the reference counts them (8N per image and joint)"} if smp_s_ms else None),
+                  "mesh_kernel": ({"median_ms": mesh_ms, "bound": "mfma", "achieved": BLEND_FLOP_PER_MESH * Ms / (mesh_ms * 1e-3) / 1e12,
+                                   "peak": MFMA_FP32_PEAK_TF, "unit": "TFLOP/s", "frac": BLEND_FLOP_PER_MESH * Ms / (mesh_ms * 1e-3) / 1e12 / MFMA_FP32_PEAK_TF,
+                                   "cus": 8 * _capi_mesh_cus(spipe) if spipe.mesh_stream is not None else 256,
+                                   "note": "frac is against the WHOLE chip's fp32 MFMA peak; the kernel runs on `cus` of the 256 CUs in this schedule"}
+                                  if mesh_ms else None),
+                  "uncertainty_sweep1": ({"median_ms": unc_ms, "bound": "hbm", "achieved": unc_bytes / (unc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                          "unit": "GB/s", "frac": unc_bytes / (unc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": unc_bytes,
+                                          "note": "inside the pipelined loop (beside the next batch's encoder)"} if unc_ms else None),
+                  "lbs_unfused": ({"median_ms": lbs_ms_s, "bound": "hbm", "achieved": LBS_BYTES_PER_MESH * Ms / (lbs_ms_s * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": LBS_BYTES_PER_MESH * Ms / (lbs_ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "note": "hps_smpl_lbs alone at %d meshes (not on the product path)" % Ms} if lbs_ms_s else None)}
     secondary = {}
+    if stress:
+        secondary["stress_n1000"] = stress
     if from_rgb:
         secondary["from_rgb"] = from_rgb
     if latency_b1:

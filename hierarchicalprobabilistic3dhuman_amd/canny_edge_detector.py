@@ -42,15 +42,23 @@ class CannyEdgeDetector(nn.Module):
             out["thresholded_thin_edges"] = thr_thin
         return out
 
-    def edge_map_into(self, img, out):
+    def edge_map_into(self, img, out, nms=None):
         """The one entry of forward()'s dict the predict front end uses (predict/predict_poseMF_shapeGaussian_net.py:92-93:
         'thresholded_thin_edges' with NMS, else 'thresholded_grad_magnitude'), written straight into channel 0 of ``out``
-        (B, K+1, H, W) -- same kernel, same arithmetic, none of the other outputs stored (hps_canny_edge_map)."""
+        (B, K+1, H, W) -- same kernel, same arithmetic, none of the other outputs stored (hps_canny_edge_map).
+
+        ``nms`` selects the ENTRY like the reference's caller does from its config (cfg.DATA.EDGE_NMS), independently of how the
+        detector was built: False -> 'thresholded_grad_magnitude' (which exists either way), True -> 'thresholded_thin_edges'
+        (KeyError, as in the reference, when the detector was built without non-max suppression).  None = the detector's flag."""
+        if nms is None:
+            nms = self.non_max_suppression
+        if nms and not self.non_max_suppression:
+            raise KeyError("thresholded_thin_edges")          # the reference's dict has no such entry without NMS (:160-166)
         _capi.require_device(img, "img")
         x = _capi.f32c(img)
         B, C, H, W = x.shape
         assert out.shape[0] == B and out.shape[2:] == (H, W) and out.is_contiguous() and out.dtype == torch.float32
         taps = self._taps_host
         _capi.call("hps_canny_edge_map", _capi.ptr(x), _capi._P(taps.ctypes.data), int(taps.shape[0]), _capi.ptr(out),
-                   int(out.stride(0)), B, C, H, W, float(self.threshold), 1 if self.non_max_suppression else 0, _capi.stream())
+                   int(out.stride(0)), B, C, H, W, float(self.threshold), 1 if nms else 0, _capi.stream())
         return out

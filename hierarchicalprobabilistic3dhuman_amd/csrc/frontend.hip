@@ -29,13 +29,16 @@ constexpr int TP = TF + 8;             // 48: LDS row pitch in floats
 // comparing |gy| with tan(22.5) |gx| and tan(67.5) |gx| and by the two sign bits (atan2's conventions for signed zeros
 // included: atan2(+0, -x) = pi -> 8, atan2(-0, -x) = -pi -> 0, atan2(+-0, +0) = 0 -> 4).  A gradient within 1e-4 (relative) of a
 // sector boundary -- where the reference's own answer hangs on atan2f's last bit -- takes the reference's formula.
+// torch evaluates `atan2(...) * (180.0 / np.pi)` with the double 180 / pi rounded ONCE to fp32 (57.29578f); 180.0f / (float)pi
+// is 57.295776f, one unit in the last place lower -- and this fallback exists precisely for last-bit cases.
+constexpr float RAD2DEG = 57.29577951308232f;
 __device__ __forceinline__ int orientation_bin(float gx, float gy) {
     const float ax = fabsf(gx), ay = fabsf(gy);
     const float T1 = 0.41421356237309503f, T2 = 2.4142135623730951f;      // tan(22.5 deg), tan(67.5 deg)
     const float b1 = T1 * ax, b2 = T2 * ax;
     if (__builtin_expect(fabsf(ay - b1) <= 1e-4f * b1 || fabsf(ay - b2) <= 1e-4f * b2, 0)) {
         if (!(ax == 0.0f && ay == 0.0f)) {
-            const float ori = atan2f(gy, gx) * (180.0f / 3.14159265358979323846f) + 180.0f;
+            const float ori = atan2f(gy, gx) * RAD2DEG + 180.0f;
             return (int)rintf(ori / 45.0f);
         }
     }
@@ -64,7 +67,7 @@ __device__ __forceinline__ int orientation_bin_fast(float gx, float gy, bool& ne
     return 4 + (1 - 2 * sy) * d;
 }
 __device__ __forceinline__ int orientation_bin_slow(float gx, float gy) {
-    const float ori = atan2f(gy, gx) * (180.0f / 3.14159265358979323846f) + 180.0f;
+    const float ori = atan2f(gy, gx) * RAD2DEG + 180.0f;
     return (int)rintf(ori / 45.0f);
 }
 

@@ -369,9 +369,11 @@ static int joint_level_launch(const float* embed, int embed_dim, int hidden, con
     const int max_in = embed_dim + 21 * num_body_joints;
     size_t lds = ((size_t)((max_in * TBL + 3) & ~3) + 128 * TBL + (NT / 128) * TBL * 128) * sizeof(float);
     if (lds > 64 * 1024) { set_error("hps_head_joint_level: embed_dim=%d too large", embed_dim); return HPS_E_UNSUPPORTED; }
-    if (wide) {
-        constexpr int NTW = 1024;
-        const size_t ldsw = ((size_t)((max_in * TBL + 3) & ~3) + 128 * TBL + (NTW / 128) * TBL * 128) * sizeof(float);
+    constexpr int NTW = 1024;
+    const size_t ldsw = ((size_t)((max_in * TBL + 3) & ~3) + 128 * TBL + (NTW / 128) * TBL * 128) * sizeof(float);
+    // the wide form needs 12 KiB more than the default; an embed_dim whose default form still fits but whose wide form does
+    // not takes the default (same results up to the K-slice summation order the latency mode already implies)
+    if (wide && ldsw <= 64 * 1024) {
         hipLaunchKernelGGL((joint_level_kernel<128, true, NTW, TBL>), dim3(n_level, ceil_div(B, TBL)), dim3(NTW), ldsw, (hipStream_t)stream,
                            embed, embed_dim, joint_ids, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper,
                            s_proper, mode, delta_i_weight, pose_f, f_level, pose_u, pose_s, pose_v, B, num_body_joints, svd_flavor);

@@ -120,6 +120,22 @@ def evaluate_pose_MF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mo
         pose_shape_model.svd_mode = model_svd_mode
 
 
+def flipped_target_rotmats(target_pose, flip=None):
+    """evaluate/evaluate_poseMF_shapeGaussian_net.py:84-92: target axis-angle poses (B,72) -> the (B,24,3,3) rotation matrices the
+    target SMPL call uses, the global orientation pre-multiplied by the rotation by pi about x.
+
+    The reference goes R -> R_x(pi) R -> cv2.Rodrigues (SO(3) log, float64) -> float32 vector -> smplx's batch_rodrigues (exp)
+    (utils/rigid_transform_utils.py:34-58); exp(log(.)) is the identity on SO(3), so the matrices are formed directly --
+    R_x(pi) is exactly diag(1,-1,-1).  tests/test_oracle_golden.py and tests/test_gpu_evaluate.py pin this against the
+    log-then-exp route with scipy's Rotation standing in for cv2 (<= 2e-6 per matrix entry, angle -> pi included)."""
+    B = target_pose.shape[0]
+    if flip is None:
+        flip = torch.diag(torch.tensor([1.0, -1.0, -1.0], device=target_pose.device))
+    R = batch_rodrigues(target_pose.reshape(-1, 3)).view(B, 24, 3, 3)
+    R[:, 0] = torch.matmul(flip, R[:, 0])                                 # 'pre' multiplication
+    return R
+
+
 def _evaluate_loop(pose_shape_model, pose_shape_cfg, smpl_model, smpl_model_male, smpl_model_female, edge_detect_model, device,
                    loader, staged, tracker, metrics, want_samples, N, flip, fnames, poses, shapes, cams, sample_on_cpu, run_seed, frame0,
                    reduce_across_ranks, save_per_frame_metrics, save_path, **_unused):
@@ -139,8 +155,7 @@ def _evaluate_loop(pose_shape_model, pose_shape_cfg, smpl_model, smpl_model_male
             if staged is not None:
                 staged.copied()
             genders = list(batch["gender"])
-            R = batch_rodrigues(target_pose.reshape(-1, 3)).view(B, 24, 3, 3)
-            R[:, 0] = torch.matmul(flip, R[:, 0])                                 # 'pre' multiplication
+            R = flipped_target_rotmats(target_pose, flip)
             target_vertices = torch.empty(B, smpl_model.num_verts, 3, device=device)
             target_reposed = torch.empty_like(target_vertices)
             target_joints = torch.empty(B, 14, 3, device=device)

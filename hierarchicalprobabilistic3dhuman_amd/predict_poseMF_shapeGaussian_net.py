@@ -90,7 +90,7 @@ def proxy_representation(rgb, joints2D, joints2D_visib, edge_detect_model, pose_
         B, K = joints2D.shape[:2]
         if out is None:
             out = torch.empty(B, K + 1, D, D, device=rgb.device, dtype=torch.float32)
-        edge_detect_model.edge_map_into(rgb, out)
+        edge_detect_model.edge_map_into(rgb, out, nms=bool(pose_shape_cfg.DATA.EDGE_NMS))       # the CONFIG picks the entry (:93)
         return make_proxy_representation(None, joints2D, joints2D_visib, D, pose_shape_cfg.DATA.HEATMAP_GAUSSIAN_STD, out=out)
     edges = edge_detect_model(rgb)
     edge = edges["thresholded_thin_edges"] if pose_shape_cfg.DATA.EDGE_NMS else edges["thresholded_grad_magnitude"]
@@ -183,6 +183,7 @@ class InferencePipeline:
                 self.mesh_stream = None
         if self.enc_stream is None:
             self.enc_stream = torch.cuda.Stream()
+        self._fresh_streams = True
 
     @torch.no_grad()
     def submit(self, proxy_rep_input=None, input_ready=None, make_input=None):
@@ -209,6 +210,16 @@ class InferencePipeline:
             if proxy_rep_input is None:
                 raise _capi.HpsError("InferencePipeline: call caller_stream(batch) before the first submit(make_input=...)")
             self._setup_streams(proxy_rep_input.shape[0])
+        if getattr(self, "_fresh_streams", False):
+            # ONE-TIME ordering of the side streams behind whatever the caller has queued so far: parameters still
+            # being written by a device-to-device load_state_dict, BN folding of a preceding warm-up infer(), ... -- whatever
+            # `input_ready` says about the INPUT, the encoder's lazy prepare() and first convolutions (and the head) must not
+            # read weights that are still in flight.  Costs nothing in steady state.
+            self.enc_stream.wait_stream(main)
+            self.head_stream.wait_stream(main)
+            if self.mesh_stream is not None and self.mesh_stream != main:
+                self.mesh_stream.wait_stream(main)
+            self._fresh_streams = False
         if input_ready is None:
             ready = torch.cuda.Event()
             ready.record(main)

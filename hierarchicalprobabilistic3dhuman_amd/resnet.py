@@ -281,6 +281,10 @@ class ResNet(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
         self._prepared = None
+        # kernel-selection modes are properties of the MODEL (set_winograd / set_latency_mode) and survive .to() / load_state_dict:
+        # prepare() re-applies them to the rebuilt _ConvBN objects
+        self._winograd = True
+        self._latency = False
         self.layout = "padded"    # "padded": halo-padded NHWC + scalar-base LDS-DMA kernel (product); "plain": the conv.hip kernels of libhps_dev.so (tests)
         self.composite = True     # padded layout: issue the launch list through hps_encoder_run (one call) instead of one by one
         self._frames = _FrameCache()
@@ -306,9 +310,14 @@ class ResNet(nn.Module):
     def set_winograd(self, on):
         """Product default True: the stride-1 3x3 layers of layer1-3 run as Winograd F(2x2, 3x3) (csrc/conv_wino.hip); False runs
         every layer on the direct implicit-GEMM kernel (csrc/conv_pad.hip) -- the cross-check of the tests."""
-        prep = self._prepared or self.prepare()
+        self._winograd = bool(on)
+        self._apply_modes(self._prepared or self.prepare())
+
+    def _apply_modes(self, prep):
         for c in [prep["stem"]] + [c for blk in prep["blocks"] for c in blk if c is not None]:
-            c.use_winograd = bool(on)
+            c.latency = self._latency
+            c.use_winograd = self._winograd and not self._latency      # latency mode runs every layer on the direct kernel
+        self._frames = _FrameCache()          # cached launch lists belong to the previous selection
 
     def set_latency_mode(self, on=True):
         """Per-model switch for latency-bound deployments (the reference's own operating point is ONE image per call,
@@ -319,11 +328,8 @@ class ResNet(nn.Module):
         SLOWER than the default.  Like set_winograd it is a property of the model, never of the batch: per-image results do not
         depend on the batch size within a mode; between the modes they differ in the last bits (another summation order, same
         1e-4 feature tolerance against the reference -- tests/test_gpu_net.py)."""
-        prep = self._prepared or self.prepare()
-        for c in [prep["stem"]] + [c for blk in prep["blocks"] for c in blk if c is not None]:
-            c.latency = bool(on)
-            c.use_winograd = not on
-        self._frames = _FrameCache()          # cached launch lists belong to the other mode
+        self._latency = bool(on)              # switching it off restores whatever set_winograd selected before
+        self._apply_modes(self._prepared or self.prepare())
 
     def invalidate(self):
         """Drop the folded BatchNorm / filter copies and the cached launch lists; the next forward rebuilds them from the
@@ -349,7 +355,7 @@ class ResNet(nn.Module):
                 down = _ConvBN(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
                 prep["blocks"].append((_ConvBN(blk.conv1, blk.bn1), _ConvBN(blk.conv2, blk.bn2), down))
         self._prepared = prep
-        self._frames = _FrameCache()          # launch lists hold pointers to the previous filters
+        self._apply_modes(prep)               # (also drops the launch lists: they hold pointers to the previous filters)
         return prep
 
     # ---- halo-padded activation frames: owned by the module, zeroed once, only interiors are ever written ----

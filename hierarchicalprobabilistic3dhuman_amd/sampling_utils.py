@@ -24,6 +24,7 @@ _pending = []               # (accepted, N, event on the launch stream) of every
 _failed = {}                # device -> int64 scalar: failed calls of launches already folded out of _pending
 _PENDING_MAX = 256
 launch_events = None        # bench.py: list collecting (start, end) HIP events around every hps_mf_sample launch
+unc_events = None           # bench.py: list collecting (B, N, start, end) HIP events around every hps_vertex_uncertainty launch
 
 
 def _m_star(b):
@@ -188,7 +189,14 @@ def vertex_uncertainty(vertices_samples):
     v = _capi.f32c(vertices_samples)
     B, N, V = v.shape[:3]
     unc = torch.empty(B, V, device=v.device, dtype=torch.float32)
+    ev = None
+    if unc_events is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     _capi.call("hps_vertex_uncertainty", _capi.ptr(v), _capi.ptr(unc), B, N, V, _capi.stream())
+    if ev is not None:
+        ev[1].record()
+        unc_events.append((B, N, ev[0], ev[1]))
     return unc
 
 

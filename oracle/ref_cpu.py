@@ -599,14 +599,32 @@ def joints2d_error_sorted(verts_samples, joints_samples, heat, cam_wp, coco_map)
 
 
 def rotmat_to_axis_angle64(R):
-    """SO(3) log map in float64 (what cv2.Rodrigues does for the target flip, utils/rigid_transform_utils.py:48-56)."""
+    """SO(3) log map in float64: what cv2.Rodrigues(3x3) does for the target flip (utils/rigid_transform_utils.py:48-56).
+    cv2 (opencv-python, unpinned in requirements.txt:1) is a third-party dependency absent from this image; this restates the
+    published algorithm of OpenCV's calib3d `Rodrigues` for a matrix input step by step: project onto SO(3) by SVD (R = U V^T);
+    r = (R21 - R12, R02 - R20, R10 - R01), s = |r| / 2 = sin(theta), c = (tr R - 1) / 2, theta = acos(c); for s >= 1e-5 the
+    vector is r * theta / (2 s); below it theta is 0 (c > 0: zero vector) or pi, where the axis comes from the DIAGONAL of
+    (R + I) / 2 = n n^T with the signs of n_y, n_z taken from R01, R02 (and R12 when n_x is the smallest component).
+    Pinned against scipy.spatial.transform.Rotation (an independent implementation of the same map) in
+    tests/test_oracle_golden.py, including R = I (whose flipped matrix is a rotation by exactly pi) and angles -> pi."""
     R = np.asarray(R, np.float64)
-    c = np.clip((np.trace(R) - 1.0) / 2.0, -1.0, 1.0)
+    U, _, Vt = np.linalg.svd(R)
+    R = U @ Vt
+    r = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    s = np.sqrt(float(r @ r) * 0.25)
+    c = min(1.0, max(-1.0, (np.trace(R) - 1.0) * 0.5))
     theta = np.arccos(c)
-    if theta < 1e-12:
-        return np.zeros(3)
-    w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / (2.0 * np.sin(theta))
-    return w * theta
+    if s < 1e-5:
+        if c > 0:
+            return np.zeros(3)
+        x = np.sqrt(max((R[0, 0] + 1.0) * 0.5, 0.0))
+        y = np.sqrt(max((R[1, 1] + 1.0) * 0.5, 0.0)) * (-1.0 if R[0, 1] < 0 else 1.0)
+        z = np.sqrt(max((R[2, 2] + 1.0) * 0.5, 0.0)) * (-1.0 if R[0, 2] < 0 else 1.0)
+        if abs(x) < abs(y) and abs(x) < abs(z) and ((R[1, 2] > 0) != (y * z > 0)):
+            z = -z
+        n = np.array([x, y, z])
+        return n * (theta / np.sqrt(float(n @ n)))
+    return r * (theta / (2.0 * s))
 
 
 def evaluate_frames(sd, smpl_neutral, smpl_by_gender, smpl_parents, frames, metrics, num_samples, edge_nms=True,

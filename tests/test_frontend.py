@@ -85,6 +85,15 @@ def test_edge_map_entry_point_equals_the_detectors_dict_entry(nms, thr, dev, gol
     cfg.DATA.PROXY_REP_SIZE, cfg.DATA.EDGE_NMS, cfg.DATA.EDGE_THRESHOLD = 64, nms, thr
     fused = proxy_representation(rgb, j, vis, det, cfg)
     assert torch.equal(fused, make_proxy_representation(want_edge, j, vis, 64, cfg.DATA.HEATMAP_GAUSSIAN_STD))
+    # the CONFIG selects the dict entry (predict/...:93), not the detector: a detector built with NMS and
+    # cfg.DATA.EDGE_NMS = False yields 'thresholded_grad_magnitude'; the converse is the reference's KeyError
+    cfg.DATA.EDGE_NMS = not nms
+    if nms:
+        other = proxy_representation(rgb, j, vis, det, cfg)
+        assert torch.equal(other[:, :1], full["thresholded_grad_magnitude"]) and torch.equal(other[:, 1:], fused[:, 1:])
+    else:
+        with pytest.raises(KeyError):
+            proxy_representation(rgb, j, vis, det, cfg)
 
 
 @pytest.mark.gpu

@@ -267,7 +267,7 @@ def test_bench_line_has_every_leg(dev):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2", "--cpu-images", "1", "--lbs-unfused-reps", "2",
-           "--latency-reps", "3", "--from-rgb-steps", "3"]
+           "--latency-reps", "3", "--from-rgb-steps", "8", "--stress-steps", "3"]
     p = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
@@ -285,7 +285,17 @@ def test_bench_line_has_every_leg(dev):
     sec = d["secondary"]
     assert sec["latency_b1"]["median_ms"] > 0 and sec["latency_b1"]["throughput_mode_median_ms"] > 0
     assert sec["from_rgb"]["images_per_s"] > 0 and len(sec["from_rgb"]["legs_images_per_s"]) == 3
-    assert sec["from_rgb"]["checksum_images"] == 64 * 3
+    assert sec["from_rgb"]["checksum_images"] == 64 * 8
+    # the three legs of the PCIe-inclusive loop must agree: a leg that is still warming is not a measurement
+    legs = sec["from_rgb"]["legs_images_per_s"]
+    assert (max(legs) - min(legs)) / max(legs) <= 0.10, legs
+    # BASELINE configs[4] and the reference's own operating point on the CPU ride in the same line
+    st = sec["stress_n1000"]
+    assert st["workload"].startswith("BASELINE configs[4]") and st["images_per_s"] > 0 and st["results_finite"]
+    assert st["sampler"]["proposals_per_s"] > 0 and 0 < st["mesh_kernel"]["frac"] < 1
+    assert 0 < st["uncertainty_sweep1"]["frac"] < 1 and 0 < st["lbs_unfused"]["frac"] < 1
+    cl = d["cpu_baseline"]["latency_b1"]
+    assert cl["all_threads"]["median_ms"] > 0 and cl["single_thread"]["cores"] == 1
     assert sec["lbs_unfused"]["frac"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["metric_checksums"]["images"] == 64 * 3
 
 

@@ -22,7 +22,8 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMON = ["--steps", "2", "--warmup", "1", "--cpu-images", "0", "--lbs-unfused-reps", "0", "--latency-reps", "0", "--from-rgb-steps", "0"]
+COMMON = ["--steps", "2", "--warmup", "1", "--cpu-images", "0", "--lbs-unfused-reps", "0", "--latency-reps", "0", "--from-rgb-steps", "0",
+          "--stress-steps", "0"]
 
 
 def _free_port():
@@ -70,6 +71,27 @@ def test_two_rank_gloo_bench_is_the_two_disjoint_shards(dev, single_rank_shards)
     assert got == want
     assert got[0] == 2 * 64 * 2                            # ranks x images per step x steps
     assert two["value"] > 0 and abs(two["value"] - 2 * 64 * 2 / (two["ms_per_step"] * 2e-3)) <= 1e-6 * two["value"]
+
+
+def test_bare_bench_command_starts_its_own_ranks(dev, single_rank_shards):
+    """The driver's command is the BARE `python bench.py --gpus N ...` (no torchrun wrapper): bench.py must start its N ranks
+    itself and print rank 0's one JSON line.  Two ranks over gloo on the one device: same shards, bit for
+    bit, as `--as-rank r 2`; and with the default backend (nccl = RCCL: one device per rank) on a one-GPU box it must refuse
+    with one clear sentence and a non-zero status instead of a traceback."""
+    two = _bench(["--gpus", "2", "--backend", "gloo"])              # ranks=None: plain `python bench.py`
+    assert two["n_gpus"] == 2 and two["backend"] == "gloo" and two["config"]["global_batch"] == 128
+    for r in range(2):
+        assert two["metric_checksums_per_rank"][r] == single_rank_shards[r]["metric_checksums_per_rank"][0], r
+    assert two["metric_checksums"]["images"] == 2 * 64 * 2
+    if torch.cuda.device_count() < 2:
+        env = dict(os.environ)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + COMMON, cwd=ROOT, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode != 0 and not p.stdout.strip()
+        err = p.stderr.decode(errors="replace")
+        assert "one device per rank" in err and "--backend gloo" in err and "Traceback" not in err, err[-2000:]
 
 
 def test_eight_rank_gloo_bench_is_baseline_config_2(dev):

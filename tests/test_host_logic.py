@@ -254,3 +254,29 @@ def test_smpl_pkl_loader_reads_the_licensed_file_format(tmp_path):
         assert from_file.parents.tolist() == from_dict.parents.tolist()
         a, b = from_file.state_dict(), from_dict.state_dict()
         assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_kernel_selection_modes_survive_invalidation():
+    """latency mode / the Winograd switch are properties of the MODEL -- .to(), load_state_dict() or invalidate()
+    rebuild the prepared layers and must re-apply them; leaving latency mode restores the earlier Winograd choice."""
+    from hierarchicalprobabilistic3dhuman_amd.resnet import resnet18
+    torch.manual_seed(0)
+    enc = resnet18(in_channels=18).eval()
+    convs = lambda: [enc._prepared["stem"]] + [c for blk in enc._prepared["blocks"] for c in blk if c is not None]
+    enc.prepare()
+    assert all(c.use_winograd and not c.latency for c in convs())
+    enc.set_latency_mode(True)
+    assert all(c.latency and not c.use_winograd for c in convs())
+    enc.invalidate()                                   # what .to() / load_state_dict trigger
+    assert enc._prepared is None
+    enc.prepare()
+    assert all(c.latency and not c.use_winograd for c in convs()), "latency mode lost by the rebuild"
+    enc.load_state_dict(enc.state_dict())
+    enc.prepare()
+    assert all(c.latency for c in convs())
+    enc.set_latency_mode(False)
+    assert all(c.use_winograd and not c.latency for c in convs())
+    enc.set_winograd(False)
+    enc.set_latency_mode(True)
+    enc.set_latency_mode(False)
+    assert all(not c.use_winograd and not c.latency for c in convs()), "set_latency_mode(False) must not force Winograd back on"
