@@ -68,6 +68,8 @@ _PROTOTYPES = {
     "hps_encoder_run": [_P, _I, _P],
     "hps_head_pose_levels": [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _P, _P, _P,
                              _P, _P, _I, _I, _I, _I, _P],
+    "hps_head_pose_levels_fused": [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _P, _I, _I, _I,
+                                   _P, _P],
     "hps_nchw_to_padded_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "hps_nchw_to_padded_nhwc_generic": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "hps_maxpool3x3s2_pad": [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -88,6 +90,8 @@ _DEV_PROTOTYPES = {
     "hps_global_avgpool": [_P, _P, _I, _I, _I, _P],
     "hps_dev_stem_winograd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hps_dev_conv3x3_winograd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "hps_dev_smpl_pose_prep_v1": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
+    "hps_dev_smpl_joints_v1": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
     "hps_dev_mesh_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
 }
 _RESTYPES = {"hps_last_error": _c.c_char_p, "hps_query_workspace": _c.c_int64, "hps_conv3x3_winograd_workspace": _c.c_size_t,
@@ -235,7 +239,7 @@ def call(name, *args):
         raise HpsError("%s failed (code %d): %s" % (name, rc, msg.decode() if msg else ""))
 
 
-WS_CONV_SPLITK, WS_SMPL_MP, WS_SMPL_XT, WS_SMPL_A, WS_SMPL_VPOSED, WS_HEAD_F, WS_HEAD_USV = range(7)
+WS_CONV_SPLITK, WS_SMPL_MP, WS_SMPL_XT, WS_SMPL_A, WS_SMPL_VPOSED, WS_HEAD_F, WS_HEAD_USV, WS_HEAD_SYNC = range(8)
 
 
 def query_workspace(what, d0=0, d1=0, d2=0):

@@ -14,7 +14,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace hps
 
-extern "C" int hps_version(void) { return 400; }  // 0.4.0: hps_head_trunk, hps_canny_edge_map, hps_nchw_to_padded_nhwc_generic (HPS_ENC_RELAYOUT_GENERIC)
+extern "C" int hps_version(void) { return 500; }  // 0.5.0: hps_head_pose_levels_fused (HPS_WS_HEAD_SYNC)
 
 extern "C" int64_t hps_query_workspace(int what, int64_t d0, int64_t d1, int64_t d2) {
     if (d0 < 0 || d1 < 0 || d2 < 0) { hps::set_error("hps_query_workspace: negative dimension"); return -1; }
@@ -28,6 +28,7 @@ extern "C" int64_t hps_query_workspace(int what, int64_t d0, int64_t d1, int64_t
         case HPS_WS_SMPL_VPOSED: return d0 * up(3 * d1, 128) * f;
         case HPS_WS_HEAD_F: return d0 * d1 * 9 * f;
         case HPS_WS_HEAD_USV: return d0 * d1 * 21 * f;
+        case HPS_WS_HEAD_SYNC: return ((d0 + 3) / 4) * (HPS_HEAD_MAX_LEVELS + 1) * (int64_t)sizeof(int32_t);
         default: hps::set_error("hps_query_workspace: unknown item %d", what); return -1;
     }
 }

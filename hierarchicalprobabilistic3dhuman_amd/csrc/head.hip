@@ -157,26 +157,25 @@ __device__ __forceinline__ void proper_svd_store(float* U, const float* S, float
 // of four waves, ~110 registers and 18 KB of LDS has the footprint of one workgroup of the kernels it runs beside in the
 // pipelined loop (fused mesh kernel, stem convolution), so it is placed as soon as one of those retires; the former
 // 1024-thread / 60 KB workgroup needed a nearly empty CU and starved behind them (2.2 ms per head instead of 0.5).
+// joint_level_body: one joint of one level for the TBL images starting at b0 (the whole workgroup); slot / n_slots: this
+// joint's position in the level (only the host-LAPACK mode's f_level uses them).
 template <int HID, bool DEVSVD, int NT, int TBL>
-__global__ __launch_bounds__(NT) void joint_level_kernel(
-    const float* __restrict__ embed, int embed_dim, const int32_t* __restrict__ joint_ids,
+__device__ __forceinline__ void joint_level_body(
+    float* smem, const int joint, const int slot, const int n_slots, const int b0,
+    const float* __restrict__ embed, int embed_dim,
     const int32_t* __restrict__ anc_ptr, const int32_t* __restrict__ anc_idx, const float* const* __restrict__ w1t_ptrs,
     const float* const* __restrict__ b1_ptrs, const float* const* __restrict__ w2_ptrs,
     const float* const* __restrict__ b2_ptrs, float* u_proper, float* s_proper,
     float* mode, float delta_i_weight, float* __restrict__ pose_f, float* __restrict__ f_level,
     float* __restrict__ pose_u, float* __restrict__ pose_s, float* __restrict__ pose_v, int B, int NJ, int svd_flavor) {
-    __builtin_amdgcn_s_setprio(3);                          // see linear_kernel
     constexpr int KS = NT / HID;
     constexpr int PARTS = NT >= 9 * TBL * 8 ? 8 : 4;       // lanes per output-layer dot product
     static_assert(NT % HID == 0 && TBL % 4 == 0 && NT >= 9 * TBL * PARTS && KS * HID >= 9, "joint_level_kernel: shape");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int joint = joint_ids[blockIdx.x];
     const int a_lo = anc_ptr[joint], P = anc_ptr[joint + 1] - a_lo;
     const int in_dim = embed_dim + 21 * P;
     float* xs = smem;                                        // [in_dim][TBL]
     float* hs = smem + (size_t)((in_dim * TBL + 3) & ~3);    // [HID][TBL]
     float* red = hs + HID * TBL;                             // [KS][TBL][HID] partial sums
-    const int b0 = blockIdx.y * TBL;
 
     // gather: cat[embed, U_proper[anc] (9P), S_proper[anc] (3P), mode[anc] (9P)]   (:126-132).  Guard-free and four elements
     // per lane in flight: the ancestor list goes to LDS first, every source address is then plain arithmetic, rows beyond B read
@@ -247,7 +246,7 @@ __global__ __launch_bounds__(NT) void joint_level_kernel(
             if (e % 4 == 0) v += delta_i_weight;
             if (b0 + r < B) {
                 pose_f[((size_t)(b0 + r) * NJ + joint) * 9 + e] = v;
-                if (f_level) f_level[((size_t)(b0 + r) * gridDim.x + blockIdx.x) * 9 + e] = v;
+                if (f_level) f_level[((size_t)(b0 + r) * n_slots + slot) * 9 + e] = v;
             }
             if (DEVSVD) red[r * 9 + e] = v;                 // the partial-sum buffer is free by now
         }
@@ -266,6 +265,75 @@ __global__ __launch_bounds__(NT) void joint_level_kernel(
             for (int e = 0; e < 9; ++e) F[e] = red[r * 9 + e];
             gesdd3::svd3(svd_flavor, F, U, S, V);
             proper_svd_store(U, S, V, (size_t)(b0 + r) * NJ + joint, pose_u, pose_s, pose_v, u_proper, s_proper, mode);
+        }
+    }
+}
+
+template <int HID, bool DEVSVD, int NT, int TBL>
+__global__ __launch_bounds__(NT) void joint_level_kernel(
+    const float* __restrict__ embed, int embed_dim, const int32_t* __restrict__ joint_ids,
+    const int32_t* __restrict__ anc_ptr, const int32_t* __restrict__ anc_idx, const float* const* __restrict__ w1t_ptrs,
+    const float* const* __restrict__ b1_ptrs, const float* const* __restrict__ w2_ptrs,
+    const float* const* __restrict__ b2_ptrs, float* u_proper, float* s_proper,
+    float* mode, float delta_i_weight, float* __restrict__ pose_f, float* __restrict__ f_level,
+    float* __restrict__ pose_u, float* __restrict__ pose_s, float* __restrict__ pose_v, int B, int NJ, int svd_flavor) {
+    __builtin_amdgcn_s_setprio(3);                          // see linear_kernel
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    joint_level_body<HID, DEVSVD, NT, TBL>(smem, joint_ids[blockIdx.x], (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y * TBL, embed,
+                                           embed_dim, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper, s_proper, mode,
+                                           delta_i_weight, pose_f, f_level, pose_u, pose_s, pose_v, B, NJ, svd_flavor);
+}
+
+// ALL kinematic levels in ONE launch (round 5, the latency mode's head: one image per call spends 8 x ~4.5 us of dispatch floor on
+// the level launches and runs the LAPACK-faithful SVD -- a long, branchy routine executed by one lane per matrix -- from a cold
+// instruction cache in every one of them).  grid = (widest level, batch tiles): workgroup (slot, tile) evaluates, level after
+// level, the slot-th joint of the level for its tile's images with the very code of joint_level_kernel (same bits), and the
+// workgroups of a tile meet between levels at a counter in global memory: level l + 1 starts when all joints of level l have
+// published their U_proper / S_proper / mode (release: __threadfence + atomic add; acquire: atomic load + __threadfence, which
+// also drops the CU's L1 lines -- a line that holds a level-l entry may have been cached with an earlier level's neighbour).
+// Images are independent through the head, so no grid-wide synchronisation is needed -- only the <= 5 workgroups of a tile wait
+// for each other.  The counters reset themselves: the last workgroup of a tile to leave zeroes them, so the workspace is zeroed
+// once when it is allocated.  A waiting workgroup only needs its tile's other workgroups to be scheduled eventually; workgroups
+// are dispatched in order (slot fastest), so a tile is never split across "resident" and "never started" for long -- the host
+// side still uses this form only for grids that fit the chip at once (hps_head_pose_levels_fused).
+struct LevelTable {
+    int n_levels;
+    int first[HPS_HEAD_MAX_LEVELS];     // index of the level's first joint in level_joints
+    int size[HPS_HEAD_MAX_LEVELS];
+};
+template <int HID, int NT, int TBL>
+__global__ __launch_bounds__(NT) void joint_levels_fused_kernel(
+    const float* __restrict__ embed, int embed_dim, const int32_t* __restrict__ level_joints, const LevelTable lv,
+    const int32_t* __restrict__ anc_ptr, const int32_t* __restrict__ anc_idx, const float* const* __restrict__ w1t_ptrs,
+    const float* const* __restrict__ b1_ptrs, const float* const* __restrict__ w2_ptrs,
+    const float* const* __restrict__ b2_ptrs, float* u_proper, float* s_proper,
+    float* mode, float delta_i_weight, float* __restrict__ pose_f,
+    float* __restrict__ pose_u, float* __restrict__ pose_s, float* __restrict__ pose_v, int B, int NJ, int svd_flavor, int* sync) {
+    __builtin_amdgcn_s_setprio(3);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int slot = blockIdx.x, tile = blockIdx.y;
+    int* cnt = sync + (size_t)tile * (HPS_HEAD_MAX_LEVELS + 1);
+    for (int l = 0; l < lv.n_levels; ++l) {
+        if (l > 0) {
+            if (threadIdx.x == 0) {
+                while (__hip_atomic_load(cnt + (l - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lv.size[l - 1]) __builtin_amdgcn_s_sleep(1);
+            }
+            __syncthreads();
+            __threadfence();                     // acquire: the other workgroups' level l - 1 results, past this CU's L1
+        }
+        if (slot < lv.size[l])
+            joint_level_body<HID, true, NT, TBL>(smem, level_joints[lv.first[l] + slot], slot, lv.size[l], tile * TBL, embed, embed_dim,
+                                                 anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper, s_proper, mode,
+                                                 delta_i_weight, pose_f, nullptr, pose_u, pose_s, pose_v, B, NJ, svd_flavor);
+        __threadfence();                         // release: this workgroup's stores of level l
+        __syncthreads();                         // (also: the next level's body reuses the LDS buffers)
+        if (threadIdx.x == 0 && slot < lv.size[l]) __hip_atomic_fetch_add(cnt + l, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the last workgroup of the tile to get here resets the tile's counters (nobody waits on them any more)
+    if (threadIdx.x == 0) {
+        const int arrived = __hip_atomic_fetch_add(cnt + HPS_HEAD_MAX_LEVELS, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == (int)gridDim.x - 1) {
+            for (int l = 0; l <= HPS_HEAD_MAX_LEVELS; ++l) __hip_atomic_store(cnt + l, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -410,6 +478,58 @@ extern "C" int hps_head_joint_level_svd(const float* embed, int embed_dim, int h
     return joint_level_launch(embed, embed_dim, hidden, joint_ids, n_level, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs,
                               u_proper, s_proper, mode, delta_i_weight, pose_f, nullptr, pose_u, pose_s, pose_v, B,
                               num_body_joints, svd_flavor, stream);
+}
+
+extern "C" int hps_head_pose_levels_fused(const float* embed, int embed_dim, int hidden, const int32_t* level_joints,
+                                          const int32_t* level_sizes_host, int n_levels, const int32_t* anc_ptr,
+                                          const int32_t* anc_idx, const float* const* w1t_ptrs, const float* const* b1_ptrs,
+                                          const float* const* w2_ptrs, const float* const* b2_ptrs, float* u_proper,
+                                          float* s_proper, float* mode, float delta_i_weight, float* pose_f, float* pose_u,
+                                          float* pose_s, float* pose_v, int B, int num_body_joints, int svd_flavor,
+                                          int32_t* sync_ws, hps_stream_t stream) {
+    const bool wide = (svd_flavor & HPS_HEAD_WIDE_WORKGROUPS) != 0;
+    svd_flavor &= ~HPS_HEAD_WIDE_WORKGROUPS;
+    if (svd_flavor != HPS_SVD_ROUNDING_REFERENCE && svd_flavor != HPS_SVD_ROUNDING_FMA) return bad_arg("hps_head_pose_levels_fused: svd_flavor");
+    if (!embed || !level_joints || !level_sizes_host || !anc_ptr || !anc_idx || !w1t_ptrs || !b1_ptrs || !w2_ptrs || !b2_ptrs ||
+        !u_proper || !s_proper || !mode || !pose_f || !pose_u || !pose_s || !pose_v || !sync_ws)
+        return bad_arg("hps_head_pose_levels_fused: null pointer");
+    if (hidden != 128) { set_error("hps_head_pose_levels_fused: hidden=%d unsupported (128 = EMBED_DIM/2)", hidden); return HPS_E_UNSUPPORTED; }
+    if (n_levels < 1 || n_levels > HPS_HEAD_MAX_LEVELS) return bad_arg("hps_head_pose_levels_fused: n_levels");
+    if (B <= 0) return HPS_OK;
+    LevelTable lv;
+    lv.n_levels = n_levels;
+    int widest = 0, first = 0;
+    for (int l = 0; l < HPS_HEAD_MAX_LEVELS; ++l) {
+        lv.first[l] = first;
+        lv.size[l] = l < n_levels ? level_sizes_host[l] : 0;
+        if (lv.size[l] < 0) return bad_arg("hps_head_pose_levels_fused: level size");
+        first += lv.size[l];
+        widest = lv.size[l] > widest ? lv.size[l] : widest;
+    }
+    if (widest == 0) return HPS_OK;
+    constexpr int NT = 256, NTW = 1024, TBL = 4;
+    const int tiles = ceil_div(B, TBL);
+    // the workgroups of a tile wait for each other: only for grids the chip holds at once (two 1024-thread or eight 256-thread
+    // workgroups per CU) -- beyond that the caller uses the per-level launches (hps_head_pose_levels), same bits
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    if ((long)widest * tiles > (long)cus) {
+        set_error("hps_head_pose_levels_fused: %d x %d workgroups do not fit the device's %d CUs at once; use hps_head_pose_levels", widest, tiles, cus);
+        return HPS_E_UNSUPPORTED;
+    }
+    const int max_in = embed_dim + 21 * num_body_joints;
+    const size_t lds = ((size_t)((max_in * TBL + 3) & ~3) + 128 * TBL + (NT / 128) * TBL * 128) * sizeof(float);
+    const size_t ldsw = ((size_t)((max_in * TBL + 3) & ~3) + 128 * TBL + (NTW / 128) * TBL * 128) * sizeof(float);
+    if (lds > 64 * 1024) { set_error("hps_head_pose_levels_fused: embed_dim=%d too large", embed_dim); return HPS_E_UNSUPPORTED; }
+    if (wide && ldsw <= 64 * 1024)
+        hipLaunchKernelGGL((joint_levels_fused_kernel<128, NTW, TBL>), dim3(widest, tiles), dim3(NTW), ldsw, (hipStream_t)stream, embed, embed_dim,
+                           level_joints, lv, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper, s_proper, mode, delta_i_weight,
+                           pose_f, pose_u, pose_s, pose_v, B, num_body_joints, svd_flavor, sync_ws);
+    else
+        hipLaunchKernelGGL((joint_levels_fused_kernel<128, NT, TBL>), dim3(widest, tiles), dim3(NT), lds, (hipStream_t)stream, embed, embed_dim,
+                           level_joints, lv, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper, s_proper, mode, delta_i_weight,
+                           pose_f, pose_u, pose_s, pose_v, B, num_body_joints, svd_flavor, sync_ws);
+    return check_launch("hps_head_pose_levels_fused");
 }
 
 extern "C" int hps_svd3_packed(const float* f, float* usv, int n, int svd_flavor, hps_stream_t stream) {

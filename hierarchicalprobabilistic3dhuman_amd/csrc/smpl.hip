@@ -8,12 +8,13 @@ namespace hps {
 
 constexpr int MAXJ = 32;  // joints per mesh handled by one 32-lane group (SMPL: 24)
 
+#ifdef HPS_DEV_BUILD
 // ---------------------------------------------------------------------------------------------
-// pose prep: 32 lanes per mesh (lane = joint), 8 meshes per 256-thread workgroup.
+// pose prep, first generation (dev library only: the bit-level cross-check of the kernel below): 32 lanes per mesh (lane = joint), 8 meshes per 256-thread workgroup.
 // Local transforms live in LDS; the kinematic chain is evaluated level by level so that every
 // G_i = G_parent(i) * L_i is the same product the reference's index-ordered loop forms.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pose_prep_kernel(
+__global__ __launch_bounds__(256) void pose_prep_kernel_v1(
     const float* __restrict__ glob, const float* __restrict__ body, int is_rotmat,
     const float* __restrict__ betas, int nb, const float* __restrict__ j_template,
     const float* __restrict__ j_shapedirs, const int32_t* __restrict__ parents,
@@ -121,6 +122,146 @@ __global__ __launch_bounds__(256) void pose_prep_kernel(
     }
 }
 
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// pose prep: 32 lanes per mesh (lane = joint), PP_G = 16 meshes per 512-thread workgroup.
+// Local transforms live in LDS; the kinematic chain is evaluated level by level so that every
+// G_i = G_parent(i) * L_i is the same product the reference's index-ordered loop forms.
+//
+// Second generation (round 5; the first stays in the dev library as the bit-level cross-check).  The first one was a chain of
+// dependent global loads with nothing beside it inside the pipelined step's exclusive mesh window (28 us for 6 528 meshes, 0.09
+// of HBM): (1) `max depth` was a loop of J dependent scalar loads in front of the kinematic levels -- now a shuffle reduction
+// of the lanes' own depths; (2) the rest joints read 3 x nb values of j_shapedirs per lane one after another from global
+// memory -- the joint regressor (J x 3 x (nb + 1) floats) is now staged in LDS by the whole workgroup with coalesced loads;
+// (3) the k-major blend operand was written as 4-byte stores 8 meshes apart (32-byte runs per operand row) -- now the pose
+// features of the workgroup's 16 meshes are transposed through LDS and every operand row leaves as one 64-byte run.
+// Same arithmetic, expression for expression: identical bits (tests/test_gpu_smpl.py).
+// ---------------------------------------------------------------------------------------------
+constexpr int PP_G = 16;                 // meshes per workgroup
+constexpr int PP_XP = PP_G + 1;          // pitch of the transposed pose features (odd: the lanes' column writes spread over the banks)
+__global__ __launch_bounds__(32 * PP_G) void pose_prep_kernel(
+    const float* __restrict__ glob, const float* __restrict__ body, int is_rotmat,
+    const float* __restrict__ betas, int nb, const float* __restrict__ j_template,
+    const float* __restrict__ j_shapedirs, const int32_t* __restrict__ parents,
+    const int32_t* __restrict__ depth, int J, float* __restrict__ xt, int kp, int mp,
+    float* __restrict__ a_out, float* __restrict__ j_posed, float* __restrict__ rot_out, int M) {
+    __shared__ float sG[PP_G][MAXJ][12];  // world transform (3x4 row-major) per joint
+    __shared__ float sJ[PP_G][MAXJ][3];   // rest joints
+    __shared__ float sBeta[PP_G][16];
+    __shared__ float sJT[MAXJ * 3];       // j_template
+    __shared__ float sJS[MAXJ * 3 * 16];  // j_shapedirs
+    __shared__ float sX[9 * (MAXJ - 1) * PP_XP];   // pose features (R_j - I), [row 9 (j - 1) + e][mesh]
+
+    const int g = threadIdx.x >> 5;     // mesh slot in the workgroup
+    const int j = threadIdx.x & 31;     // joint
+    const int m0 = blockIdx.x * PP_G;
+    const int m = m0 + g;
+    const bool live = (m < M) && (j < J);
+
+    if (m < M && j < nb && j < 16) sBeta[g][j] = betas[(size_t)m * nb + j];
+    for (int i = threadIdx.x; i < J * 3; i += 32 * PP_G) sJT[i] = j_template[i];
+    for (int i = threadIdx.x; i < J * 3 * nb; i += 32 * PP_G) sJS[i] = j_shapedirs[i];
+    __syncthreads();
+
+    float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+    float Jr[3] = {0.f, 0.f, 0.f};
+    int par = -1, dep = 0;
+    if (live) {
+        par = parents[j];
+        dep = depth[j];
+        if (is_rotmat) {
+            const float* src = (j == 0) ? glob + (size_t)m * 9 : body + ((size_t)m * (J - 1) + (j - 1)) * 9;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) R[e] = src[e];
+        } else {
+            const float* src = (j == 0) ? glob + (size_t)m * 3 : body + ((size_t)m * (J - 1) + (j - 1)) * 3;
+            rodrigues_dev(src[0], src[1], src[2], R);
+        }
+        // rest joint: J = J_regressor (v_template + shapedirs beta) = j_template + j_shapedirs beta
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float acc = sJT[j * 3 + c];
+            for (int l = 0; l < nb; ++l) acc += sJS[(j * 3 + c) * nb + l] * sBeta[g][l];
+            Jr[c] = acc;
+            sJ[g][j][c] = acc;
+        }
+        if (rot_out) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) rot_out[((size_t)m * J + j) * 9 + e] = R[e];
+        }
+    }
+    // deepest kinematic level: a reduction over the 32 lanes of a mesh (every mesh slot computes the same value)
+    int max_depth = (j < J) ? depth[j] : 0;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) max_depth = max(max_depth, __shfl_xor(max_depth, d));
+    max_depth = __builtin_amdgcn_readfirstlane(max_depth);
+    __syncthreads();
+
+    // local transform L = [R | J - J_parent]; root: [R | J]
+    float T[12];
+    if (live) {
+        float rel[3] = {Jr[0], Jr[1], Jr[2]};
+        if (par >= 0) {
+            rel[0] -= sJ[g][par][0]; rel[1] -= sJ[g][par][1]; rel[2] -= sJ[g][par][2];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            T[r * 4 + 0] = R[r * 3 + 0]; T[r * 4 + 1] = R[r * 3 + 1]; T[r * 4 + 2] = R[r * 3 + 2];
+            T[r * 4 + 3] = rel[r];
+        }
+        if (dep == 0) {
+#pragma unroll
+            for (int e = 0; e < 12; ++e) sG[g][j][e] = T[e];
+        }
+    }
+    for (int lvl = 1; lvl <= max_depth; ++lvl) {
+        __syncthreads();
+        if (live && dep == lvl) {
+            float P[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) P[e] = sG[g][par][e];
+            float Gn[12];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    Gn[r * 4 + c] = P[r * 4 + 0] * T[0 * 4 + c] + P[r * 4 + 1] * T[1 * 4 + c] + P[r * 4 + 2] * T[2 * 4 + c];
+                Gn[r * 4 + 3] = P[r * 4 + 0] * T[3] + P[r * 4 + 1] * T[7] + P[r * 4 + 2] * T[11] + P[r * 4 + 3];
+            }
+#pragma unroll
+            for (int e = 0; e < 12; ++e) { T[e] = Gn[e]; sG[g][j][e] = Gn[e]; }
+        }
+    }
+    // T now holds the world transform G_j (roots kept their local transform).
+    if (live) {
+        float* ao = a_out + ((size_t)m * J + j) * 12;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            ao[r * 4 + 0] = T[r * 4 + 0]; ao[r * 4 + 1] = T[r * 4 + 1]; ao[r * 4 + 2] = T[r * 4 + 2];
+            // A = G - pad(G [J;0]) : translation minus rotated rest joint
+            ao[r * 4 + 3] = T[r * 4 + 3] - (T[r * 4 + 0] * Jr[0] + T[r * 4 + 1] * Jr[1] + T[r * 4 + 2] * Jr[2]);
+            j_posed[((size_t)m * J + j) * 3 + r] = T[r * 4 + 3];
+        }
+        // pose feature rows 9 (j - 1) + e = (R_j - I), transposed through LDS
+        if (j >= 1) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) sX[(9 * (j - 1) + e) * PP_XP + g] = R[e] - ((e % 4 == 0) ? 1.0f : 0.0f);
+        }
+    }
+    __syncthreads();
+    // blend operand, k-major: row k of the workgroup's meshes is one run of PP_G floats (betas, pose features, zero padding rows)
+    const int n_live = min(PP_G, M - m0), n_pose = 9 * (J - 1);
+    for (int i = threadIdx.x; i < kp * PP_G; i += 32 * PP_G) {
+        const int k = i / PP_G, gg = i % PP_G;
+        if (gg >= n_live) continue;
+        float v = 0.0f;
+        if (k < nb) v = sBeta[gg][k];
+        else if (k < nb + n_pose) v = sX[(k - nb) * PP_XP + gg];
+        xt[(size_t)k * mp + m0 + gg] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // LBS.  A workgroup owns VPT*256 consecutive vertices for its whole life (each lane keeps the K
 // (joint, weight) pairs of its VPT vertices in registers) and walks a contiguous chunk of meshes, G at a
@@ -196,10 +337,11 @@ __global__ __launch_bounds__(256) void lbs_kernel(const float* __restrict__ v_po
     }
 }
 
+#ifdef HPS_DEV_BUILD
 // ---------------------------------------------------------------------------------------------
-// joints: one 128-thread workgroup per mesh; thread r evaluates CSR row r on the mesh's vertices.
+// joints, first generation (dev library only: the bit-level cross-check of the kernel below): one 128-thread workgroup per mesh; thread r evaluates CSR row r on the mesh's vertices.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void joints_kernel(const float* __restrict__ verts, const float* __restrict__ j_posed,
+__global__ __launch_bounds__(128) void joints_kernel_v1(const float* __restrict__ verts, const float* __restrict__ j_posed,
                                                      const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_col,
                                                      const float* __restrict__ csr_val, int n_rows, int J,
                                                      const float* __restrict__ transl, float* __restrict__ joints, int V) {
@@ -237,6 +379,93 @@ __global__ __launch_bounds__(128) void joints_kernel(const float* __restrict__ v
         }
         float* d = joints + ((size_t)m * n_out + r) * 3;
         d[0] = x; d[1] = y; d[2] = z;
+    }
+}
+
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// joints: thread r evaluates CSR row r (a vertex pick or a regressed joint) on the vertices of JN_G meshes, one after another.
+//
+// Second generation (round 5; the first stays in the dev library as the bit-level cross-check).  The first one ran one
+// workgroup per mesh, and every row walked a chain of dependent loads -- row pointer -> column -> vertex, four entries at a
+// time: 45 us for 6 528 meshes inside the pipelined step's exclusive mesh window (0.08 of HBM).  Now a thread reads its row's
+// (column, weight) entries ONCE into registers (JN_L = 12 of them: every row of the reference's regressors; longer rows of
+// another model take the generic loop) and then, mesh after mesh, requests all of the row's vertices before the first is
+// used -- two meshes' worth of gathers in flight.  The sum of a row is the same chain of fused multiply-adds in row order:
+// identical bits.
+// ---------------------------------------------------------------------------------------------
+constexpr int JN_G = 4;      // meshes per workgroup
+constexpr int JN_L = 12;     // row entries kept in registers
+__global__ __launch_bounds__(128) void joints_kernel(const float* __restrict__ verts, const float* __restrict__ j_posed,
+                                                     const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_col,
+                                                     const float* __restrict__ csr_val, int n_rows, int J,
+                                                     const float* __restrict__ transl, float* __restrict__ joints, int V, int M) {
+    const int n_out = J + n_rows;
+    const int m0 = blockIdx.x * JN_G, m1 = min(M, m0 + JN_G);
+    for (int r = threadIdx.x; r < n_out; r += 128) {      // (one round for the reference's 90 joints)
+    if (r < J) {                                   // kinematic joints: the forward-kinematics translations (+ transl)
+        for (int m = m0; m < m1; ++m) {
+            float tx = 0.f, ty = 0.f, tz = 0.f;
+            if (transl) { tx = transl[m * 3 + 0]; ty = transl[m * 3 + 1]; tz = transl[m * 3 + 2]; }
+            const float* s = j_posed + ((size_t)m * J + r) * 3;
+            float* d = joints + ((size_t)m * n_out + r) * 3;
+            d[0] = s[0] + tx; d[1] = s[1] + ty; d[2] = s[2] + tz;
+        }
+        continue;
+    }
+    const int e0 = csr_ptr[r - J], len = csr_ptr[r - J + 1] - e0;
+    if (len <= JN_L) {
+        int col[JN_L];
+        float val[JN_L];
+#pragma unroll
+        for (int i = 0; i < JN_L; ++i) {           // entries behind the row's end repeat its first one (never added: see below)
+            const int e = e0 + (i < len ? i : 0);
+            col[i] = len > 0 ? csr_col[e] * 3 : 0;
+            val[i] = len > 0 ? csr_val[e] : 0.0f;
+        }
+        auto gather = [&](int m, f3 (&p)[JN_L]) {
+            const float* vm = verts + (size_t)m * V * 3;      // verts already include transl
+#pragma unroll
+            for (int i = 0; i < JN_L; ++i) p[i] = *reinterpret_cast<const f3*>(vm + col[i]);
+        };
+        auto reduce_store = [&](int m, const f3 (&p)[JN_L]) {
+            float x = 0.f, y = 0.f, z = 0.f;
+#pragma unroll
+            for (int i = 0; i < JN_L; ++i) {
+                const float nx = x + val[i] * p[i].x, ny = y + val[i] * p[i].y, nz = z + val[i] * p[i].z;
+                const bool on = i < len;
+                x = on ? nx : x; y = on ? ny : y; z = on ? nz : z;
+            }
+            float* d = joints + ((size_t)m * n_out + r) * 3;
+            d[0] = x; d[1] = y; d[2] = z;
+        };
+        int m = m0;
+        for (; m + 2 <= m1; m += 2) {
+            f3 pa[JN_L], pb[JN_L];
+            gather(m, pa);
+            gather(m + 1, pb);
+            reduce_store(m, pa);
+            reduce_store(m + 1, pb);
+        }
+        if (m < m1) {
+            f3 pa[JN_L];
+            gather(m, pa);
+            reduce_store(m, pa);
+        }
+        continue;
+    }
+    for (int m = m0; m < m1; ++m) {                // generic rows (longer than JN_L): entry by entry, in row order
+        const float* vm = verts + (size_t)m * V * 3;
+        float x = 0.f, y = 0.f, z = 0.f;
+        for (int e = e0; e < e0 + len; ++e) {
+            const float wv = csr_val[e];
+            const float* s = vm + (size_t)csr_col[e] * 3;
+            x += wv * s[0]; y += wv * s[1]; z += wv * s[2];
+        }
+        float* d = joints + ((size_t)m * n_out + r) * 3;
+        d[0] = x; d[1] = y; d[2] = z;
+    }
     }
 }
 
@@ -538,11 +767,27 @@ extern "C" int hps_smpl_pose_prep(const float* glob, const float* body, int is_r
         return bad_arg("hps_smpl_pose_prep: num_joints must be 1..32 and num_betas 0..16");
     if (kp < num_betas + 9 * (num_joints - 1) || mp < M) return bad_arg("hps_smpl_pose_prep: kp/mp too small");
     if (M <= 0) return HPS_OK;
-    hipLaunchKernelGGL(pose_prep_kernel, dim3(ceil_div(M, 8)), dim3(256), 0, (hipStream_t)stream, glob, body,
+    hipLaunchKernelGGL(pose_prep_kernel, dim3(ceil_div(M, PP_G)), dim3(32 * PP_G), 0, (hipStream_t)stream, glob, body,
                        is_rotmat, betas, num_betas, j_template, j_shapedirs, parents, depth, num_joints, xt, kp, mp,
                        a, j_posed, rot_out, M);
     return check_launch("hps_smpl_pose_prep");
 }
+
+#ifdef HPS_DEV_BUILD
+extern "C" int hps_dev_smpl_pose_prep_v1(const float* glob, const float* body, int is_rotmat, const float* betas,
+                                         int num_betas, const float* j_template, const float* j_shapedirs,
+                                         const int32_t* parents, const int32_t* depth, int num_joints, float* xt, int kp,
+                                         int mp, float* a, float* j_posed, float* rot_out, int M, hps_stream_t stream) {
+    if (!glob || !body || !betas || !j_template || !j_shapedirs || !parents || !depth || !xt || !a || !j_posed)
+        return bad_arg("hps_dev_smpl_pose_prep_v1: null pointer");
+    if (num_joints < 1 || num_joints > MAXJ || num_betas < 0 || num_betas > 16) return bad_arg("hps_dev_smpl_pose_prep_v1: dims");
+    if (M <= 0) return HPS_OK;
+    hipLaunchKernelGGL(pose_prep_kernel_v1, dim3(ceil_div(M, 8)), dim3(256), 0, (hipStream_t)stream, glob, body,
+                       is_rotmat, betas, num_betas, j_template, j_shapedirs, parents, depth, num_joints, xt, kp, mp,
+                       a, j_posed, rot_out, M);
+    return check_launch("hps_dev_smpl_pose_prep_v1");
+}
+#endif
 
 // LBS launch geometry.  variant 0 = the default chosen for the shipped path; the others exist for tuning
 // (hps_dev_lbs_variant).  target_blocks ~ how many workgroups are resident at once on 256 CUs.
@@ -615,10 +860,23 @@ extern "C" int hps_smpl_joints(const float* verts, const float* j_posed, const i
                                const float* transl, float* joints, int M, int V, hps_stream_t stream) {
     if (!verts || !j_posed || !csr_ptr || !csr_col || !csr_val || !joints) return bad_arg("hps_smpl_joints: null pointer");
     if (M <= 0) return HPS_OK;
-    hipLaunchKernelGGL(joints_kernel, dim3(M), dim3(128), 0, (hipStream_t)stream, verts, j_posed, csr_ptr, csr_col,
-                       csr_val, n_rows, num_joints, transl, joints, V);
+    if (num_joints < 0 || n_rows < 0) return bad_arg("hps_smpl_joints: num_joints / n_rows");
+    hipLaunchKernelGGL(joints_kernel, dim3(ceil_div(M, JN_G)), dim3(128), 0, (hipStream_t)stream, verts, j_posed, csr_ptr, csr_col,
+                       csr_val, n_rows, num_joints, transl, joints, V, M);
     return check_launch("hps_smpl_joints");
 }
+
+#ifdef HPS_DEV_BUILD
+extern "C" int hps_dev_smpl_joints_v1(const float* verts, const float* j_posed, const int32_t* csr_ptr,
+                                      const int32_t* csr_col, const float* csr_val, int n_rows, int num_joints,
+                                      const float* transl, float* joints, int M, int V, hps_stream_t stream) {
+    if (!verts || !j_posed || !csr_ptr || !csr_col || !csr_val || !joints) return bad_arg("hps_dev_smpl_joints_v1: null pointer");
+    if (M <= 0) return HPS_OK;
+    hipLaunchKernelGGL(joints_kernel_v1, dim3(M), dim3(128), 0, (hipStream_t)stream, verts, j_posed, csr_ptr, csr_col,
+                       csr_val, n_rows, num_joints, transl, joints, V);
+    return check_launch("hps_dev_smpl_joints_v1");
+}
+#endif
 
 #ifdef HPS_DEV_BUILD
 extern "C" int hps_dev_unc_mode(int mode) {

@@ -56,6 +56,7 @@ typedef void* hps_stream_t; /* hipStream_t */
  * layer's partial sums are then added in another order: results differ in the last bits, so this is a property of the model
  * (PoseMFShapeGaussianNet.set_latency_mode), never of the batch. */
 #define HPS_HEAD_WIDE_WORKGROUPS 0x100
+#define HPS_HEAD_MAX_LEVELS 32 /* kinematic depth levels hps_head_pose_levels_fused handles (the body tree has 8) */
 
 #define HPS_ACT_NONE 0
 #define HPS_ACT_ELU 1
@@ -81,9 +82,10 @@ int hps_stream_destroy(hps_stream_t stream);
  *   HPS_WS_SMPL_VPOSED (d0 = M, d1 = V)                         v_posed of the unfused hps_smpl_blend with 128-byte aligned rows
  *   HPS_WS_HEAD_F      (d0 = B, d1 = largest level size)        f_level_dev / f_host_pinned of hps_head_pose_levels
  *   HPS_WS_HEAD_USV    (d0 = B, d1 = largest level size)        usv_level_dev / usv_host_pinned of hps_head_pose_levels
+ *   HPS_WS_HEAD_SYNC   (d0 = B)                                 sync_ws of hps_head_pose_levels_fused (must be ZERO before its first use)
  * Unused dims are ignored.  Returns -1 (and sets hps_last_error) for an unknown `what` or negative dims. */
 enum { HPS_WS_CONV_SPLITK = 0, HPS_WS_SMPL_MP = 1, HPS_WS_SMPL_XT = 2, HPS_WS_SMPL_A = 3, HPS_WS_SMPL_VPOSED = 4,
-       HPS_WS_HEAD_F = 5, HPS_WS_HEAD_USV = 6 };
+       HPS_WS_HEAD_F = 5, HPS_WS_HEAD_USV = 6, HPS_WS_HEAD_SYNC = 7 };
 int64_t hps_query_workspace(int what, int64_t d0, int64_t d1, int64_t d2);
 
 /* ------------------------------------------------------------------------------------------
@@ -268,6 +270,22 @@ int hps_head_joint_level_svd(const float* embed, int embed_dim, int hidden, cons
                              float* s_proper, float* mode, float delta_i_weight, float* pose_f, float* pose_u,
                              float* pose_s, float* pose_v, int B, int num_body_joints, int svd_flavor,
                              hps_stream_t stream);
+
+/* The whole joint loop (models/poseMF_shapeGaussian_net.py:121-160) in ONE launch, device SVD: what hps_head_pose_levels issues as
+ * one hps_head_joint_level_svd launch per kinematic level (level_joints: the levels' joint ids back to back, level_sizes_host: HOST
+ * array of the n_levels <= HPS_HEAD_MAX_LEVELS level sizes), with the same per-joint code -- identical bits.  Workgroup (slot, tile)
+ * walks the levels for its four images; the <= widest-level workgroups of a tile meet between levels at counters in sync_ws
+ * (hps_query_workspace(HPS_WS_HEAD_SYNC, B) bytes; ZERO before the first use, the kernel leaves it zero).  For latency-bound calls
+ * on one or a few images: eight dispatches become one, and the branchy LAPACK-faithful SVD runs from a warm instruction cache from
+ * the second level on.  Returns HPS_E_UNSUPPORTED when widest level x ceil(B / 4) workgroups exceed the device's CU count (the
+ * waiting workgroups must all be schedulable at once): use hps_head_pose_levels then. */
+int hps_head_pose_levels_fused(const float* embed, int embed_dim, int hidden, const int32_t* level_joints,
+                               const int32_t* level_sizes_host, int n_levels, const int32_t* anc_ptr,
+                               const int32_t* anc_idx, const float* const* w1t_ptrs, const float* const* b1_ptrs,
+                               const float* const* w2_ptrs, const float* const* b2_ptrs, float* u_proper,
+                               float* s_proper, float* mode, float delta_i_weight, float* pose_f, float* pose_u,
+                               float* pose_s, float* pose_v, int B, int num_body_joints, int svd_flavor,
+                               int32_t* sync_ws, hps_stream_t stream);
 
 /* The same device SVD for n row-major 3x3 matrices: f (n,9) -> usv (n,21) packed [U (9) | S (3) | V (9)]; replaces
  * torch.svd(F.cpu()) (:137).  Non-finite or non-converging input (LAPACK: INFO != 0) gives NaN factors. */

@@ -59,6 +59,17 @@ int hps_conv2d_bn_act_v3(const float* x, const float* wn, const float* zeros, co
                          int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, int variant,
                          int ksplit, float* splitk_ws, hps_stream_t stream);
 
+/* First generations of hps_smpl_pose_prep (8 meshes per workgroup, operand rows written 4 bytes at a time) and hps_smpl_joints (one
+ * workgroup per mesh, dependent load chains per row): same arguments, same bits -- the cross-check of the round-5 kernels
+ * (tests/test_gpu_smpl.py). */
+int hps_dev_smpl_pose_prep_v1(const float* glob, const float* body, int is_rotmat, const float* betas, int num_betas,
+                              const float* j_template, const float* j_shapedirs, const int32_t* parents, const int32_t* depth,
+                              int num_joints, float* xt, int kp, int mp, float* a, float* j_posed, float* rot_out, int M,
+                              hps_stream_t stream);
+int hps_dev_smpl_joints_v1(const float* verts, const float* j_posed, const int32_t* csr_ptr, const int32_t* csr_col,
+                           const float* csr_val, int n_rows, int num_joints, const float* transl, float* joints, int M, int V,
+                           hps_stream_t stream);
+
 /* Tuning hook (tests/dev only): kernel choice of hps_smpl_blend: 0 / 1 = tiled (default), 2 = stationary-A (same bits). */
 int hps_dev_blend_mode(int mode);
 

@@ -616,3 +616,51 @@ def test_latency_mode_of_the_whole_net(dev, net_gpu, net_cpu, golden, golden_inp
     for a, b in zip(default, again):
         if torch.is_tensor(a):
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_all_levels_in_one_launch_equal_the_per_level_launches(dev, net_gpu):
+    """in latency mode the eight kinematic levels are ONE launch (hps_head_pose_levels_fused: workgroups of an
+    image tile hand their level's results to each other through counters in global memory).  The per-joint code is the per-level
+    kernel's: all eight outputs bit for bit, for batches that leave ragged tiles, for many calls in a row (the counters reset
+    themselves), on two streams at once (a workspace per stream), and the fall-back to per-level launches when the grid would not
+    fit the chip at once."""
+    feats = {B: (torch.rand(B, 512, generator=torch.Generator().manual_seed(70 + B)) * 2).to(dev) for B in (1, 2, 3, 4, 5, 17, 64, 204, 300)}
+
+    def run(B, fused):
+        net_gpu.fused_levels = fused
+        out = net_gpu(None, input_feats=feats[B])
+        return [t.clone() for t in out[:5]] + [out[5].loc.clone(), out[5].scale.clone(), out[6].clone(), out[7].clone()]
+
+    try:
+        net_gpu.set_latency_mode(True)
+        for B in feats:
+            want = run(B, False)
+            for rep in range(3 if B > 5 else 12):
+                got = run(B, True)
+                for i, (a, b) in enumerate(zip(want, got)):
+                    assert torch.equal(a, b), (B, rep, i, float((a - b).abs().max()))
+        # the workspace is left zero (self-resetting counters), whatever the batch
+        p = net_gpu._prepared
+        syncs = [v for k, v in p.items() if isinstance(k, tuple) and k[0] == "sync"]
+        assert syncs and all(int(v.abs().sum()) == 0 for v in syncs)
+        assert not any(k[2] == (300 + 3) // 4 for k in p if isinstance(k, tuple) and k[0] == "sync")     # 5 x 75 workgroups > 256 CUs: per-level launches
+        # two streams in flight at once
+        want = {B: run(B, False) for B in (1, 5)}
+        net_gpu.fused_levels = True
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        outs = {1: [], 5: []}
+        for rep in range(10):
+            for st, B in ((s1, 1), (s2, 5)):
+                with torch.cuda.stream(st):
+                    o = net_gpu(None, input_feats=feats[B])
+                    outs[B].append([o[0], o[1], o[2], o[3], o[4]])
+        torch.cuda.synchronize()
+        for B in (1, 5):
+            for o in outs[B]:
+                for a, b in zip(want[B][:5], o):
+                    assert torch.equal(a, b), B
+    finally:
+        net_gpu.fused_levels = True
+        net_gpu.set_latency_mode(False)

@@ -291,3 +291,102 @@ def test_c_abi_rejects_unsupported_k(dev, smpl_gpu):
     with pytest.raises(_capi.HpsError):
         _capi.call("hps_smpl_mesh_fused", _capi.ptr(z), _capi.ptr(z), _capi.ptr(z), _capi.ptr(z), _capi.iptr(zi), _capi.ptr(z),
                    5, 24, None, _capi.ptr(z), 1, 1, 16, 64, 384, _capi.stream())
+
+
+def _pose_prep(name, smpl, g, b, is_rotmat, be, M, dev, J=None, parents=None, depth=None):
+    """hps_smpl_pose_prep (or its first generation in the dev library) through the C ABI -> (xt, a, j_posed, rot)."""
+    P = _capi.ptr
+    J = smpl.NUM_JOINTS if J is None else J
+    mp = _capi.query_workspace(_capi.WS_SMPL_MP, M)
+    kp = smpl._kp
+    xt = torch.full((kp, mp), -3.0, device=dev)
+    a = torch.full((M, J, 12), -3.0, device=dev)
+    jp = torch.full((M, J, 3), -3.0, device=dev)
+    rot = torch.full((M, J, 9), -3.0, device=dev)
+    _capi.call(name, P(g), P(b), is_rotmat, P(be), smpl.num_betas, P(smpl._j_template), P(smpl._j_shapedirs),
+               _capi.iptr(smpl._parents_i32 if parents is None else parents), _capi.iptr(smpl._depth_i32 if depth is None else depth), J,
+               P(xt), kp, mp, P(a), P(jp), P(rot), M, _capi.stream())
+    return xt, a, jp, rot
+
+
+@pytest.mark.parametrize("M", [1, 15, 16, 17, 130, 6528])
+def test_pose_prep_second_generation_gives_the_first_ones_bits(M, dev, smpl_gpu):
+    """the round-5 pose-prep kernel (16 meshes per workgroup, joint regressor staged in LDS, the k-major blend
+    operand transposed through LDS, depth by a shuffle reduction) against the first generation kept in the dev library: every
+    output bit for bit -- both input routes, mesh counts that leave ragged workgroups, and the rows of the operand it must not
+    touch (columns of meshes that do not exist) left alone."""
+    betas, aa, _ = _pose(M, 40 + M, scale=0.9)
+    R = O.batch_rodrigues(aa.view(-1, 3)).view(M, 24, 9)
+    for is_rotmat, g, b in ((1, R[:, 0].contiguous(), R[:, 1:].reshape(M, -1).contiguous()),
+                            (0, aa[:, 0].contiguous(), aa[:, 1:].reshape(M, -1).contiguous())):
+        args = (smpl_gpu, g.to(dev), b.to(dev), is_rotmat, betas.to(dev), M, dev)
+        new = _pose_prep("hps_smpl_pose_prep", *args)
+        with _capi.dev_library():
+            old = _pose_prep("hps_dev_smpl_pose_prep_v1", *args)
+        for name, x, y in zip(("xt", "a", "j_posed", "rot"), new, old):
+            assert torch.equal(x, y), (M, is_rotmat, name, float((x - y).abs().max()))
+        assert bool((new[0][:, M:] == -3.0).all())                       # padding columns of the operand are not written
+
+
+def test_pose_prep_with_other_kinematic_trees(dev, smpl_gpu):
+    """Joint counts other than 24 and a chain-shaped tree (depth J - 1: more levels than the body's 8): same bits as the first
+    generation."""
+    for J, chain in ((7, False), (22, False), (32, True), (5, True)):
+        g0 = torch.Generator().manual_seed(J)
+        M = 37
+        parents = torch.tensor([-1] + ([i for i in range(J - 1)] if chain else [max(0, (i - 1) // 2) for i in range(1, J)]), dtype=torch.int32)
+        depth = torch.zeros(J, dtype=torch.int32)
+        for j in range(1, J):
+            depth[j] = depth[parents[j]] + 1
+        jt = torch.randn(J, 3, generator=g0).to(dev)
+        jsd = (0.1 * torch.randn(J, 3, 10, generator=g0)).to(dev)
+        R = O.batch_rodrigues(torch.randn(M * J, 3, generator=g0)).view(M, J, 9)
+        betas = torch.randn(M, 10, generator=g0).to(dev)
+
+        class Shim:
+            NUM_JOINTS, num_betas, _kp = J, 10, ((10 + 9 * (J - 1) + 15) // 16) * 16
+            _j_template, _j_shapedirs = jt, jsd
+        args = (Shim, R[:, 0].contiguous().to(dev), R[:, 1:].reshape(M, -1).contiguous().to(dev), 1, betas, M, dev, J, parents.to(dev), depth.to(dev))
+        new = _pose_prep("hps_smpl_pose_prep", *args)
+        with _capi.dev_library():
+            old = _pose_prep("hps_dev_smpl_pose_prep_v1", *args)
+        for name, x, y in zip(("xt", "a", "j_posed", "rot"), new, old):
+            assert torch.equal(x, y), (J, chain, name)
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 130, 6528])
+def test_joints_second_generation_gives_the_first_ones_bits(M, dev, smpl_gpu):
+    """the round-5 joint kernel (a row's entries in registers, four meshes per workgroup, two meshes of
+    gathers in flight) against the first generation: the reference's 90 joints bit for bit, with and without translation; and a
+    synthetic regressor with rows of 0, 1, 12, 13 and 40 entries and more than 128 output rows (the generic path)."""
+    P = _capi.ptr
+    g = torch.Generator().manual_seed(900 + M)
+    V, J = smpl_gpu.num_verts, 24
+    verts = torch.randn(M, V, 3, generator=g).to(dev)
+    jp = torch.randn(M, J, 3, generator=g).to(dev)
+    transl = torch.randn(M, 3, generator=g).to(dev)
+    lens = [0, 1, 12, 13, 40, 5, 7] + [int(x) for x in torch.randint(0, 15, (150,), generator=g)]
+    ptr = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    col = torch.randint(0, V, (int(ptr[-1]),), generator=g, dtype=torch.int32)
+    val = torch.randn(int(ptr[-1]), generator=g)
+    cases = [(smpl_gpu._csr_ptr, smpl_gpu._csr_col, smpl_gpu._csr_val, smpl_gpu._n_joint_rows),
+             (ptr.to(dev), col.to(dev), val.to(dev), len(lens))]
+    for cp, cc, cv, n_rows in cases:
+        for tr in (None, transl):
+            outs = []
+            for name in ("hps_smpl_joints", "hps_dev_smpl_joints_v1"):
+                o = torch.full((M, J + n_rows, 3), -5.0, device=dev)
+                with _capi.dev_library():
+                    _capi.call(name, P(verts), P(jp), _capi.iptr(cp), _capi.iptr(cc), P(cv), n_rows, J, P(tr) if tr is not None else None,
+                               P(o), M, V, _capi.stream())
+                outs.append(o)
+            assert torch.equal(outs[0], outs[1]), (M, n_rows, tr is not None, float((outs[0] - outs[1]).abs().max()))
+    # and the product library's own kernel (not just the dev build of the same source)
+    o = torch.empty(M, J + smpl_gpu._n_joint_rows, 3, device=dev)
+    _capi.call("hps_smpl_joints", P(verts), P(jp), _capi.iptr(smpl_gpu._csr_ptr), _capi.iptr(smpl_gpu._csr_col), P(smpl_gpu._csr_val),
+               smpl_gpu._n_joint_rows, J, None, P(o), M, V, _capi.stream())
+    with _capi.dev_library():
+        o1 = torch.empty_like(o)
+        _capi.call("hps_dev_smpl_joints_v1", P(verts), P(jp), _capi.iptr(smpl_gpu._csr_ptr), _capi.iptr(smpl_gpu._csr_col), P(smpl_gpu._csr_val),
+                   smpl_gpu._n_joint_rows, J, None, P(o1), M, V, _capi.stream())
+    assert torch.equal(o, o1)
