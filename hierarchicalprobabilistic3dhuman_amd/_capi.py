@@ -32,7 +32,7 @@ _PROTOTYPES = {
     "hps_smpl_lbs": [_P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
     "hps_smpl_mesh_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "hps_smpl_mesh_fused_np": [_I],
-    "hps_smpl_joints": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
+    "hps_smpl_joints": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _P],
     "hps_vertex_uncertainty": [_P, _P, _I, _I, _I, _P],
     "hps_query_workspace": [_I, _c.c_int64, _c.c_int64, _c.c_int64],
     "hps_mf_sample": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _c.c_float, _P, _P, _P, _c.c_uint64,
@@ -68,8 +68,6 @@ _PROTOTYPES = {
     "hps_encoder_run": [_P, _I, _P],
     "hps_head_pose_levels": [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _P, _P, _P,
                              _P, _P, _I, _I, _I, _I, _P],
-    "hps_head_pose_levels_fused": [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _P, _I, _I, _I,
-                                   _P, _P],
     "hps_nchw_to_padded_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "hps_nchw_to_padded_nhwc_generic": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "hps_maxpool3x3s2_pad": [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -82,6 +80,8 @@ _DEV_PROTOTYPES = {
     "hps_conv2d_bn_act_v2": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "hps_conv2d_bn_act_v3": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "hps_dev_conv_pad_ablate": [_I],
+    "hps_dev_splitk_two_pass": [_I],
+    "hps_dev_wino_two_pass": [_I],
     "hps_dev_unc_mode": [_I],
     "hps_dev_mesh_lds_floor": [_I],
     "hps_dev_blend_mode": [_I],
@@ -90,6 +90,8 @@ _DEV_PROTOTYPES = {
     "hps_global_avgpool": [_P, _P, _I, _I, _I, _P],
     "hps_dev_stem_winograd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hps_dev_conv3x3_winograd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "hps_dev_head_pose_levels_fused": [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _P, _I, _I, _I,
+                                   _P, _P],
     "hps_dev_smpl_pose_prep_v1": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
     "hps_dev_smpl_joints_v1": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
     "hps_dev_mesh_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],

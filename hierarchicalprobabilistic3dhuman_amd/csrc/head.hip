@@ -167,7 +167,8 @@ __device__ __forceinline__ void joint_level_body(
     const float* const* __restrict__ b1_ptrs, const float* const* __restrict__ w2_ptrs,
     const float* const* __restrict__ b2_ptrs, float* u_proper, float* s_proper,
     float* mode, float delta_i_weight, float* __restrict__ pose_f, float* __restrict__ f_level,
-    float* __restrict__ pose_u, float* __restrict__ pose_s, float* __restrict__ pose_v, int B, int NJ, int svd_flavor) {
+    float* __restrict__ pose_u, float* __restrict__ pose_s, float* __restrict__ pose_v, int B, int NJ, int svd_flavor,
+    int* published = nullptr) {
     constexpr int KS = NT / HID;
     constexpr int PARTS = NT >= 9 * TBL * 8 ? 8 : 4;       // lanes per output-layer dot product
     static_assert(NT % HID == 0 && TBL % 4 == 0 && NT >= 9 * TBL * PARTS && KS * HID >= 9, "joint_level_kernel: shape");
@@ -265,6 +266,8 @@ __device__ __forceinline__ void joint_level_body(
             for (int e = 0; e < 9; ++e) F[e] = red[r * 9 + e];
             gesdd3::svd3(svd_flavor, F, U, S, V);
             proper_svd_store(U, S, V, (size_t)(b0 + r) * NJ + joint, pose_u, pose_s, pose_v, u_proper, s_proper, mode);
+            // joint_levels_fused_kernel: this lane's stores are what the next level's workgroups wait for -- released by the lane itself
+            if (published) __hip_atomic_fetch_add(published, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -284,18 +287,25 @@ __global__ __launch_bounds__(NT) void joint_level_kernel(
                                            delta_i_weight, pose_f, f_level, pose_u, pose_s, pose_v, B, NJ, svd_flavor);
 }
 
-// ALL kinematic levels in ONE launch (round 5, the latency mode's head: one image per call spends 8 x ~4.5 us of dispatch floor on
-// the level launches and runs the LAPACK-faithful SVD -- a long, branchy routine executed by one lane per matrix -- from a cold
-// instruction cache in every one of them).  grid = (widest level, batch tiles): workgroup (slot, tile) evaluates, level after
+#ifdef HPS_DEV_BUILD
+// EXPERIMENT, dev library only (measured and NOT adopted): ALL kinematic levels in ONE launch.  The hypothesis
+// was that one image per call spends 8 x ~4.5 us of dispatch floor on the level launches and runs the LAPACK-faithful SVD -- a
+// long, branchy routine executed by one lane per matrix -- from a cold instruction cache in every one of them.  Measured on one
+// box, interleaved (tools/latency_b1.py --latency [--per-level], profiles/r05_experiments.txt): batch-1 infer() 0.716-0.718 ms
+// with this kernel (202 us for the eight levels) against 0.708-0.709 ms with eight launches (8 x 22.6 us) -- stream-ordered
+// launches already start back to back (the next dispatch is prepared while its predecessor runs), so there is no floor to
+// remove, the SVD's ~15 us per level is a genuine dependent-instruction chain (warm or cold), and a cross-workgroup hand-over
+// through L2 costs about what a dispatch does.  Kept as the bit-level cross-check of "images are independent through the head".  grid = (widest level, batch tiles): workgroup (slot, tile) evaluates, level after
 // level, the slot-th joint of the level for its tile's images with the very code of joint_level_kernel (same bits), and the
 // workgroups of a tile meet between levels at a counter in global memory: level l + 1 starts when all joints of level l have
-// published their U_proper / S_proper / mode (release: __threadfence + atomic add; acquire: atomic load + __threadfence, which
+// published their U_proper / S_proper / mode (release: the lane that ran a matrix's SVD and stored its results adds 1 to the
+// level's counter with release semantics; acquire: one lane polls the counter, then every wave executes an acquire fence, which
 // also drops the CU's L1 lines -- a line that holds a level-l entry may have been cached with an earlier level's neighbour).
 // Images are independent through the head, so no grid-wide synchronisation is needed -- only the <= 5 workgroups of a tile wait
 // for each other.  The counters reset themselves: the last workgroup of a tile to leave zeroes them, so the workspace is zeroed
 // once when it is allocated.  A waiting workgroup only needs its tile's other workgroups to be scheduled eventually; workgroups
 // are dispatched in order (slot fastest), so a tile is never split across "resident" and "never started" for long -- the host
-// side still uses this form only for grids that fit the chip at once (hps_head_pose_levels_fused).
+// side still uses this form only for grids that fit the chip at once (hps_dev_head_pose_levels_fused).
 struct LevelTable {
     int n_levels;
     int first[HPS_HEAD_MAX_LEVELS];     // index of the level's first joint in level_joints
@@ -313,23 +323,23 @@ __global__ __launch_bounds__(NT) void joint_levels_fused_kernel(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int slot = blockIdx.x, tile = blockIdx.y;
     int* cnt = sync + (size_t)tile * (HPS_HEAD_MAX_LEVELS + 1);
+    const int n_live = min(TBL, B - tile * TBL);            // images of this tile: one published (joint, image) result each
     for (int l = 0; l < lv.n_levels; ++l) {
         if (l > 0) {
             if (threadIdx.x == 0) {
-                while (__hip_atomic_load(cnt + (l - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lv.size[l - 1]) __builtin_amdgcn_s_sleep(1);
+                while (__hip_atomic_load(cnt + (l - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lv.size[l - 1] * n_live) __builtin_amdgcn_s_sleep(1);
             }
-            __syncthreads();
-            __threadfence();                     // acquire: the other workgroups' level l - 1 results, past this CU's L1
+            __syncthreads();                                          // (also: the previous level's body is done with the LDS buffers)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // per wave: drop the CU's L1 lines, see the other workgroups' results
         }
         if (slot < lv.size[l])
             joint_level_body<HID, true, NT, TBL>(smem, level_joints[lv.first[l] + slot], slot, lv.size[l], tile * TBL, embed, embed_dim,
                                                  anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper, s_proper, mode,
-                                                 delta_i_weight, pose_f, nullptr, pose_u, pose_s, pose_v, B, NJ, svd_flavor);
-        __threadfence();                         // release: this workgroup's stores of level l
-        __syncthreads();                         // (also: the next level's body reuses the LDS buffers)
-        if (threadIdx.x == 0 && slot < lv.size[l]) __hip_atomic_fetch_add(cnt + l, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                                                 delta_i_weight, pose_f, nullptr, pose_u, pose_s, pose_v, B, NJ, svd_flavor, cnt + l);
     }
-    // the last workgroup of the tile to get here resets the tile's counters (nobody waits on them any more)
+    // the last workgroup of the tile to get here resets the tile's counters (nobody waits on them any more: a workgroup arrives
+    // here only after its last wait)
+    __syncthreads();
     if (threadIdx.x == 0) {
         const int arrived = __hip_atomic_fetch_add(cnt + HPS_HEAD_MAX_LEVELS, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (arrived == (int)gridDim.x - 1) {
@@ -337,6 +347,8 @@ __global__ __launch_bounds__(NT) void joint_levels_fused_kernel(
         }
     }
 }
+
+#endif
 
 // proper SVD + mode (:139-152): thread per (image, joint of the level); input packed [U | S | V] per matrix
 __global__ void svd_finish_kernel(const float* __restrict__ usv, const int32_t* __restrict__ joint_ids, int n_level,
@@ -480,7 +492,8 @@ extern "C" int hps_head_joint_level_svd(const float* embed, int embed_dim, int h
                               num_body_joints, svd_flavor, stream);
 }
 
-extern "C" int hps_head_pose_levels_fused(const float* embed, int embed_dim, int hidden, const int32_t* level_joints,
+#ifdef HPS_DEV_BUILD
+extern "C" int hps_dev_head_pose_levels_fused(const float* embed, int embed_dim, int hidden, const int32_t* level_joints,
                                           const int32_t* level_sizes_host, int n_levels, const int32_t* anc_ptr,
                                           const int32_t* anc_idx, const float* const* w1t_ptrs, const float* const* b1_ptrs,
                                           const float* const* w2_ptrs, const float* const* b2_ptrs, float* u_proper,
@@ -489,12 +502,12 @@ extern "C" int hps_head_pose_levels_fused(const float* embed, int embed_dim, int
                                           int32_t* sync_ws, hps_stream_t stream) {
     const bool wide = (svd_flavor & HPS_HEAD_WIDE_WORKGROUPS) != 0;
     svd_flavor &= ~HPS_HEAD_WIDE_WORKGROUPS;
-    if (svd_flavor != HPS_SVD_ROUNDING_REFERENCE && svd_flavor != HPS_SVD_ROUNDING_FMA) return bad_arg("hps_head_pose_levels_fused: svd_flavor");
+    if (svd_flavor != HPS_SVD_ROUNDING_REFERENCE && svd_flavor != HPS_SVD_ROUNDING_FMA) return bad_arg("hps_dev_head_pose_levels_fused: svd_flavor");
     if (!embed || !level_joints || !level_sizes_host || !anc_ptr || !anc_idx || !w1t_ptrs || !b1_ptrs || !w2_ptrs || !b2_ptrs ||
         !u_proper || !s_proper || !mode || !pose_f || !pose_u || !pose_s || !pose_v || !sync_ws)
-        return bad_arg("hps_head_pose_levels_fused: null pointer");
-    if (hidden != 128) { set_error("hps_head_pose_levels_fused: hidden=%d unsupported (128 = EMBED_DIM/2)", hidden); return HPS_E_UNSUPPORTED; }
-    if (n_levels < 1 || n_levels > HPS_HEAD_MAX_LEVELS) return bad_arg("hps_head_pose_levels_fused: n_levels");
+        return bad_arg("hps_dev_head_pose_levels_fused: null pointer");
+    if (hidden != 128) { set_error("hps_dev_head_pose_levels_fused: hidden=%d unsupported (128 = EMBED_DIM/2)", hidden); return HPS_E_UNSUPPORTED; }
+    if (n_levels < 1 || n_levels > HPS_HEAD_MAX_LEVELS) return bad_arg("hps_dev_head_pose_levels_fused: n_levels");
     if (B <= 0) return HPS_OK;
     LevelTable lv;
     lv.n_levels = n_levels;
@@ -502,7 +515,7 @@ extern "C" int hps_head_pose_levels_fused(const float* embed, int embed_dim, int
     for (int l = 0; l < HPS_HEAD_MAX_LEVELS; ++l) {
         lv.first[l] = first;
         lv.size[l] = l < n_levels ? level_sizes_host[l] : 0;
-        if (lv.size[l] < 0) return bad_arg("hps_head_pose_levels_fused: level size");
+        if (lv.size[l] < 0) return bad_arg("hps_dev_head_pose_levels_fused: level size");
         first += lv.size[l];
         widest = lv.size[l] > widest ? lv.size[l] : widest;
     }
@@ -514,13 +527,13 @@ extern "C" int hps_head_pose_levels_fused(const float* embed, int embed_dim, int
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
     if ((long)widest * tiles > (long)cus) {
-        set_error("hps_head_pose_levels_fused: %d x %d workgroups do not fit the device's %d CUs at once; use hps_head_pose_levels", widest, tiles, cus);
+        set_error("hps_dev_head_pose_levels_fused: %d x %d workgroups do not fit the device's %d CUs at once; use hps_head_pose_levels", widest, tiles, cus);
         return HPS_E_UNSUPPORTED;
     }
     const int max_in = embed_dim + 21 * num_body_joints;
     const size_t lds = ((size_t)((max_in * TBL + 3) & ~3) + 128 * TBL + (NT / 128) * TBL * 128) * sizeof(float);
     const size_t ldsw = ((size_t)((max_in * TBL + 3) & ~3) + 128 * TBL + (NTW / 128) * TBL * 128) * sizeof(float);
-    if (lds > 64 * 1024) { set_error("hps_head_pose_levels_fused: embed_dim=%d too large", embed_dim); return HPS_E_UNSUPPORTED; }
+    if (lds > 64 * 1024) { set_error("hps_dev_head_pose_levels_fused: embed_dim=%d too large", embed_dim); return HPS_E_UNSUPPORTED; }
     if (wide && ldsw <= 64 * 1024)
         hipLaunchKernelGGL((joint_levels_fused_kernel<128, NTW, TBL>), dim3(widest, tiles), dim3(NTW), ldsw, (hipStream_t)stream, embed, embed_dim,
                            level_joints, lv, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper, s_proper, mode, delta_i_weight,
@@ -529,8 +542,10 @@ extern "C" int hps_head_pose_levels_fused(const float* embed, int embed_dim, int
         hipLaunchKernelGGL((joint_levels_fused_kernel<128, NT, TBL>), dim3(widest, tiles), dim3(NT), lds, (hipStream_t)stream, embed, embed_dim,
                            level_joints, lv, anc_ptr, anc_idx, w1t_ptrs, b1_ptrs, w2_ptrs, b2_ptrs, u_proper, s_proper, mode, delta_i_weight,
                            pose_f, pose_u, pose_s, pose_v, B, num_body_joints, svd_flavor, sync_ws);
-    return check_launch("hps_head_pose_levels_fused");
+    return check_launch("hps_dev_head_pose_levels_fused");
 }
+
+#endif
 
 extern "C" int hps_svd3_packed(const float* f, float* usv, int n, int svd_flavor, hps_stream_t stream) {
     if (!f || !usv) return bad_arg("hps_svd3_packed: null pointer");

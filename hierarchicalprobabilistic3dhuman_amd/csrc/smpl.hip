@@ -385,87 +385,65 @@ __global__ __launch_bounds__(128) void joints_kernel_v1(const float* __restrict_
 #endif
 
 // ---------------------------------------------------------------------------------------------
-// joints: thread r evaluates CSR row r (a vertex pick or a regressed joint) on the vertices of JN_G meshes, one after another.
+// joints: JN_G meshes per workgroup, two phases.  (1) GATHER: thread e fetches the vertex of CSR entry e of each of the workgroup's
+// meshes into LDS -- one independent 12-byte load per (entry, mesh), every thread busy, nothing fetched twice; (2) SUM: thread
+// (mesh, row) adds its row's entries from LDS as ONE chain of explicit fused multiply-adds in row order.
 //
-// Second generation (round 5; the first stays in the dev library as the bit-level cross-check).  The first one ran one
-// workgroup per mesh, and every row walked a chain of dependent loads -- row pointer -> column -> vertex, four entries at a
-// time: 45 us for 6 528 meshes inside the pipelined step's exclusive mesh window (0.08 of HBM).  Now a thread reads its row's
-// (column, weight) entries ONCE into registers (JN_L = 12 of them: every row of the reference's regressors; longer rows of
-// another model take the generic loop) and then, mesh after mesh, requests all of the row's vertices before the first is
-// used -- two meshes' worth of gathers in flight.  The sum of a row is the same chain of fused multiply-adds in row order:
-// identical bits.
+// Third form (round 5; the first stays in the dev library as the cross-check).  The first ran one workgroup per mesh and every row
+// walked its entries four at a time through dependent loads (row pointer -> column -> vertex): 45 us for 6 528 meshes inside the
+// pipelined step's exclusive mesh window, 60 us alone with the vertices coming from HBM.  A second form kept thread = row with the
+// row's entries in registers and several meshes per workgroup -- and was SLOWER (74 us): the rows are 1 to 12 entries long, so the
+// padded 12-slot rows issued three times the loads, and a quarter of the workgroups left the memory system with fewer requests in
+// flight.  What bounds this kernel is the number of scattered 12-byte requests the memory system has in flight, not the chain.
+// The sum of a row no longer depends on what the vectoriser does with a loop (the first generation's four-entry groups came out of
+// hipcc as a mix of v_pk_mul + add and v_pk_fma -- two of every four products rounded separately, an accident of that build):
+// results are within one unit in the last place of it, and a mesh's joints do not depend on the batch.
 // ---------------------------------------------------------------------------------------------
-constexpr int JN_G = 4;      // meshes per workgroup
-constexpr int JN_L = 12;     // row entries kept in registers
-__global__ __launch_bounds__(128) void joints_kernel(const float* __restrict__ verts, const float* __restrict__ j_posed,
-                                                     const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_col,
-                                                     const float* __restrict__ csr_val, int n_rows, int J,
-                                                     const float* __restrict__ transl, float* __restrict__ joints, int V, int M) {
+constexpr int JN_G = 4;        // meshes per workgroup
+constexpr int JN_T = 320;      // threads: >= the 276 entries of the reference's regressors (one gather round)
+__global__ __launch_bounds__(JN_T) void joints_kernel(const float* __restrict__ verts, const float* __restrict__ j_posed,
+                                                      const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_col,
+                                                      const float* __restrict__ csr_val, int n_rows, int J,
+                                                      const float* __restrict__ transl, float* __restrict__ joints, int V, int M, int nnz) {
+    extern __shared__ __attribute__((aligned(16))) float sj[];       // [JN_G][nnz] vertices (x, y, z), then [nnz] weights
+    float* sP = sj;
+    float* sW = sj + (size_t)JN_G * nnz * 3;
     const int n_out = J + n_rows;
-    const int m0 = blockIdx.x * JN_G, m1 = min(M, m0 + JN_G);
-    for (int r = threadIdx.x; r < n_out; r += 128) {      // (one round for the reference's 90 joints)
-    if (r < J) {                                   // kinematic joints: the forward-kinematics translations (+ transl)
-        for (int m = m0; m < m1; ++m) {
+    const int m0 = blockIdx.x * JN_G, g_n = min(JN_G, M - m0);
+    for (int e = threadIdx.x; e < nnz; e += JN_T) {
+        const int c = csr_col[e] * 3;
+        sW[e] = csr_val[e];
+        f3 p[JN_G];
+#pragma unroll
+        for (int g = 0; g < JN_G; ++g)       // a mesh beyond M re-reads the last one (never summed)
+            p[g] = *reinterpret_cast<const f3*>(verts + (size_t)(m0 + min(g, g_n - 1)) * V * 3 + c);     // verts already include transl
+#pragma unroll
+        for (int g = 0; g < JN_G; ++g) {
+            float* d = sP + ((size_t)g * nnz + e) * 3;
+            d[0] = p[g].x; d[1] = p[g].y; d[2] = p[g].z;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_out * g_n; i += JN_T) {
+        const int g = i / n_out, r = i - g * n_out;
+        const int m = m0 + g;
+        float x, y, z;
+        if (r < J) {                             // kinematic joints: the forward-kinematics translations (+ transl)
             float tx = 0.f, ty = 0.f, tz = 0.f;
             if (transl) { tx = transl[m * 3 + 0]; ty = transl[m * 3 + 1]; tz = transl[m * 3 + 2]; }
             const float* s = j_posed + ((size_t)m * J + r) * 3;
-            float* d = joints + ((size_t)m * n_out + r) * 3;
-            d[0] = s[0] + tx; d[1] = s[1] + ty; d[2] = s[2] + tz;
-        }
-        continue;
-    }
-    const int e0 = csr_ptr[r - J], len = csr_ptr[r - J + 1] - e0;
-    if (len <= JN_L) {
-        int col[JN_L];
-        float val[JN_L];
-#pragma unroll
-        for (int i = 0; i < JN_L; ++i) {           // entries behind the row's end repeat its first one (never added: see below)
-            const int e = e0 + (i < len ? i : 0);
-            col[i] = len > 0 ? csr_col[e] * 3 : 0;
-            val[i] = len > 0 ? csr_val[e] : 0.0f;
-        }
-        auto gather = [&](int m, f3 (&p)[JN_L]) {
-            const float* vm = verts + (size_t)m * V * 3;      // verts already include transl
-#pragma unroll
-            for (int i = 0; i < JN_L; ++i) p[i] = *reinterpret_cast<const f3*>(vm + col[i]);
-        };
-        auto reduce_store = [&](int m, const f3 (&p)[JN_L]) {
-            float x = 0.f, y = 0.f, z = 0.f;
-#pragma unroll
-            for (int i = 0; i < JN_L; ++i) {
-                const float nx = x + val[i] * p[i].x, ny = y + val[i] * p[i].y, nz = z + val[i] * p[i].z;
-                const bool on = i < len;
-                x = on ? nx : x; y = on ? ny : y; z = on ? nz : z;
+            x = s[0] + tx; y = s[1] + ty; z = s[2] + tz;
+        } else {
+            x = y = z = 0.f;
+            const int e1 = csr_ptr[r - J + 1];
+            for (int e = csr_ptr[r - J]; e < e1; ++e) {
+                const float w = sW[e];
+                const float* s = sP + ((size_t)g * nnz + e) * 3;
+                x = __builtin_fmaf(w, s[0], x); y = __builtin_fmaf(w, s[1], y); z = __builtin_fmaf(w, s[2], z);
             }
-            float* d = joints + ((size_t)m * n_out + r) * 3;
-            d[0] = x; d[1] = y; d[2] = z;
-        };
-        int m = m0;
-        for (; m + 2 <= m1; m += 2) {
-            f3 pa[JN_L], pb[JN_L];
-            gather(m, pa);
-            gather(m + 1, pb);
-            reduce_store(m, pa);
-            reduce_store(m + 1, pb);
-        }
-        if (m < m1) {
-            f3 pa[JN_L];
-            gather(m, pa);
-            reduce_store(m, pa);
-        }
-        continue;
-    }
-    for (int m = m0; m < m1; ++m) {                // generic rows (longer than JN_L): entry by entry, in row order
-        const float* vm = verts + (size_t)m * V * 3;
-        float x = 0.f, y = 0.f, z = 0.f;
-        for (int e = e0; e < e0 + len; ++e) {
-            const float wv = csr_val[e];
-            const float* s = vm + (size_t)csr_col[e] * 3;
-            x += wv * s[0]; y += wv * s[1]; z += wv * s[2];
         }
         float* d = joints + ((size_t)m * n_out + r) * 3;
         d[0] = x; d[1] = y; d[2] = z;
-    }
     }
 }
 
@@ -856,13 +834,15 @@ extern "C" int hps_dev_lbs_variant(const float* v_posed, int ld_vposed, const fl
 #endif
 
 extern "C" int hps_smpl_joints(const float* verts, const float* j_posed, const int32_t* csr_ptr,
-                               const int32_t* csr_col, const float* csr_val, int n_rows, int num_joints,
+                               const int32_t* csr_col, const float* csr_val, int n_rows, int nnz, int num_joints,
                                const float* transl, float* joints, int M, int V, hps_stream_t stream) {
     if (!verts || !j_posed || !csr_ptr || !csr_col || !csr_val || !joints) return bad_arg("hps_smpl_joints: null pointer");
     if (M <= 0) return HPS_OK;
-    if (num_joints < 0 || n_rows < 0) return bad_arg("hps_smpl_joints: num_joints / n_rows");
-    hipLaunchKernelGGL(joints_kernel, dim3(ceil_div(M, JN_G)), dim3(128), 0, (hipStream_t)stream, verts, j_posed, csr_ptr, csr_col,
-                       csr_val, n_rows, num_joints, transl, joints, V, M);
+    if (num_joints < 0 || n_rows < 0 || nnz < 0) return bad_arg("hps_smpl_joints: num_joints / n_rows / nnz");
+    const size_t lds = ((size_t)JN_G * 3 + 1) * (size_t)nnz * sizeof(float);       // the reference's regressors: 276 entries -> 14 KB
+    if (lds > 64 * 1024) { set_error("hps_smpl_joints: %d regressor entries exceed the LDS stage (at most %d)", nnz, (int)(64 * 1024 / ((JN_G * 3 + 1) * 4))); return HPS_E_UNSUPPORTED; }
+    hipLaunchKernelGGL(joints_kernel, dim3(ceil_div(M, JN_G)), dim3(JN_T), lds, (hipStream_t)stream, verts, j_posed, csr_ptr, csr_col,
+                       csr_val, n_rows, num_joints, transl, joints, V, M, nnz);
     return check_launch("hps_smpl_joints");
 }
 

@@ -104,13 +104,12 @@ class PoseMFShapeGaussianNet(nn.Module):
         self.svd_mode = "device"       # "device": in-kernel gesdd-faithful SVD; "host": MKL sgesdd round trip (the routine itself)
         self.svd_flavor = None         # None: the rounding flavour of this host's MKL (calibrated); 0 / 1 force one
         self.latency_mode = False      # set_latency_mode(): encoder on direct kernels with many K slices, joint MLPs on wide workgroups
-        self.fused_levels = True       # latency mode: all kinematic levels in ONE launch (hps_head_pose_levels_fused) when the grid fits the chip
+        self.fused_levels = False      # experiment (tests / tools, dev library): all kinematic levels in ONE launch -- measured slower than eight launches
 
     def set_latency_mode(self, on=True):
         """One switch for one-image-at-a-time deployments (the reference's run_predict operating point): the encoder's latency mode
         (ResNet.set_latency_mode) and 1024-thread / eight-K-slice workgroups for the joint MLPs of the head
-        (HPS_HEAD_WIDE_WORKGROUPS; device SVD mode only), all eight kinematic levels in one launch (hps_head_pose_levels_fused: the
-        same per-joint code, identical bits to the per-level launches) while the batch is small enough.  A property of the model: within a mode results do not depend on the
+        (HPS_HEAD_WIDE_WORKGROUPS; device SVD mode only).  A property of the model: within a mode results do not depend on the
         batch size; between the modes they differ in the last bits (other summation orders)."""
         self.latency_mode = bool(on)
         self.image_encoder.set_latency_mode(on)
@@ -238,17 +237,19 @@ class PoseMFShapeGaussianNet(nn.Module):
             VP = _capi._P
             if device_svd and self.latency_mode and self.fused_levels and len(p["levels"]) <= 32 and \
                     max_n * ((B + 3) // 4) <= torch.cuda.get_device_properties(dev).multi_processor_count:
-                # one launch for the whole joint loop: the workgroups of an image tile hand their level's results to each other
-                # through counters in a small zeroed workspace (one per stream: two forwards in flight must not share counters)
+                # EXPERIMENT (dev library; measured slower than the eight launches, csrc/head.hip): one launch for the whole joint
+                # loop -- the workgroups of an image tile hand their level's results to each other through counters in a small
+                # zeroed workspace (one per stream: two forwards in flight must not share counters)
                 key = ("sync", torch.cuda.current_stream().cuda_stream, (B + 3) // 4)
                 sync = p.get(key)
                 if sync is None:
                     sync = p[key] = torch.zeros(_capi.query_workspace(_capi.WS_HEAD_SYNC, B) // 4, dtype=torch.int32, device=dev)
-                _capi.call("hps_head_pose_levels_fused", P(embed), embed_dim, embed_dim // 2, _capi.iptr(p["level_joints"]),
-                           VP(sizes.data_ptr()), len(p["levels"]), _capi.iptr(p["anc_ptr"]), _capi.iptr(p["anc_idx"]),
-                           VP(p["w1t_ptrs"].data_ptr()), VP(p["b1_ptrs"].data_ptr()), VP(p["w2_ptrs"].data_ptr()),
-                           VP(p["b2_ptrs"].data_ptr()), P(U_proper), P(S_proper), P(mode), delta, P(pose_F), P(pose_U), P(pose_S),
-                           P(pose_V), B, nj, self._flavor() | _capi.HEAD_WIDE_WORKGROUPS, _capi.iptr(sync), s)
+                with _capi.dev_library():
+                    _capi.call("hps_dev_head_pose_levels_fused", P(embed), embed_dim, embed_dim // 2, _capi.iptr(p["level_joints"]),
+                               VP(sizes.data_ptr()), len(p["levels"]), _capi.iptr(p["anc_ptr"]), _capi.iptr(p["anc_idx"]),
+                               VP(p["w1t_ptrs"].data_ptr()), VP(p["b1_ptrs"].data_ptr()), VP(p["w2_ptrs"].data_ptr()),
+                               VP(p["b2_ptrs"].data_ptr()), P(U_proper), P(S_proper), P(mode), delta, P(pose_F), P(pose_U), P(pose_S),
+                               P(pose_V), B, nj, self._flavor() | _capi.HEAD_WIDE_WORKGROUPS, _capi.iptr(sync), s)
                 return pose_F, pose_U, pose_S, pose_V, mode, shape_dist, glob, cam
             if device_svd:
                 f_dev = usv_dev = None

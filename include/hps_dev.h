@@ -70,6 +70,22 @@ int hps_dev_smpl_joints_v1(const float* verts, const float* j_posed, const int32
                            const float* csr_val, int n_rows, int num_joints, const float* transl, float* joints, int M, int V,
                            hps_stream_t stream);
 
+/* EXPERIMENT (measured, not adopted: csrc/head.hip).  The whole joint loop (models/poseMF_shapeGaussian_net.py:121-160) in ONE launch, device SVD: what hps_head_pose_levels issues as
+ * one hps_head_joint_level_svd launch per kinematic level (level_joints: the levels' joint ids back to back, level_sizes_host: HOST
+ * array of the n_levels <= HPS_HEAD_MAX_LEVELS level sizes), with the same per-joint code -- identical bits.  Workgroup (slot, tile)
+ * walks the levels for its four images; the <= widest-level workgroups of a tile meet between levels at counters in sync_ws
+ * (hps_query_workspace(HPS_WS_HEAD_SYNC, B) bytes; ZERO before the first use, the kernel leaves it zero).  For latency-bound calls
+ * on one or a few images: eight dispatches become one, and the branchy LAPACK-faithful SVD runs from a warm instruction cache from
+ * the second level on.  Returns HPS_E_UNSUPPORTED when widest level x ceil(B / 4) workgroups exceed the device's CU count (the
+ * waiting workgroups must all be schedulable at once): use hps_head_pose_levels then. */
+int hps_dev_head_pose_levels_fused(const float* embed, int embed_dim, int hidden, const int32_t* level_joints,
+                               const int32_t* level_sizes_host, int n_levels, const int32_t* anc_ptr,
+                               const int32_t* anc_idx, const float* const* w1t_ptrs, const float* const* b1_ptrs,
+                               const float* const* w2_ptrs, const float* const* b2_ptrs, float* u_proper,
+                               float* s_proper, float* mode, float delta_i_weight, float* pose_f, float* pose_u,
+                               float* pose_s, float* pose_v, int B, int num_body_joints, int svd_flavor,
+                               int32_t* sync_ws, hps_stream_t stream);
+
 /* Tuning hook (tests/dev only): kernel choice of hps_smpl_blend: 0 / 1 = tiled (default), 2 = stationary-A (same bits). */
 int hps_dev_blend_mode(int mode);
 
@@ -80,6 +96,12 @@ int hps_dev_unc_mode(int mode);
 /* Experiment: request at least `bytes` of dynamic LDS for the fused mesh kernel (unused space), i.e. cap its workgroups per CU
  * (36 KiB -> 4, 52 KiB -> 3, 72 KiB -> 2, 150 KiB -> 1).  0 restores the product value. */
 int hps_dev_mesh_lds_floor(int bytes);
+
+/* Cross-check hook: 1 = the split-K convolutions (hps_conv2d_bn_act_pad with ksplit > 1, hps_conv3x3_winograd on 8 x 8 maps) leave
+ * their slices to the round-4 second launch (splitk_pad_epilogue_kernel / wino_splitk_epilogue_kernel) instead of letting the last
+ * workgroup to arrive finish each output tile; 0 = the product form.  Same bits either way (tests/test_gpu_net.py). */
+int hps_dev_splitk_two_pass(int on);
+int hps_dev_wino_two_pass(int on);
 
 /* Tuning hook (tests/dev only): 1 = hps_conv2d_bn_act_pad skips its epilogue (results are garbage), 0 = normal. */
 int hps_dev_conv_pad_ablate(int mode);
