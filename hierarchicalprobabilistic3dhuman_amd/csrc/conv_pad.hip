@@ -49,7 +49,7 @@ struct PadGeom {
     int opad;                              // halo of the output (and residual) frame
     int relu, tiles_m, ksplit;
     int ws_hdr;                            // split-K: floats of the arrival-counter header in front of the slices (splitk_header_floats)
-    int two_pass;                          // dev library only: 1 = leave the slices to splitk_pad_epilogue_kernel (the round-4 second launch)
+    int two_pass;                          // 1 = leave the slices to splitk_pad_epilogue_kernel (more than SPLITK_INKERNEL_MAX slices; dev switch)
     unsigned magic_howo, magic_wo;
     int ablate;                            // tuning only (hps_dev_conv_pad_ablate): 1 = no epilogue
 };
@@ -387,9 +387,12 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
     }
 }
 
-#ifdef HPS_DEV_BUILD
-// The round-4 second pass of a split-K convolution (dev library: the cross-check of the in-kernel finish, hps_dev_splitk_two_pass):
-// y = act(scale * (sum of the slices, in slice order) + shift + residual), y / residual in the padded output frame
+// Second pass of a split-K convolution with MANY slices (ksplit > SPLITK_INKERNEL_MAX: the latency mode's 12-18 slices), and the
+// cross-check of the in-kernel finish (dev library, hps_dev_splitk_two_pass): y = act(scale * (sum of the slices, in slice order)
+// + shift + residual), y / residual in the padded output frame.  Why both forms: finishing a tile inside the kernel means ONE
+// workgroup reads all of the tile's slices -- 128 x 128 x 4 floats = 256 KB are 2 us of one CU's L2 bandwidth and save a launch
+// (throughput mode: -8 us per layer), but 18 slices are 1.2 MB = 9 us on one CU where this kernel spreads them over the chip in
+// 5-7 us (measured: batch-1 latency 0.71 -> 1.02 ms with every layer finished in-kernel).
 __global__ __launch_bounds__(256) void splitk_pad_epilogue_kernel(const float* __restrict__ slices,
                                                                   const float* __restrict__ scale,
                                                                   const float* __restrict__ shift,
@@ -401,6 +404,8 @@ __global__ __launch_bounds__(256) void splitk_pad_epilogue_kernel(const float* _
     const unsigned m = e / (unsigned)g.Cout, co = e - m * g.Cout;
     splitk_finish4(reinterpret_cast<const float4*>(slices), (size_t)i, (size_t)total4, g.ksplit, m, co, scale, shift, residual, y, g);
 }
+constexpr int SPLITK_INKERNEL_MAX = 4;     // slices up to which the last workgroup to arrive finishes the tile (a rule on the layer, never on the batch)
+#ifdef HPS_DEV_BUILD
 static int g_splitk_two_pass = 0;
 #else
 constexpr int g_splitk_two_pass = 0;
@@ -524,13 +529,11 @@ static int launch_conv_pad(const float* x, const float* wn, const float* scale, 
         if (int rc = grant_lds<&conv_pad_kernel<BM, BN, WM, WN>>((int)lds, "hps_conv2d_bn_act_pad")) return rc;
     hipLaunchKernelGGL((conv_pad_kernel<BM, BN, WM, WN>), dim3(g.tiles_m * tiles_n, g.ksplit), dim3(256), lds, s, x, wn, scale,
                        shift, residual, y, partial, g);
-#ifdef HPS_DEV_BUILD
     if (g.ksplit > 1 && g.two_pass) {
         const long total4 = (long)g.Mtot * g.Cout / 4;
         hipLaunchKernelGGL(splitk_pad_epilogue_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, partial + g.ws_hdr, scale,
                            shift, residual, y, total4, g);
     }
-#endif
     return check_launch("hps_conv2d_bn_act_pad");
 }
 
@@ -581,7 +584,7 @@ extern "C" int hps_conv2d_bn_act_pad(const float* x, const float* wn, const floa
     g.magic_wo = div_magic((unsigned)g.Wo);
     g.ablate = g_pad_ablate;
     g.ws_hdr = (int)splitk_header_floats(g.Mtot, Cout);
-    g.two_pass = g_splitk_two_pass;
+    g.two_pass = (g_splitk_two_pass || g.ksplit > SPLITK_INKERNEL_MAX) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     if (g.ksplit > 1) variant = Cout % 128 == 0 ? 1 : 2;     // split-K runs on the 128-row tiles
     if (variant == 0) {

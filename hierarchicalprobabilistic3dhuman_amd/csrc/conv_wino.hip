@@ -111,8 +111,10 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
                                                            const float* __restrict__ resfin, float* __restrict__ yfin, int* counters,
                                                            const WinoGeom g) {
     typedef __attribute__((address_space(3))) void* lptr_t;
-    extern __shared__ __attribute__((aligned(16))) float smem[];     // sA[2][W_OPER] | sB[2][W_OPER] | raw[3][W_RAW]
-    __shared__ int s_last;                                           // quad geometry: this workgroup finishes the item's output tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // sA[2][W_OPER] | sB[2][W_OPER] | raw[3][W_RAW] | quad: one flag word
+    // quad geometry: "this workgroup finishes the item's output tile" -- a word behind the buffers of the dynamic allocation (a static
+    // __shared__ variable would be added to the 160 KiB the kernel is granted and the launch refused)
+    int& s_last = *reinterpret_cast<int*>(smem + 4 * W_OPER + 3 * W_RAW);
     float* sA = smem;
     float* sB = smem + 2 * W_OPER;
     float* sR = smem + 4 * W_OPER;
@@ -637,7 +639,7 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
     g.magic_img = wino_magic((unsigned)g.blocks_img);
     g.magic_x = wino_magic((unsigned)g.blocks_x);
     g.magic_ks = wino_magic((unsigned)g.ksplit);
-    const size_t lds = (size_t)(4 * W_OPER + 3 * W_RAW) * sizeof(float);           // 162 176 bytes
+    const size_t lds = (size_t)(4 * W_OPER + 3 * W_RAW) * sizeof(float) + (quad ? 16 : 0);           // 162 176 bytes (+ the quad geometry's flag word)
     // persistent grid: one workgroup per CU (256 on MI355X), items strided over the workgroups
     const dim3 grid((unsigned)(g.items < 256 ? g.items : 256));
     int grant_rc = HPS_OK;

@@ -314,9 +314,10 @@ int hps_head_svd_finish(const float* usv_level, const int32_t* joint_ids, int n_
  * (the 18-channel 7x7 stem, models/resnet.py:150, :203): (Cout, KH * ceil32(KW*Cin)), one filter row = KW*Cin contiguous
  * NHWC floats taken as a single tap, zero filled tail.  variant / ksplit as for _v3.
  * ksplit > 1: K is cut into ksplit slices computed by separate workgroups; splitk_ws holds hps_query_workspace(HPS_WS_CONV_SPLITK,
- * ksplit, B*Ho*Wo, Cout) bytes = [one int32 arrival counter per output tile | the slices' partial sums].  The workgroup that arrives
- * LAST at a tile adds the tile's slices in slice order (a fixed order whoever it is: deterministic, no floating-point atomics),
- * applies BatchNorm / residual / ReLU and resets the counter -- one launch per layer.  THE COUNTERS MUST BE ZERO BEFORE THE FIRST
+ * ksplit, B*Ho*Wo, Cout) bytes = [one int32 arrival counter per output tile | the slices' partial sums].  Up to four slices the
+ * workgroup that arrives LAST at a tile adds the tile's slices in slice order (a fixed order whoever it is: deterministic, no
+ * floating-point atomics), applies BatchNorm / residual / ReLU and resets the counter -- one launch per layer; with more slices (the
+ * latency mode's 12-18) a second kernel does the same sum spread over the chip.  THE COUNTERS MUST BE ZERO BEFORE THE FIRST
  * LAUNCH THAT USES THE BUFFER (zero the buffer once when it is allocated); every launch leaves them zero, and layers with the same
  * output shape (B*Ho*Wo, Cout) may share one buffer on one stream whatever their ksplit.  Lane offsets are 32-bit: tensors < 4 GiB. */
 int hps_conv2d_bn_act_pad(const float* x, const float* wn, const float* scale, const float* shift,

@@ -669,9 +669,10 @@ def test_all_levels_in_one_launch_equal_the_per_level_launches(dev, net_gpu):
 
 @pytest.mark.gpu
 def test_split_k_layers_finish_inside_the_kernel(dev, net_gpu):
-    """Round 5: the K slices of a split-K convolution (direct kernel: layer4.0.conv1 by default, eleven layers in latency mode;
+    """Round 5: the K slices of a split-K convolution with up to four slices (direct kernel: layer4.0.conv1 in the default mode;
     Winograd on 8 x 8 maps: layer4's other three) are added by the LAST workgroup to arrive at each output tile -- in slice order,
-    so the result does not depend on who that is -- instead of by a second launch per layer.  Against the round-4 two-launch form
+    so the result does not depend on who that is -- instead of by a second launch per layer (the latency mode's 12-18 slices keep
+    the second launch: one workgroup reading 1.2 MB of slices is slower than a kernel that spreads them over the chip).  Against the round-4 two-launch form
     kept in the dev library (hps_dev_splitk_two_pass): encoder features bit for bit in both modes, for batches whose last tile is
     ragged, call after call (the arrival counters in the workspace header reset themselves), and the header is left zero."""
     enc = net_gpu.image_encoder
