@@ -14,14 +14,14 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace hps
 
-extern "C" int hps_version(void) { return 500; }  // 0.5.0: second-generation pose-prep / joint kernels, split-K slices summed by the last workgroup to arrive
+extern "C" int hps_version(void) { return 500; }  // 0.5.0: second-generation pose-prep / joint kernels (hps_smpl_joints takes the regressor entry count)
 
 extern "C" int64_t hps_query_workspace(int what, int64_t d0, int64_t d1, int64_t d2) {
     if (d0 < 0 || d1 < 0 || d2 < 0) { hps::set_error("hps_query_workspace: negative dimension"); return -1; }
     const int64_t f = (int64_t)sizeof(float);
     auto up = [](int64_t x, int64_t m) { return (x + m - 1) / m * m; };
     switch (what) {
-        case HPS_WS_CONV_SPLITK: return d0 <= 1 ? 0 : (hps::splitk_header_floats(d1, d2) + d0 * d1 * d2) * f;
+        case HPS_WS_CONV_SPLITK: return d0 <= 1 ? 0 : d0 * d1 * d2 * f;
         case HPS_WS_SMPL_MP: return up(d0, 128);
         case HPS_WS_SMPL_XT: return d1 * up(d0, 128) * f;
         case HPS_WS_SMPL_A: return d0 * d1 * 12 * f;

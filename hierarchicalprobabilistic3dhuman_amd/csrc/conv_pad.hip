@@ -48,8 +48,6 @@ struct PadGeom {
     int Ho, Wo, Mtot, Kp, Cout;
     int opad;                              // halo of the output (and residual) frame
     int relu, tiles_m, ksplit;
-    int ws_hdr;                            // split-K: floats of the arrival-counter header in front of the slices (splitk_header_floats)
-    int two_pass;                          // 1 = leave the slices to splitk_pad_epilogue_kernel (more than SPLITK_INKERNEL_MAX slices; dev switch)
     unsigned magic_howo, magic_wo;
     int ablate;                            // tuning only (hps_dev_conv_pad_ablate): 1 = no epilogue
 };
@@ -65,36 +63,6 @@ __device__ __forceinline__ unsigned out_pixel_offset(unsigned m, const PadGeom& 
     const unsigned b = fastdiv(m, howo, g.magic_howo), rem = m - b * howo;
     const unsigned ho = fastdiv(rem, (unsigned)g.Wo, g.magic_wo), wo = rem - ho * g.Wo;
     return ((b * (g.Ho + 2 * g.opad) + ho + g.opad) * (g.Wo + 2 * g.opad) + wo + g.opad) * (unsigned)g.Cout;
-}
-
-// y = act(scale * (sum of the K slices, in slice order) + shift + residual) for four consecutive channels of one output pixel: the
-// ONE definition of a split-K layer's finish (explicit fused multiply-add: the same bits wherever it is inlined)
-__device__ __forceinline__ void splitk_finish4(const float4* __restrict__ slices, size_t i4, size_t total4, int ksplit, unsigned m, unsigned co,
-                                               const float* __restrict__ scale, const float* __restrict__ shift,
-                                               const float* __restrict__ residual, float* __restrict__ y, const PadGeom& g) {
-    float4 acc = slices[i4];
-    int k = 1;
-    for (; k + 4 <= ksplit; k += 4) {              // four slices requested before the first is added; the additions stay in slice order
-        float4 v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = slices[(size_t)(k + q) * total4 + i4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { acc.x += v[q].x; acc.y += v[q].y; acc.z += v[q].z; acc.w += v[q].w; }
-    }
-    for (; k < ksplit; ++k) {
-        const float4 v = slices[(size_t)k * total4 + i4];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    const size_t o = (size_t)out_pixel_offset(m, g) + co;
-    const float4 sc = *reinterpret_cast<const float4*>(scale + co), sh = *reinterpret_cast<const float4*>(shift + co);
-    float4 v = make_float4(__builtin_fmaf(acc.x, sc.x, sh.x), __builtin_fmaf(acc.y, sc.y, sh.y), __builtin_fmaf(acc.z, sc.z, sh.z),
-                           __builtin_fmaf(acc.w, sc.w, sh.w));
-    if (residual) {
-        const float4 r = *reinterpret_cast<const float4*>(residual + o);
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-    }
-    if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    *reinterpret_cast<float4*>(y + o) = v;
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -259,8 +227,7 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
     // k order is unchanged), so a lane ends up with ONE pixel (column = lane & 31) and, per register quad q, four
     // consecutive output channels: row = (r & 3) + 8 q + 4 (lane >> 5)  ->  128-bit accesses along Cout.
     if (g.ksplit > 1) {
-        float* slices = partial + g.ws_hdr;
-        float* dst = slices + (size_t)blockIdx.y * g.Mtot * g.Cout;
+        float* dst = partial + (size_t)blockIdx.y * g.Mtot * g.Cout;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wm0 + i * 32 + il;
@@ -272,28 +239,6 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
                     *reinterpret_cast<float4*>(dst + (size_t)m * g.Cout + n0 + wn0 + j * 32 + 8 * q + 4 * kl) =
                         make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
         }
-        if (g.two_pass) return;
-        // The LAST of the tile's ksplit workgroups to get here finishes the tile (round 5; the slice-sum pass used to be a second
-        // launch per layer -- eleven launches of ~6 us in the encoder's latency mode).  Whoever it is, it reads all slices back in
-        // slice order: the result does not depend on the arrival order.
-        int* counter = reinterpret_cast<int*>(partial) + blockIdx.x;
-        int* s_last = reinterpret_cast<int*>(smem);          // (the K-loop buffers are free: every wave is past its last fragment read)
-        __threadfence();                                     // release: this thread's slice stores are visible device-wide
-        __syncthreads();
-        if (tid == 0) *s_last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == g.ksplit - 1;
-        __syncthreads();
-        if (!*s_last) return;
-        __threadfence();                                     // acquire: the other workgroups' slices
-        const size_t total4 = (size_t)g.Mtot * g.Cout / 4;
-        constexpr int C4 = BN / 4;
-        for (int idx = tid; idx < BM * C4; idx += 256) {
-            const int r = idx / C4, c4 = (idx - r * C4) * 4;
-            const int m = m0 + r;
-            if (m >= g.Mtot) break;
-            splitk_finish4(reinterpret_cast<const float4*>(slices), ((size_t)m * g.Cout + n0 + c4) / 4, total4, g.ksplit, (unsigned)m,
-                           (unsigned)(n0 + c4), scale, shift, residual, y, g);
-        }
-        if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
         return;
     }
 
@@ -387,29 +332,32 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
     }
 }
 
-// Second pass of a split-K convolution with MANY slices (ksplit > SPLITK_INKERNEL_MAX: the latency mode's 12-18 slices), and the
-// cross-check of the in-kernel finish (dev library, hps_dev_splitk_two_pass): y = act(scale * (sum of the slices, in slice order)
-// + shift + residual), y / residual in the padded output frame.  Why both forms: finishing a tile inside the kernel means ONE
-// workgroup reads all of the tile's slices -- 128 x 128 x 4 floats = 256 KB are 2 us of one CU's L2 bandwidth and save a launch
-// (throughput mode: -8 us per layer), but 18 slices are 1.2 MB = 9 us on one CU where this kernel spreads them over the chip in
-// 5-7 us (measured: batch-1 latency 0.71 -> 1.02 ms with every layer finished in-kernel).
-__global__ __launch_bounds__(256) void splitk_pad_epilogue_kernel(const float* __restrict__ slices,
+// second pass of a split-K convolution: y = act(scale * (sum of the slices, in slice order) + shift + residual),
+// y / residual in the padded output frame
+__global__ __launch_bounds__(256) void splitk_pad_epilogue_kernel(const float* __restrict__ partial,
                                                                   const float* __restrict__ scale,
                                                                   const float* __restrict__ shift,
                                                                   const float* __restrict__ residual,
                                                                   float* __restrict__ y, long total4, const PadGeom g) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
+    float4 acc = reinterpret_cast<const float4*>(partial)[i];
+    for (int k = 1; k < g.ksplit; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(partial)[(size_t)k * total4 + i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
     const unsigned e = (unsigned)(i * 4);
     const unsigned m = e / (unsigned)g.Cout, co = e - m * g.Cout;
-    splitk_finish4(reinterpret_cast<const float4*>(slices), (size_t)i, (size_t)total4, g.ksplit, m, co, scale, shift, residual, y, g);
+    const size_t o = (size_t)out_pixel_offset(m, g) + co;
+    const float4 sc = *reinterpret_cast<const float4*>(scale + co), sh = *reinterpret_cast<const float4*>(shift + co);
+    float4 v = make_float4(acc.x * sc.x + sh.x, acc.y * sc.y + sh.y, acc.z * sc.z + sh.z, acc.w * sc.w + sh.w);
+    if (residual) {
+        const float4 r = *reinterpret_cast<const float4*>(residual + o);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4*>(y + o) = v;
 }
-constexpr int SPLITK_INKERNEL_MAX = 4;     // slices up to which the last workgroup to arrive finishes the tile (a rule on the layer, never on the batch)
-#ifdef HPS_DEV_BUILD
-static int g_splitk_two_pass = 0;
-#else
-constexpr int g_splitk_two_pass = 0;
-#endif
 
 // (B,C,H,W) -> (B, H + 2P, W + 2P, C) interior (the halo is zeroed once by the owner of the buffer).  A workgroup moves
 // one run of up to 256 pixels of an image row: lanes along w read each channel plane coalesced into LDS [pixel][C], then
@@ -529,9 +477,9 @@ static int launch_conv_pad(const float* x, const float* wn, const float* scale, 
         if (int rc = grant_lds<&conv_pad_kernel<BM, BN, WM, WN>>((int)lds, "hps_conv2d_bn_act_pad")) return rc;
     hipLaunchKernelGGL((conv_pad_kernel<BM, BN, WM, WN>), dim3(g.tiles_m * tiles_n, g.ksplit), dim3(256), lds, s, x, wn, scale,
                        shift, residual, y, partial, g);
-    if (g.ksplit > 1 && g.two_pass) {
+    if (g.ksplit > 1) {
         const long total4 = (long)g.Mtot * g.Cout / 4;
-        hipLaunchKernelGGL(splitk_pad_epilogue_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, partial + g.ws_hdr, scale,
+        hipLaunchKernelGGL(splitk_pad_epilogue_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, partial, scale,
                            shift, residual, y, total4, g);
     }
     return check_launch("hps_conv2d_bn_act_pad");
@@ -583,8 +531,6 @@ extern "C" int hps_conv2d_bn_act_pad(const float* x, const float* wn, const floa
     g.magic_howo = div_magic((unsigned)(g.Ho * g.Wo));
     g.magic_wo = div_magic((unsigned)g.Wo);
     g.ablate = g_pad_ablate;
-    g.ws_hdr = (int)splitk_header_floats(g.Mtot, Cout);
-    g.two_pass = (g_splitk_two_pass || g.ksplit > SPLITK_INKERNEL_MAX) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     if (g.ksplit > 1) variant = Cout % 128 == 0 ? 1 : 2;     // split-K runs on the 128-row tiles
     if (variant == 0) {
@@ -607,11 +553,6 @@ extern "C" int hps_conv2d_bn_act_pad(const float* x, const float* wn, const floa
 extern "C" int hps_dev_conv_pad_ablate(int mode) {
     g_pad_ablate = mode;
     return HPS_OK;
-}
-extern "C" int hps_dev_wino_two_pass(int on);
-extern "C" int hps_dev_splitk_two_pass(int on) {      // both split-K kernels: 1 = the round-4 form (slices summed by a second launch)
-    g_splitk_two_pass = on ? 1 : 0;
-    return hps_dev_wino_two_pass(on);
 }
 #endif
 

@@ -58,8 +58,6 @@ struct WinoGeom {
     // quad geometry (8 x 8 maps, four images per item, K split into slices that write raw partial sums)
     int B, ksplit, cps, raw;      // images, K slices, chunks per slice, raw = 1: store Y without BatchNorm / residual / ReLU
     unsigned magic_ks;
-    int fin_opad, fin_relu;       // quad geometry: halo and ReLU flag of the FINAL output frame (the item itself stores raw slices)
-    int two_pass;                 // dev library only: 1 = leave the slices to wino_splitk_epilogue_kernel (the round-4 second launch)
 };
 
 __device__ __forceinline__ unsigned wino_div(unsigned n, unsigned d, unsigned magic) {
@@ -80,41 +78,13 @@ __device__ __forceinline__ unsigned wino_div(unsigned n, unsigned d, unsigned ma
 // quarter of a layer's time.  The transform role becomes thread = (tile, ONE channel); the DMA pieces are dealt over eight waves;
 // the output transform needs the other column pair's s[.][2] (resp. s[.][1]): two floats per (tile, channel) cross through the
 // then idle sA buffers; every sum is formed in the four-wave kernel's order (identical bits).
-// Quad geometry: y = act(scale * (sum of the K slices, in slice order) + shift + residual) for four consecutive channels of pixel
-// m = (image * 8 + row) * 8 + column, into the padded 8 x 8 output frame -- the ONE definition of the finish (explicit fused
-// multiply-add: the same bits wherever it is inlined)
-__device__ __forceinline__ void wino_finish4(const float4* __restrict__ slices, size_t i4, size_t total4, int ksplit, unsigned m, unsigned co,
-                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                             const float* __restrict__ residual, float* __restrict__ y, int Cout, int opad, int relu) {
-    float4 acc = slices[i4];
-    for (int k = 1; k < ksplit; ++k) {
-        const float4 v = slices[(size_t)k * total4 + i4];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    const unsigned b = m >> 6, py = (m >> 3) & 7, px = m & 7, fw = 8 + 2 * opad;
-    const size_t o = ((size_t)(b * fw + py + opad) * fw + px + opad) * Cout + co;
-    const float4 sc = *reinterpret_cast<const float4*>(scale + co), sh = *reinterpret_cast<const float4*>(shift + co);
-    float4 v = make_float4(__builtin_fmaf(acc.x, sc.x, sh.x), __builtin_fmaf(acc.y, sc.y, sh.y), __builtin_fmaf(acc.z, sc.z, sh.z),
-                           __builtin_fmaf(acc.w, sc.w, sh.w));
-    if (residual) {
-        const float4 r = *reinterpret_cast<const float4*>(residual + o);
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-    }
-    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    *reinterpret_cast<float4*>(y + o) = v;
-}
-
 template <int AB, bool QUAD, bool W8 = false>
 __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ residual, float* __restrict__ y,
-                                                           const float* __restrict__ resfin, float* __restrict__ yfin, int* counters,
                                                            const WinoGeom g) {
     typedef __attribute__((address_space(3))) void* lptr_t;
-    extern __shared__ __attribute__((aligned(16))) float smem[];     // sA[2][W_OPER] | sB[2][W_OPER] | raw[3][W_RAW] | quad: one flag word
-    // quad geometry: "this workgroup finishes the item's output tile" -- a word behind the buffers of the dynamic allocation (a static
-    // __shared__ variable would be added to the 160 KiB the kernel is granted and the launch refused)
-    int& s_last = *reinterpret_cast<int*>(smem + 4 * W_OPER + 3 * W_RAW);
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // sA[2][W_OPER] | sB[2][W_OPER] | raw[3][W_RAW]
     float* sA = smem;
     float* sB = smem + 2 * W_OPER;
     float* sR = smem + 4 * W_OPER;
@@ -539,51 +509,39 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
                 for (int r = 0; r < 16; ++r) t += acc[p][r];
             if (t == 12345.678f) y[0] = t;
         }
-        if (QUAD && !g.two_pass) {
-            // The LAST of the tile's K slices to get here finishes the tile: it adds the slices in slice order (whoever it is: the
-            // result does not depend on the arrival order), applies BatchNorm / residual / ReLU and writes the padded output frame --
-            // round 4 ran a second launch per layer for this (wino_splitk_epilogue_kernel, 3 x 8.9 us per step).
-            const unsigned tq = wino_div((unsigned)item, (unsigned)g.ksplit, g.magic_ks);       // tile = quad * n_ct + cout tile
-            __threadfence();                                 // release: this thread's slice stores
-            __syncthreads();
-            if (tid == 0) s_last = __hip_atomic_fetch_add(counters + tq, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == g.ksplit - 1;
-            __syncthreads();
-            if (s_last) {
-                __threadfence();                             // acquire: the other workgroups' slices
-                const unsigned b0 = 4 * wino_div(tq, (unsigned)g.n_ct, g.magic_ct);
-                const size_t total4 = (size_t)g.B * 64 * g.Cout / 4;
-                for (int idx = tid; idx < cur_nimg * 1024; idx += NW * 64) {       // (image, pixel, four channels of the 64)
-                    const unsigned c4 = (idx & 15) * 4, m = (b0 + (idx >> 10)) * 64 + ((idx >> 4) & 63), co = cur_ct * WC + c4;
-                    wino_finish4(reinterpret_cast<const float4*>(y), ((size_t)m * g.Cout + co) / 4, total4, g.ksplit, m, co, scale, shift,
-                                 resfin, yfin, g.Cout, g.fin_opad, g.fin_relu);
-                }
-                if (tid == 0) __hip_atomic_store(counters + tq, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
-            }
-        }
         if (next >= g.items) break;
         item = next;
     }
 }
 
-#ifdef HPS_DEV_BUILD
-// The round-4 second pass of the quad geometry (dev library: the cross-check of the in-kernel finish, hps_dev_splitk_two_pass):
-// thread per four channels
-__global__ __launch_bounds__(256) void wino_splitk_epilogue_kernel(const float* __restrict__ slices, const float* __restrict__ scale,
+// second pass of the quad geometry: y = act(scale * (sum of the K slices, in slice order) + shift + residual) into the padded
+// 8 x 8 output frames; thread per four channels
+__global__ __launch_bounds__(256) void wino_splitk_epilogue_kernel(const float* __restrict__ partial, const float* __restrict__ scale,
                                                                    const float* __restrict__ shift, const float* __restrict__ residual,
                                                                    float* __restrict__ y, int total4, int ksplit, int Cout, int opad,
                                                                    int relu) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
+    float4 acc = reinterpret_cast<const float4*>(partial)[i];
+    for (int k = 1; k < ksplit; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(partial)[(size_t)k * total4 + i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
     const unsigned e = (unsigned)i * 4u;
     const unsigned m = e / (unsigned)Cout, co = e - m * Cout;               // m = (image * 8 + row) * 8 + column
-    wino_finish4(reinterpret_cast<const float4*>(slices), (size_t)i, (size_t)total4, ksplit, m, co, scale, shift, residual, y, Cout, opad, relu);
+    const unsigned b = m >> 6, py = (m >> 3) & 7, px = m & 7, fw = 8 + 2 * opad;
+    const size_t o = ((size_t)(b * fw + py + opad) * fw + px + opad) * Cout + co;
+    const float4 sc = *reinterpret_cast<const float4*>(scale + co), sh = *reinterpret_cast<const float4*>(shift + co);
+    float4 v = make_float4(acc.x * sc.x + sh.x, acc.y * sc.y + sh.y, acc.z * sc.z + sh.z, acc.w * sc.w + sh.w);
+    if (residual) {
+        const float4 r = *reinterpret_cast<const float4*>(residual + o);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4*>(y + o) = v;
 }
-#endif
 
 static unsigned wino_magic(unsigned d) { return d <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / d); }
-#ifdef HPS_DEV_BUILD
-static int g_wino_two_pass = 0;          // dev library only (hps_dev_splitk_two_pass)
-#endif
 
 }  // namespace hps
 
@@ -595,7 +553,7 @@ static int wino_quad_ksplit(int Cin) { return (Cin / WK) % 4 == 0 && (Cin / WK) 
 
 extern "C" size_t hps_conv3x3_winograd_workspace(int B, int H, int W, int Cin, int Cout) {
     if (H != 8 || W != 8 || B <= 0 || Cin <= 0 || Cout <= 0) return 0;
-    return ((size_t)splitk_header_floats((long)B * 64, Cout) + (size_t)wino_quad_ksplit(Cin) * B * 64 * Cout) * sizeof(float);
+    return (size_t)wino_quad_ksplit(Cin) * B * 64 * Cout * sizeof(float);
 }
 
 static int wino_launch(const float* x, const float* u, const float* scale, const float* shift, const float* residual,
@@ -622,13 +580,7 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
     g.Cin = Cin; g.Cout = Cout; g.n_ct = Cout / WC; g.relu = relu;
     g.items = B * g.blocks_img * g.n_ct;
     g.B = B; g.ksplit = 1; g.cps = Cin / WK; g.raw = 0;
-    g.fin_opad = opad; g.fin_relu = relu; g.two_pass = 0;
-    float* slices = nullptr;
-    if (quad) {
-        slices = splitk_ws + splitk_header_floats((long)B * 64, Cout);      // arrival counters first (zero before the first use), then the slices
-#ifdef HPS_DEV_BUILD
-        g.two_pass = g_wino_two_pass;
-#endif                     // the kernel writes raw partial sums (slice, image, 8, 8, Cout); the second pass finishes
+    if (quad) {                     // the kernel writes raw partial sums (slice, image, 8, 8, Cout); the second pass finishes
         g.ksplit = wino_quad_ksplit(Cin);
         g.cps = Cin / WK / g.ksplit;
         g.raw = 1;
@@ -639,7 +591,7 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
     g.magic_img = wino_magic((unsigned)g.blocks_img);
     g.magic_x = wino_magic((unsigned)g.blocks_x);
     g.magic_ks = wino_magic((unsigned)g.ksplit);
-    const size_t lds = (size_t)(4 * W_OPER + 3 * W_RAW) * sizeof(float) + (quad ? 16 : 0);           // 162 176 bytes (+ the quad geometry's flag word)
+    const size_t lds = (size_t)(4 * W_OPER + 3 * W_RAW) * sizeof(float);           // 162 176 bytes
     // persistent grid: one workgroup per CU (256 on MI355X), items strided over the workgroups
     const dim3 grid((unsigned)(g.items < 256 ? g.items : 256));
     int grant_rc = HPS_OK;
@@ -648,13 +600,13 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
         constexpr bool q = decltype(Q)::value;
         if ((grant_rc = grant_lds<&conv_wino_kernel<ab, q>>(160 * 1024, "hps_conv3x3_winograd")) != HPS_OK) return;
         hipLaunchKernelGGL((conv_wino_kernel<ab, q>), grid, dim3(256), lds, (hipStream_t)stream, x, u, scale, shift, quad ? nullptr : residual,
-                           quad ? slices : y, residual, y, reinterpret_cast<int*>(splitk_ws), g);
+                           quad ? splitk_ws : y, g);
     };
     auto launch8 = [&](auto Q) {                              // the eight-wave form (the product)
         constexpr bool q = decltype(Q)::value;
         if ((grant_rc = grant_lds<&conv_wino_kernel<0, q, true>>(160 * 1024, "hps_conv3x3_winograd")) != HPS_OK) return;
         hipLaunchKernelGGL((conv_wino_kernel<0, q, true>), grid, dim3(512), lds, (hipStream_t)stream, x, u, scale, shift, quad ? nullptr : residual,
-                           quad ? slices : y, residual, y, reinterpret_cast<int*>(splitk_ws), g);
+                           quad ? splitk_ws : y, g);
     };
     typedef std::integral_constant<bool, false> F;
     typedef std::integral_constant<bool, true> T;
@@ -667,15 +619,11 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
             launch8(T());
         if (grant_rc != HPS_OK) return grant_rc;
         const int rc = check_launch("hps_conv3x3_winograd");
-#ifdef HPS_DEV_BUILD
-        if (rc == HPS_OK && g.two_pass) {
-            const int total4 = B * 64 * Cout / 4;
-            hipLaunchKernelGGL(wino_splitk_epilogue_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slices,
-                               scale, shift, residual, y, total4, g.ksplit, Cout, opad, relu);
-            return check_launch("hps_conv3x3_winograd (slices)");
-        }
-#endif
-        return rc;
+        if (rc != HPS_OK) return rc;
+        const int total4 = B * 64 * Cout / 4;
+        hipLaunchKernelGGL(wino_splitk_epilogue_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, splitk_ws,
+                           scale, shift, residual, y, total4, g.ksplit, Cout, opad, relu);
+        return check_launch("hps_conv3x3_winograd (slices)");
     }
     switch (ablate) {
         case 0: launch8(F()); break;                                            // the product form: eight waves
@@ -705,10 +653,6 @@ extern "C" int hps_conv3x3_winograd(const float* x, const float* u, const float*
 }
 
 #ifdef HPS_DEV_BUILD
-extern "C" int hps_dev_wino_two_pass(int on) {
-    g_wino_two_pass = on ? 1 : 0;
-    return HPS_OK;
-}
 extern "C" int hps_dev_conv3x3_winograd(const float* x, const float* u, const float* scale, const float* shift, const float* residual,
                                         float* y, int B, int H, int W, int ipad, int Cin, int Cout, int opad, int relu,
                                         float* splitk_ws, int ablate, hps_stream_t stream) {

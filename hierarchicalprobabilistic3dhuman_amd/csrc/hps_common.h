@@ -32,13 +32,6 @@ inline int bad_arg(const char* what) {
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-// Split-K workspaces (hps_conv2d_bn_act_pad, hps_conv3x3_winograd on 8 x 8 maps) begin with a header of arrival counters, one
-// int32 per output tile, in front of the slices' partial sums: the workgroup that finds ksplit - 1 arrivals before its own adds the
-// slices of that tile in slice order, applies BatchNorm / residual / ReLU and resets the counter (round 5: formerly a second
-// launch per layer).  The header's size depends on the layer's OUTPUT (M = B * Ho * Wo pixels, Cout) only -- not on ksplit or the
-// tile shape -- so the convolutions of a block can share one workspace: an upper bound of every kernel's tile count, in floats.
-__host__ __device__ inline long splitk_header_floats(long M, long Cout) { return ((M + 63) / 64 * ((Cout + 63) / 64) + 63) / 64 * 64; }
-
 // Dynamic LDS above 64 KiB has to be granted per kernel function AND per device (the attribute lives with the device's copy
 // of the code object): once per (kernel instantiation, current device), safe from several host threads, result checked.
 // No behaviour depends on it.  Returns HPS_OK or the hipError_t.

@@ -447,6 +447,36 @@ __global__ __launch_bounds__(JN_T) void joints_kernel(const float* __restrict__ 
     }
 }
 
+// joints for regressors whose entries do not fit the LDS stage of joints_kernel (more than ~1 260 entries; the reference's have 276):
+// thread per (mesh, row), the row's entries straight from global memory -- the same chain of fused multiply-adds, the same bits.
+__global__ __launch_bounds__(256) void joints_rows_kernel(const float* __restrict__ verts, const float* __restrict__ j_posed,
+                                                          const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_col,
+                                                          const float* __restrict__ csr_val, int n_rows, int J,
+                                                          const float* __restrict__ transl, float* __restrict__ joints, int V, int M) {
+    const int n_out = J + n_rows;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)M * n_out) return;
+    const int m = (int)(i / n_out), r = (int)(i - (long)m * n_out);
+    float x, y, z;
+    if (r < J) {
+        float tx = 0.f, ty = 0.f, tz = 0.f;
+        if (transl) { tx = transl[m * 3 + 0]; ty = transl[m * 3 + 1]; tz = transl[m * 3 + 2]; }
+        const float* s = j_posed + ((size_t)m * J + r) * 3;
+        x = s[0] + tx; y = s[1] + ty; z = s[2] + tz;
+    } else {
+        x = y = z = 0.f;
+        const float* vm = verts + (size_t)m * V * 3;
+        const int e1 = csr_ptr[r - J + 1];
+        for (int e = csr_ptr[r - J]; e < e1; ++e) {
+            const float w = csr_val[e];
+            const float* s = vm + (size_t)csr_col[e] * 3;
+            x = __builtin_fmaf(w, s[0], x); y = __builtin_fmaf(w, s[1], y); z = __builtin_fmaf(w, s[2], z);
+        }
+    }
+    float* d = joints + (size_t)i * 3;
+    d[0] = x; d[1] = y; d[2] = z;
+}
+
 // ---------------------------------------------------------------------------------------------
 // vertex uncertainty: lane per vertex, two sweeps over the image's N samples (the second sweep
 // re-reads lines the first one left in L2 / Infinity Cache).
@@ -840,7 +870,12 @@ extern "C" int hps_smpl_joints(const float* verts, const float* j_posed, const i
     if (M <= 0) return HPS_OK;
     if (num_joints < 0 || n_rows < 0 || nnz < 0) return bad_arg("hps_smpl_joints: num_joints / n_rows / nnz");
     const size_t lds = ((size_t)JN_G * 3 + 1) * (size_t)nnz * sizeof(float);       // the reference's regressors: 276 entries -> 14 KB
-    if (lds > 64 * 1024) { set_error("hps_smpl_joints: %d regressor entries exceed the LDS stage (at most %d)", nnz, (int)(64 * 1024 / ((JN_G * 3 + 1) * 4))); return HPS_E_UNSUPPORTED; }
+    if (lds > 64 * 1024) {           // a regressor too large for the LDS stage: the generic form (same bits)
+        const long total = (long)M * (num_joints + n_rows);
+        hipLaunchKernelGGL(joints_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, verts, j_posed, csr_ptr,
+                           csr_col, csr_val, n_rows, num_joints, transl, joints, V, M);
+        return check_launch("hps_smpl_joints");
+    }
     hipLaunchKernelGGL(joints_kernel, dim3(ceil_div(M, JN_G)), dim3(JN_T), lds, (hipStream_t)stream, verts, j_posed, csr_ptr, csr_col,
                        csr_val, n_rows, num_joints, transl, joints, V, M, nnz);
     return check_launch("hps_smpl_joints");

@@ -126,7 +126,7 @@ class _ConvBN:
             P = _capi.ptr
             need = self.wino_workspace_bytes(B, H, W, ipad)
             if need and (ws is None or ws.numel() * 4 < need):
-                ws = torch.zeros(need // 4, device=xp.device, dtype=torch.float32)       # (zero: the arrival counters in its header)
+                ws = torch.empty(need // 4, device=xp.device, dtype=torch.float32)
             _capi.call("hps_conv3x3_winograd", P(xp), P(self.wino_u), P(self.scale), P(self.shift),
                        P(residual) if residual is not None else None, P(out), B, H, W, ipad, C, self.cout, opad, 1 if relu else 0,
                        P(ws) if need else None, _capi.stream())
@@ -138,8 +138,7 @@ class _ConvBN:
         assert tuple(out.shape) == (B, Ho + 2 * opad, Wo + 2 * opad, self.cout)
         ksplit = 1 if row_mode else (self.ksplit if self.ksplit > 0 else self._auto_ksplit(Ho * Wo))
         if ksplit > 1 and ws is None:
-            # header of arrival counters (zero before the first use; the kernel leaves it zero) + the K slices
-            ws = torch.zeros(_capi.query_workspace(_capi.WS_CONV_SPLITK, ksplit, B * Ho * Wo, self.cout) // 4, device=xp.device, dtype=torch.float32)
+            ws = torch.empty(ksplit, B * Ho * Wo, self.cout, device=xp.device, dtype=torch.float32)
         P = _capi.ptr
         _capi.call("hps_conv2d_bn_act_pad", P(xp), P(self.wrow if row_mode else self.wn), P(self.scale), P(self.shift),
                    P(residual) if residual is not None else None, P(out), B, H, W, ipad, C, self.cout, self.kh, self.kw,
@@ -393,9 +392,7 @@ class ResNet(nn.Module):
             ks = max(c._auto_ksplit(h * w) if c.ksplit == 0 else c.ksplit for c in (c1, c2))
             ws_bytes = max(_capi.query_workspace(_capi.WS_CONV_SPLITK, ks, B * h * w, c1.cout),
                            c1.wino_workspace_bytes(B, hin, win), c2.wino_workspace_bytes(B, h, w))
-            # split-K workspace of the block's convolutions: [arrival counters | K slices]; the counters must be zero before the first
-            # launch and every launch leaves them zero (include/hps.h: hps_conv2d_bn_act_pad)
-            ent["ws"] = torch.zeros(ws_bytes // 4, device=device, dtype=torch.float32) if ws_bytes else None
+            ent["ws"] = torch.empty(ws_bytes // 4, device=device, dtype=torch.float32) if ws_bytes else None
             fs["blocks"].append(ent)
         fs["hw"] = (h, w)
         # the launch list of hps_encoder_run: every pointer but the input image and the feature output is fixed

@@ -75,8 +75,7 @@ int hps_stream_create_cu_partition(int first_cu, int num_cus, hps_stream_t* stre
 int hps_stream_destroy(hps_stream_t stream);
 
 /* Scratch / workspace sizes in BYTES for the buffers the caller hands to the entry points below (the library never allocates):
- *   HPS_WS_CONV_SPLITK (d0 = ksplit, d1 = B*Ho*Wo, d2 = Cout)  splitk_ws of hps_conv2d_bn_act_pad (0 when ksplit <= 1): a header of
- *                                                               arrival counters (its size depends on d1, d2 only) + the K slices
+ *   HPS_WS_CONV_SPLITK (d0 = ksplit, d1 = B*Ho*Wo, d2 = Cout)  splitk_ws of hps_conv2d_bn_act_pad (0 when ksplit <= 1)
  *   HPS_WS_SMPL_MP     (d0 = M)                                 NOT bytes: the padded mesh count mp (M rounded up to 128)
  *   HPS_WS_SMPL_XT     (d0 = M, d1 = kp)                        xt of hps_smpl_pose_prep: kp * mp floats
  *   HPS_WS_SMPL_A      (d0 = M, d1 = num_joints)                a of hps_smpl_pose_prep: M * J * 12 floats
@@ -158,8 +157,9 @@ int hps_smpl_mesh_fused_np(int V);
 /* Joints: out[m, 0:J] = j_posed[m] ; out[m, J + r] = sum_e csr_val[e] * verts[m, csr_col[e]]
  * for CSR rows r = 0..n_rows-1 (the 21 smplx vertex picks as 1-entry rows, then the extra / cocoplus /
  * h36m regressors of models/smpl_official.py:30-34), each row summed as one chain of fused multiply-adds in entry order.
- * nnz = csr_ptr[n_rows], the number of entries (the host built the matrix and knows it; at most 5 041 -- the entries' vertices
- * are staged in LDS, HPS_E_UNSUPPORTED beyond).  transl optional (M,3).  out: (M, J + n_rows, 3). */
+ * nnz = csr_ptr[n_rows], the number of entries (the host built the matrix and knows it; up to 1 260 entries their vertices are
+ * gathered through LDS, larger regressors take a thread-per-row kernel with the same bits).  transl optional (M,3).
+ * out: (M, J + n_rows, 3). */
 int hps_smpl_joints(const float* verts, const float* j_posed, const int32_t* csr_ptr,
                     const int32_t* csr_col, const float* csr_val, int n_rows, int nnz, int num_joints,
                     const float* transl, float* joints, int M, int V, hps_stream_t stream);
@@ -312,14 +312,8 @@ int hps_head_svd_finish(const float* usv_level, const int32_t* joint_ids, int n_
  * filter tap is in bounds; y (and residual) are frames (B, Ho + 2 opad, Wo + 2 opad, Cout) of which only the interior
  * is written (the owner zeroes the halo once).  wn: n-major filter (Cout, KH*KW*Cin), Cin % 32 == 0; or, row_mode != 0
  * (the 18-channel 7x7 stem, models/resnet.py:150, :203): (Cout, KH * ceil32(KW*Cin)), one filter row = KW*Cin contiguous
- * NHWC floats taken as a single tap, zero filled tail.  variant / ksplit as for _v3.
- * ksplit > 1: K is cut into ksplit slices computed by separate workgroups; splitk_ws holds hps_query_workspace(HPS_WS_CONV_SPLITK,
- * ksplit, B*Ho*Wo, Cout) bytes = [one int32 arrival counter per output tile | the slices' partial sums].  Up to four slices the
- * workgroup that arrives LAST at a tile adds the tile's slices in slice order (a fixed order whoever it is: deterministic, no
- * floating-point atomics), applies BatchNorm / residual / ReLU and resets the counter -- one launch per layer; with more slices (the
- * latency mode's 12-18) a second kernel does the same sum spread over the chip.  THE COUNTERS MUST BE ZERO BEFORE THE FIRST
- * LAUNCH THAT USES THE BUFFER (zero the buffer once when it is allocated); every launch leaves them zero, and layers with the same
- * output shape (B*Ho*Wo, Cout) may share one buffer on one stream whatever their ksplit.  Lane offsets are 32-bit: tensors < 4 GiB. */
+ * NHWC floats taken as a single tap, zero filled tail.  variant / ksplit / splitk_ws as for _v3
+ * (splitk_ws (ksplit, B*Ho*Wo, Cout)).  Lane offsets are 32-bit: tensors < 4 GiB. */
 int hps_conv2d_bn_act_pad(const float* x, const float* wn, const float* scale, const float* shift,
                           const float* residual, float* y, int B, int H, int W, int ipad, int Cin, int Cout,
                           int KH, int KW, int stride, int pad, int opad, int relu, int row_mode, int variant,
@@ -333,9 +327,7 @@ int hps_conv2d_bn_act_pad(const float* x, const float* wn, const float* scale, c
  * with G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1].  Requirements: Cin % 8 == 0, Cout % 64 == 0 and either
  * H % 16 == 0, W % 16 == 0 (items of 8 x 8 tiles of one image) or H == W == 8 (layer4: items of four images; K is cut
  * into slices whose partial sums go through splitk_ws -- hps_conv3x3_winograd_workspace(B, H, W, Cin, Cout) bytes, 0 for
- * the first geometry, where splitk_ws may be NULL; the buffer starts with the same header of arrival counters as
- * hps_conv2d_bn_act_pad's (ZERO before the first use, left zero by every launch) and the workgroup that finishes a tile's last
- * slice adds the slices in slice order and applies BatchNorm / residual / ReLU).  Results equal the
+ * the first geometry, where splitk_ws may be NULL -- and are added in slice order by a second kernel).  Results equal the
  * direct convolution up to fp32 rounding of a different summation order; the order depends on the layer only, never on
  * the batch size. */
 int hps_conv3x3_winograd(const float* x, const float* u, const float* scale, const float* shift,

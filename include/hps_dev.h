@@ -97,12 +97,6 @@ int hps_dev_unc_mode(int mode);
  * (36 KiB -> 4, 52 KiB -> 3, 72 KiB -> 2, 150 KiB -> 1).  0 restores the product value. */
 int hps_dev_mesh_lds_floor(int bytes);
 
-/* Cross-check hook: 1 = the split-K convolutions (hps_conv2d_bn_act_pad with ksplit > 1, hps_conv3x3_winograd on 8 x 8 maps) leave
- * their slices to the round-4 second launch (splitk_pad_epilogue_kernel / wino_splitk_epilogue_kernel) instead of letting the last
- * workgroup to arrive finish each output tile; 0 = the product form.  Same bits either way (tests/test_gpu_net.py). */
-int hps_dev_splitk_two_pass(int on);
-int hps_dev_wino_two_pass(int on);
-
 /* Tuning hook (tests/dev only): 1 = hps_conv2d_bn_act_pad skips its epilogue (results are garbage), 0 = normal. */
 int hps_dev_conv_pad_ablate(int mode);
 

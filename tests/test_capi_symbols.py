@@ -56,9 +56,7 @@ def test_version_and_error_string():
 def test_query_workspace_is_the_single_source_of_scratch_sizes():
     """hps_query_workspace(op, dims...) -- every caller-provided scratch size comes from the library."""
     q = _capi.query_workspace
-    # split-K: a header of arrival counters (one per 64 x 64 output tile, rounded up to 64: a function of the OUTPUT shape only) + the slices
-    assert q(_capi.WS_CONV_SPLITK, 4, 64 * 8 * 8, 512) == (512 + 4 * 64 * 8 * 8 * 512) * 4 and q(_capi.WS_CONV_SPLITK, 1, 10, 10) == 0
-    assert q(_capi.WS_CONV_SPLITK, 18, 64, 512) - q(_capi.WS_CONV_SPLITK, 12, 64, 512) == 6 * 64 * 512 * 4      # same header whatever ksplit
+    assert q(_capi.WS_CONV_SPLITK, 4, 64 * 8 * 8, 512) == 4 * 64 * 8 * 8 * 512 * 4 and q(_capi.WS_CONV_SPLITK, 1, 10, 10) == 0
     assert q(_capi.WS_SMPL_MP, 6528) == 6528 and q(_capi.WS_SMPL_MP, 6529) == 6656 and q(_capi.WS_SMPL_MP, 1) == 128
     assert q(_capi.WS_SMPL_XT, 6528, 224) == 224 * 6528 * 4
     assert q(_capi.WS_SMPL_A, 3, 24) == 3 * 24 * 12 * 4
@@ -68,8 +66,7 @@ def test_query_workspace_is_the_single_source_of_scratch_sizes():
     # the K-slice buffer of the Winograd layer4 geometry: 4 slices x B x 8 x 8 x Cout floats; none for the 16x16-block geometry,
     # one slice when the 8 x 8 geometry has fewer than 32 chunks
     w = lib.hps_conv3x3_winograd_workspace
-    assert w(64, 8, 8, 512, 512) == (512 + 4 * 64 * 64 * 512) * 4 and w(5, 8, 8, 64, 128) == (64 + 1 * 5 * 64 * 128) * 4
-    assert w(64, 8, 8, 512, 512) == q(_capi.WS_CONV_SPLITK, 4, 64 * 64, 512)          # the two kernels of a block can share one buffer
+    assert w(64, 8, 8, 512, 512) == 4 * 64 * 64 * 512 * 4 and w(5, 8, 8, 64, 128) == 1 * 5 * 64 * 128 * 4
     assert w(64, 16, 16, 256, 256) == 0 and w(64, 64, 64, 64, 64) == 0 and w(0, 8, 8, 512, 512) == 0
     assert lib.hps_query_workspace(99, 1, 1, 1) == -1 and b"unknown item" in lib.hps_last_error()
     assert lib.hps_query_workspace(_capi.WS_SMPL_MP, -1, 0, 0) == -1

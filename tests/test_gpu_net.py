@@ -666,38 +666,3 @@ def test_all_levels_in_one_launch_equal_the_per_level_launches(dev, net_gpu):
         net_gpu.fused_levels = False
         net_gpu.set_latency_mode(False)
 
-
-@pytest.mark.gpu
-def test_split_k_layers_finish_inside_the_kernel(dev, net_gpu):
-    """Round 5: the K slices of a split-K convolution with up to four slices (direct kernel: layer4.0.conv1 in the default mode;
-    Winograd on 8 x 8 maps: layer4's other three) are added by the LAST workgroup to arrive at each output tile -- in slice order,
-    so the result does not depend on who that is -- instead of by a second launch per layer (the latency mode's 12-18 slices keep
-    the second launch: one workgroup reading 1.2 MB of slices is slower than a kernel that spreads them over the chip).  Against the round-4 two-launch form
-    kept in the dev library (hps_dev_splitk_two_pass): encoder features bit for bit in both modes, for batches whose last tile is
-    ragged, call after call (the arrival counters in the workspace header reset themselves), and the header is left zero."""
-    enc = net_gpu.image_encoder
-    xs = {B: torch.rand(B, 18, 256, 256, generator=torch.Generator().manual_seed(400 + B)).to(dev) for B in (1, 3, 5, 16)}
-    try:
-        for latency in (False, True):
-            net_gpu.set_latency_mode(latency)
-            for B, x in xs.items():
-                got = [enc(x).clone() for _ in range(3)]
-                with _capi.dev_library():
-                    same_source = enc(x).clone()
-                    _capi.call("hps_dev_splitk_two_pass", 1)
-                    try:
-                        want = enc(x).clone()
-                    finally:
-                        _capi.call("hps_dev_splitk_two_pass", 0)
-                for g in got + [same_source]:
-                    assert torch.equal(g, want), (latency, B, float((g - want).abs().max()))
-        # every workspace header is zero again
-        prep = enc._prepared
-        for fs in enc._frames.values():
-            for (c1, c2, down), ent in zip(prep["blocks"], fs["blocks"]):
-                if ent["ws"] is not None:
-                    hdr = int(_capi.query_workspace(_capi.WS_CONV_SPLITK, 2, ent["c1"].shape[0] * (ent["c1"].shape[1] - 2) * (ent["c1"].shape[2] - 2),
-                                                    c1.cout)) // 4 - 2 * ent["c1"].shape[0] * (ent["c1"].shape[1] - 2) * (ent["c1"].shape[2] - 2) * c1.cout
-                    assert hdr > 0 and int(ent["ws"][:hdr].view(torch.int32).abs().sum()) == 0
-    finally:
-        net_gpu.set_latency_mode(False)
