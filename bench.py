@@ -175,8 +175,9 @@ def main():
                          "shard, its Philox offsets) -- what the multi-rank tests compare the per-rank checksums against")
     ap.add_argument("--from-rgb-steps", type=int, default=16,
                     help="after the timed region: steps of the PCIe-inclusive path from host RGB crops + keypoints for secondary.from_rgb (0 = skip)")
-    ap.add_argument("--from-rgb-variant", choices=("default", "no-copy"), default="default",
-                    help="diagnostic: 'no-copy' runs the from-RGB loop on device-resident crops (isolates the cost of the H2D copies)")
+    ap.add_argument("--from-rgb-variant", choices=("default", "no-copy", "nchw"), default="default",
+                    help="diagnostic: 'no-copy' runs the from-RGB loop on device-resident crops (isolates the cost of the H2D copies); "
+                         "'nchw' builds the (B,18,D,D) tensor and lets the encoder split it into phase frames (the round-4 route)")
     ap.add_argument("--latency-reps", type=int, default=40,
                     help="after the timed region: batch-1, num_samples=50 calls timed one by one for secondary.latency_b1 (0 = skip)")
     ap.add_argument("--stress-steps", type=int, default=8,
@@ -373,15 +374,18 @@ def main():
             vis = (torch.rand(B, 17, generator=g) > 0.15).float()
             host_sets.append([t.contiguous().pin_memory() for t in (rgb, j2d, vis)])
         stager = StagedUpload(slots=2)
+        # the front end writes the proxy representation straight into the Winograd stem's phase frames (hps_proxy_rep_phase_frames):
+        # no (B,18,D,D) tensor, no hps_stem_phase_split on this path ("nchw": the round-4 route through the NCHW tensor, for A/B)
+        enc_direct = net.image_encoder if args.from_rgb_variant != "nchw" else None
 
         resident = [[t.to(dev) for t in hs] for hs in host_sets] if args.from_rgb_variant == "no-copy" else None
 
         def rgb_step(k):
             if resident is not None:          # diagnostic: the same loop without the H2D copies
                 rgb_d, j_d, v_d = resident[k % INPUT_SETS]
-                return pipe.submit(make_input=lambda: proxy_representation(rgb_d, j_d, v_d, canny, cfg), input_ready=False)
+                return pipe.submit(make_input=lambda: proxy_representation(rgb_d, j_d, v_d, canny, cfg, encoder=enc_direct), input_ready=False)
             (rgb_d, j_d, v_d), ready = stager.upload(host_sets[k % INPUT_SETS])
-            t = pipe.submit(make_input=lambda: proxy_representation(rgb_d, j_d, v_d, canny, cfg), input_ready=ready)
+            t = pipe.submit(make_input=lambda: proxy_representation(rgb_d, j_d, v_d, canny, cfg, encoder=enc_direct), input_ready=ready)
             stager.release(t[1])
             return t
 
@@ -422,8 +426,9 @@ def main():
                     "checksum_images": float(rgb_sums[0]), "checksum_sum_unc": float(rgb_sums[1]),
                     "encoder_avg_ms": sum(rgb_enc_ms) / max(1, len(rgb_enc_ms)),
                     "mesh_kernel_avg_ms": sum(rgb_mesh_ms) / max(1, len(rgb_mesh_ms)),
+                    "input_route": "phase frames written directly (hps_proxy_rep_phase_frames)" if enc_direct is not None else "NCHW tensor + hps_stem_phase_split",
                     "note": "PCIe-inclusive: page-locked host RGB crops + 17 keypoints + visibility -> non-blocking H2D on a copy "
-                            "stream (two device slots) -> hps_canny_edge_map + hps_proxy_rep on the encoder's stream -> the same "
+                            "stream (two device slots) -> hps_canny_edge_map + hps_proxy_rep_phase_frames on the encoder's stream -> the same "
                             "pipelined step as the headline; median of three legs of %d steps (all listed) after %d warm-up steps, wall clock"
                             % (args.from_rgb_steps, rgb_warm),
                     "legs_spread": (max(leg_rates) - min(leg_rates)) / max(leg_rates)}

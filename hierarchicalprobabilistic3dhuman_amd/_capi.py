@@ -62,6 +62,7 @@ _PROTOTYPES = {
     "hps_conv3x3_winograd_workspace": [_I, _I, _I, _I, _I],
     "hps_stem_phase_frames_bytes": [_I, _I, _I],
     "hps_stem_phase_split": [_P, _P, _I, _I, _I, _I, _P],
+    "hps_proxy_rep_phase_frames": [_P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _P],
     "hps_stem_winograd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "hps_sums_f64": [_P, _P, _P, _I, _c.c_double, _P, _P, _P],
     "hps_sizeof_enc_op": [],

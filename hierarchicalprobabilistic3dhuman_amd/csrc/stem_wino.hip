@@ -413,6 +413,31 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
     }
 }
 
+// Pixels w0 .. w0 + n - 1 (w0 even) of image row h of image b, staged in LDS as sp[pixel][18 channel slots] (slot order of the
+// frames: 0 2 1 3 | 4 6 5 7 | ... | 16 17), -> the two phase frames the row belongs to.  t = thread of a 256-thread workgroup.
+__device__ __forceinline__ void phase_row_store(const float* sp, float* __restrict__ frames, long b, int h, int w0, int n, int H, int W, int t) {
+    constexpr int C = SW_C;
+    const int FR = H / 2 + 4, FC = W / 2 + 4;
+    const int ry = (h + 3) & 1, i = (h + 3) >> 1;
+    const v2f* s2 = reinterpret_cast<const v2f*>(sp);
+#pragma unroll
+    for (int rx = 0; rx < 2; ++rx) {
+        // pixels w0 + wl with (w0 + wl + 3) & 1 == rx (w0 is even): wl = 1 - rx, 3 - rx, ...
+        const int first = 1 - rx, count = (n - first + 1) / 2;
+        const int j0 = (w0 + first + 3) >> 1;
+        v2f* row = reinterpret_cast<v2f*>(frames + ((b * 4 + ry * 2 + rx) * FR + i) * (long)(FC / 2) * SW_PAIR);
+        // ten 8-byte words per pixel: its nine channel pairs and, behind the second pixel of a pair, the padding (written as zero
+        // although it never changes: a run that leaves 8-byte holes in its 64-byte sectors makes the memory side read-modify-write
+        // them -- 0.17 instead of 0.11 ms)
+        for (int e = t; e < count * 10; e += 256) {
+            const int pi = e / 10, sl = e - pi * 10;
+            const int j = j0 + pi;                                   // pixel of the phase row: pair j / 2, 19 8-byte words per pair
+            if (sl < C / 2) row[(j >> 1) * (SW_PAIR / 2) + (j & 1) * (C / 2) + sl] = s2[(first + 2 * pi) * (C / 2) + sl];
+            else if (j & 1) row[(j >> 1) * (SW_PAIR / 2) + C] = (v2f){0.0f, 0.0f};
+        }
+    }
+}
+
 // (B, 18, H, W) -> the four phase frames of every image: frames[b][2 ry + rx][i][j][18] = x[b][:, 2 i + ry - 3, 2 j + rx - 3],
 // frame = (H / 2 + 4) x (W / 2 + 4) pixels (out-of-image pixels stay zero: the owner zeroes the buffer once).  The 18 channels
 // of a pixel are stored in the order 0 2 1 3 | 4 6 5 7 | 8 10 9 11 | 12 14 13 15 | 16 17: the MFMA lane of parity kl reads the
@@ -440,24 +465,57 @@ __global__ __launch_bounds__(256) void stem_phase_split_kernel(const float* __re
         }
     }
     __syncthreads();
-    const int FR = H / 2 + 4, FC = W / 2 + 4;
-    const int ry = (h + 3) & 1, i = (h + 3) >> 1;
-    const v2f* s2 = reinterpret_cast<const v2f*>(sp);
+    phase_row_store(sp, frames, b, h, w0, n, H, W, t);
+}
+
+// The proxy representation (predict/predict_poseMF_shapeGaussian_net.py:93-100: channel 0 = edge map, channels 1..17 = visibility-masked
+// Gaussian heat-maps, utils/label_conversions.py:105-124) written STRAIGHT into the four phase frames of the Winograd stem: what
+// hps_proxy_rep followed by hps_stem_phase_split produces, bit for bit, without the (B,18,H,W) tensor in between (-302 MB written,
+// -302 MB read per 64 images: the front end generates every input pixel anyway -- VERDICT r4 item 3b).  The Gaussian is evaluated with
+// proxy_rep_kernel's operations on the same operands (row term once per workgroup and row, column term once per thread and joint).
+// A workgroup = FRAME_ROWS rows of up to 256 columns of one image; thread = column.
+constexpr int FRAME_ROWS = 8;
+__global__ __launch_bounds__(256) void proxy_rep_frames_kernel(const float* __restrict__ edge, const float* __restrict__ joints2d,
+                                                               const float* __restrict__ visib, float* __restrict__ frames, int H, int W,
+                                                               float std, int runs_per_row) {
+    constexpr int C = SW_C, K = SW_C - 1;
+    __shared__ float sp[256 * C];
+    __shared__ float s_row[FRAME_ROWS][K];           // ((y - v) / std)^2 / 2
+    __shared__ float s_vis[K];
+    const int t = threadIdx.x;
+    const int run = blockIdx.x % runs_per_row;
+    const int y0 = (blockIdx.x / runs_per_row) * FRAME_ROWS;
+    const long b = blockIdx.y;
+    const int w0 = run * 256, n = min(256, W - w0), x = w0 + t;
+    for (int i = t; i < FRAME_ROWS * K; i += 256) {
+        const int r = i / K, k = i - r * K;
+        const float v = joints2d[((size_t)b * K + k) * 2 + 1];
+        const float a = ((float)(y0 + r) - v) / std;
+        s_row[r][k] = (a * a) / 2.0f;
+    }
+    if (t < K) s_vis[t] = visib ? visib[(size_t)b * K + t] : 1.0f;
+    float c2[K];
 #pragma unroll
-    for (int rx = 0; rx < 2; ++rx) {
-        // pixels w0 + wl with (w0 + wl + 3) & 1 == rx (w0 is even): wl = 1 - rx, 3 - rx, ...
-        const int first = 1 - rx, count = (n - first + 1) / 2;
-        const int j0 = (w0 + first + 3) >> 1;
-        v2f* row = reinterpret_cast<v2f*>(frames + ((b * 4 + ry * 2 + rx) * FR + i) * (long)(FC / 2) * SW_PAIR);
-        // ten 8-byte words per pixel: its nine channel pairs and, behind the second pixel of a pair, the padding (written as zero
-        // although it never changes: a run that leaves 8-byte holes in its 64-byte sectors makes the memory side read-modify-write
-        // them -- 0.17 instead of 0.11 ms)
-        for (int e = t; e < count * 10; e += 256) {
-            const int pi = e / 10, sl = e - pi * 10;
-            const int j = j0 + pi;                                   // pixel of the phase row: pair j / 2, 19 8-byte words per pair
-            if (sl < C / 2) row[(j >> 1) * (SW_PAIR / 2) + (j & 1) * (C / 2) + sl] = s2[(first + 2 * pi) * (C / 2) + sl];
-            else if (j & 1) row[(j >> 1) * (SW_PAIR / 2) + C] = (v2f){0.0f, 0.0f};
+    for (int k = 0; k < K; ++k) {
+        const float u = joints2d[((size_t)b * K + k) * 2 + 0];
+        const float c = ((float)x - u) / std;
+        c2[k] = (c * c) / 2.0f;
+    }
+    const int rows = min(FRAME_ROWS, H - y0);
+    for (int r = 0; r < rows; ++r) {
+        __syncthreads();                              // s_row / s_vis written (first round); sp free again (later rounds)
+        if (t < n) {
+            sp[t * C + 0] = edge ? edge[((size_t)b * H + y0 + r) * W + x] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int c = k + 1;
+                const int slot = c >= 16 ? c : (c & ~3) + ((c & 1) << 1) + ((c >> 1) & 1);
+                const float hv = expf(-s_row[r][k] - c2[k]);
+                sp[t * C + slot] = visib ? hv * s_vis[k] : hv;
+            }
         }
+        __syncthreads();
+        phase_row_store(sp, frames, b, y0 + r, w0, n, H, W, t);
     }
 }
 
@@ -482,6 +540,19 @@ extern "C" int hps_stem_phase_split(const float* x, float* frames, int B, int C,
     if (blocks > 0x7fffffffL) return bad_arg("hps_stem_phase_split: too many rows");
     hipLaunchKernelGGL(stem_phase_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, frames, H, W, runs);
     return check_launch("hps_stem_phase_split");
+}
+
+extern "C" int hps_proxy_rep_phase_frames(const float* edge, const float* joints2d, const float* visib, float* frames, int B, int K,
+                                          int H, int W, float std, hps_stream_t stream) {
+    if (!joints2d || !frames) return bad_arg("hps_proxy_rep_phase_frames: null pointer");
+    if (K != SW_C - 1) return bad_arg("hps_proxy_rep_phase_frames: 17 joints (the 18-channel proxy representation)");
+    if (H <= 0 || W <= 0 || (H % 32) || (W % 32)) return bad_arg("hps_proxy_rep_phase_frames: H and W must be multiples of 32");
+    if (B <= 0) return HPS_OK;
+    if (B > 65535) return bad_arg("hps_proxy_rep_phase_frames: at most 65 535 images per call");
+    const int runs = ceil_div(W, 256);
+    hipLaunchKernelGGL(proxy_rep_frames_kernel, dim3((unsigned)(runs * ceil_div(H, FRAME_ROWS)), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                       edge, joints2d, visib, frames, H, W, std, runs);
+    return check_launch("hps_proxy_rep_phase_frames");
 }
 
 static int stem_wino_launch(const float* frames, const float* u, const float* scale, const float* shift, float* y, int B, int H,

@@ -17,6 +17,7 @@ from . import _capi
 from .rigid_transform_utils import rot6d_to_rotmat, batch_rodrigues
 from .sampling_utils import pose_matrix_fisher_sampling_torch, vertex_uncertainty, check_sampling
 from .label_conversions import make_proxy_representation
+from .resnet import FilledStemFrames
 
 
 @torch.no_grad()
@@ -80,12 +81,28 @@ def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mea
                 unc=unc)
 
 
-def proxy_representation(rgb, joints2D, joints2D_visib, edge_detect_model, pose_shape_cfg, out=None):
+def proxy_representation(rgb, joints2D, joints2D_visib, edge_detect_model, pose_shape_cfg, out=None, encoder=None):
     """predict/predict_poseMF_shapeGaussian_net.py:88-100: RGB crop (B,3,D,D), 2D joints (B,17,2) in crop pixels and
     their visibility (B,17) -> the (B,18,D,D) network input.  ``edge_detect_model`` is a CannyEdgeDetector: its edge map goes
     straight into channel 0 (hps_canny_edge_map: the five other outputs of the detector's dict are not materialised), the
-    heat-map kernel fills channels 1..17.  Any other callable with the reference's interface works through its output dict."""
+    heat-map kernel fills channels 1..17.  Any other callable with the reference's interface works through its output dict.
+
+    ``encoder``: the ResNet that will consume the result ON THE CURRENT STREAM (InferencePipeline.submit(make_input=...) calls this
+    function on the encoder's stream).  When its Winograd stem takes this shape, the proxy representation is written straight into
+    the stem's phase frames (hps_proxy_rep_phase_frames: the same values hps_proxy_rep + hps_stem_phase_split would leave there,
+    without the (B,18,D,D) tensor) and the returned FilledStemFrames is what ``encoder(...)`` accepts in its place."""
     D = pose_shape_cfg.DATA.PROXY_REP_SIZE
+    if encoder is not None and hasattr(edge_detect_model, "edge_map_into"):
+        B, K = joints2D.shape[:2]
+        filled = encoder.stem_frames(B, K + 1, D, D, rgb.device) if K == 17 else None
+        if filled is not None:
+            edge = torch.empty(B, 1, D, D, device=rgb.device, dtype=torch.float32)
+            edge_detect_model.edge_map_into(rgb, edge, nms=bool(pose_shape_cfg.DATA.EDGE_NMS))
+            j = _capi.f32c(joints2D)
+            vis = None if joints2D_visib is None else _capi.f32c(joints2D_visib.to(rgb.device).float()).reshape(B, K)
+            _capi.call("hps_proxy_rep_phase_frames", _capi.ptr(edge), _capi.ptr(j), _capi.ptr(vis) if vis is not None else None,
+                       _capi.ptr(filled.frames), B, K, D, D, float(pose_shape_cfg.DATA.HEATMAP_GAUSSIAN_STD), _capi.stream())
+            return filled
     if hasattr(edge_detect_model, "edge_map_into"):
         B, K = joints2D.shape[:2]
         if out is None:
@@ -229,7 +246,8 @@ class InferencePipeline:
         if make_input is not None:
             with torch.cuda.stream(self.enc_stream):
                 proxy_rep_input = make_input()
-            _capi.require_device(proxy_rep_input, "proxy_rep_input")
+            if not isinstance(proxy_rep_input, FilledStemFrames):
+                _capi.require_device(proxy_rep_input, "proxy_rep_input")
         gate = None
         if self._smpl_done is None or not self._exclusive:
             pass

@@ -228,6 +228,19 @@ def _stem_winograd_filters(w):
     return torch.cat([packed, torch.zeros(256, dtype=torch.float64)]).float()
 
 
+class FilledStemFrames:
+    """Marker returned by ResNet.stem_frames(): the encoder's own phase frames for a (B, C, H, W) input on the current stream have
+    been (or are about to be, on that stream) filled by the caller -- hps_proxy_rep_phase_frames -- instead of by
+    hps_stem_phase_split from an NCHW tensor.  ``ResNet.forward(filled)`` then starts at the stem convolution."""
+
+    def __init__(self, frames, shape, device):
+        self.frames, self.shape, self.device = frames, tuple(shape), device
+        self.is_cuda = True
+
+    def record_stream(self, stream):            # the frames belong to the encoder (allocated once per shape and stream)
+        pass
+
+
 class _FrameCache(dict):
     """Per-(batch shape, stream) activation frames and launch lists; device-bound scratch, never copied or pickled."""
 
@@ -433,20 +446,41 @@ class ResNet(nn.Module):
         # input frame (hps_nchw_to_padded_nhwc_generic) in front of the row-mode / direct stem
         return self.layout == "padded"
 
+    def stem_frames(self, B, C, H, W, device):
+        """The phase-frame buffer the Winograd stem will read for a (B, C, H, W) input on the CURRENT stream, wrapped as a
+        FilledStemFrames for the caller to fill (hps_proxy_rep_phase_frames) and hand to forward(); None when this shape does not
+        take the Winograd stem (then build the NCHW tensor as usual)."""
+        prep = self._prepared or self.prepare()
+        if self.layout != "padded" or not prep["stem"].stem_winograd_ok(C, H, W):
+            return None
+        fs = self._frame_set(prep, B, C, H, W, device)
+        return FilledStemFrames(fs["in"], (B, C, H, W), device) if fs["stem_wino"] else None
+
     def _forward_padded(self, prep, x, gate=None):
         """``gate``: optional callable invoked after the input relayout has been enqueued and before the first convolution
         (InferencePipeline: the HBM-bound relayout may run beside the previous batch's MFMA-bound mesh kernel; the
         convolutions wait)."""
+        filled = isinstance(x, FilledStemFrames)
         B, C, H, W = x.shape
         s = _capi.stream()
         P = _capi.ptr
         fs = self._frame_set(prep, B, C, H, W, x.device)
+        if filled and (not fs["stem_wino"] or fs["in"].data_ptr() != x.frames.data_ptr()):
+            raise _capi.HpsError("FilledStemFrames belong to another stream / shape / kernel selection than this forward (fill the "
+                                 "frames stem_frames() returned on the stream the encoder runs on)")
         if self.composite and fs["variants"] == self._variant_state(prep):
             # one call across the C ABI for the whole encoder (csrc/composite.hip); two when the list is gated
             feats = torch.empty(B, fs["blocks"][-1]["c2"].shape[3], device=x.device, dtype=torch.float32)
             ops = fs["ops"]
-            ops[0].x = x.data_ptr()
             ops[len(ops) - 1].y = feats.data_ptr()
+            if filled:                                   # the phase frames are already filled: the list starts at the stem convolution
+                import ctypes
+                if gate is not None:
+                    gate()
+                rest = ctypes.cast(ctypes.byref(ops, ctypes.sizeof(_capi.EncOp)), ctypes.POINTER(_capi.EncOp))
+                _capi.call("hps_encoder_run", rest, len(ops) - 1, s)
+                return feats
+            ops[0].x = x.data_ptr()
             if gate is None:
                 _capi.call("hps_encoder_run", ops, len(ops), s)
             else:
@@ -458,7 +492,8 @@ class ResNet(nn.Module):
             return feats
         stem = prep["stem"]
         if fs["stem_wino"]:
-            _capi.call("hps_stem_phase_split", P(x), P(fs["in"]), B, C, H, W, s)
+            if not filled:
+                _capi.call("hps_stem_phase_split", P(x), P(fs["in"]), B, C, H, W, s)
             if gate is not None:
                 gate()
             y = fs["stem"]
@@ -485,10 +520,12 @@ class ResNet(nn.Module):
 
     def forward(self, x, _gate=None):
         """models/resnet.py:202-217: (B,C,H,W) NCHW fp32 -> (B,512)."""
-        _capi.require_device(x, "encoder input")
         if self.training:
             raise RuntimeError("the MI355X encoder path is inference-only (eval-mode BatchNorm); call .eval()")
         prep = self._prepared or self.prepare()
+        if isinstance(x, FilledStemFrames):
+            return self._forward_padded(prep, x, gate=_gate)
+        _capi.require_device(x, "encoder input")
         x = _capi.f32c(x)
         B, C, H, W = x.shape
         if self._padded_ok(C, H, W):

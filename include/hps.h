@@ -354,6 +354,13 @@ size_t hps_conv3x3_winograd_workspace(int B, int H, int W, int Cin, int Cout);
  *     G (3 taps) = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]; 81 * 1152 floats plus 256 floats of readable slack. */
 size_t hps_stem_phase_frames_bytes(int B, int H, int W);
 int hps_stem_phase_split(const float* x, float* frames, int B, int C, int H, int W, hps_stream_t stream);
+/* The proxy representation (predict/predict_poseMF_shapeGaussian_net.py:93-100; heat-maps: utils/label_conversions.py:105-124) written
+ * straight into the phase frames: exactly what hps_proxy_rep (edge -> channel 0, visibility-masked Gaussians of the K = 17 joints ->
+ * channels 1..17) followed by hps_stem_phase_split leaves in `frames`, bit for bit, without the (B,18,H,W) tensor in between.
+ * edge: (B,H,W) plane or NULL (zeros); joints2d (B,17,2) (u = column, v = row); visib (B,17) or NULL.  For callers that build the
+ * network input on the device anyway (the from-RGB pipeline); the NCHW entry stays the contract of the reference's call surface. */
+int hps_proxy_rep_phase_frames(const float* edge, const float* joints2d, const float* visib, float* frames, int B, int K, int H,
+                               int W, float std, hps_stream_t stream);
 int hps_stem_winograd(const float* frames, const float* u, const float* scale, const float* shift, float* y, int B, int H,
                       int W, int opad, int relu, hps_stream_t stream);
 

@@ -206,23 +206,66 @@ def test_pipeline_from_host_rgb_equals_infer_on_the_proxy_representation(dev, ne
     pipe.caller_stream(B)
     stager = StagedUpload(slots=2)
 
-    def step(k):
-        (rgb_d, j_d, v_d), ready = stager.upload(host[k])
-        t = pipe.submit(make_input=lambda: proxy_representation(rgb_d, j_d, v_d, det, cfg), input_ready=ready)
-        stager.release(t[1])
-        return t
+    # encoder=None: the (B,18,D,D) tensor is built and the encoder splits it into phase frames; encoder=...: the front end writes the
+    # Winograd stem's phase frames directly (hps_proxy_rep_phase_frames, round 5) -- the same frames, so the same bits
+    for enc in (None, net_gpu.image_encoder):
+        def step(k):
+            (rgb_d, j_d, v_d), ready = stager.upload(host[k])
+            t = pipe.submit(make_input=lambda: proxy_representation(rgb_d, j_d, v_d, det, cfg, encoder=enc), input_ready=ready)
+            stager.release(t[1])
+            return t
 
-    got = []
-    t = step(0)
-    for k in range(len(host)):
-        nxt = step(k + 1) if k + 1 < len(host) else None
-        r = pipe.finish(t, seed=60 + k, after=nxt)
-        got.append({key: r[key].clone() for key in want[k]})
-        t = nxt
-    torch.cuda.synchronize()
-    for w, g_ in zip(want, got):
-        for key in w:
-            assert torch.equal(w[key], g_[key]), key
+        got = []
+        t = step(0)
+        for k in range(len(host)):
+            nxt = step(k + 1) if k + 1 < len(host) else None
+            r = pipe.finish(t, seed=60 + k, after=nxt)
+            got.append({key: r[key].clone() for key in want[k]})
+            t = nxt
+        torch.cuda.synchronize()
+        for w, g_ in zip(want, got):
+            for key in w:
+                assert torch.equal(w[key], g_[key]), (key, enc is not None)
+
+
+def test_front_end_writes_the_stems_phase_frames_directly(dev, net_gpu):
+    """VERDICT r4 item 3b.  hps_proxy_rep_phase_frames leaves in the encoder's phase-frame buffer exactly what hps_proxy_rep +
+    hps_stem_phase_split leave there -- every float of the buffer, halo and padding included -- for visibility masks, joints outside
+    the image and both edge-map selections; features from the filled frames equal features from the NCHW tensor; shapes the
+    Winograd stem does not take fall back to the tensor."""
+    from hierarchicalprobabilistic3dhuman_amd import configs
+    from hierarchicalprobabilistic3dhuman_amd.canny_edge_detector import CannyEdgeDetector
+    from hierarchicalprobabilistic3dhuman_amd.predict_poseMF_shapeGaussian_net import proxy_representation
+    from hierarchicalprobabilistic3dhuman_amd.resnet import FilledStemFrames
+    enc = net_gpu.image_encoder
+    for B, D, nms in ((2, 256, True), (5, 256, False), (3, 64, True)):
+        cfg = configs.get_cfg_defaults()
+        cfg.DATA.PROXY_REP_SIZE, cfg.DATA.EDGE_NMS = D, nms
+        det = CannyEdgeDetector(True, cfg.DATA.EDGE_GAUSSIAN_STD, cfg.DATA.EDGE_GAUSSIAN_SIZE, cfg.DATA.EDGE_THRESHOLD).to(dev)
+        g = torch.Generator().manual_seed(B * 7 + D)
+        rgb = torch.nn.functional.interpolate(torch.rand(B, 3, D // 8, D // 8, generator=g), size=(D, D), mode="bilinear", align_corners=False).to(dev)
+        j2d = (torch.rand(B, 17, 2, generator=g) * 1.4 - 0.2) * D                      # some joints outside the image
+        vis = (torch.rand(B, 17, generator=g) > 0.3).float()
+        for v in (vis.to(dev), None):
+            proxy = proxy_representation(rgb, j2d.to(dev), v, det, cfg)
+            assert torch.is_tensor(proxy) and proxy.shape == (B, 18, D, D)
+            want_feats = enc(proxy).clone()
+            filled_buf = enc.stem_frames(B, 18, D, D, dev)
+            want_frames = filled_buf.frames.clone()                                      # as hps_stem_phase_split left them
+            filled_buf.frames.fill_(-9.0)                                                # prove every in-image float is rewritten ...
+            filled = proxy_representation(rgb, j2d.to(dev), v, det, cfg, encoder=enc)
+            assert isinstance(filled, FilledStemFrames) and filled.frames.data_ptr() == filled_buf.frames.data_ptr()
+            touched = filled.frames != -9.0
+            assert torch.equal(filled.frames[touched], want_frames[touched])
+            assert bool((want_frames[~touched] == 0).all())                              # ... and only the zero halo / slack is not
+            filled.frames.copy_(torch.where(touched, filled.frames, torch.zeros_like(filled.frames)))
+            assert torch.equal(filled.frames, want_frames)
+            assert torch.equal(enc(filled), want_feats)
+    # a shape the Winograd stem does not take: the tensor route
+    cfg.DATA.PROXY_REP_SIZE = 48
+    rgb = torch.rand(2, 3, 48, 48).to(dev)
+    out = proxy_representation(rgb, (torch.rand(2, 17, 2) * 48).to(dev), None, det, cfg, encoder=enc)
+    assert torch.is_tensor(out) and out.shape == (2, 18, 48, 48)
 
 
 def test_predict_loop_from_host_proxies_equals_infer(dev, net_gpu, smpl_gpu, tmp_path):
