@@ -100,8 +100,11 @@ def proxy_representation(rgb, joints2D, joints2D_visib, edge_detect_model, pose_
             edge_detect_model.edge_map_into(rgb, edge, nms=bool(pose_shape_cfg.DATA.EDGE_NMS))
             j = _capi.f32c(joints2D)
             vis = None if joints2D_visib is None else _capi.f32c(joints2D_visib.to(rgb.device).float()).reshape(B, K)
-            _capi.call("hps_proxy_rep_phase_frames", _capi.ptr(edge), _capi.ptr(j), _capi.ptr(vis) if vis is not None else None,
-                       _capi.ptr(filled.frames), B, K, D, D, float(pose_shape_cfg.DATA.HEATMAP_GAUSSIAN_STD), _capi.stream())
+            std = float(pose_shape_cfg.DATA.HEATMAP_GAUSSIAN_STD)
+            # the edge map is computed now (it may run beside the previous batch's mesh kernel); the frames themselves are written
+            # by encoder.forward(filled) right in front of the stem convolution, on the stream that call runs on
+            filled.fill = lambda: _capi.call("hps_proxy_rep_phase_frames", _capi.ptr(edge), _capi.ptr(j), _capi.ptr(vis) if vis is not None else None,
+                                             _capi.ptr(filled.frames), B, K, D, D, std, _capi.stream())
             return filled
     if hasattr(edge_detect_model, "edge_map_into"):
         B, K = joints2D.shape[:2]

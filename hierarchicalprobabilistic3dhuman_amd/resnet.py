@@ -233,9 +233,19 @@ class FilledStemFrames:
     been (or are about to be, on that stream) filled by the caller -- hps_proxy_rep_phase_frames -- instead of by
     hps_stem_phase_split from an NCHW tensor.  ``ResNet.forward(filled)`` then starts at the stem convolution."""
 
-    def __init__(self, frames, shape, device):
+    def __init__(self, frames, shape, device, fill=None):
         self.frames, self.shape, self.device = frames, tuple(shape), device
         self.is_cuda = True
+        # ``fill``: the launch that writes the frames, deferred to forward() -- issued right in front of the stem convolution, where
+        # hps_stem_phase_split would have run: the stem then reads frames that were just written (L2 / Infinity Cache), not frames
+        # written before the previous batch's mesh kernel streamed 540 MB through the caches (measured: filling them early made the
+        # stem 0.2 ms slower and lost more than the skipped phase split gained)
+        self.fill = fill
+
+    def run_fill(self):
+        if self.fill is not None:
+            fill, self.fill = self.fill, None
+            fill()
 
     def record_stream(self, stream):            # the frames belong to the encoder (allocated once per shape and stream)
         pass
@@ -473,10 +483,11 @@ class ResNet(nn.Module):
             feats = torch.empty(B, fs["blocks"][-1]["c2"].shape[3], device=x.device, dtype=torch.float32)
             ops = fs["ops"]
             ops[len(ops) - 1].y = feats.data_ptr()
-            if filled:                                   # the phase frames are already filled: the list starts at the stem convolution
+            if filled:                                   # the caller fills the phase frames: the list starts at the stem convolution
                 import ctypes
                 if gate is not None:
                     gate()
+                x.run_fill()
                 rest = ctypes.cast(ctypes.byref(ops, ctypes.sizeof(_capi.EncOp)), ctypes.POINTER(_capi.EncOp))
                 _capi.call("hps_encoder_run", rest, len(ops) - 1, s)
                 return feats
@@ -496,6 +507,8 @@ class ResNet(nn.Module):
                 _capi.call("hps_stem_phase_split", P(x), P(fs["in"]), B, C, H, W, s)
             if gate is not None:
                 gate()
+            if filled:
+                x.run_fill()
             y = fs["stem"]
             _capi.call("hps_stem_winograd", P(fs["in"]), P(stem.stem_u), P(stem.scale), P(stem.shift), P(y), B, H, W, 0, 1, s)
         else:

@@ -255,6 +255,8 @@ def test_front_end_writes_the_stems_phase_frames_directly(dev, net_gpu):
             filled_buf.frames.fill_(-9.0)                                                # prove every in-image float is rewritten ...
             filled = proxy_representation(rgb, j2d.to(dev), v, det, cfg, encoder=enc)
             assert isinstance(filled, FilledStemFrames) and filled.frames.data_ptr() == filled_buf.frames.data_ptr()
+            assert filled.fill is not None and bool((filled.frames == -9.0).all())       # the fill is deferred to forward(): nothing written yet
+            filled.run_fill()
             touched = filled.frames != -9.0
             assert torch.equal(filled.frames[touched], want_frames[touched])
             assert bool((want_frames[~touched] == 0).all())                              # ... and only the zero halo / slack is not
