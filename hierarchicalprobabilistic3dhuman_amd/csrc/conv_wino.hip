@@ -549,7 +549,15 @@ using namespace hps;
 
 // K slices of the quad geometry: a rule on the layer only (never on the batch: the summation order of a pixel must not change
 // with B).  Four slices when each still has >= 8 chunks (layer4: 64 chunks -> 4 x 16), else one.
-static int wino_quad_ksplit(int Cin) { return (Cin / WK) % 4 == 0 && (Cin / WK) / 4 >= 8 ? 4 : 1; }
+#ifdef HPS_DEV_BUILD
+static int g_wino_quad_ks = 0;           // dev library only (hps_dev_wino_quad_ksplit): 0 = the product rule
+#else
+constexpr int g_wino_quad_ks = 0;
+#endif
+static int wino_quad_ksplit(int Cin) {
+    if (g_wino_quad_ks > 0 && (Cin / WK) % g_wino_quad_ks == 0) return g_wino_quad_ks;
+    return (Cin / WK) % 4 == 0 && (Cin / WK) / 4 >= 8 ? 4 : 1;
+}
 
 extern "C" size_t hps_conv3x3_winograd_workspace(int B, int H, int W, int Cin, int Cout) {
     if (H != 8 || W != 8 || B <= 0 || Cin <= 0 || Cout <= 0) return 0;
@@ -653,6 +661,10 @@ extern "C" int hps_conv3x3_winograd(const float* x, const float* u, const float*
 }
 
 #ifdef HPS_DEV_BUILD
+extern "C" int hps_dev_wino_quad_ksplit(int ks) {       // experiment: K slices of the 8 x 8 geometry (0 = the product rule)
+    g_wino_quad_ks = ks;
+    return HPS_OK;
+}
 extern "C" int hps_dev_conv3x3_winograd(const float* x, const float* u, const float* scale, const float* shift, const float* residual,
                                         float* y, int B, int H, int W, int ipad, int Cin, int Cout, int opad, int relu,
                                         float* splitk_ws, int ablate, hps_stream_t stream) {

@@ -97,6 +97,10 @@ int hps_dev_unc_mode(int mode);
  * (36 KiB -> 4, 52 KiB -> 3, 72 KiB -> 2, 150 KiB -> 1).  0 restores the product value. */
 int hps_dev_mesh_lds_floor(int bytes);
 
+/* Experiment hook: K slices of hps_conv3x3_winograd's 8 x 8 geometry (0 = the product rule: four when >= 32 chunks).  Also changes
+ * hps_conv3x3_winograd_workspace's answer. */
+int hps_dev_wino_quad_ksplit(int ks);
+
 /* Tuning hook (tests/dev only): 1 = hps_conv2d_bn_act_pad skips its epilogue (results are garbage), 0 = normal. */
 int hps_dev_conv_pad_ablate(int mode);
 
