@@ -65,7 +65,11 @@ __device__ __forceinline__ unsigned out_pixel_offset(unsigned m, const PadGeom& 
     return ((b * (g.Ho + 2 * g.opad) + ho + g.opad) * (g.Wo + 2 * g.opad) + wo + g.opad) * (unsigned)g.Cout;
 }
 
-template <int BM, int BN, int WM, int WN>
+// ST = K-loop stages (LDS buffers per operand).  2: the next chunk's DMA pieces are issued during this chunk's MFMAs (the throughput
+// form: several workgroups per CU cover each other's DMA latency).  3 (round 5, latency mode: hps_conv2d_bn_act_pad variant 5): TWO
+// chunks ahead -- at batch 1 a 64 x 64 tile's chunk is 16 MFMAs per wave (0.43 us) with ONE workgroup on the CU, and a chunk fetched
+// one ahead arrived ~0.6 us after it was needed: 1.0 us per chunk, 18.3 us for a layer1 convolution of 18 chunks.
+template <int BM, int BN, int WM, int WN, int ST = 2>
 __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__ x, const float* __restrict__ wn,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ residual, float* __restrict__ y,
@@ -77,8 +81,8 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
     typedef __attribute__((address_space(3))) void* lptr_t;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sA = smem;                                   // [2][BM][32]
-    float* sB = smem + 2 * BM * PBK;                    // [2][BN][32]
+    float* sA = smem;                                   // [ST][BM][32]
+    float* sB = smem + ST * BM * PBK;                   // [ST][BN][32]
 
     const int tile_n = blockIdx.x / g.tiles_m, tile_m = blockIdx.x % g.tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -164,24 +168,28 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
     }
 #endif
     dma_chunk(0);
+    if (ST == 3 && c_begin + 1 < c_end) dma_chunk(1);
     for (int c = c_begin; c < c_end; ++c) {
-        const int buf = (c - c_begin) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of chunk c have landed
-        __syncthreads();                                     // ... everyone's have, and buf^1 is no longer being read
+        const int buf = ST == 3 ? (c - c_begin) % 3 : (c - c_begin) & 1;
+        // this wave's pieces of chunk c have landed (three stages: chunk c + 1's A_LD + B_LD pieces, issued after them, may still fly)
+        if (ST == 3 && c + 1 < c_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + B_LD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                     // ... everyone's have, and the buffer refilled below is no longer being read
         // The next chunk's DMA pieces are issued ONE PER FOUR MFMAs, not in a burst after the barrier: every 1 KiB piece costs the
         // SIMD 36-57 cycles that no other wave's MFMAs cover (tools/mfma_dma_overlap.hip: the loop skeleton runs at 139.4 TF/s with
         // the burst and 143.0 spread); on the stem 0.906 -> 0.888 ms (tests/dev/stem_ablate.py, mode 3 = burst).
         static_assert(A_LD + B_LD <= (PBK / 8) * TM * TN, "one DMA piece per accumulator block of a chunk at most");
 #ifdef HPS_DEV_BUILD
-        const bool spread = g.ablate != 3;               // hps_dev_conv_pad_ablate(3): the earlier burst
+        const bool spread = g.ablate != 3 || ST == 3;    // hps_dev_conv_pad_ablate(3): the earlier burst (two-stage form only)
 #else
         constexpr bool spread = true;
 #endif
-        const bool more = c + 1 < c_end;
+        const bool more = c + (ST - 1) < c_end;          // the chunk fetched during this one: c + 1 (two stages) / c + 2 (three)
         const float* na_src = a_src;
         const float* nb_src = b_src;
-        const unsigned nla = __builtin_amdgcn_readfirstlane(lds_a + (buf ^ 1) * BM * PBK * 4);
-        const unsigned nlb = __builtin_amdgcn_readfirstlane(lds_b + (buf ^ 1) * BN * PBK * 4);
+        const int nbuf = ST == 3 ? (c - c_begin + 2) % 3 : buf ^ 1;
+        const unsigned nla = __builtin_amdgcn_readfirstlane(lds_a + nbuf * BM * PBK * 4);
+        const unsigned nlb = __builtin_amdgcn_readfirstlane(lds_b + nbuf * BN * PBK * 4);
         if (more) {
             if (spread) advance();
             else dma_chunk(buf ^ 1);
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
     constexpr int EP = WN + 4;                 // patch pitch (floats)
     constexpr int LPP = WN / 4;                // lanes per pixel
     constexpr int PPI = 64 / LPP;              // pixels per wave instruction
-    static_assert(4 * 32 * EP <= 2 * (BM + BN) * PBK, "the epilogue patches fit in the K-loop buffers");
+    static_assert(4 * 32 * EP <= ST * (BM + BN) * PBK, "the epilogue patches fit in the K-loop buffers");
     __syncthreads();                           // every wave is done with the K-loop buffers
     float* patch = smem + wave * 32 * EP;
     const int c4 = (lane % LPP) * 4;
@@ -341,9 +349,20 @@ __global__ __launch_bounds__(256) void splitk_pad_epilogue_kernel(const float* _
                                                                   float* __restrict__ y, long total4, const PadGeom g) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
-    float4 acc = reinterpret_cast<const float4*>(partial)[i];
-    for (int k = 1; k < g.ksplit; ++k) {
-        const float4 v = reinterpret_cast<const float4*>(partial)[(size_t)k * total4 + i];
+    // Six slices requested before the first is added (the additions stay in slice order: the same bits).  As a plain loop hipcc
+    // waited out one L2 round trip per slice: 5-7 us for the latency mode's 12-18 slices, eleven times per image.
+    const float4* p4 = reinterpret_cast<const float4*>(partial) + i;
+    float4 acc = p4[0];
+    int k = 1;
+    for (; k + 6 <= g.ksplit; k += 6) {
+        float4 v[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) v[q] = p4[(size_t)(k + q) * total4];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { acc.x += v[q].x; acc.y += v[q].y; acc.z += v[q].z; acc.w += v[q].w; }
+    }
+    for (; k < g.ksplit; ++k) {
+        const float4 v = p4[(size_t)k * total4];
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     const unsigned e = (unsigned)(i * 4);
@@ -467,15 +486,15 @@ __global__ __launch_bounds__(256) void avgpool_pad_kernel(const float* __restric
     y[i] = acc / (float)(H * W);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int ST = 2>
 static int launch_conv_pad(const float* x, const float* wn, const float* scale, const float* shift, const float* residual,
                            float* y, float* partial, PadGeom g, hipStream_t s) {
     g.tiles_m = ceil_div(g.Mtot, BM);
     const int tiles_n = g.Cout / BN;
-    const size_t lds = (size_t)2 * (BM + BN) * PBK * sizeof(float);
+    const size_t lds = (size_t)ST * (BM + BN) * PBK * sizeof(float);
     if (lds > 64 * 1024)
-        if (int rc = grant_lds<&conv_pad_kernel<BM, BN, WM, WN>>((int)lds, "hps_conv2d_bn_act_pad")) return rc;
-    hipLaunchKernelGGL((conv_pad_kernel<BM, BN, WM, WN>), dim3(g.tiles_m * tiles_n, g.ksplit), dim3(256), lds, s, x, wn, scale,
+        if (int rc = grant_lds<&conv_pad_kernel<BM, BN, WM, WN, ST>>((int)lds, "hps_conv2d_bn_act_pad")) return rc;
+    hipLaunchKernelGGL((conv_pad_kernel<BM, BN, WM, WN, ST>), dim3(g.tiles_m * tiles_n, g.ksplit), dim3(256), lds, s, x, wn, scale,
                        shift, residual, y, partial, g);
     if (g.ksplit > 1) {
         const long total4 = (long)g.Mtot * g.Cout / 4;
@@ -532,7 +551,10 @@ extern "C" int hps_conv2d_bn_act_pad(const float* x, const float* wn, const floa
     g.magic_wo = div_magic((unsigned)g.Wo);
     g.ablate = g_pad_ablate;
     hipStream_t s = (hipStream_t)stream;
-    if (g.ksplit > 1) variant = Cout % 128 == 0 ? 1 : 2;     // split-K runs on the 128-row tiles
+    // split-K runs on the 128-row tiles unless the caller asks for the 64 x 64 ones (variants 3 / 5: the latency mode, where a
+    // single image's 8 x 8 ... 32 x 32 maps leave half of a 128-row tile empty and a quarter as many workgroups on the chip);
+    // the summation order of an output does not depend on the tile shape: the same bits
+    if (g.ksplit > 1 && variant != 3 && variant != 5) variant = Cout % 128 == 0 ? 1 : 2;
     if (variant == 0) {
         // same rule as hps_conv2d_bn_act_v3 (measured per layer): largest tile that still gives every CU a workgroup
         if (Cout % 128 == 0 && ((long)g.Mtot / 128) * (Cout / 128) >= 256) variant = 1;
@@ -545,6 +567,7 @@ extern "C" int hps_conv2d_bn_act_pad(const float* x, const float* wn, const floa
         case 2: return launch_conv_pad<128, 64, 64, 32>(x, wn, scale, shift, residual, y, splitk_ws, g, s);
         case 3: return launch_conv_pad<64, 64, 32, 32>(x, wn, scale, shift, residual, y, splitk_ws, g, s);
         case 4: return launch_conv_pad<256, 64, 64, 64>(x, wn, scale, shift, residual, y, splitk_ws, g, s);
+        case 5: return launch_conv_pad<64, 64, 32, 32, 3>(x, wn, scale, shift, residual, y, splitk_ws, g, s);      // three-stage K loop (latency mode)
         default: return bad_arg("hps_conv2d_bn_act_pad: variant");
     }
 }

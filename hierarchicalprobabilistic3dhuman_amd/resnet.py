@@ -97,6 +97,14 @@ class _ConvBN:
             return 4
         return 1
 
+    def _tile_variant(self, ksplit):
+        """Tile choice handed to hps_conv2d_bn_act_pad.  Latency mode: 64 x 64 tiles with a three-stage K loop for every layer (variant
+        5), split-K layers included -- a single image's maps leave 128-row tiles half empty and a quarter as many workgroups on the
+        chip; an output's summation order does not depend on the tile shape, so the mode's bits are those of the 128-row tiles."""
+        if self.latency and self.variant == 0:
+            return 5
+        return self.variant if ksplit <= 1 else 0
+
     def winograd_ok(self, H, W, ipad):
         """Winograd F(2x2, 3x3) applies: a 3x3 / 1 / 1 layer on a map that splits into 16 x 16-pixel blocks (8 x 8 tiles, one
         work item of csrc/conv_wino.hip) or on 8 x 8 maps (layer4: four images per item, K in slices) -- a rule on the layer
@@ -142,7 +150,7 @@ class _ConvBN:
         P = _capi.ptr
         _capi.call("hps_conv2d_bn_act_pad", P(xp), P(self.wrow if row_mode else self.wn), P(self.scale), P(self.shift),
                    P(residual) if residual is not None else None, P(out), B, H, W, ipad, C, self.cout, self.kh, self.kw,
-                   self.stride, self.pad, opad, 1 if relu else 0, 1 if row_mode else 0, self.variant if ksplit <= 1 else 0,
+                   self.stride, self.pad, opad, 1 if relu else 0, 1 if row_mode else 0, self._tile_variant(ksplit),
                    ksplit, P(ws) if ksplit > 1 else None, _capi.stream())
         return out
 
@@ -167,7 +175,7 @@ class _ConvBN:
                            shift=dp(self.shift), residual=dp(residual), y=dp(out), splitk_ws=dp(ws) if ksplit > 1 else None,
                            B=B, H=H, W=W, ipad=ipad, Cin=C, Cout=self.cout, KH=self.kh, KW=self.kw, stride=self.stride,
                            pad=self.pad, opad=opad, relu=1 if relu else 0, row_mode=1 if row_mode else 0,
-                           variant=self.variant if ksplit <= 1 else 0, ksplit=ksplit)
+                           variant=self._tile_variant(ksplit), ksplit=ksplit)
 
     def out_hw(self, H, W):
         return (H + 2 * self.pad - self.kh) // self.stride + 1, (W + 2 * self.pad - self.kw) // self.stride + 1
