@@ -66,9 +66,10 @@ __device__ __forceinline__ unsigned out_pixel_offset(unsigned m, const PadGeom& 
 }
 
 // ST = K-loop stages (LDS buffers per operand).  2: the next chunk's DMA pieces are issued during this chunk's MFMAs (the throughput
-// form: several workgroups per CU cover each other's DMA latency).  3 (round 5, latency mode: hps_conv2d_bn_act_pad variant 5): TWO
-// chunks ahead -- at batch 1 a 64 x 64 tile's chunk is 16 MFMAs per wave (0.43 us) with ONE workgroup on the CU, and a chunk fetched
-// one ahead arrived ~0.6 us after it was needed: 1.0 us per chunk, 18.3 us for a layer1 convolution of 18 chunks.
+// form: several workgroups per CU cover each other's DMA latency).  3 / 4 (round 5, latency mode: hps_conv2d_bn_act_pad variant 5):
+// two / three chunks ahead -- at batch 1 a 64 x 64 tile's chunk is 16 MFMAs per wave (0.43 us) with ONE workgroup on the CU, and a
+// chunk fetched one ahead arrived ~0.6 us after it was needed: 1.0 us per chunk, 18.3 us for a layer1 convolution of 18 chunks
+// (three stages: 15.3 us).
 template <int BM, int BN, int WM, int WN, int ST = 2>
 __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__ x, const float* __restrict__ wn,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
@@ -168,26 +169,33 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
     }
 #endif
     dma_chunk(0);
-    if (ST == 3 && c_begin + 1 < c_end) dma_chunk(1);
+#pragma unroll
+    for (int q = 1; q < ST - 1; ++q)
+        if (c_begin + q < c_end) dma_chunk(q);
     for (int c = c_begin; c < c_end; ++c) {
-        const int buf = ST == 3 ? (c - c_begin) % 3 : (c - c_begin) & 1;
-        // this wave's pieces of chunk c have landed (three stages: chunk c + 1's A_LD + B_LD pieces, issued after them, may still fly)
-        if (ST == 3 && c + 1 < c_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + B_LD) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int buf = ST == 2 ? (c - c_begin) & 1 : (c - c_begin) % ST;
+        // this wave's pieces of chunk c have landed; with more than two stages the pieces of up to ST - 2 younger chunks, issued after
+        // them (A_LD + B_LD per chunk), may still be in flight
+        {
+            const int younger = min(ST - 2, c_end - 1 - c);
+            if (ST >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (A_LD + B_LD)) : "memory");
+            else if (ST >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD + B_LD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();                                     // ... everyone's have, and the buffer refilled below is no longer being read
         // The next chunk's DMA pieces are issued ONE PER FOUR MFMAs, not in a burst after the barrier: every 1 KiB piece costs the
         // SIMD 36-57 cycles that no other wave's MFMAs cover (tools/mfma_dma_overlap.hip: the loop skeleton runs at 139.4 TF/s with
         // the burst and 143.0 spread); on the stem 0.906 -> 0.888 ms (tests/dev/stem_ablate.py, mode 3 = burst).
         static_assert(A_LD + B_LD <= (PBK / 8) * TM * TN, "one DMA piece per accumulator block of a chunk at most");
 #ifdef HPS_DEV_BUILD
-        const bool spread = g.ablate != 3 || ST == 3;    // hps_dev_conv_pad_ablate(3): the earlier burst (two-stage form only)
+        const bool spread = g.ablate != 3 || ST != 2;    // hps_dev_conv_pad_ablate(3): the earlier burst (two-stage form only)
 #else
         constexpr bool spread = true;
 #endif
-        const bool more = c + (ST - 1) < c_end;          // the chunk fetched during this one: c + 1 (two stages) / c + 2 (three)
+        const bool more = c + (ST - 1) < c_end;          // the chunk fetched during this one: c + 1 (two stages), c + 2, c + 3
         const float* na_src = a_src;
         const float* nb_src = b_src;
-        const int nbuf = ST == 3 ? (c - c_begin + 2) % 3 : buf ^ 1;
+        const int nbuf = ST == 2 ? buf ^ 1 : (c - c_begin + ST - 1) % ST;
         const unsigned nla = __builtin_amdgcn_readfirstlane(lds_a + nbuf * BM * PBK * 4);
         const unsigned nlb = __builtin_amdgcn_readfirstlane(lds_b + nbuf * BN * PBK * 4);
         if (more) {
@@ -567,7 +575,10 @@ extern "C" int hps_conv2d_bn_act_pad(const float* x, const float* wn, const floa
         case 2: return launch_conv_pad<128, 64, 64, 32>(x, wn, scale, shift, residual, y, splitk_ws, g, s);
         case 3: return launch_conv_pad<64, 64, 32, 32>(x, wn, scale, shift, residual, y, splitk_ws, g, s);
         case 4: return launch_conv_pad<256, 64, 64, 64>(x, wn, scale, shift, residual, y, splitk_ws, g, s);
-        case 5: return launch_conv_pad<64, 64, 32, 32, 3>(x, wn, scale, shift, residual, y, splitk_ws, g, s);      // three-stage K loop (latency mode)
+        case 5: return launch_conv_pad<64, 64, 32, 32, 4>(x, wn, scale, shift, residual, y, splitk_ws, g, s);      // four-stage K loop (latency mode)
+#ifdef HPS_DEV_BUILD
+        case 6: return launch_conv_pad<64, 64, 32, 32, 3>(x, wn, scale, shift, residual, y, splitk_ws, g, s);      // three stages (A/B)
+#endif
         default: return bad_arg("hps_conv2d_bn_act_pad: variant");
     }
 }

@@ -98,7 +98,7 @@ class _ConvBN:
         return 1
 
     def _tile_variant(self, ksplit):
-        """Tile choice handed to hps_conv2d_bn_act_pad.  Latency mode: 64 x 64 tiles with a three-stage K loop for every layer (variant
+        """Tile choice handed to hps_conv2d_bn_act_pad.  Latency mode: 64 x 64 tiles with a four-stage K loop for every layer (variant
         5), split-K layers included -- a single image's maps leave 128-row tiles half empty and a quarter as many workgroups on the
         chip; an output's summation order does not depend on the tile shape, so the mode's bits are those of the 128-row tiles."""
         if self.latency and self.variant == 0:

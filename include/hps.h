@@ -313,7 +313,7 @@ int hps_head_svd_finish(const float* usv_level, const int32_t* joint_ids, int n_
  * is written (the owner zeroes the halo once).  wn: n-major filter (Cout, KH*KW*Cin), Cin % 32 == 0; or, row_mode != 0
  * (the 18-channel 7x7 stem, models/resnet.py:150, :203): (Cout, KH * ceil32(KW*Cin)), one filter row = KW*Cin contiguous
  * NHWC floats taken as a single tap, zero filled tail.  variant: 0 automatic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x64
- * workgroup tiles, 5 = 64x64 with a three-stage K loop (chunks fetched two ahead: the form for one or a few images, where a CU
+ * workgroup tiles, 5 = 64x64 with a four-stage K loop (chunks fetched three ahead: the form for one or a few images, where a CU
  * holds one workgroup and nothing else covers the fetch latency).  ksplit > 1 ((KH*KW*Cin/32) divisible by ksplit): K in ksplit
  * slices, on the 128-row tiles unless variant is 3 or 5; splitk_ws (ksplit, B*Ho*Wo, Cout) floats; the slices are added in slice
  * order by a second kernel that also applies BN / residual / ReLU (deterministic, no atomics).  The tile shape never changes an

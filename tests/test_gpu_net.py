@@ -150,7 +150,7 @@ def test_padded_conv_kernel(cfg, dev):
                     cb.padded(xp, ipad, out, 1, residual=_frame(resh, 1), relu=True)
                     assert torch.equal(out[:, 1:-1, 1:-1], plain_k), ("split-K", ks)
             cb.ksplit = 0
-    # the latency mode's form (round 5): 64 x 64 tiles with a three-stage K loop (variant 5), with and without K slices -- the tile
+    # the latency mode's form (round 5): 64 x 64 tiles with a four-stage K loop (variant 5), with and without K slices -- the tile
     # shape and the prefetch distance never change an output's summation order: the bits of the default tiles, slice count for slice count
     for ks in (1, 2, 3, 4, 6, 9, 18):
         if ks > 1 and (Cin % 32 != 0 or (k * k * Cin // 32) % ks != 0):
@@ -166,7 +166,7 @@ def test_padded_conv_kernel(cfg, dev):
         cb.latency, cb.variant = True, 0                                              # -> variant 5 through _tile_variant
         got5 = torch.zeros_like(want_k)
         cb.padded(xp, ipad, got5, 1, residual=_frame(resh, 1), relu=True)
-        assert cb._tile_variant(ks) == 5 and torch.equal(got5, want_k), ("three stages", ks)
+        assert cb._tile_variant(ks) == 5 and torch.equal(got5, want_k), ("four stages", ks)
     cb.latency, cb.variant, cb.ksplit = False, 0, 0
 
 
