@@ -55,14 +55,18 @@ static_assert(F_XP == FW && F_BP % FW == 0, "DMA pieces must divide evenly over 
 // HAS_T: a per-mesh translation is added (smplx SMPL.forward step (7)).
 // TAIL: k-pairs of the LAST chunk that carry data (compile-time: a run-time bound inside the unrolled MFMA run cost 30 % -- the
 // branch per k-step broke the pinned schedule and put an accumulator into scratch); 8 = the whole chunk.
-template <int K, int ABL, int JC, bool HAS_T, int TAIL = FBK / 2>
+// ST: operand chunks resident in LDS (K-loop stages).  2 = the throughput form (four workgroups per CU cover each other's fetch
+// latency; 36 KiB).  4 (round 5) = chunks fetched THREE ahead, for calls whose meshes fill at most two tiles (one image at a time:
+// 52 meshes): 108-216 workgroups, at most one per CU, and the 14 chunks of the 18.6 MB blend matrix arrived one round trip after the
+// other (55 us for 52 meshes).  Pure pipelining: the same MFMAs in the same order, identical bits.
+template <int K, int ABL, int JC, bool HAS_T, int TAIL = FBK / 2, int ST = 2>
 __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
     const float* __restrict__ xt, const float* __restrict__ bmat_p, const float* __restrict__ v_template,
     const float* __restrict__ a, const int32_t* __restrict__ w_idx, const float* __restrict__ w_val, int J,
     const float* __restrict__ transl, f3* __restrict__ verts, int M, int V, int kp, int mp, int np, int tiles_m,
     int tiles_m_per_xcd) {
     typedef __attribute__((address_space(3))) void* lptr_t;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // union: 2 operand chunks | A of 32 of the tile's meshes
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // union: ST operand chunks | A of 32 of the tile's meshes
 
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     const int tile_m = (local % tiles_m_per_xcd) * 8 + xcd, panel = local / tiles_m_per_xcd;
@@ -127,20 +131,34 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
     // padding (SMPL: K = 217 -> kp = 218, TAIL = 5: nine MFMAs fewer of 336 per wave; adding their zero products changes nothing,
     // so the bits are those of the padded sum).
     const int nchunks = (kp + FBK - 1) / FBK;
-    if (ABL != 4) dma_chunk(0);
+    if (ABL != 4) {
+        dma_chunk(0);
+#pragma unroll
+        for (int q = 1; q < ST - 1; ++q)
+            if (q < nchunks) dma_chunk(q);
+    }
     static_assert(1 + F_BP / FW == FBK / 4, "four DMA pieces per wave and chunk, one per two k-steps");
-    auto do_chunk = [&](auto pairs_c, int c, bool more) __attribute__((always_inline)) {
+    constexpr int PIECES = 1 + F_BP / FW;                  // DMA pieces per wave and chunk
+    auto do_chunk = [&](auto pairs_c, int c, bool more_in) __attribute__((always_inline)) {
         constexpr int PAIRS = decltype(pairs_c)::value;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                   // chunk c has landed; everyone is done with the other buffer
+        const bool more = ST == 2 ? more_in : (ABL != 4 && c + ST - 1 < nchunks);      // is a chunk fetched during this one?
+        // chunk c has landed (with more than two stages up to ST - 2 younger chunks, PIECES pieces each, may still be in flight)
+        {
+            const int younger = min(ST - 2, nchunks - 1 - c);
+            if (ST >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+            else if (ST >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                   // ... for everyone; and everyone is done with the buffer refilled below
         // the next chunk's four DMA pieces go out one per two k-steps of this chunk's MFMAs, not in a burst (csrc/conv_pad.hip,
         // tools/mfma_dma_overlap.hip: a piece costs the SIMD 36-57 cycles that are better paid between MFMAs than before them)
-        constexpr bool burst = ABL == 5;                  // dev ablation: the earlier burst after the barrier
+        constexpr bool burst = ABL == 5 && ST == 2;       // dev ablation: the earlier burst after the barrier
         const float* nx_src = x_src;
         const float* nb_src = b_src;
+        const int nbuf = ST == 2 ? (c + 1) & 1 : (c + ST - 1) % ST;
         if (more && burst) dma_chunk((c + 1) & 1);
         else if (more) { b_src += (size_t)FBK * np; x_src += (size_t)FBK * mp; }
-        const float* sX = smem + (c & 1) * F_CHUNK_FLOATS;
+        const float* sX = smem + (ST == 2 ? (c & 1) : c % ST) * F_CHUNK_FLOATS;
         const float* sB = sX + FBK * FM;
         // all fragments of the chunk first (independent LDS reads in flight), then the MFMAs back to back
         float af[PAIRS], bx[PAIRS], by[PAIRS], bz[PAIRS];
@@ -162,7 +180,7 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
             acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k], bz[k], acc[2], 0, 0, 0);
             if (more && !burst && (k & 1) == 0) {
                 __builtin_amdgcn_sched_barrier(0);
-                dma_piece(k / 2, (c + 1) & 1, nx_src, nb_src);
+                dma_piece(k / 2, nbuf, nx_src, nb_src);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -238,6 +256,7 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
 
 #ifdef HPS_DEV_BUILD
 static size_t g_mesh_lds_floor = 0;        // hps_dev_mesh_lds_floor
+static int g_mesh_stages = 0;              // hps_dev_mesh_stages: 2 = always the two-stage K loop (A/B and bit-level cross-check)
 #endif
 
 template <int K, int ABL, int JC, bool HAS_T>
@@ -249,12 +268,23 @@ static int launch_fused_cfg(const float* xt, const float* bmat_p, const float* v
     if (g_mesh_lds_floor > lds) lds = g_mesh_lds_floor;     // experiment: fewer workgroups per CU (a larger LDS request, unused)
 #endif
     const int tiles_m = ceil_div(M, FM), n_panels = ceil_div(V, FV);
+    // at most two mesh tiles (one image at a time: 52 meshes): at most one workgroup per CU -- the four-stage K loop (same bits)
+    const bool few = tiles_m <= 2
+#ifdef HPS_DEV_BUILD
+                     && g_mesh_stages != 2
+#endif
+        ;
     const int tiles_m_per_xcd = ceil_div(tiles_m, 8);
     const dim3 grid(tiles_m_per_xcd * 8 * n_panels);
     // the last chunk's data-carrying k-pairs: SMPL (K = 10 + 207 -> kp = 218) has 5 of 8; that case is instantiated for the product
     // configuration, every other tail runs the whole (zero-padded) chunk
     const int tail = (kp - FBK * ((kp + FBK - 1) / FBK - 1)) / 2;
-    if (K == 4 && JC == 24 && ABL == 0 && tail == 5) {
+    if (K == 4 && JC == 24 && ABL == 0 && tail == 5 && few) {
+        lds = (size_t)4 * max(4 * F_CHUNK_FLOATS, 32 * J * 12);
+        if (int rc = grant_lds<&mesh_fused_kernel<K, ABL, JC, HAS_T, 5, 4>>(160 * 1024, "hps_smpl_mesh_fused")) return rc;
+        hipLaunchKernelGGL((mesh_fused_kernel<K, ABL, JC, HAS_T, 5, 4>), grid, dim3(FT), lds, s, xt, bmat_p, v_template,
+                           a, w_idx, w_val, J, transl, reinterpret_cast<f3*>(verts), M, V, kp, mp, np, tiles_m, tiles_m_per_xcd);
+    } else if (K == 4 && JC == 24 && ABL == 0 && tail == 5) {
         if (int rc = grant_lds<&mesh_fused_kernel<K, ABL, JC, HAS_T, 5>>(160 * 1024, "hps_smpl_mesh_fused")) return rc;
         hipLaunchKernelGGL((mesh_fused_kernel<K, ABL, JC, HAS_T, 5>), grid, dim3(FT), lds, s, xt, bmat_p, v_template,
                            a, w_idx, w_val, J, transl, reinterpret_cast<f3*>(verts), M, V, kp, mp, np, tiles_m, tiles_m_per_xcd);
@@ -316,6 +346,10 @@ extern "C" int hps_smpl_mesh_fused(const float* xt, const float* bmat_p, const f
 }
 
 #ifdef HPS_DEV_BUILD
+extern "C" int hps_dev_mesh_stages(int stages) {
+    g_mesh_stages = stages;
+    return HPS_OK;
+}
 extern "C" int hps_dev_mesh_lds_floor(int bytes) {
     g_mesh_lds_floor = bytes > 0 ? (size_t)bytes : 0;
     return HPS_OK;

@@ -93,6 +93,10 @@ int hps_dev_blend_mode(int mode);
  * with 128 vertices per workgroup in LDS, 3 = with 64. */
 int hps_dev_unc_mode(int mode);
 
+/* Cross-check hook: 2 = hps_smpl_mesh_fused always runs its two-stage K loop (calls of at most two mesh tiles otherwise take the
+ * four-stage form: same bits), 0 = the product rule. */
+int hps_dev_mesh_stages(int stages);
+
 /* Experiment: request at least `bytes` of dynamic LDS for the fused mesh kernel (unused space), i.e. cap its workgroups per CU
  * (36 KiB -> 4, 52 KiB -> 3, 72 KiB -> 2, 150 KiB -> 1).  0 restores the product value. */
 int hps_dev_mesh_lds_floor(int bytes);
