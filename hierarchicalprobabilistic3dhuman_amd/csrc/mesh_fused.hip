@@ -68,8 +68,12 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
     typedef __attribute__((address_space(3))) void* lptr_t;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // union: ST operand chunks | A of 32 of the tile's meshes
 
+    // tiles_m_per_xcd == 0: fewer than eight mesh tiles -- plain mapping (block = panel * tiles_m + tile), consecutive panels on
+    // consecutive XCDs.  (With the XCD-aware mapping below a call of ONE mesh tile -- one image at a time, 52 meshes -- had all of
+    // its 108 working blocks at ids = 0 mod 8: on ONE XCD's 32 CUs, the other seven idle: 55-58 us per call.)
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    const int tile_m = (local % tiles_m_per_xcd) * 8 + xcd, panel = local / tiles_m_per_xcd;
+    const int tile_m = tiles_m_per_xcd ? (local % tiles_m_per_xcd) * 8 + xcd : (int)blockIdx.x % tiles_m;
+    const int panel = tiles_m_per_xcd ? local / tiles_m_per_xcd : (int)blockIdx.x / tiles_m;
     if (tile_m >= tiles_m) return;
     const int m0 = tile_m * FM;
 
@@ -274,8 +278,8 @@ static int launch_fused_cfg(const float* xt, const float* bmat_p, const float* v
                      && g_mesh_stages != 2
 #endif
         ;
-    const int tiles_m_per_xcd = ceil_div(tiles_m, 8);
-    const dim3 grid(tiles_m_per_xcd * 8 * n_panels);
+    const int tiles_m_per_xcd = tiles_m >= 8 ? ceil_div(tiles_m, 8) : 0;          // 0: plain block mapping (see the kernel)
+    const dim3 grid(tiles_m_per_xcd ? tiles_m_per_xcd * 8 * n_panels : tiles_m * n_panels);
     // the last chunk's data-carrying k-pairs: SMPL (K = 10 + 207 -> kp = 218) has 5 of 8; that case is instantiated for the product
     // configuration, every other tail runs the whole (zero-padded) chunk
     const int tail = (kp - FBK * ((kp + FBK - 1) / FBK - 1)) / 2;
