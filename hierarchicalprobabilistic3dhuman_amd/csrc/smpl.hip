@@ -125,43 +125,48 @@ __global__ __launch_bounds__(256) void pose_prep_kernel_v1(
 #endif
 
 // ---------------------------------------------------------------------------------------------
-// pose prep: 32 lanes per mesh (lane = joint), PP_G = 16 meshes per 512-thread workgroup.
+// pose prep: 32 lanes per mesh (lane = joint), 8 meshes per 256-thread workgroup.
 // Local transforms live in LDS; the kinematic chain is evaluated level by level so that every
 // G_i = G_parent(i) * L_i is the same product the reference's index-ordered loop forms.
 //
-// Second generation (round 5; the first stays in the dev library as the bit-level cross-check).  The first one was a chain of
-// dependent global loads with nothing beside it inside the pipelined step's exclusive mesh window (28 us for 6 528 meshes, 0.09
-// of HBM): (1) `max depth` was a loop of J dependent scalar loads in front of the kinematic levels -- now a shuffle reduction
-// of the lanes' own depths; (2) the rest joints read 3 x nb values of j_shapedirs per lane one after another from global
-// memory -- the joint regressor (J x 3 x (nb + 1) floats) is now staged in LDS by the whole workgroup with coalesced loads;
-// (3) the k-major blend operand was written as 4-byte stores 8 meshes apart (32-byte runs per operand row) -- now the pose
-// features of the workgroup's 16 meshes are transposed through LDS and every operand row leaves as one 64-byte run.
-// Same arithmetic, expression for expression: identical bits (tests/test_gpu_smpl.py).
+// Second generation (round 5; the first stays in the dev library as the bit-level cross-check): the first one was a chain of
+// dependent global loads (28 us for 6 528 meshes in the pipelined step, 19.4 us alone).  (1) `max depth` was a loop of J dependent
+// scalar loads in front of the kinematic levels -- now a shuffle reduction of the lanes' own depths; (2) the rest joints read
+// 3 x nb values of j_shapedirs one after another -- now all of a lane's 3 x nb coefficients are requested before the first is
+// used (the sums keep their order: identical bits).  Same workgroup footprint as before ON PURPOSE: this kernel runs beside the
+// encoder's persistent kernels, which leave a CU at most ~6 KB of LDS and no registers -- an intermediate version with 16 meshes
+// per workgroup, the regressor staged in LDS and the k-major operand transposed through LDS for 64-byte runs (512 threads, 57 KB)
+// was faster alone (15.1 us) and waited three times as long for a CU in the loop (82 us on average, up to 0.39 ms, in front of
+// the exclusive mesh kernel).
 // ---------------------------------------------------------------------------------------------
-constexpr int PP_G = 16;                 // meshes per workgroup
-constexpr int PP_XP = PP_G + 1;          // pitch of the transposed pose features (odd: the lanes' column writes spread over the banks)
-__global__ __launch_bounds__(32 * PP_G) void pose_prep_kernel(
+__global__ __launch_bounds__(256) void pose_prep_kernel(
     const float* __restrict__ glob, const float* __restrict__ body, int is_rotmat,
     const float* __restrict__ betas, int nb, const float* __restrict__ j_template,
     const float* __restrict__ j_shapedirs, const int32_t* __restrict__ parents,
     const int32_t* __restrict__ depth, int J, float* __restrict__ xt, int kp, int mp,
     float* __restrict__ a_out, float* __restrict__ j_posed, float* __restrict__ rot_out, int M) {
-    __shared__ float sG[PP_G][MAXJ][12];  // world transform (3x4 row-major) per joint
-    __shared__ float sJ[PP_G][MAXJ][3];   // rest joints
-    __shared__ float sBeta[PP_G][16];
-    __shared__ float sJT[MAXJ * 3];       // j_template
-    __shared__ float sJS[MAXJ * 3 * 16];  // j_shapedirs
-    __shared__ float sX[9 * (MAXJ - 1) * PP_XP];   // pose features (R_j - I), [row 9 (j - 1) + e][mesh]
+    __shared__ float sG[8][MAXJ][12];  // world transform (3x4 row-major) per joint
+    __shared__ float sJ[8][MAXJ][3];   // rest joints
+    __shared__ float sBeta[8][16];
 
     const int g = threadIdx.x >> 5;     // mesh slot in the workgroup
     const int j = threadIdx.x & 31;     // joint
-    const int m0 = blockIdx.x * PP_G;
-    const int m = m0 + g;
+    const int m = blockIdx.x * 8 + g;
     const bool live = (m < M) && (j < J);
 
     if (m < M && j < nb && j < 16) sBeta[g][j] = betas[(size_t)m * nb + j];
-    for (int i = threadIdx.x; i < J * 3; i += 32 * PP_G) sJT[i] = j_template[i];
-    for (int i = threadIdx.x; i < J * 3 * nb; i += 32 * PP_G) sJS[i] = j_shapedirs[i];
+    // this lane's joint-regressor coefficients: 3 x nb independent loads in flight (a lane beyond J re-reads joint J - 1)
+    float sd[3][16];
+    float jt[3];
+    {
+        const int jc = min(j, J - 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            jt[c] = j_template[jc * 3 + c];
+#pragma unroll
+            for (int l = 0; l < 16; ++l) sd[c][l] = j_shapedirs[(jc * 3 + c) * nb + max(0, min(l, nb - 1))];
+        }
+    }
     __syncthreads();
 
     float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
@@ -181,8 +186,10 @@ __global__ __launch_bounds__(32 * PP_G) void pose_prep_kernel(
         // rest joint: J = J_regressor (v_template + shapedirs beta) = j_template + j_shapedirs beta
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float acc = sJT[j * 3 + c];
-            for (int l = 0; l < nb; ++l) acc += sJS[(j * 3 + c) * nb + l] * sBeta[g][l];
+            float acc = jt[c];
+#pragma unroll
+            for (int l = 0; l < 16; ++l)
+                if (l < nb) acc += sd[c][l] * sBeta[g][l];
             Jr[c] = acc;
             sJ[g][j][c] = acc;
         }
@@ -243,22 +250,17 @@ __global__ __launch_bounds__(32 * PP_G) void pose_prep_kernel(
             ao[r * 4 + 3] = T[r * 4 + 3] - (T[r * 4 + 0] * Jr[0] + T[r * 4 + 1] * Jr[1] + T[r * 4 + 2] * Jr[2]);
             j_posed[((size_t)m * J + j) * 3 + r] = T[r * 4 + 3];
         }
-        // pose feature rows 9 (j - 1) + e = (R_j - I), transposed through LDS
+        // blend operand, k-major: pose feature rows nb + 9 (j-1) + e = (R_j - I)
         if (j >= 1) {
 #pragma unroll
-            for (int e = 0; e < 9; ++e) sX[(9 * (j - 1) + e) * PP_XP + g] = R[e] - ((e % 4 == 0) ? 1.0f : 0.0f);
+            for (int e = 0; e < 9; ++e)
+                xt[(size_t)(nb + 9 * (j - 1) + e) * mp + m] = R[e] - ((e % 4 == 0) ? 1.0f : 0.0f);
         }
     }
-    __syncthreads();
-    // blend operand, k-major: row k of the workgroup's meshes is one run of PP_G floats (betas, pose features, zero padding rows)
-    const int n_live = min(PP_G, M - m0), n_pose = 9 * (J - 1);
-    for (int i = threadIdx.x; i < kp * PP_G; i += 32 * PP_G) {
-        const int k = i / PP_G, gg = i % PP_G;
-        if (gg >= n_live) continue;
-        float v = 0.0f;
-        if (k < nb) v = sBeta[gg][k];
-        else if (k < nb + n_pose) v = sX[(k - nb) * PP_XP + gg];
-        xt[(size_t)k * mp + m0 + gg] = v;
+    if (m < M) {
+        // betas rows and zero padding rows (lanes stride over them)
+        for (int k = j; k < nb; k += 32) xt[(size_t)k * mp + m] = sBeta[g][k];
+        for (int k = nb + 9 * (J - 1) + j; k < kp; k += 32) xt[(size_t)k * mp + m] = 0.0f;
     }
 }
 
@@ -385,96 +387,60 @@ __global__ __launch_bounds__(128) void joints_kernel_v1(const float* __restrict_
 #endif
 
 // ---------------------------------------------------------------------------------------------
-// joints: JN_G meshes per workgroup, two phases.  (1) GATHER: thread e fetches the vertex of CSR entry e of each of the workgroup's
-// meshes into LDS -- one independent 12-byte load per (entry, mesh), every thread busy, nothing fetched twice; (2) SUM: thread
-// (mesh, row) adds its row's entries from LDS as ONE chain of explicit fused multiply-adds in row order.
+// joints: one 128-thread workgroup per mesh; thread r evaluates CSR row r (a vertex pick or a regressed joint) on the mesh's
+// vertices, four entries in flight, summed as ONE chain of explicit fused multiply-adds in row order.
 //
-// Third form (round 5; the first stays in the dev library as the cross-check).  The first ran one workgroup per mesh and every row
-// walked its entries four at a time through dependent loads (row pointer -> column -> vertex): 45 us for 6 528 meshes inside the
-// pipelined step's exclusive mesh window, 60 us alone with the vertices coming from HBM.  A second form kept thread = row with the
-// row's entries in registers and several meshes per workgroup -- and was SLOWER (74 us): the rows are 1 to 12 entries long, so the
-// padded 12-slot rows issued three times the loads, and a quarter of the workgroups left the memory system with fewer requests in
-// flight.  What bounds this kernel is the number of scattered 12-byte requests the memory system has in flight, not the chain.
-// The sum of a row no longer depends on what the vectoriser does with a loop (the first generation's four-entry groups came out of
-// hipcc as a mix of v_pk_mul + add and v_pk_fma -- two of every four products rounded separately, an accident of that build):
-// results are within one unit in the last place of it, and a mesh's joints do not depend on the batch.
+// Round 5 kept the first generation's shape and only pinned its arithmetic: hipcc's SLP vectoriser had compiled the four-entry
+// groups `x += w * p` as a mix of v_pk_mul + add and v_pk_fma -- two of every four products rounded separately, an accident of that
+// build (the first generation in the dev library still has it: results agree within one unit in the last place).  Two re-designs
+// were built and measured against it at 6 528 meshes with the vertices coming from HBM (tests/dev/pair_time.py,
+// profiles/r05_experiments.txt): thread = row with the row's entries in registers and four meshes per workgroup -- 74 us against
+// 60 (padded 12-slot rows issue three times the loads); one gather per (entry, mesh) into LDS, then the chains -- 59 us.  The kernel
+// is bound by the rate of scattered 12-byte requests (276 per mesh), not by its dependency chains, and the small footprint matters
+// more: it runs beside the next batch's encoder, whose persistent kernels leave a CU almost no LDS or registers (the LDS form
+// averaged 69 us in the loop where this one takes 45).
 // ---------------------------------------------------------------------------------------------
-constexpr int JN_G = 4;        // meshes per workgroup
-constexpr int JN_T = 320;      // threads: >= the 276 entries of the reference's regressors (one gather round)
-__global__ __launch_bounds__(JN_T) void joints_kernel(const float* __restrict__ verts, const float* __restrict__ j_posed,
-                                                      const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_col,
-                                                      const float* __restrict__ csr_val, int n_rows, int J,
-                                                      const float* __restrict__ transl, float* __restrict__ joints, int V, int M, int nnz) {
-    extern __shared__ __attribute__((aligned(16))) float sj[];       // [JN_G][nnz] vertices (x, y, z), then [nnz] weights
-    float* sP = sj;
-    float* sW = sj + (size_t)JN_G * nnz * 3;
+__global__ __launch_bounds__(128) void joints_kernel(const float* __restrict__ verts, const float* __restrict__ j_posed,
+                                                     const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_col,
+                                                     const float* __restrict__ csr_val, int n_rows, int J,
+                                                     const float* __restrict__ transl, float* __restrict__ joints, int V) {
+    const int m = blockIdx.x;
     const int n_out = J + n_rows;
-    const int m0 = blockIdx.x * JN_G, g_n = min(JN_G, M - m0);
-    for (int e = threadIdx.x; e < nnz; e += JN_T) {
-        const int c = csr_col[e] * 3;
-        sW[e] = csr_val[e];
-        f3 p[JN_G];
-#pragma unroll
-        for (int g = 0; g < JN_G; ++g)       // a mesh beyond M re-reads the last one (never summed)
-            p[g] = *reinterpret_cast<const f3*>(verts + (size_t)(m0 + min(g, g_n - 1)) * V * 3 + c);     // verts already include transl
-#pragma unroll
-        for (int g = 0; g < JN_G; ++g) {
-            float* d = sP + ((size_t)g * nnz + e) * 3;
-            d[0] = p[g].x; d[1] = p[g].y; d[2] = p[g].z;
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n_out * g_n; i += JN_T) {
-        const int g = i / n_out, r = i - g * n_out;
-        const int m = m0 + g;
+    float tx = 0.f, ty = 0.f, tz = 0.f;
+    if (transl) { tx = transl[m * 3 + 0]; ty = transl[m * 3 + 1]; tz = transl[m * 3 + 2]; }
+    const float* vm = verts + (size_t)m * V * 3;  // verts already include transl
+    for (int r = threadIdx.x; r < n_out; r += blockDim.x) {
         float x, y, z;
-        if (r < J) {                             // kinematic joints: the forward-kinematics translations (+ transl)
-            float tx = 0.f, ty = 0.f, tz = 0.f;
-            if (transl) { tx = transl[m * 3 + 0]; ty = transl[m * 3 + 1]; tz = transl[m * 3 + 2]; }
+        if (r < J) {
             const float* s = j_posed + ((size_t)m * J + r) * 3;
             x = s[0] + tx; y = s[1] + ty; z = s[2] + tz;
         } else {
             x = y = z = 0.f;
+            // four entries of the row in flight (column -> vertex is a dependent load chain); added in row order
             const int e1 = csr_ptr[r - J + 1];
-            for (int e = csr_ptr[r - J]; e < e1; ++e) {
-                const float w = sW[e];
-                const float* s = sP + ((size_t)g * nnz + e) * 3;
-                x = __builtin_fmaf(w, s[0], x); y = __builtin_fmaf(w, s[1], y); z = __builtin_fmaf(w, s[2], z);
+            int e = csr_ptr[r - J];
+            for (; e + 4 <= e1; e += 4) {
+                float wv[4];
+                f3 p[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    wv[i] = csr_val[e + i];
+                    p[i] = *reinterpret_cast<const f3*>(vm + (size_t)csr_col[e + i] * 3);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    x = __builtin_fmaf(wv[i], p[i].x, x); y = __builtin_fmaf(wv[i], p[i].y, y); z = __builtin_fmaf(wv[i], p[i].z, z);
+                }
+            }
+            for (; e < e1; ++e) {
+                const float wv = csr_val[e];
+                const float* s = vm + (size_t)csr_col[e] * 3;
+                x = __builtin_fmaf(wv, s[0], x); y = __builtin_fmaf(wv, s[1], y); z = __builtin_fmaf(wv, s[2], z);
             }
         }
         float* d = joints + ((size_t)m * n_out + r) * 3;
         d[0] = x; d[1] = y; d[2] = z;
     }
-}
-
-// joints for regressors whose entries do not fit the LDS stage of joints_kernel (more than ~1 260 entries; the reference's have 276):
-// thread per (mesh, row), the row's entries straight from global memory -- the same chain of fused multiply-adds, the same bits.
-__global__ __launch_bounds__(256) void joints_rows_kernel(const float* __restrict__ verts, const float* __restrict__ j_posed,
-                                                          const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_col,
-                                                          const float* __restrict__ csr_val, int n_rows, int J,
-                                                          const float* __restrict__ transl, float* __restrict__ joints, int V, int M) {
-    const int n_out = J + n_rows;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)M * n_out) return;
-    const int m = (int)(i / n_out), r = (int)(i - (long)m * n_out);
-    float x, y, z;
-    if (r < J) {
-        float tx = 0.f, ty = 0.f, tz = 0.f;
-        if (transl) { tx = transl[m * 3 + 0]; ty = transl[m * 3 + 1]; tz = transl[m * 3 + 2]; }
-        const float* s = j_posed + ((size_t)m * J + r) * 3;
-        x = s[0] + tx; y = s[1] + ty; z = s[2] + tz;
-    } else {
-        x = y = z = 0.f;
-        const float* vm = verts + (size_t)m * V * 3;
-        const int e1 = csr_ptr[r - J + 1];
-        for (int e = csr_ptr[r - J]; e < e1; ++e) {
-            const float w = csr_val[e];
-            const float* s = vm + (size_t)csr_col[e] * 3;
-            x = __builtin_fmaf(w, s[0], x); y = __builtin_fmaf(w, s[1], y); z = __builtin_fmaf(w, s[2], z);
-        }
-    }
-    float* d = joints + (size_t)i * 3;
-    d[0] = x; d[1] = y; d[2] = z;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -775,7 +741,7 @@ extern "C" int hps_smpl_pose_prep(const float* glob, const float* body, int is_r
         return bad_arg("hps_smpl_pose_prep: num_joints must be 1..32 and num_betas 0..16");
     if (kp < num_betas + 9 * (num_joints - 1) || mp < M) return bad_arg("hps_smpl_pose_prep: kp/mp too small");
     if (M <= 0) return HPS_OK;
-    hipLaunchKernelGGL(pose_prep_kernel, dim3(ceil_div(M, PP_G)), dim3(32 * PP_G), 0, (hipStream_t)stream, glob, body,
+    hipLaunchKernelGGL(pose_prep_kernel, dim3(ceil_div(M, 8)), dim3(256), 0, (hipStream_t)stream, glob, body,
                        is_rotmat, betas, num_betas, j_template, j_shapedirs, parents, depth, num_joints, xt, kp, mp,
                        a, j_posed, rot_out, M);
     return check_launch("hps_smpl_pose_prep");
@@ -864,20 +830,13 @@ extern "C" int hps_dev_lbs_variant(const float* v_posed, int ld_vposed, const fl
 #endif
 
 extern "C" int hps_smpl_joints(const float* verts, const float* j_posed, const int32_t* csr_ptr,
-                               const int32_t* csr_col, const float* csr_val, int n_rows, int nnz, int num_joints,
+                               const int32_t* csr_col, const float* csr_val, int n_rows, int num_joints,
                                const float* transl, float* joints, int M, int V, hps_stream_t stream) {
     if (!verts || !j_posed || !csr_ptr || !csr_col || !csr_val || !joints) return bad_arg("hps_smpl_joints: null pointer");
     if (M <= 0) return HPS_OK;
-    if (num_joints < 0 || n_rows < 0 || nnz < 0) return bad_arg("hps_smpl_joints: num_joints / n_rows / nnz");
-    const size_t lds = ((size_t)JN_G * 3 + 1) * (size_t)nnz * sizeof(float);       // the reference's regressors: 276 entries -> 14 KB
-    if (lds > 64 * 1024) {           // a regressor too large for the LDS stage: the generic form (same bits)
-        const long total = (long)M * (num_joints + n_rows);
-        hipLaunchKernelGGL(joints_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, verts, j_posed, csr_ptr,
-                           csr_col, csr_val, n_rows, num_joints, transl, joints, V, M);
-        return check_launch("hps_smpl_joints");
-    }
-    hipLaunchKernelGGL(joints_kernel, dim3(ceil_div(M, JN_G)), dim3(JN_T), lds, (hipStream_t)stream, verts, j_posed, csr_ptr, csr_col,
-                       csr_val, n_rows, num_joints, transl, joints, V, M, nnz);
+    if (num_joints < 0 || n_rows < 0) return bad_arg("hps_smpl_joints: num_joints / n_rows");
+    hipLaunchKernelGGL(joints_kernel, dim3(M), dim3(128), 0, (hipStream_t)stream, verts, j_posed, csr_ptr, csr_col,
+                       csr_val, n_rows, num_joints, transl, joints, V);
     return check_launch("hps_smpl_joints");
 }
 

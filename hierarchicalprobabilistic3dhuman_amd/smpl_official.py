@@ -134,7 +134,6 @@ class SMPL(nn.Module):
             val_.extend(dense[r, nz].tolist())
             ptr_.append(len(col_))
         self._n_joint_rows = dense.shape[0]
-        self._n_joint_nnz = len(col_)
         self.register_buffer("_csr_ptr", torch.tensor(ptr_, dtype=torch.int32), persistent=False)
         self.register_buffer("_csr_col", torch.tensor(col_, dtype=torch.int32), persistent=False)
         self.register_buffer("_csr_val", torch.tensor(val_, dtype=torch.float32), persistent=False)
@@ -214,7 +213,7 @@ class SMPL(nn.Module):
         if kwargs.get("_after_mesh") is not None:
             kwargs["_after_mesh"]()
         _capi.call("hps_smpl_joints", P(verts), P(j_posed), _capi.iptr(self._csr_ptr), _capi.iptr(self._csr_col),
-                   P(self._csr_val), self._n_joint_rows, self._n_joint_nnz, J, P(tr) if tr is not None else None, P(joints), M, V, s)
+                   P(self._csr_val), self._n_joint_rows, J, P(tr) if tr is not None else None, P(joints), M, V, s)
         full_pose = torch.cat([g, b], dim=1) if return_full_pose else None
         if self.keep_intermediates:                                         # tests / profiling only
             self._last = dict(xt=xt, a=a, j_posed=j_posed)

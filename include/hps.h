@@ -157,11 +157,9 @@ int hps_smpl_mesh_fused_np(int V);
 /* Joints: out[m, 0:J] = j_posed[m] ; out[m, J + r] = sum_e csr_val[e] * verts[m, csr_col[e]]
  * for CSR rows r = 0..n_rows-1 (the 21 smplx vertex picks as 1-entry rows, then the extra / cocoplus /
  * h36m regressors of models/smpl_official.py:30-34), each row summed as one chain of fused multiply-adds in entry order.
- * nnz = csr_ptr[n_rows], the number of entries (the host built the matrix and knows it; up to 1 260 entries their vertices are
- * gathered through LDS, larger regressors take a thread-per-row kernel with the same bits).  transl optional (M,3).
- * out: (M, J + n_rows, 3). */
+ * transl optional (M,3). out: (M, J+n_rows, 3). */
 int hps_smpl_joints(const float* verts, const float* j_posed, const int32_t* csr_ptr,
-                    const int32_t* csr_col, const float* csr_val, int n_rows, int nnz, int num_joints,
+                    const int32_t* csr_col, const float* csr_val, int n_rows, int num_joints,
                     const float* transl, float* joints, int M, int V, hps_stream_t stream);
 
 /* Per-vertex uncertainty of utils/sampling_utils.py:189-190, batched over images:

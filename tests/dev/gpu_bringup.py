@@ -113,7 +113,7 @@ def sec_smpl_perf():
         t_lbs = timeit(lambda: _capi.call("hps_smpl_lbs", P(L["v_posed_raw"]), L["ldv"], P(L["a"]), _capi.iptr(smpl._w_idx),
                                           P(smpl._w_val), smpl._lbs_k, J, None, P(verts), M, V, s), 20, 5)
         t_j = timeit(lambda: _capi.call("hps_smpl_joints", P(verts), P(L["j_posed"]), _capi.iptr(smpl._csr_ptr),
-                                        _capi.iptr(smpl._csr_col), P(smpl._csr_val), smpl._n_joint_rows, smpl._n_joint_nnz, J, None,
+                                        _capi.iptr(smpl._csr_col), P(smpl._csr_val), smpl._n_joint_rows, J, None,
                                         P(joints), M, V, s))
         gb = 166896.0 * M / 1e9
         print("M=%d: forward %.3f ms | prep %.3f blend %.3f (%.1f TF) lbs %.3f (%.2f TB/s alg, %.1f%% of 8) joints %.3f" % (

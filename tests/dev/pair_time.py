@@ -36,8 +36,7 @@ def main():
                    _capi.iptr(smpl._depth_i32), J, P(xt), smpl._kp, mp, P(a), P(jp), None, M, _capi.stream())
 
     def jnt(name):
-        extra = (smpl._n_joint_nnz,) if name == "hps_smpl_joints" else ()
-        _capi.call(name, P(verts), P(jp), _capi.iptr(smpl._csr_ptr), _capi.iptr(smpl._csr_col), P(smpl._csr_val), smpl._n_joint_rows, *extra, J, None,
+        _capi.call(name, P(verts), P(jp), _capi.iptr(smpl._csr_ptr), _capi.iptr(smpl._csr_col), P(smpl._csr_val), smpl._n_joint_rows, J, None,
                    P(joints), M, V, _capi.stream())
 
     arms = {"pose_prep v1": lambda: prep("hps_dev_smpl_pose_prep_v1"), "pose_prep r5": lambda: prep("hps_smpl_pose_prep"),
