@@ -132,12 +132,13 @@ __global__ __launch_bounds__(256) void pose_prep_kernel_v1(
 // Second generation (round 5; the first stays in the dev library as the bit-level cross-check): the first one was a chain of
 // dependent global loads (28 us for 6 528 meshes in the pipelined step, 19.4 us alone).  (1) `max depth` was a loop of J dependent
 // scalar loads in front of the kinematic levels -- now a shuffle reduction of the lanes' own depths; (2) the rest joints read
-// 3 x nb values of j_shapedirs one after another -- now all of a lane's 3 x nb coefficients are requested before the first is
-// used (the sums keep their order: identical bits).  Same workgroup footprint as before ON PURPOSE: this kernel runs beside the
-// encoder's persistent kernels, which leave a CU at most ~6 KB of LDS and no registers -- an intermediate version with 16 meshes
-// per workgroup, the regressor staged in LDS and the k-major operand transposed through LDS for 64-byte runs (512 threads, 57 KB)
-// was faster alone (15.1 us) and waited three times as long for a CU in the loop (82 us on average, up to 0.39 ms, in front of
-// the exclusive mesh kernel).
+// 3 x nb values of j_shapedirs per lane one after another from global memory -- the joint regressor (J x 3 x (nb + 1) floats) is
+// now staged in LDS by the whole workgroup with coalesced loads (the sums keep their order: identical bits).  The workgroup stays
+// SMALL on purpose (256 threads, 22 KB of LDS): this kernel runs beside the encoder's persistent kernels, which leave a CU little
+// LDS and no registers -- an intermediate version with 16 meshes per workgroup and the k-major operand transposed through LDS for
+// 64-byte runs (512 threads, 57 KB) was as fast alone (15.1 us) and waited three times as long for a CU in the loop (82 us on
+// average, up to 0.39 ms, in front of the exclusive mesh kernel); requesting a lane's 48 coefficients at once from global memory
+// instead of staging them was slower than the first generation (25.4 us).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pose_prep_kernel(
     const float* __restrict__ glob, const float* __restrict__ body, int is_rotmat,
@@ -148,6 +149,8 @@ __global__ __launch_bounds__(256) void pose_prep_kernel(
     __shared__ float sG[8][MAXJ][12];  // world transform (3x4 row-major) per joint
     __shared__ float sJ[8][MAXJ][3];   // rest joints
     __shared__ float sBeta[8][16];
+    __shared__ float sJT[MAXJ * 3];       // j_template
+    __shared__ float sJS[MAXJ * 3 * 16];  // j_shapedirs
 
     const int g = threadIdx.x >> 5;     // mesh slot in the workgroup
     const int j = threadIdx.x & 31;     // joint
@@ -155,18 +158,8 @@ __global__ __launch_bounds__(256) void pose_prep_kernel(
     const bool live = (m < M) && (j < J);
 
     if (m < M && j < nb && j < 16) sBeta[g][j] = betas[(size_t)m * nb + j];
-    // this lane's joint-regressor coefficients: 3 x nb independent loads in flight (a lane beyond J re-reads joint J - 1)
-    float sd[3][16];
-    float jt[3];
-    {
-        const int jc = min(j, J - 1);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            jt[c] = j_template[jc * 3 + c];
-#pragma unroll
-            for (int l = 0; l < 16; ++l) sd[c][l] = j_shapedirs[(jc * 3 + c) * nb + max(0, min(l, nb - 1))];
-        }
-    }
+    for (int i = threadIdx.x; i < J * 3; i += 256) sJT[i] = j_template[i];
+    for (int i = threadIdx.x; i < J * 3 * nb; i += 256) sJS[i] = j_shapedirs[i];
     __syncthreads();
 
     float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
@@ -186,10 +179,8 @@ __global__ __launch_bounds__(256) void pose_prep_kernel(
         // rest joint: J = J_regressor (v_template + shapedirs beta) = j_template + j_shapedirs beta
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float acc = jt[c];
-#pragma unroll
-            for (int l = 0; l < 16; ++l)
-                if (l < nb) acc += sd[c][l] * sBeta[g][l];
+            float acc = sJT[j * 3 + c];
+            for (int l = 0; l < nb; ++l) acc += sJS[(j * 3 + c) * nb + l] * sBeta[g][l];
             Jr[c] = acc;
             sJ[g][j][c] = acc;
         }
