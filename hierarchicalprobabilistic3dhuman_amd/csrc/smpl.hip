@@ -129,16 +129,16 @@ __global__ __launch_bounds__(256) void pose_prep_kernel_v1(
 // Local transforms live in LDS; the kinematic chain is evaluated level by level so that every
 // G_i = G_parent(i) * L_i is the same product the reference's index-ordered loop forms.
 //
-// Second generation (round 5; the first stays in the dev library as the bit-level cross-check): the first one was a chain of
-// dependent global loads (28 us for 6 528 meshes in the pipelined step, 19.4 us alone).  (1) `max depth` was a loop of J dependent
-// scalar loads in front of the kinematic levels -- now a shuffle reduction of the lanes' own depths; (2) the rest joints read
-// 3 x nb values of j_shapedirs per lane one after another from global memory -- the joint regressor (J x 3 x (nb + 1) floats) is
-// now staged in LDS by the whole workgroup with coalesced loads (the sums keep their order: identical bits).  The workgroup stays
-// SMALL on purpose (256 threads, 22 KB of LDS): this kernel runs beside the encoder's persistent kernels, which leave a CU little
-// LDS and no registers -- an intermediate version with 16 meshes per workgroup and the k-major operand transposed through LDS for
-// 64-byte runs (512 threads, 57 KB) was as fast alone (15.1 us) and waited three times as long for a CU in the loop (82 us on
-// average, up to 0.39 ms, in front of the exclusive mesh kernel); requesting a lane's 48 coefficients at once from global memory
-// instead of staging them was slower than the first generation (25.4 us).
+// Second generation (round 5; the first stays in the dev library as the bit-level cross-check).  (1) `max depth` was a loop of J
+// dependent scalar loads in front of the kinematic levels -- now a shuffle reduction of the lanes' own depths; (2) the rest joints
+// read 3 x nb values of j_shapedirs per lane one after another from global memory -- the joint regressor (J x 3 x (nb + 1) floats)
+// is now staged in LDS by the whole workgroup with coalesced loads (the sums keep their order: identical bits).  Measured alone at
+// 6 528 meshes (tests/dev/pair_time.py): 19.5 -> 19.0 us -- neither chain was what the kernel waits for.  What did shorten it was
+// 16 meshes per workgroup with the k-major operand transposed through LDS for 64-byte runs (512 threads, 57 KB: 15.1 us alone) --
+// and that form waited three times as long for a CU in the pipelined loop (82 us on average, up to 0.39 ms, in front of the
+// exclusive mesh kernel: it runs beside the encoder's persistent kernels, which leave a CU little LDS and no registers), so the
+// workgroup stays SMALL on purpose (256 threads, 22 KB).  Requesting a lane's 48 coefficients at once from global memory instead
+// of staging them was slower than the first generation (25.4 us).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pose_prep_kernel(
     const float* __restrict__ glob, const float* __restrict__ body, int is_rotmat,
