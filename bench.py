@@ -163,6 +163,8 @@ def main():
                     help="let the mesh kernel run beside the neighbouring batches' encoders (auto: for batches below 32 images, whose "
                          "encoder cannot fill the chip)")
     ap.add_argument("--encoder-cus", type=int, default=None, help="CUs per XCD of the encoder's partition when the mesh kernel overlaps (0 = shared CUs)")
+    ap.add_argument("--head-cus", type=int, default=None,
+                    help="exclusive schedule: CUs per XCD reserved for the head's kernels (the mesh kernel runs on the others); 0 = shared CUs")
     ap.add_argument("--unfused-mesh", action="store_true", help="blend GEMM + LBS as two kernels (the unfused definition) instead of the fused mesh kernel")
     ap.add_argument("--trace-steps", action="store_true", help="print host-side per-step times to stderr (debugging)")
     ap.add_argument("--cpu-images", type=int, default=64, help="images in the CPU-baseline sample (0 = skip); 64 = one full batch, SURVEY 8(d)")
@@ -226,6 +228,8 @@ def main():
     pipe.exclusive_mesh = {"auto": None, "on": False, "off": True}[args.mesh_overlap]
     if args.encoder_cus is not None:
         pipe.encoder_cus = args.encoder_cus
+    if args.head_cus is not None:
+        pipe.head_cus = args.head_cus
 
     step_marks = []
 
@@ -557,7 +561,9 @@ def main():
                        "meshes_per_step_per_gpu": M, "parallelism": "images sharded over %d GPU(s)" % world,
                        "mesh_kernel": "fused blend GEMM + LBS" if fused else "blend GEMM, then LBS",
                        "step_pipelining": "none" if args.no_pipeline else (
-                           "encoder of step i+1 (own stream) overlaps the latency-bound head of step i (high-priority stream); the mesh kernels (pose prep / blend + LBS / joints) of a batch run alone"
+                           ("encoder of step i+1 (own stream) overlaps the latency-bound head of step i (high-priority stream); the mesh kernels (pose prep / blend + LBS / joints) of a batch run alone"
+                            + ("; the head on %d CUs of every XCD, the caller's stream (sampling, mesh kernels, uncertainty) on the other %d" % (32 - _capi_mesh_cus(pipe), _capi_mesh_cus(pipe))
+                               if pipe.mesh_stream is not None else ""))
                            if pipe._exclusive else
                            "encoder of step i+1 beside the head AND the mesh kernels of step i (small batch: neither fills the chip)" +
                            (", on disjoint CU subsets (encoder: %d of the 32 CUs of every XCD)" % (32 - _capi_mesh_cus(pipe)) if pipe.mesh_stream is not None else ", sharing all CUs"))},

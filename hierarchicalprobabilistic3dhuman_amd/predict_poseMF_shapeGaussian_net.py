@@ -167,6 +167,14 @@ class InferencePipeline:
         # B = 16, N = 100 the mesh kernel is a tenth of that and a partition would only slow the encoder down.  None = decide from
         # the work: 8 CUs per XCD when the batch is small enough to overlap at all AND carries at least 12 000 meshes, else 0.
         self.encoder_cus = None
+        # head_cus > 0 (exclusive schedule only): the head's chain of small dependent kernels runs on head_cus CUs of every XCD that the
+        # mesh kernel's stream does not use (the caller's stream becomes the partition of the other 32 - head_cus; the encoder keeps
+        # the whole chip).  Why: the head of batch i + 1 is ready when the mesh kernel of batch i starts, but beside that kernel's
+        # four workgroups per CU it only gets a slot when one retires, so most of its 11 launches slipped into the next encoder's stem
+        # and Winograd layers -- whose persistent one-per-CU workgroups cannot start on a CU a level kernel holds (kernel trace: level
+        # kernels 90-115 us instead of 45, layer1 convolutions 103-120 us instead of 93).  On CUs of its own the head finishes inside
+        # the mesh kernel's window.  None = decide from the batch (see _setup_streams).
+        self.head_cus = None
         # (measured and dropped: making the next encoder wait for the uncertainty pass as well -- B = 16, N = 1000: 3.15 -> 3.24 ms
         # per step; B = 64, N = 100: 3.53 -> 3.51)
 
@@ -200,6 +208,21 @@ class InferencePipeline:
             except _capi.HpsError as e:
                 import warnings
                 warnings.warn("InferencePipeline: no CU partition on this device (%s); encoder and mesh kernels share the CUs" % e)
+                self.mesh_stream = None
+        h = self.head_cus
+        if h is None:
+            h = 0
+        if self._exclusive and h:
+            per_xcd = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count // 8
+            try:
+                if not 0 < int(h) < per_xcd:
+                    raise _capi.HpsError("head_cus = %d does not fit %d CUs per XCD" % (h, per_xcd))
+                self.mesh_stream = _capi.cu_partition_stream(0, per_xcd - int(h))
+                self.head_stream = _capi.cu_partition_stream(per_xcd - int(h), int(h))
+                self._mesh_cus = per_xcd - int(h)
+            except _capi.HpsError as e:
+                import warnings
+                warnings.warn("InferencePipeline: no CU partition on this device (%s); the head shares the CUs" % e)
                 self.mesh_stream = None
         if self.enc_stream is None:
             self.enc_stream = torch.cuda.Stream()
