@@ -31,6 +31,7 @@ _PROTOTYPES = {
     "hps_smpl_blend": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hps_smpl_lbs": [_P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
     "hps_smpl_mesh_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "hps_smpl_mesh_fused_picks": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "hps_smpl_mesh_fused_np": [_I],
     "hps_smpl_joints": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
     "hps_vertex_uncertainty": [_P, _P, _I, _I, _I, _P],

@@ -59,12 +59,15 @@ static_assert(F_XP == FW && F_BP % FW == 0, "DMA pieces must divide evenly over 
 // latency; 36 KiB).  4 (round 5) = chunks fetched THREE ahead, for calls whose meshes fill at most two tiles (one image at a time:
 // 52 meshes): 108-216 workgroups, at most one per CU, and the 14 chunks of the 18.6 MB blend matrix arrived one round trip after the
 // other (55 us for 52 meshes).  Pure pipelining: the same MFMAs in the same order, identical bits.
-template <int K, int ABL, int JC, bool HAS_T, int TAIL = FBK / 2, int ST = 2>
+// PICK (round 5): the vertices the joint regressors read (pick_slot[v] >= 0: 198 of SMPL's 6 890) are ALSO written to a compact
+// (M, n_picked, 3) array -- the lane that skins a vertex has it in registers, and hps_smpl_joints then reads 2.4 KB per mesh in one
+// place instead of gathering 276 scattered 12-byte records from the 83 KB mesh (60 us per 6 528 meshes, bound by the request rate).
+template <int K, int ABL, int JC, bool HAS_T, int TAIL = FBK / 2, int ST = 2, bool PICK = false>
 __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
     const float* __restrict__ xt, const float* __restrict__ bmat_p, const float* __restrict__ v_template,
     const float* __restrict__ a, const int32_t* __restrict__ w_idx, const float* __restrict__ w_val, int J,
     const float* __restrict__ transl, f3* __restrict__ verts, int M, int V, int kp, int mp, int np, int tiles_m,
-    int tiles_m_per_xcd) {
+    int tiles_m_per_xcd, const int32_t* __restrict__ pick_slot, f3* __restrict__ picked, int n_picked) {
     typedef __attribute__((address_space(3))) void* lptr_t;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // union: ST operand chunks | A of 32 of the tile's meshes
 
@@ -93,6 +96,7 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
         w[k] = w_val[(size_t)vc * K + k];
     }
     const f3 vt = reinterpret_cast<const f3*>(v_template)[vc];
+    const int pick = PICK && live_v ? pick_slot[vc] : -1;     // this lane's slot in the compact array of regressor vertices, or -1
 
     // LDS-DMA pieces (1 KiB each): a chunk is F_XP pieces of xt rows ([FBK][FM]) and F_BP of bmat_p rows ([FBK][FN]);
     // wave w moves mesh-operand piece w and blend-matrix pieces w, w + 4, w + 8.
@@ -211,6 +215,8 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
     for (int k = 0; k < K; ++k) aoff[k] = slot0 * a_stride + idx[k];
     char* const vbase = reinterpret_cast<char*>(verts) + (size_t)(m0 + wm * 32) * V * 12;      // wave-uniform
     const unsigned voff = ((unsigned)(4 * kl) * (unsigned)V + (unsigned)v) * 12u;              // per lane
+    char* const pbase = PICK ? reinterpret_cast<char*>(picked) + (size_t)(m0 + wm * 32) * n_picked * 12 : nullptr;
+    const unsigned poff = PICK ? ((unsigned)(4 * kl) * (unsigned)n_picked + (unsigned)max(pick, 0)) * 12u : 0u;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();                                   // operand chunks / the previous pass's transforms are dead
@@ -254,6 +260,7 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
             // block's entry waits vmcnt(0) -- i.e. for the previous mesh's store -- on account of the v_template load.
             asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z));
             if (live_v && m < M) *reinterpret_cast<f3*>(vbase + (size_t)dr * V * 12 + voff) = o;
+            if (PICK && pick >= 0 && m < M) *reinterpret_cast<f3*>(pbase + (size_t)dr * n_picked * 12 + poff) = o;
         }
     }
 }
@@ -266,7 +273,7 @@ static int g_mesh_stages = 0;              // hps_dev_mesh_stages: 2 = always th
 template <int K, int ABL, int JC, bool HAS_T>
 static int launch_fused_cfg(const float* xt, const float* bmat_p, const float* v_template, const float* a, const int32_t* w_idx,
                         const float* w_val, int J, const float* transl, float* verts, int M, int V, int kp, int mp, int np,
-                        hipStream_t s) {
+                        hipStream_t s, const int32_t* pick_slot = nullptr, float* picked = nullptr, int n_picked = 0) {
     size_t lds = (size_t)4 * max(2 * F_CHUNK_FLOATS, 32 * J * 12);
 #ifdef HPS_DEV_BUILD
     if (g_mesh_lds_floor > lds) lds = g_mesh_lds_floor;     // experiment: fewer workgroups per CU (a larger LDS request, unused)
@@ -283,29 +290,42 @@ static int launch_fused_cfg(const float* xt, const float* bmat_p, const float* v
     // the last chunk's data-carrying k-pairs: SMPL (K = 10 + 207 -> kp = 218) has 5 of 8; that case is instantiated for the product
     // configuration, every other tail runs the whole (zero-padded) chunk
     const int tail = (kp - FBK * ((kp + FBK - 1) / FBK - 1)) / 2;
-    if (K == 4 && JC == 24 && ABL == 0 && tail == 5 && few) {
-        lds = (size_t)4 * max(4 * F_CHUNK_FLOATS, 32 * J * 12);
-        if (int rc = grant_lds<&mesh_fused_kernel<K, ABL, JC, HAS_T, 5, 4>>(160 * 1024, "hps_smpl_mesh_fused")) return rc;
-        hipLaunchKernelGGL((mesh_fused_kernel<K, ABL, JC, HAS_T, 5, 4>), grid, dim3(FT), lds, s, xt, bmat_p, v_template,
-                           a, w_idx, w_val, J, transl, reinterpret_cast<f3*>(verts), M, V, kp, mp, np, tiles_m, tiles_m_per_xcd);
-    } else if (K == 4 && JC == 24 && ABL == 0 && tail == 5) {
-        if (int rc = grant_lds<&mesh_fused_kernel<K, ABL, JC, HAS_T, 5>>(160 * 1024, "hps_smpl_mesh_fused")) return rc;
-        hipLaunchKernelGGL((mesh_fused_kernel<K, ABL, JC, HAS_T, 5>), grid, dim3(FT), lds, s, xt, bmat_p, v_template,
-                           a, w_idx, w_val, J, transl, reinterpret_cast<f3*>(verts), M, V, kp, mp, np, tiles_m, tiles_m_per_xcd);
-    } else {
-        if (int rc = grant_lds<&mesh_fused_kernel<K, ABL, JC, HAS_T>>(160 * 1024, "hps_smpl_mesh_fused")) return rc;
-        hipLaunchKernelGGL((mesh_fused_kernel<K, ABL, JC, HAS_T>), grid, dim3(FT), lds, s, xt, bmat_p, v_template,
-                           a, w_idx, w_val, J, transl, reinterpret_cast<f3*>(verts), M, V, kp, mp, np, tiles_m, tiles_m_per_xcd);
+    f3* pk = reinterpret_cast<f3*>(picked);
+#define HPS_MESH_LAUNCH(...)                                                                                                       \
+    do {                                                                                                                           \
+        if (int rc = grant_lds<&mesh_fused_kernel<__VA_ARGS__>>(160 * 1024, "hps_smpl_mesh_fused")) return rc;                    \
+        hipLaunchKernelGGL((mesh_fused_kernel<__VA_ARGS__>), grid, dim3(FT), lds, s, xt, bmat_p, v_template, a, w_idx, w_val, J,   \
+                           transl, reinterpret_cast<f3*>(verts), M, V, kp, mp, np, tiles_m, tiles_m_per_xcd, pick_slot, pk, n_picked); \
+    } while (0)
+    if constexpr (K == 4 && JC == 24 && ABL == 0) {          // the product configuration (SMPL): tail, stages and the side output
+        if (tail == 5) {
+            if (few) {
+                lds = (size_t)4 * max(4 * F_CHUNK_FLOATS, 32 * J * 12);
+                if (pick_slot) HPS_MESH_LAUNCH(K, ABL, JC, HAS_T, 5, 4, true);
+                else HPS_MESH_LAUNCH(K, ABL, JC, HAS_T, 5, 4, false);
+            } else {
+                if (pick_slot) HPS_MESH_LAUNCH(K, ABL, JC, HAS_T, 5, 2, true);
+                else HPS_MESH_LAUNCH(K, ABL, JC, HAS_T, 5, 2, false);
+            }
+            return check_launch("hps_smpl_mesh_fused");
+        }
     }
+    if (pick_slot) {
+        set_error("hps_smpl_mesh_fused_picks: the side output exists for K = 4, 24 joints, kp = 218 (SMPL) only");
+        return HPS_E_UNSUPPORTED;
+    }
+    HPS_MESH_LAUNCH(K, ABL, JC, HAS_T);
+#undef HPS_MESH_LAUNCH
     return check_launch("hps_smpl_mesh_fused");
 }
 
 template <int K, int ABL = 0>
 static int launch_fused(const float* xt, const float* bmat_p, const float* v_template, const float* a, const int32_t* w_idx,
                         const float* w_val, int J, const float* transl, float* verts, int M, int V, int kp, int mp, int np,
-                        hipStream_t s) {
-    if (J == 24 && !transl) return launch_fused_cfg<K, ABL, 24, false>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s);
-    if (J == 24) return launch_fused_cfg<K, ABL, 24, true>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s);
+                        hipStream_t s, const int32_t* pick_slot = nullptr, float* picked = nullptr, int n_picked = 0) {
+    if (J == 24 && !transl) return launch_fused_cfg<K, ABL, 24, false>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s, pick_slot, picked, n_picked);
+    if (J == 24) return launch_fused_cfg<K, ABL, 24, true>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s, pick_slot, picked, n_picked);
+    if (pick_slot) { set_error("hps_smpl_mesh_fused_picks: 24 joints only"); return HPS_E_UNSUPPORTED; }
     if constexpr (K == 4) {          // a run-time joint count costs registers: only the K = 4 instantiation stays free of scratch
         if (!transl) return launch_fused_cfg<K, ABL, 0, false>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s);
         return launch_fused_cfg<K, ABL, 0, true>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s);
@@ -347,6 +367,18 @@ extern "C" int hps_smpl_mesh_fused(const float* xt, const float* bmat_p, const f
         default: set_error("hps_smpl_mesh_fused: K=%d unsupported (4 with any joint count; 8, 12 with 24 joints); use "
                            "hps_smpl_blend + hps_smpl_lbs", K); return HPS_E_UNSUPPORTED;
     }
+}
+
+extern "C" int hps_smpl_mesh_fused_picks(const float* xt, const float* bmat_p, const float* v_template, const float* a,
+                                         const int32_t* w_idx, const float* w_val, int K, int num_joints, const float* transl,
+                                         float* verts, int M, int V, int kp, int mp, int np, const int32_t* pick_slot, float* picked,
+                                         int n_picked, hps_stream_t stream) {
+    if (!pick_slot || !picked || n_picked <= 0) return bad_arg("hps_smpl_mesh_fused_picks: pick_slot / picked / n_picked");
+    const int rc = fused_check_args(xt, bmat_p, v_template, a, w_idx, w_val, verts, num_joints, M, V, kp, mp, np);
+    if (rc != HPS_OK) return rc > 0 ? HPS_OK : rc;
+    if (K != 4) { set_error("hps_smpl_mesh_fused_picks: K = %d (the side output exists for K = 4 only)", K); return HPS_E_UNSUPPORTED; }
+    return launch_fused<4>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, (hipStream_t)stream,
+                           pick_slot, picked, n_picked);
 }
 
 #ifdef HPS_DEV_BUILD

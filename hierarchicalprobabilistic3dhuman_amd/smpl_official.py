@@ -134,6 +134,16 @@ class SMPL(nn.Module):
             val_.extend(dense[r, nz].tolist())
             ptr_.append(len(col_))
         self._n_joint_rows = dense.shape[0]
+        # the distinct vertices those rows read (SMPL: 198 of 6 890) get a slot in a compact array the fused mesh kernel fills beside
+        # the vertices (hps_smpl_mesh_fused_picks); the joint kernel then reads that array through the entries' slots
+        uniq = sorted(set(col_))
+        slot_of = {v: i for i, v in enumerate(uniq)}
+        pick_slot = np.full(V, -1, np.int32)
+        pick_slot[uniq] = np.arange(len(uniq), dtype=np.int32)
+        self._n_picked = len(uniq)
+        self.register_buffer("_pick_slot", torch.tensor(pick_slot, dtype=torch.int32), persistent=False)
+        self.register_buffer("_csr_slot", torch.tensor([slot_of[v] for v in col_], dtype=torch.int32), persistent=False)
+        self.picked_joints = True       # False: gather the regressor vertices from the mesh (the round-4 route; same bits)
         self.register_buffer("_csr_ptr", torch.tensor(ptr_, dtype=torch.int32), persistent=False)
         self.register_buffer("_csr_col", torch.tensor(col_, dtype=torch.int32), persistent=False)
         self.register_buffer("_csr_val", torch.tensor(val_, dtype=torch.float32), persistent=False)
@@ -192,12 +202,22 @@ class SMPL(nn.Module):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         trp = P(tr) if tr is not None else None
         v_posed = None
+        picked = None
         if self.fused_mesh and self._fused_ok:
+            # the SMPL configuration also gets the regressor vertices as a compact side output of the mesh kernel
+            use_picks = self.picked_joints and self._lbs_k == 4 and J == 24 and self._k_used == 218 and self._n_picked > 0
+            if use_picks:
+                picked = torch.empty(M, self._n_picked, 3, **f32)
             if ev is not None:
                 ev[0].record()
-            _capi.call("hps_smpl_mesh_fused", P(xt), P(self._bmat_p), P(self._v_template_flat), P(a),
-                       _capi.iptr(self._w_idx), P(self._w_val), self._lbs_k, J, trp, P(verts), M, V, self._k_used, mp,
-                       self._np_fused, s)
+            if use_picks:
+                _capi.call("hps_smpl_mesh_fused_picks", P(xt), P(self._bmat_p), P(self._v_template_flat), P(a),
+                           _capi.iptr(self._w_idx), P(self._w_val), self._lbs_k, J, trp, P(verts), M, V, self._k_used, mp,
+                           self._np_fused, _capi.iptr(self._pick_slot), P(picked), self._n_picked, s)
+            else:
+                _capi.call("hps_smpl_mesh_fused", P(xt), P(self._bmat_p), P(self._v_template_flat), P(a),
+                           _capi.iptr(self._w_idx), P(self._w_val), self._lbs_k, J, trp, P(verts), M, V, self._k_used, mp,
+                           self._np_fused, s)
         else:
             ldv = self._np if self.pad_v_posed else N          # row pitch of v_posed in floats (128-byte aligned rows)
             v_posed = torch.empty(M, ldv, **f32)
@@ -212,8 +232,12 @@ class SMPL(nn.Module):
             self.lbs_events.append((M, ev[0], ev[1]))
         if kwargs.get("_after_mesh") is not None:
             kwargs["_after_mesh"]()
-        _capi.call("hps_smpl_joints", P(verts), P(j_posed), _capi.iptr(self._csr_ptr), _capi.iptr(self._csr_col),
-                   P(self._csr_val), self._n_joint_rows, J, P(tr) if tr is not None else None, P(joints), M, V, s)
+        if picked is not None:      # the regressor vertices lie side by side: same rows, same values, same sums
+            _capi.call("hps_smpl_joints", P(picked), P(j_posed), _capi.iptr(self._csr_ptr), _capi.iptr(self._csr_slot),
+                       P(self._csr_val), self._n_joint_rows, J, P(tr) if tr is not None else None, P(joints), M, self._n_picked, s)
+        else:
+            _capi.call("hps_smpl_joints", P(verts), P(j_posed), _capi.iptr(self._csr_ptr), _capi.iptr(self._csr_col),
+                       P(self._csr_val), self._n_joint_rows, J, P(tr) if tr is not None else None, P(joints), M, V, s)
         full_pose = torch.cat([g, b], dim=1) if return_full_pose else None
         if self.keep_intermediates:                                         # tests / profiling only
             self._last = dict(xt=xt, a=a, j_posed=j_posed)

@@ -151,6 +151,16 @@ int hps_smpl_lbs(const float* v_posed, int ld_vposed, const float* a, const int3
 int hps_smpl_mesh_fused(const float* xt, const float* bmat_p, const float* v_template, const float* a,
                         const int32_t* w_idx, const float* w_val, int K, int num_joints, const float* transl,
                         float* verts, int M, int V, int kp, int mp, int np, hps_stream_t stream);
+/* hps_smpl_mesh_fused with a side output for the joint regression (round 5): pick_slot (V,) int32 gives every vertex its slot in a
+ * compact array or -1, and the lane that skins a vertex with a slot also writes it to picked (M, n_picked, 3).  hps_smpl_joints then
+ * runs on `picked` (verts = picked, V = n_picked, csr_col = the entries' SLOTS): the same sums over the same values, read from
+ * 12 n_picked contiguous bytes per mesh instead of gathered from the whole mesh (SMPL: 276 entries on 198 distinct vertices; the gather
+ * was bound by its request rate, 60 us per 6 528 meshes).  Exists for the SMPL configuration (K = 4, 24 joints, kp = 218):
+ * HPS_E_UNSUPPORTED otherwise -- use hps_smpl_mesh_fused and gather. */
+int hps_smpl_mesh_fused_picks(const float* xt, const float* bmat_p, const float* v_template, const float* a,
+                              const int32_t* w_idx, const float* w_val, int K, int num_joints, const float* transl,
+                              float* verts, int M, int V, int kp, int mp, int np, const int32_t* pick_slot, float* picked,
+                              int n_picked, hps_stream_t stream);
 /* Column count of bmat_p for a model with V vertices (192 per started panel of 64 vertices). */
 int hps_smpl_mesh_fused_np(int V);
 

@@ -407,3 +407,42 @@ def test_joints_second_generation(M, dev, smpl_gpu):
                 alone = run("hps_smpl_joints", cp, cc, cv, n_rows, tr[i:i + 1].contiguous() if tr is not None else None,
                             verts[i:i + 1].contiguous(), jp[i:i + 1].contiguous(), False)
                 assert torch.equal(alone[0], new[i]), (M, i)
+
+
+@pytest.mark.parametrize("M", [1, 52, 63, 64, 65, 130, 700, 6528])
+def test_mesh_kernel_side_output_feeds_the_joint_regression(M, dev, smpl_gpu):
+    """Round 5: the fused mesh kernel also writes the 198 vertices the joint regressors read to a compact (M, 198, 3) array
+    (hps_smpl_mesh_fused_picks) and hps_smpl_joints runs on that array through the entries' slots.  Same vertices (the compact array
+    is exactly verts[:, picked vertices]), same joints bit for bit as the gather from the whole mesh, vertices untouched -- with and
+    without translation, for mesh counts that leave ragged tiles and both K-loop forms (<= 2 tiles: four stages)."""
+    betas, aa, transl = _pose(M, 500 + M, scale=0.7)
+    R = O.batch_rodrigues(aa.view(-1, 3)).view(M, 24, 3, 3)
+    for tr in (None, transl.to(dev)):
+        args = dict(betas=betas.to(dev), body_pose=R[:, 1:].to(dev), global_orient=R[:, :1].to(dev), pose2rot=False, transl=tr)
+        assert smpl_gpu.picked_joints
+        with_picks = smpl_gpu(**args)
+        try:
+            smpl_gpu.picked_joints = False
+            gathered = smpl_gpu(**args)
+        finally:
+            smpl_gpu.picked_joints = True
+        assert torch.equal(with_picks.vertices, gathered.vertices)
+        assert torch.equal(with_picks.joints, gathered.joints), float((with_picks.joints - gathered.joints).abs().max())
+    # the side output itself, through the C ABI
+    P = _capi.ptr
+    mp = _capi.query_workspace(_capi.WS_SMPL_MP, M)
+    g = torch.Generator().manual_seed(M)
+    xt = (torch.randn(smpl_gpu._kp, mp, generator=g) * 0.1).to(dev)
+    a = torch.randn(M, 24, 12, generator=g).to(dev)
+    verts = torch.zeros(M, smpl_gpu.num_verts, 3, device=dev)
+    picked = torch.full((M, smpl_gpu._n_picked, 3), -7.0, device=dev)
+    _capi.call("hps_smpl_mesh_fused_picks", P(xt), P(smpl_gpu._bmat_p), P(smpl_gpu._v_template_flat), P(a), _capi.iptr(smpl_gpu._w_idx),
+               P(smpl_gpu._w_val), 4, 24, None, P(verts), M, smpl_gpu.num_verts, smpl_gpu._k_used, mp, smpl_gpu._np_fused,
+               _capi.iptr(smpl_gpu._pick_slot), P(picked), smpl_gpu._n_picked, _capi.stream())
+    uniq = (smpl_gpu._pick_slot >= 0).nonzero().flatten()
+    assert uniq.numel() == smpl_gpu._n_picked == 198
+    assert torch.equal(picked, verts[:, uniq])
+    with pytest.raises(_capi.HpsError):          # configurations without the side output say so
+        _capi.call("hps_smpl_mesh_fused_picks", P(xt), P(smpl_gpu._bmat_p), P(smpl_gpu._v_template_flat), P(a), _capi.iptr(smpl_gpu._w_idx),
+                   P(smpl_gpu._w_val), 8, 24, None, P(verts), M, smpl_gpu.num_verts, smpl_gpu._k_used, mp, smpl_gpu._np_fused,
+                   _capi.iptr(smpl_gpu._pick_slot), P(picked), smpl_gpu._n_picked, _capi.stream())
