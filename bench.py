@@ -165,6 +165,7 @@ def main():
     ap.add_argument("--encoder-cus", type=int, default=None, help="CUs per XCD of the encoder's partition when the mesh kernel overlaps (0 = shared CUs)")
     ap.add_argument("--head-cus", type=int, default=None,
                     help="exclusive schedule: CUs per XCD reserved for the head's kernels (the mesh kernel runs on the others); 0 = shared CUs")
+    ap.add_argument("--gather-joints", action="store_true", help="A/B: the joint regression gathers its vertices from the meshes (round 4) instead of reading the mesh kernel's compact side output")
     ap.add_argument("--unfused-mesh", action="store_true", help="blend GEMM + LBS as two kernels (the unfused definition) instead of the fused mesh kernel")
     ap.add_argument("--trace-steps", action="store_true", help="print host-side per-step times to stderr (debugging)")
     ap.add_argument("--cpu-images", type=int, default=64, help="images in the CPU-baseline sample (0 = skip); 64 = one full batch, SURVEY 8(d)")
@@ -210,6 +211,7 @@ def main():
     net = net.to(dev)
     smpl = SMPL(smpl_data.synthetic_smpl_model(0), batch_size=1, gender="neutral", num_betas=10).to(dev)
     smpl.fused_mesh = not args.unfused_mesh
+    smpl.picked_joints = not args.gather_joints
 
     lo, hi = sharding.shard_range(B * shard_world, shard_rank, shard_world)   # weak scaling: B images per GPU
     # INPUT_SETS different global batches rotate through the steps (step i reads set i % INPUT_SETS: no step re-reads the
