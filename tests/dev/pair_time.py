@@ -39,8 +39,15 @@ def main():
         _capi.call(name, P(verts), P(jp), _capi.iptr(smpl._csr_ptr), _capi.iptr(smpl._csr_col), P(smpl._csr_val), smpl._n_joint_rows, J, None,
                    P(joints), M, V, _capi.stream())
 
+    picked = verts[:, (smpl._pick_slot >= 0).nonzero().flatten()].contiguous()       # what hps_smpl_mesh_fused_picks leaves beside the vertices
+
+    def jnt_picked():
+        _capi.call("hps_smpl_joints", P(picked), P(jp), _capi.iptr(smpl._csr_ptr), _capi.iptr(smpl._csr_slot), P(smpl._csr_val), smpl._n_joint_rows, J, None,
+                   P(joints), M, smpl._n_picked, _capi.stream())
+
     arms = {"pose_prep v1": lambda: prep("hps_dev_smpl_pose_prep_v1"), "pose_prep r5": lambda: prep("hps_smpl_pose_prep"),
-            "joints v1": lambda: jnt("hps_dev_smpl_joints_v1"), "joints r5": lambda: jnt("hps_smpl_joints")}
+            "joints v1": lambda: jnt("hps_dev_smpl_joints_v1"), "joints r5": lambda: jnt("hps_smpl_joints"),
+            "joints r5 on the mesh kernel's compact side output": jnt_picked}
     times = {k: [] for k in arms}
     flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)          # > the 256 MB Infinity Cache: the vertices come from HBM, as in the step
     with _capi.dev_library():
@@ -56,7 +63,7 @@ def main():
                     times[k].append(e0.elapsed_time(e1) * 1e3)
     for k, v in times.items():
         v.sort()
-        print("%-14s M = %d: median %7.1f us  (min %7.1f, max %7.1f)" % (k, M, v[len(v) // 2], v[0], v[-1]))
+        print("%-52s M = %d: median %7.1f us  (min %7.1f, max %7.1f)" % (k, M, v[len(v) // 2], v[0], v[-1]))
 
 
 if __name__ == "__main__":
