@@ -580,9 +580,19 @@ __global__ __launch_bounds__(256) void heatmap_argmax_kernel(const float* __rest
     const float* h = heat + (size_t)blockIdx.x * HW;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < HW; i += 256) {
+    // strided scan: each lane keeps its first maximum; eight of its elements are requested before the first is compared (same order)
+    int i = threadIdx.x;
+    for (; i + 7 * 256 < HW; i += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = h[i + q * 256];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (v[q] > best) { best = v[q]; bi = i + q * 256; }
+    }
+    for (; i < HW; i += 256) {
         const float v = h[i];
-        if (v > best) { best = v; bi = i; }                  // strided scan: each lane keeps its first maximum
+        if (v > best) { best = v; bi = i; }
     }
     __shared__ float sv[256];
     __shared__ int si[256];
