@@ -163,6 +163,7 @@ def main():
                     help="let the mesh kernel run beside the neighbouring batches' encoders (auto: for batches below 32 images, whose "
                          "encoder cannot fill the chip)")
     ap.add_argument("--encoder-cus", type=int, default=None, help="CUs per XCD of the encoder's partition when the mesh kernel overlaps (0 = shared CUs)")
+    ap.add_argument("--no-inline-mesh", action="store_true", help="A/B: the mesh kernel on the caller's stream with an event on either side (round 4) instead of on the encoder's stream")
     ap.add_argument("--head-cus", type=int, default=None,
                     help="exclusive schedule: CUs per XCD reserved for the head's kernels (the mesh kernel runs on the others); 0 = shared CUs")
     ap.add_argument("--gather-joints", action="store_true", help="A/B: the joint regression gathers its vertices from the meshes (round 4) instead of reading the mesh kernel's compact side output")
@@ -232,6 +233,7 @@ def main():
         pipe.encoder_cus = args.encoder_cus
     if args.head_cus is not None:
         pipe.head_cus = args.head_cus
+    pipe.inline_mesh = not args.no_inline_mesh
 
     step_marks = []
 

@@ -175,6 +175,13 @@ class InferencePipeline:
         # kernels 90-115 us instead of 45, layer1 convolutions 103-120 us instead of 93).  On CUs of its own the head finishes inside
         # the mesh kernel's window.  None = decide from the batch (see _setup_streams).
         self.head_cus = None
+        # inline_mesh (exclusive schedule): the chip-filling mesh kernel of batch i is enqueued ON THE ENCODER'S STREAM, behind encoder
+        # i + 1 and in front of encoder i + 2, instead of on the caller's stream with an event on either side.  The two take turns
+        # anyway; as neighbours in one stream they start back to back, where each cross-stream hand-over (event record -> wait on
+        # another hardware queue) left the chip idle for ~25 us -- twice per step on the critical path (kernel trace: encoder end ->
+        # mesh kernel start 24-27 us, mesh kernel end -> next phase split 24-26 us).  Pose prep (before) and joints / uncertainty (after)
+        # stay on the caller's stream and meet the mesh kernel through events that are off the critical path.
+        self.inline_mesh = True
         # (measured and dropped: making the next encoder wait for the uncertainty pass as well -- B = 16, N = 1000: 3.15 -> 3.24 ms
         # per step; B = 64, N = 100: 3.53 -> 3.51)
 
@@ -319,11 +326,20 @@ class InferencePipeline:
         main = torch.cuda.current_stream()
         main.wait_event(done)
         feats.record_stream(main)
+        inline = self._exclusive and self.inline_mesh and self.mesh_stream is None and self.enc_stream is not None
+
         def hook():
-            if after is not None and self._exclusive:
+            if inline:
+                # everything the mesh kernel reads was produced on `main` (sampling, assembly, pose prep): one event, normally long
+                # signalled when encoder i + 1 drains; from here to smpl_done() the current stream is the encoder's
+                ready = torch.cuda.Event()
+                ready.record(main)
+                self.enc_stream.wait_event(ready)
+                torch.cuda.set_stream(self.enc_stream)
+            elif after is not None and self._exclusive:
                 main.wait_event(after[1])
             if tr is not None:
-                tr["mesh0"].record(main)
+                tr["mesh0"].record(torch.cuda.current_stream())
         hs = self.head_stream
 
         tr = None
@@ -348,6 +364,15 @@ class InferencePipeline:
             return outs
 
         def smpl_done():
+            if inline:
+                done_ev = torch.cuda.Event()
+                done_ev.record(self.enc_stream)
+                if tr is not None:
+                    tr["mesh1"].record(self.enc_stream)
+                torch.cuda.set_stream(main)
+                main.wait_event(done_ev)                 # joints / uncertainty read the vertices
+                self._smpl_done = None                   # the next encoder follows the mesh kernel in stream order
+                return
             self._smpl_done = torch.cuda.Event()
             self._smpl_done.record(main)
             if tr is not None:

@@ -190,24 +190,30 @@ class SMPL(nn.Module):
         P = _capi.ptr
         verts = torch.empty(M, V, 3, **f32)
         joints = torch.empty(M, J + self._n_joint_rows, 3, **f32)
+        # the SMPL configuration also gets the regressor vertices as a compact side output of the mesh kernel
+        use_picks = (self.fused_mesh and self._fused_ok and self.picked_joints and self._lbs_k == 4 and J == 24 and self._k_used == 218
+                     and self._n_picked > 0)
+        picked = torch.empty(M, self._n_picked, 3, **f32) if use_picks else None
         _capi.call("hps_smpl_pose_prep", P(g), P(b), is_rotmat, P(be), self.num_betas, P(self._j_template),
                    P(self._j_shapedirs), _capi.iptr(self._parents_i32), _capi.iptr(self._depth_i32), J, P(xt),
                    self._kp, mp, P(a), P(j_posed), None, M, s)
         # InferencePipeline: only the chip-filling mesh kernel(s) run alone; pose prep (before) and the joint regression (after)
         # may share the GPU with the neighbouring batches' encoders
         if kwargs.get("_before_mesh") is not None:
+            entry_stream = torch.cuda.current_stream()
             kwargs["_before_mesh"]()
+            now = torch.cuda.current_stream()
+            if now != entry_stream:              # the hook moved the mesh kernel to another stream (InferencePipeline.inline_mesh)
+                s = _capi.stream()
+                for t in (xt, a, verts, picked, be, g, b):
+                    if t is not None:
+                        t.record_stream(now)
         ev = None
         if self.lbs_events is not None:      # bench.py: HIP events around the mesh kernel launch, on its own stream
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         trp = P(tr) if tr is not None else None
         v_posed = None
-        picked = None
         if self.fused_mesh and self._fused_ok:
-            # the SMPL configuration also gets the regressor vertices as a compact side output of the mesh kernel
-            use_picks = self.picked_joints and self._lbs_k == 4 and J == 24 and self._k_used == 218 and self._n_picked > 0
-            if use_picks:
-                picked = torch.empty(M, self._n_picked, 3, **f32)
             if ev is not None:
                 ev[0].record()
             if use_picks:
@@ -232,6 +238,7 @@ class SMPL(nn.Module):
             self.lbs_events.append((M, ev[0], ev[1]))
         if kwargs.get("_after_mesh") is not None:
             kwargs["_after_mesh"]()
+            s = _capi.stream()                   # (the hook may have switched back to the caller's stream)
         if picked is not None:      # the regressor vertices lie side by side: same rows, same values, same sums
             _capi.call("hps_smpl_joints", P(picked), P(j_posed), _capi.iptr(self._csr_ptr), _capi.iptr(self._csr_slot),
                        P(self._csr_val), self._n_joint_rows, J, P(tr) if tr is not None else None, P(joints), M, self._n_picked, s)
