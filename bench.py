@@ -163,6 +163,8 @@ def main():
                     help="let the mesh kernel run beside the neighbouring batches' encoders (auto: for batches below 32 images, whose "
                          "encoder cannot fill the chip)")
     ap.add_argument("--encoder-cus", type=int, default=None, help="CUs per XCD of the encoder's partition when the mesh kernel overlaps (0 = shared CUs)")
+    ap.add_argument("--event-every", type=int, default=1,
+                    help="record the HIP timing events around the mesh kernel / encoder on every n-th step only (0 = never: no roofline from this run)")
     ap.add_argument("--no-inline-mesh", action="store_true", help="A/B: the mesh kernel on the caller's stream with an event on either side (round 4) instead of on the encoder's stream")
     ap.add_argument("--head-cus", type=int, default=None,
                     help="exclusive schedule: CUs per XCD reserved for the head's kernels (the mesh kernel runs on the others); 0 = shared CUs")
@@ -237,12 +239,24 @@ def main():
 
     step_marks = []
 
+    ev_lists = {"lbs": None, "enc": None}
+
+    def sample_events(step):
+        # timing events on every args.event_every-th step only: an event record is a marker packet the command processor handles in
+        # ~15 us, and with the mesh kernel on the encoder's stream the markers sit on the critical path
+        on = args.event_every > 0 and step % args.event_every == 0
+        smpl.lbs_events = ev_lists["lbs"] if on else None
+        return on
+
     def run_steps(first, count, on_result=None):
         # input_ready=False: the inputs are resident and complete before the loop starts (nothing produces them on a stream)
+        pipe.enc_events = ev_lists["enc"] if sample_events(first) else None
         ticket = pipe.submit(xs[first % INPUT_SETS], input_ready=False)
         res = None
         for i in range(count):
+            pipe.enc_events = ev_lists["enc"] if (args.event_every > 0 and (first + i + 1) % args.event_every == 0) else None
             nxt = pipe.submit(xs[(first + i + 1) % INPUT_SETS], input_ready=False) if i + 1 < count else None
+            sample_events(first + i)
             res = pipe.finish(ticket, seed=1234 + first + i, image_offset=offset_of(first + i), after=nxt)
             if on_result is not None:
                 on_result(res)
@@ -269,8 +283,8 @@ def main():
                 infer(net, smpl, xs[i % INPUT_SETS], num_samples=N, use_mean_shape=True, seed=1234 + i, image_offset=offset_of(i))))
     sharding.gather_metric_sums(warm_sums)
     torch.cuda.synchronize()
-    smpl.lbs_events = []
-    pipe.enc_events = []
+    smpl.lbs_events = ev_lists["lbs"] = []
+    pipe.enc_events = ev_lists["enc"] = []
     if args.trace_steps:
         pipe.trace = []
     sampling_utils.launch_events = []
@@ -294,7 +308,7 @@ def main():
 
     # LBS kernel time from HIP events recorded around each launch on the launch stream
     M = B * (N + 2)
-    lbs_ms = [e0.elapsed_time(e1) for (m, e0, e1) in smpl.lbs_events if m == M]
+    lbs_ms = [e0.elapsed_time(e1) for (m, e0, e1) in (ev_lists["lbs"] or []) if m == M]
     smpl.lbs_events = None
     lbs_avg_ms = sum(lbs_ms) / max(1, len(lbs_ms))
     achieved = LBS_BYTES_PER_MESH * M / (lbs_avg_ms * 1e-3) / 1e9 if lbs_ms else None
@@ -306,7 +320,7 @@ def main():
 
     # secondary figures of SURVEY section 8(d), same method (HIP events on the launch stream, timed region only); the
     # encoder shares the GPU with the previous batch's head and uncertainty kernels while it runs
-    enc_events_kept = list(pipe.enc_events or [])
+    enc_events_kept = list(ev_lists["enc"] or [])
     enc_ms = [e0.elapsed_time(e1) for (e0, e1) in enc_events_kept]
     smp_ms = [e0.elapsed_time(e1) for (e0, e1) in (sampling_utils.launch_events or [])]
     pipe.enc_events, sampling_utils.launch_events = None, None

@@ -60,6 +60,13 @@ struct WinoGeom {
     unsigned magic_ks;
 };
 
+#ifdef HPS_DEV_BUILD
+__device__ unsigned long long g_wino_stamps[256 * 16];      // profiling (ablate 11): shader-clock stamps of workgroup b's second item at [16 b + k]
+#define WINO_STAMP(k) do { if (ab == 11 && tid == 0 && nth_item == 1) g_wino_stamps[blockIdx.x * 16 + (k)] = clock64(); } while (0)
+#else
+#define WINO_STAMP(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ unsigned wino_div(unsigned n, unsigned d, unsigned magic) {
     unsigned q = __umulhi(n, magic);
     if (n - q * d >= d) ++q;
@@ -78,7 +85,12 @@ __device__ __forceinline__ unsigned wino_div(unsigned n, unsigned d, unsigned ma
 // quarter of a layer's time.  The transform role becomes thread = (tile, ONE channel); the DMA pieces are dealt over eight waves;
 // the output transform needs the other column pair's s[.][2] (resp. s[.][1]): two floats per (tile, channel) cross through the
 // then idle sA buffers; every sum is formed in the four-wave kernel's order (identical bits).
-template <int AB, bool QUAD, bool W8 = false>
+// TR (eight waves only; dev library, ablate = 23): the MFMA operands change places -- filters are the A operand, tiles the B operand -- so a
+// lane owns ONE tile and sixteen output channels in groups of four consecutive ones: the epilogue loads the residual and stores the output
+// as 16-byte vectors (8 + 8 memory instructions per lane instead of 32 + 32 of four bytes).  Every product and every sum is the same:
+// identical bits -- but 2-6 % SLOWER per layer (tests/dev/wino8_check.py): a 16-byte store of 64 lanes touches 32 lines of 128 bytes where
+// a 4-byte store of a lane-per-channel wave writes two whole lines.
+template <int AB, bool QUAD, bool W8 = false, bool TR = false>
 __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ residual, float* __restrict__ y,
@@ -282,6 +294,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
 
     int item = blockIdx.x;
     if (item >= g.items) return;
+    int nth_item = 0;
     int ct;
     size_t out_base;
     locate(item, ct, out_base);
@@ -296,10 +309,15 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
             for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of windows 0..2 and filters 0 (and the last stores)
+        WINO_STAMP(6);
         __syncthreads();                                     // ... everyone's
+        WINO_STAMP(7);
         t_read(0);
         t_write(0);
+        WINO_STAMP(8);
         for (int c = 0; c < nchunks; ++c) {
+            if (c == 1) WINO_STAMP(9);
+            if (c == 2) WINO_STAMP(10);
             const int buf = c & 1;
             if (c > 0) {
                 // filters of chunk c were issued in iteration c - 1 BEFORE window c + 2: with in-order returns, all but the
@@ -339,14 +357,14 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     const float4 a = a4[pp & 1], b = b4[pp & 1];
-                    acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[pp], 0, 0, 0);
-                    acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[pp], 0, 0, 0);
+                    acc[pp] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc[pp], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[pp], 0, 0, 0);
+                    acc[pp] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc[pp], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[pp], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (pp < 4 && more) { t_read2(c + 1, 2 * pp); t_read2(c + 1, 2 * pp + 1); }
                     if (pp == 5 && more) t_write(c + 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[pp], 0, 0, 0);
-                    acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[pp], 0, 0, 0);
+                    acc[pp] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc[pp], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[pp], 0, 0, 0);
+                    acc[pp] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc[pp], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[pp], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 continue;
@@ -395,16 +413,102 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
         const int cur_ct = ct, cur_nimg = nimg;
         const size_t cur_out = out_base;
         const int next = item + gridDim.x;
+        ++nth_item;                                          // (stamps 0-5 belong to the end of the first item, 6-10 to the start of the second)
+        WINO_STAMP(0);
         __syncthreads();                                     // everyone is done with this item's LDS
+        WINO_STAMP(1);
         if (next < g.items) {
             locate(next, ct, out_base);
             prologue_dma();
         }
+        WINO_STAMP(2);
 
         // ---- output transform Y = A^T M A, BatchNorm, residual, ReLU.  A lane owns one output channel (MFMA column) and 16 tiles
         //      (MFMA rows dr = (r & 3) + 8 (r >> 2), + 4 kl, of the wave's 32 = tile rows 4 wm + (dr >> 3), columns 4 kl + (dr & 3)):
         //      per output pixel a half-wave stores 128 contiguous bytes ----
-        if (W8) {
+        if (W8 && ab == 4) {                                 // profiling: no epilogue
+            float t = 0.f;
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[p][r];
+            if (t == 12345.678f) y[0] = t;
+        } else if (W8 && TR) {
+            // The lane's tile is (4 wm + (il >> 3), il & 7) of the item, its channels 8 g + 4 kl + (r & 3) of the wave's 32 for
+            // register r = 4 g + (r & 3).  Row transform, exchange of one column with the partner wave and column transform exactly
+            // as in the other eight-wave form (per register: the sums do not care which of tile / channel a register stands for).
+            const int t_y = il >> 3, t_x = il & 7;
+            const int cb = cur_ct * WC + wn * 32 + 4 * kl;
+            const size_t lane_base = (QUAD ? cur_out + (size_t)(2 * wm + (t_x >> 2)) * g.out_img + (size_t)(2 * t_y) * g.out_row + (size_t)(2 * (t_x & 3) + pg) * g.Cout
+                                           : cur_out + (size_t)(2 * (4 * wm + t_y)) * g.out_row + (size_t)(2 * t_x + pg) * g.Cout) + cb;
+            const bool store_ok = !QUAD || 2 * wm + (t_x >> 2) < cur_nimg;
+            float2* xch = reinterpret_cast<float2*>(sA);
+            float k0[2][16], k1[2][16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    k0[jj][r] = acc[0 + jj][r] + acc[2 + jj][r] + acc[4 + jj][r];
+                    k1[jj][r] = acc[2 + jj][r] - acc[4 + jj][r] - acc[6 + jj][r];
+                }
+            const int w4 = wave & 3;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float2 e = pg == 0 ? make_float2(k0[1][r], k1[1][r]) : make_float2(k0[0][r], k1[0][r]);
+                xch[((pg * 16 + r) * 4 + w4) * 64 + lane] = e;
+            }
+            constexpr bool finish = !QUAD;                   // the 8 x 8 geometry always writes raw partial sums (wino_launch: g.raw = 1)
+            float4 res[2][4], sc4[4], sh4[4];
+            if (finish) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    sc4[q] = *reinterpret_cast<const float4*>(scale + cb + 8 * q);
+                    sh4[q] = *reinterpret_cast<const float4*>(shift + cb + 8 * q);
+                }
+                if (residual) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            res[a][q] = *reinterpret_cast<const float4*>(residual + lane_base + (size_t)a * g.out_row + 8 * q);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float out[2][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * q + e;
+                    const float2 o = xch[(((1 - pg) * 16 + r) * 4 + w4) * 64 + lane];
+                    float yv[2];
+                    if (pg == 0) {
+                        yv[0] = k0[0][r] + k0[1][r] + o.x;
+                        yv[1] = k1[0][r] + k1[1][r] + o.y;
+                    } else {
+                        yv[0] = o.x - k0[0][r] - k0[1][r];
+                        yv[1] = o.y - k1[0][r] - k1[1][r];
+                    }
+                    const float sc = e == 0 ? sc4[q].x : e == 1 ? sc4[q].y : e == 2 ? sc4[q].z : sc4[q].w;
+                    const float sh = e == 0 ? sh4[q].x : e == 1 ? sh4[q].y : e == 2 ? sh4[q].z : sh4[q].w;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        float v = yv[a];
+                        if (finish) {
+                            v = v * sc + sh;
+                            if (residual) v += e == 0 ? res[a][q].x : e == 1 ? res[a][q].y : e == 2 ? res[a][q].z : res[a][q].w;
+                            if (g.relu) v = fmaxf(v, 0.0f);
+                        }
+                        out[a][e] = v;
+                    }
+                }
+                if (store_ok) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        *reinterpret_cast<float4*>(y + lane_base + (size_t)a * g.out_row + 8 * q) = make_float4(out[a][0], out[a][1], out[a][2], out[a][3]);
+                }
+            }
+        } else if (W8) {
             // Row transform s = A^T M for the wave's two columns jj (identical sums, in the four-wave kernel's order), then the column
             // transform needs ONE column of the other pair: y(a, 0) = (s_a[0] + s_a[1]) + s_a[2] is formed by the waves of columns
             // 0-1 with s_a[2] from their partners, y(a, 1) = (s_a[1] - s_a[2]) - s_a[3] by the waves of columns 2-3 with s_a[1].
@@ -438,7 +542,9 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
                     for (int a = 0; a < 2; ++a)
                         res[r][a] = residual[lane_base + (size_t)(2 * (r >> 2) + a) * g.out_row + (size_t)(2 * (r & 3)) * g.Cout];
             }
+            WINO_STAMP(3);
             __syncthreads();
+            WINO_STAMP(4);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float2 o = xch[(((1 - pg) * 16 + r) * 4 + w4) * 64 + lane];
@@ -461,6 +567,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
                     if (store_ok) y[lane_base + (size_t)(2 * (r >> 2) + a) * g.out_row + (size_t)(2 * (r & 3)) * g.Cout] = v;
                 }
             }
+            WINO_STAMP(5);
         } else if (ab != 4) {
             const int co = cur_ct * WC + wn * 32 + il;
             const float sc = scale[co], sh = shift[co];
@@ -610,21 +717,24 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
         hipLaunchKernelGGL((conv_wino_kernel<ab, q>), grid, dim3(256), lds, (hipStream_t)stream, x, u, scale, shift, quad ? nullptr : residual,
                            quad ? splitk_ws : y, g);
     };
-    auto launch8 = [&](auto Q) {                              // the eight-wave form (the product)
-        constexpr bool q = decltype(Q)::value;
-        if ((grant_rc = grant_lds<&conv_wino_kernel<0, q, true>>(160 * 1024, "hps_conv3x3_winograd")) != HPS_OK) return;
-        hipLaunchKernelGGL((conv_wino_kernel<0, q, true>), grid, dim3(512), lds, (hipStream_t)stream, x, u, scale, shift, quad ? nullptr : residual,
+    auto launch8 = [&](auto Q, auto TRF, auto AB) {           // the eight-wave forms (the product: TRF = true)
+        constexpr bool q = decltype(Q)::value, tr = decltype(TRF)::value;
+        constexpr int ab = decltype(AB)::value;
+        if ((grant_rc = grant_lds<&conv_wino_kernel<ab, q, true, tr>>(160 * 1024, "hps_conv3x3_winograd")) != HPS_OK) return;
+        hipLaunchKernelGGL((conv_wino_kernel<ab, q, true, tr>), grid, dim3(512), lds, (hipStream_t)stream, x, u, scale, shift, quad ? nullptr : residual,
                            quad ? splitk_ws : y, g);
     };
+    typedef std::integral_constant<int, 0> Z;
     typedef std::integral_constant<bool, false> F;
     typedef std::integral_constant<bool, true> T;
     if (quad) {
-        if (ablate != 0 && ablate != 21) return bad_arg("hps_conv3x3_winograd: ablations exist for the 16 x 16-block geometry only");
+        if (ablate != 0 && ablate != 21 && ablate != 23) return bad_arg("hps_conv3x3_winograd: ablations exist for the 16 x 16-block geometry only");
 #ifdef HPS_DEV_BUILD
         if (ablate == 21) launch(std::integral_constant<int, 0>(), T());      // the four-wave form
+        else if (ablate == 23) launch8(T(), T(), Z());                        // eight waves, a lane owns a tile (16-byte stores: slower)
         else
 #endif
-            launch8(T());
+            launch8(T(), F(), Z());
         if (grant_rc != HPS_OK) return grant_rc;
         const int rc = check_launch("hps_conv3x3_winograd");
         if (rc != HPS_OK) return rc;
@@ -634,8 +744,16 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
         return check_launch("hps_conv3x3_winograd (slices)");
     }
     switch (ablate) {
-        case 0: launch8(F()); break;                                            // the product form: eight waves
+        case 0: launch8(F(), F(), Z()); break;                                  // the product form: eight waves, a lane owns a channel
 #ifdef HPS_DEV_BUILD
+        case 23: launch8(F(), T(), Z()); break;                                 // eight waves, a lane owns a tile (16-byte stores; identical bits, slower)
+        case 24: launch8(F(), F(), std::integral_constant<int, 4>()); break;    // profiling: the product form without its epilogue
+        case 31: launch8(F(), F(), std::integral_constant<int, 1>()); break;    // ... without patch reads / transform / window DMA
+        case 33: launch8(F(), F(), std::integral_constant<int, 3>()); break;    // ... without filter DMA
+        case 35: launch8(F(), F(), std::integral_constant<int, 5>()); break;    // ... window DMA but no transform
+        case 36: launch8(F(), F(), std::integral_constant<int, 6>()); break;    // ... transform but no window DMA
+        case 40: launch8(F(), F(), std::integral_constant<int, 10>()); break;   // ... no barrier per chunk (races)
+        case 11: launch8(F(), F(), std::integral_constant<int, 11>()); break;   // profiling: lane = channel form with clock stamps (hps_dev_wino_stamps)
         case 21: launch(std::integral_constant<int, 0>(), F()); break;          // the four-wave form (identical bits; the ablations below are its)
         case 1: launch(std::integral_constant<int, 1>(), F()); break;
         case 2: launch(std::integral_constant<int, 2>(), F()); break;
@@ -661,6 +779,10 @@ extern "C" int hps_conv3x3_winograd(const float* x, const float* u, const float*
 }
 
 #ifdef HPS_DEV_BUILD
+extern "C" int hps_dev_wino_stamps(unsigned long long* host_out, int n) {      // n <= 4096 stamps of the last ablate-11 launch
+    if (!host_out || n < 0 || n > 256 * 16) return bad_arg("hps_dev_wino_stamps");
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wino_stamps), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? HPS_OK : HPS_E_UNSUPPORTED;
+}
 extern "C" int hps_dev_wino_quad_ksplit(int ks) {       // experiment: K slices of the 8 x 8 geometry (0 = the product rule)
     g_wino_quad_ks = ks;
     return HPS_OK;

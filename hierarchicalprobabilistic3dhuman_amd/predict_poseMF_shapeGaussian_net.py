@@ -336,6 +336,9 @@ class InferencePipeline:
                 ready.record(main)
                 self.enc_stream.wait_event(ready)
                 torch.cuda.set_stream(self.enc_stream)
+                if tr is not None:
+                    tr["mesh0"].record(self.enc_stream)
+                return "ordered"                         # smpl_done() makes `main` wait for the mesh kernel (see SMPL.forward)
             elif after is not None and self._exclusive:
                 main.wait_event(after[1])
             if tr is not None:

@@ -201,13 +201,19 @@ class SMPL(nn.Module):
         # may share the GPU with the neighbouring batches' encoders
         if kwargs.get("_before_mesh") is not None:
             entry_stream = torch.cuda.current_stream()
-            kwargs["_before_mesh"]()
+            ordered = kwargs["_before_mesh"]()
             now = torch.cuda.current_stream()
             if now != entry_stream:              # the hook moved the mesh kernel to another stream (InferencePipeline.inline_mesh)
                 s = _capi.stream()
-                for t in (xt, a, verts, picked, be, g, b):
-                    if t is not None:
-                        t.record_stream(now)
+                # The operands were allocated on the entry stream.  A hook that returns "ordered" promises that its _after_mesh
+                # partner makes the entry stream wait for the mesh kernel before anything else is queued there: the allocator hands
+                # these blocks back to the entry stream's pool only, so every reuse is ordered behind the kernel.  Without the promise
+                # the tensors are registered with the other stream -- which costs an event record ON THAT STREAM for each of them
+                # when they are freed (seven markers of ~6 us in front of the next encoder, measured: profiles/r05_experiments.txt).
+                if ordered != "ordered":
+                    for t in (xt, a, verts, picked, be, g, b):
+                        if t is not None:
+                            t.record_stream(now)
         ev = None
         if self.lbs_events is not None:      # bench.py: HIP events around the mesh kernel launch, on its own stream
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

@@ -104,6 +104,8 @@ int hps_dev_mesh_lds_floor(int bytes);
 /* Experiment hook: K slices of hps_conv3x3_winograd's 8 x 8 geometry (0 = the product rule: four when >= 32 chunks).  Also changes
  * hps_conv3x3_winograd_workspace's answer. */
 int hps_dev_wino_quad_ksplit(int ks);
+/* profiling: shader-clock stamps written by hps_dev_conv3x3_winograd(ablate = 11): workgroup b's phase k at [16 b + k] */
+int hps_dev_wino_stamps(unsigned long long* host_out, int n);
 
 /* Tuning hook (tests/dev only): 1 = hps_conv2d_bn_act_pad skips its epilogue (results are garbage), 0 = normal. */
 int hps_dev_conv_pad_ablate(int mode);

@@ -1,5 +1,6 @@
-"""The eight-wave form of the Winograd kernel (the product: hps_dev_conv3x3_winograd, ablate = 0) against the four-wave kernel (ablate = 21): identical
-bits (with / without residual and ReLU, full and small batches), and the time of both.  Dev library.  usage: wino8_check.py"""
+"""The eight-wave forms of the Winograd kernel (the product: hps_dev_conv3x3_winograd, ablate = 0 -- a lane owns a channel, 4-byte stores; ablate = 23 --
+a lane owns a tile, 16-byte stores) against the four-wave kernel (ablate = 21): identical bits (with / without residual and ReLU, full and small
+batches), and the time of all three (+ the product without its epilogue, ablate = 24).  Dev library.  usage: wino8_check.py"""
 import os
 import sys
 
@@ -41,15 +42,15 @@ with _capi.dev_library():
             for use_res in (False, True):
                 for relu in (1, 0):
                     outs = []
-                    for ab in (21, 0):
+                    for ab in (21, 23, 0):
                         out = torch.zeros(B, H + 2, H + 2, C, device=dev)
                         _capi.call("hps_dev_conv3x3_winograd", P(x), P(cb.wino_u), P(cb.scale), P(cb.shift), P(res) if use_res else None, P(out),
                                    B, H, H, 1, C, C, 1, relu, P(ws) if H == 8 else None, ab, _capi.stream())
                         torch.cuda.synchronize()
                         outs.append(out)
-                    same = torch.equal(outs[0], outs[1])
-                    err = float((outs[0] - outs[1]).abs().max())
-                    halo = float(outs[1][:, 0].abs().max() + outs[1][:, :, 0].abs().max() + outs[1][:, -1].abs().max() + outs[1][:, :, -1].abs().max())
+                    same = torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+                    err = float((outs[0] - outs[2]).abs().max())
+                    halo = float(outs[2][:, 0].abs().max() + outs[2][:, :, 0].abs().max() + outs[2][:, -1].abs().max() + outs[2][:, :, -1].abs().max())
                     print("%2dx%-2d C=%3d B=%2d residual=%d relu=%d: identical=%s max|diff|=%.3g halo=%.1g" % (H, H, C, B, use_res, relu, same, err, halo), flush=True)
         x = F.pad(torch.relu(torch.randn(64, H, H, C, device=dev)), (0, 0, 1, 1, 1, 1)).contiguous()
         out = torch.zeros(64, H + 2, H + 2, C, device=dev)
@@ -57,10 +58,15 @@ with _capi.dev_library():
         for use_res in (False, True):
             ts = []
             for rep in range(3):
-                for ab in (21, 0):
+                for ab in (21, 23, 0) + ((24, 31, 33, 35, 36, 40) if H != 8 else ()):
                     fn = lambda: _capi.call("hps_dev_conv3x3_winograd", P(x), P(cb.wino_u), P(cb.scale), P(cb.shift), P(res) if use_res else None,
                                             P(out), 64, H, H, 1, C, C, 1, 1, P(ws) if H == 8 else None, ab, _capi.stream())
                     ts.append((ab, timeit(fn)))
             t4 = sorted(t for a, t in ts if a == 21)[1]
+            t8t = sorted(t for a, t in ts if a == 23)[1]
             t8 = sorted(t for a, t in ts if a == 0)[1]
-            print("%2dx%-2d C=%3d B=64 residual=%d: four waves %.4f ms, eight waves %.4f ms (%+.1f %%)" % (H, H, C, use_res, t4, t8, 100 * (t8 / t4 - 1)), flush=True)
+            print("%2dx%-2d C=%3d B=64 residual=%d: four waves %.4f ms, eight waves (lane = channel, product) %.4f ms (%+.1f %%), eight waves (lane = tile) %.4f ms"
+                  % (H, H, C, use_res, t4, t8, 100 * (t8 / t4 - 1), t8t), flush=True)
+            if H != 8:
+                print("      product form without: epilogue %.4f | patch reads, transform, window DMA %.4f | filter DMA %.4f | transform (window DMA kept) %.4f | "
+                      "window DMA (transform kept) %.4f | barrier per chunk %.4f" % tuple(sorted(t for a, t in ts if a == ab)[1] for ab in (24, 31, 33, 35, 36, 40)), flush=True)

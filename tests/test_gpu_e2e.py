@@ -181,6 +181,34 @@ def test_pipelined_steps_equal_sequential_infer(dev, net_gpu, smpl_gpu, golden_i
             assert torch.equal(w[k], g[k]), k
 
 
+def test_mesh_kernel_on_the_encoder_stream_equals_the_separate_stream_schedule(dev, net_gpu, smpl_gpu):
+    """InferencePipeline.inline_mesh (the mesh kernel queued on the encoder's stream; its operands are NOT registered with that stream -- the
+    caller's stream waits for the kernel instead, SMPL.forward "ordered") returns the bits of the schedule that keeps the kernel on the caller's
+    stream, over steps that free and re-allocate every operand (the allocator reuses the blocks at once)."""
+    from hierarchicalprobabilistic3dhuman_amd.predict_poseMF_shapeGaussian_net import InferencePipeline
+    torch.manual_seed(5)
+    xs = [torch.rand(32, 18, 256, 256, device=dev) for _ in range(2)]
+    sums = {}
+    for inline in (True, False, True):
+        pipe = InferencePipeline(net_gpu, smpl_gpu, num_samples=20)
+        pipe.inline_mesh = inline
+        acc = []
+        t = pipe.submit(xs[0], input_ready=False)
+        for i in range(6):
+            nxt = pipe.submit(xs[(i + 1) % 2], input_ready=False) if i < 5 else None
+            res = pipe.finish(t, seed=90 + i, after=nxt)
+            acc.append(torch.stack([res["verts_samples"].double().sum(), res["unc"].double().sum(), res["joints_samples"].double().sum()
+                                    if "joints_samples" in res else res["verts_mode"].double().sum()]))
+            scratch = torch.empty_like(res["verts_samples"]).fill_(float(i))      # churn: the freed blocks are taken again immediately
+            del res, scratch
+            t = nxt
+        torch.cuda.synchronize()
+        got = torch.stack(acc).cpu()
+        assert torch.isfinite(got).all()
+        sums.setdefault(inline, []).append(got)
+    assert torch.equal(sums[True][0], sums[False][0]) and torch.equal(sums[True][0], sums[True][1])
+
+
 def test_pipeline_from_host_rgb_equals_infer_on_the_proxy_representation(dev, net_gpu, smpl_gpu):
     """The reference's order of work (predict/...:61-104) as the pipelined loop runs it: page-locked host RGB crops + keypoints ->
     StagedUpload (copy stream, two device slots) -> submit(make_input=...) builds the proxy representation on the encoder's stream
