@@ -84,6 +84,7 @@ _DEV_PROTOTYPES = {
     "hps_dev_conv_pad_ablate": [_I],
     "hps_dev_wino_quad_ksplit": [_I],
     "hps_dev_wino_stamps": [_P, _I],
+    "hps_dev_conv3x3_winograd_half": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "hps_dev_unc_mode": [_I],
     "hps_dev_mesh_lds_floor": [_I],
     "hps_dev_mesh_stages": [_I],

@@ -357,14 +357,18 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     const float4 a = a4[pp & 1], b = b4[pp & 1];
+                    if (ab == 12) __builtin_amdgcn_s_setprio(3);
                     acc[pp] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc[pp], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[pp], 0, 0, 0);
                     acc[pp] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc[pp], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[pp], 0, 0, 0);
+                    if (ab == 12) __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (pp < 4 && more) { t_read2(c + 1, 2 * pp); t_read2(c + 1, 2 * pp + 1); }
                     if (pp == 5 && more) t_write(c + 1);
                     __builtin_amdgcn_sched_barrier(0);
+                    if (ab == 12) __builtin_amdgcn_s_setprio(3);
                     acc[pp] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc[pp], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[pp], 0, 0, 0);
                     acc[pp] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc[pp], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[pp], 0, 0, 0);
+                    if (ab == 12) __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 continue;
@@ -648,6 +652,244 @@ __global__ __launch_bounds__(256) void wino_splitk_epilogue_kernel(const float* 
     *reinterpret_cast<float4*>(y + o) = v;
 }
 
+#ifdef HPS_DEV_BUILD
+// ------------------------------------------------------------------------------------------------------------------------------------
+// The half-item form (dev library only; experiment of round 5, measured 12-16 % SLOWER than the product -- tests/dev/wino_half_check.py): the same arithmetic on work items of 4 x 8 tiles (8 x 16 output pixels) x 64
+// output channels, FOUR waves per workgroup and 66 KB of LDS, so that TWO workgroups share a CU and one's barriers, DMA waits and epilogue
+// run under the other's MFMAs.  K is streamed in half-chunks of four channels -- {0, 4, 1, 5} then {2, 6, 3, 7} of an eight-channel chunk,
+// i.e. the k pairs (0, 4), (1, 5), (2, 6), (3, 7) in the product kernel's order: identical bits.  Waves = (column pair pg of the sixteen
+// positions) x (32-channel half wn): eight positions, 128 accumulator registers each; the raw windows stay eight channels wide (a ring of
+// three 10 x 18-pixel windows, each serving two half-chunks), the filters come in a second packing u4[half-chunk][cout tile][16 positions]
+// [64 channels][kl][slot] (resnet.py), the input transform is split by output rows between the thread halves (rows 0-1: patch rows 0-2,
+// rows 2-3: patch rows 1-3), and the epilogue is the eight-wave form's with the exchange buffer in sA + the idle filter buffer.
+// What it showed: the epilogue does hide (4.1 -> 1.8 us per layer), but every MFMA now carries twice the LDS and DMA instructions (b64
+// fragments, 16 KB of filters per 16 MFMAs and workgroup: ~10 TB/s of L2 -> LDS traffic chip-wide) and the K loop runs at 0.61 of the MFMA
+// rate instead of 0.74.
+constexpr int H_A = 16 * 32 * 4;              // floats of one transformed-input buffer   [position][tile][kl][slot]   (8 KB)
+constexpr int H_B = 16 * 64 * 4;              // floats of one filter buffer              [position][channel][kl][slot] (16 KB)
+constexpr int H_WIN = 10 * 18;                // pixels of an item's raw window
+constexpr int H_RAW = 6 * 256;                // floats of a ring slot: six 1 KiB DMA pieces (the window is 5 760 bytes)
+
+template <int AB>
+__global__ __launch_bounds__(256, 2) void conv_wino_half_kernel(const float* __restrict__ x, const float* __restrict__ u4,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                const float* __restrict__ residual, float* __restrict__ y, const WinoGeom g) {
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // sB[0] | sA[0] | sA[1] | sB[1] | ring[3]
+    float* sB0 = smem;
+    float* sA = smem + H_B;
+    float* sB1 = smem + H_B + 2 * H_A;
+    float* sR = smem + 2 * H_B + 2 * H_A;
+    constexpr int ab = AB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kl = lane >> 5, il = lane & 31;
+    const int pg = wave >> 1, wn = wave & 1;
+    const int nh = g.Cin / 4, n8 = g.Cin / 8;
+
+    // ---- raw-window DMA role: piece q covers window entries e = 64 q + lane (pixel e >> 1, 16-byte half e & 1); wave w moves piece w in the
+    //      first half-step of a window's turn and (w < 2) piece 4 + w in the second ----
+    unsigned r_off[2];
+    bool r_ok[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int e = 64 * (wave + 4 * t) + lane;
+        r_ok[t] = (t == 0 || wave < 2) && e < 2 * H_WIN;
+        const int px = r_ok[t] ? (e >> 1) : 0;
+        r_off[t] = (unsigned)(((px / 18) * g.in_row + (px % 18) * g.Cin + (e & 1) * 4) * 4);
+    }
+    const unsigned lds_r0 = (unsigned)(size_t)(lptr_t)(sR);
+    const unsigned lds_b[2] = {(unsigned)(size_t)(lptr_t)(sB0), (unsigned)(size_t)(lptr_t)(sB1)};
+
+    // ---- transform role: thread = (row half hh = tid >> 7, tile (ty, tx) = ((tid >> 5) & 3, (tid >> 2) & 7), channel slot ch = tid & 3 = 2 kl + slot) ----
+    const int hh = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int ltile = (tid >> 2) & 31, ch = tid & 3;
+    const int w_slot = ((2 * (ltile >> 3) + hh) * 18 + 2 * (ltile & 7)) * 8 + (ch & 1) + 4 * (ch >> 1);    // patch pixel (hh, 0), channel of half-chunk parity 0
+    const int a_slot = ltile * 4 + ch + hh * 8 * 128;                                                   // (tile, kl, slot) of position 8 hh in sA
+
+    const float* fa = sA + il * 4 + kl * 2;                        // this lane's fragment of position 0, buffer 0
+    const int fb_off = (wn * 32 + il) * 4 + kl * 2;
+
+    const float* x_item = nullptr;
+    const float* u_item = nullptr;
+    auto locate = [&](int item, int& ct, size_t& out_base) {
+        const unsigned hb = wino_div((unsigned)item, (unsigned)g.n_ct, g.magic_ct);       // (image, block, half)
+        ct = item - hb * g.n_ct;
+        const unsigned blk = hb >> 1, half = hb & 1;
+        const unsigned b = wino_div(blk, (unsigned)g.blocks_img, g.magic_img), rem = blk - b * g.blocks_img;
+        const unsigned by = wino_div(rem, (unsigned)g.blocks_x, g.magic_x), bx = rem - by * g.blocks_x;
+        x_item = x + (size_t)b * g.in_img + (size_t)(16 * by + 8 * half + g.ipad - 1) * g.in_row + (size_t)(16 * bx + g.ipad - 1) * g.Cin;
+        u_item = u4 + (size_t)ct * H_B;
+        out_base = (size_t)b * g.out_img + (size_t)(16 * by + 8 * half + g.opad) * g.out_row + (size_t)(16 * bx + g.opad) * g.Cout;
+    };
+    auto dma_raw_piece = [&](int c8, int t) {                  // window of chunk c8 -> ring slot c8 % 3, piece wave + 4 t
+        if (r_ok[t]) lds_dma16(r_off[t], x_item + c8 * 8, lds_r0 + (unsigned)((c8 % 3) * H_RAW * 4 + (wave + 4 * t) * 1024));
+    };
+    auto dma_filter_piece = [&](int h, int q) {                // filters of half-chunk h -> sB[h & 1]; wave w moves pieces 4 w .. 4 w + 3
+        lds_dma16((unsigned)((wave * 4 + q) * 1024 + lane * 16), u_item + (size_t)h * g.n_ct * H_B, lds_b[h & 1] + (unsigned)((wave * 4 + q) * 1024));
+    };
+    float d[12];                                               // the thread's three patch rows x four columns (one channel)
+    auto t_read3 = [&](int h, int q) {                         // patch row q (0..2) of the thread's half
+        const float* src = sR + (((h >> 1) % 3) * H_RAW) + w_slot + 2 * (h & 1) + q * 18 * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[q * 4 + j] = src[j * 8];
+    };
+    auto t_write = [&](int h) {
+        float* dst = sA + (h & 1) * H_A + a_slot;
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (hh == 0) {                                     // rows 0, 1 of t = B^T d from patch rows 0, 1, 2
+                t[j] = d[0 * 4 + j] - d[2 * 4 + j];
+                t[4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
+            } else {                                           // rows 2, 3 from patch rows 1, 2, 3 (the thread's local rows 0, 1, 2)
+                t[j] = d[1 * 4 + j] - d[0 * 4 + j];
+                t[4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            dst[(i * 4 + 0) * 128] = t[i * 4 + 0] - t[i * 4 + 2];
+            dst[(i * 4 + 1) * 128] = t[i * 4 + 1] + t[i * 4 + 2];
+            dst[(i * 4 + 2) * 128] = t[i * 4 + 2] - t[i * 4 + 1];
+            dst[(i * 4 + 3) * 128] = t[i * 4 + 1] - t[i * 4 + 3];
+        }
+    };
+    auto prologue_dma = [&]() {                                // first DMAs of an item: filters of half-chunk 0, windows 0..2
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma_filter_piece(0, q);
+#pragma unroll
+        for (int c8 = 0; c8 < 3; ++c8)
+            if (c8 < n8) { dma_raw_piece(c8, 0); dma_raw_piece(c8, 1); }
+    };
+
+    int item = blockIdx.x;
+    if (item >= g.items) return;
+    int ct;
+    size_t out_base;
+    locate(item, ct, out_base);
+    prologue_dma();
+
+    for (;;) {
+        f32x16 acc[8];                                         // acc[2 i + jj] = position 4 i + 2 pg + jj
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 3; ++q) t_read3(0, q);
+        t_write(0);
+        for (int h = 0; h < nh; ++h) {
+            const int buf = h & 1;
+            if (h > 0) {
+                // the filters of half-chunk h went out in half-step h - 1 BEFORE that step's window piece (needed three half-steps later)
+                const int cfree = (h - 2) >> 1;                // the window whose slot half-step h - 1 refilled (h - 1 >= 1)
+                const bool issued = h >= 2 && cfree + 3 < n8 && (((h - 1) & 1) || wave < 2);
+                if (issued) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();                                   // operands of half-chunk h complete; the other buffers and the ring slot of window (h - 1) / 2 - ... are free
+            const bool more = h + 1 < nh;
+            const int cnew = ((h - 1) >> 1) + 3;               // h >= 1: window to fetch into the slot that window (h - 1) / 2 left
+            const bool fetch = h >= 1 && cnew < n8;
+            const float* pa = fa + buf * H_A + pg * 2 * 128;
+            const float* pb = (buf ? sB1 : sB0) + fb_off + pg * 2 * 256;
+            float2 a2[2], b2[2];
+            a2[0] = *reinterpret_cast<const float2*>(pa);
+            b2[0] = *reinterpret_cast<const float2*>(pb);
+#pragma unroll
+            for (int pp = 0; pp < 8; ++pp) {                   // pp = 2 i + jj: position 4 i + 2 pg + jj
+                const int pn = 4 * ((pp + 1) >> 1) + ((pp + 1) & 1);
+                if (more && pp < 4) dma_filter_piece(h + 1, pp);
+                if (fetch && pp == 5) dma_raw_piece(cnew, (h - 1) & 1 ? 1 : 0);
+                if (pp < 7) {
+                    a2[(pp + 1) & 1] = *reinterpret_cast<const float2*>(pa + pn * 128);
+                    b2[(pp + 1) & 1] = *reinterpret_cast<const float2*>(pb + pn * 256);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float2 a = a2[pp & 1], b = b2[pp & 1];
+                acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[pp], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && pp < 3) t_read3(h + 1, pp);
+                if (more && pp == 5) t_write(h + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[pp], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        const int cur_ct = ct;
+        const size_t cur_out = out_base;
+        const int next = item + gridDim.x;
+        __syncthreads();                                       // everyone is done with this item's LDS
+        if (next < g.items) {
+            locate(next, ct, out_base);
+            prologue_dma();
+        }
+        if (ab == 4) {                                         // profiling: no epilogue
+            float t = 0.f;
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[p][r];
+            if (t == 12345.678f) y[0] = t;
+        } else {
+            // the eight-wave form's epilogue with one tile group: a lane owns channel co and the 16 tiles (r >> 2, 4 kl + (r & 3)) of the item
+            const int co = cur_ct * WC + wn * 32 + il;
+            const float sc = scale[co], sh = shift[co];
+            const size_t lane_base = cur_out + (size_t)(8 * kl) * g.Cout + co + (size_t)pg * g.Cout;
+            float2* xch = reinterpret_cast<float2*>(sA);       // 32 KB: sA[0], sA[1] and the idle filter buffer sB[1]
+            float k0[2][16], k1[2][16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    k0[jj][r] = acc[0 + jj][r] + acc[2 + jj][r] + acc[4 + jj][r];
+                    k1[jj][r] = acc[2 + jj][r] - acc[4 + jj][r] - acc[6 + jj][r];
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float2 e = pg == 0 ? make_float2(k0[1][r], k1[1][r]) : make_float2(k0[0][r], k1[0][r]);
+                xch[((pg * 16 + r) * 2 + wn) * 64 + lane] = e;
+            }
+            float res[16][2];
+            if (residual) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        res[r][a] = residual[lane_base + (size_t)(2 * (r >> 2) + a) * g.out_row + (size_t)(2 * (r & 3)) * g.Cout];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float2 o = xch[(((1 - pg) * 16 + r) * 2 + wn) * 64 + lane];
+                float yv[2];
+                if (pg == 0) {
+                    yv[0] = k0[0][r] + k0[1][r] + o.x;
+                    yv[1] = k1[0][r] + k1[1][r] + o.y;
+                } else {
+                    yv[0] = o.x - k0[0][r] - k0[1][r];
+                    yv[1] = o.y - k1[0][r] - k1[1][r];
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float v = yv[a] * sc + sh;
+                    if (residual) v += res[r][a];
+                    if (g.relu) v = fmaxf(v, 0.0f);
+                    y[lane_base + (size_t)(2 * (r >> 2) + a) * g.out_row + (size_t)(2 * (r & 3)) * g.Cout] = v;
+                }
+            }
+        }
+        if (next >= g.items) break;
+        item = next;
+    }
+}
+#endif  // HPS_DEV_BUILD
+
 static unsigned wino_magic(unsigned d) { return d <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / d); }
 
 }  // namespace hps
@@ -753,6 +995,7 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
         case 35: launch8(F(), F(), std::integral_constant<int, 5>()); break;    // ... window DMA but no transform
         case 36: launch8(F(), F(), std::integral_constant<int, 6>()); break;    // ... transform but no window DMA
         case 40: launch8(F(), F(), std::integral_constant<int, 10>()); break;   // ... no barrier per chunk (races)
+        case 42: launch8(F(), F(), std::integral_constant<int, 12>()); break;   // experiment: raised wave priority around the MFMAs
         case 11: launch8(F(), F(), std::integral_constant<int, 11>()); break;   // profiling: lane = channel form with clock stamps (hps_dev_wino_stamps)
         case 21: launch(std::integral_constant<int, 0>(), F()); break;          // the four-wave form (identical bits; the ablations below are its)
         case 1: launch(std::integral_constant<int, 1>(), F()); break;
@@ -778,6 +1021,44 @@ extern "C" int hps_conv3x3_winograd(const float* x, const float* u, const float*
     return wino_launch(x, u, scale, shift, residual, y, B, H, W, ipad, Cin, Cout, opad, relu, splitk_ws, 0, stream);
 }
 
+#ifdef HPS_DEV_BUILD
+// experiment: the half-item form (two four-wave workgroups per CU); u4 = resnet.py's half-chunk packing of the transformed filters
+extern "C" int hps_dev_conv3x3_winograd_half(const float* x, const float* u4, const float* scale, const float* shift, const float* residual,
+                                             float* y, int B, int H, int W, int ipad, int Cin, int Cout, int opad, int relu, int ablate,
+                                             int wgs_per_cu, hps_stream_t stream) {
+    if (!x || !u4 || !scale || !shift || !y) return bad_arg("hps_dev_conv3x3_winograd_half: null pointer");
+    if (B <= 0) return HPS_OK;
+    if (H <= 0 || W <= 0 || (H % 16) || (W % 16) || Cin % 8 != 0 || Cout % WC != 0 || ipad < 1 || opad < 0)
+        return bad_arg("hps_dev_conv3x3_winograd_half: shape");
+    WinoGeom g;
+    g.in_row = (W + 2 * ipad) * Cin;
+    g.in_img = (H + 2 * ipad) * g.in_row;
+    g.out_row = (W + 2 * opad) * Cout;
+    g.out_img = (H + 2 * opad) * g.out_row;
+    g.ipad = ipad; g.opad = opad;
+    g.blocks_x = W / 16;
+    g.blocks_img = (H / 16) * (W / 16);
+    g.Cin = Cin; g.Cout = Cout; g.n_ct = Cout / WC; g.relu = relu;
+    g.items = B * g.blocks_img * 2 * g.n_ct;
+    g.B = B; g.ksplit = 1; g.cps = Cin / WK; g.raw = 0;
+    g.magic_ct = wino_magic((unsigned)g.n_ct);
+    g.magic_img = wino_magic((unsigned)g.blocks_img);
+    g.magic_x = wino_magic((unsigned)g.blocks_x);
+    g.magic_ks = wino_magic(1u);
+    const size_t lds = (size_t)(2 * H_A + 2 * H_B + 3 * H_RAW) * sizeof(float);        // 67 584 bytes
+    const int wgs = 256 * (wgs_per_cu > 0 ? wgs_per_cu : 2);
+    const dim3 grid((unsigned)(g.items < wgs ? g.items : wgs));
+    int rc = HPS_OK;
+    if (ablate == 4) {
+        if ((rc = grant_lds<&conv_wino_half_kernel<4>>(160 * 1024, "hps_dev_conv3x3_winograd_half")) != HPS_OK) return rc;
+        hipLaunchKernelGGL((conv_wino_half_kernel<4>), grid, dim3(256), lds, (hipStream_t)stream, x, u4, scale, shift, residual, y, g);
+    } else {
+        if ((rc = grant_lds<&conv_wino_half_kernel<0>>(160 * 1024, "hps_dev_conv3x3_winograd_half")) != HPS_OK) return rc;
+        hipLaunchKernelGGL((conv_wino_half_kernel<0>), grid, dim3(256), lds, (hipStream_t)stream, x, u4, scale, shift, residual, y, g);
+    }
+    return check_launch("hps_dev_conv3x3_winograd_half");
+}
+#endif
 #ifdef HPS_DEV_BUILD
 extern "C" int hps_dev_wino_stamps(unsigned long long* host_out, int n) {      // n <= 4096 stamps of the last ablate-11 launch
     if (!host_out || n < 0 || n > 256 * 16) return bad_arg("hps_dev_wino_stamps");

@@ -104,6 +104,10 @@ int hps_dev_mesh_lds_floor(int bytes);
 /* Experiment hook: K slices of hps_conv3x3_winograd's 8 x 8 geometry (0 = the product rule: four when >= 32 chunks).  Also changes
  * hps_conv3x3_winograd_workspace's answer. */
 int hps_dev_wino_quad_ksplit(int ks);
+/* experiment: Winograd layer on half items (4 x 8 tiles), two four-wave workgroups per CU; u4 = the half-chunk packing of the filters */
+int hps_dev_conv3x3_winograd_half(const float* x, const float* u4, const float* scale, const float* shift, const float* residual,
+                                  float* y, int B, int H, int W, int ipad, int Cin, int Cout, int opad, int relu, int ablate,
+                                  int wgs_per_cu, hps_stream_t stream);
 /* profiling: shader-clock stamps written by hps_dev_conv3x3_winograd(ablate = 11): workgroup b's phase k at [16 b + k] */
 int hps_dev_wino_stamps(unsigned long long* host_out, int n);
 

@@ -58,7 +58,7 @@ with _capi.dev_library():
         for use_res in (False, True):
             ts = []
             for rep in range(3):
-                for ab in (21, 23, 0) + ((24, 31, 33, 35, 36, 40) if H != 8 else ()):
+                for ab in (21, 23, 0) + ((24, 31, 33, 35, 36, 40, 42) if H != 8 else ()):
                     fn = lambda: _capi.call("hps_dev_conv3x3_winograd", P(x), P(cb.wino_u), P(cb.scale), P(cb.shift), P(res) if use_res else None,
                                             P(out), 64, H, H, 1, C, C, 1, 1, P(ws) if H == 8 else None, ab, _capi.stream())
                     ts.append((ab, timeit(fn)))
@@ -69,4 +69,4 @@ with _capi.dev_library():
                   % (H, H, C, use_res, t4, t8, 100 * (t8 / t4 - 1), t8t), flush=True)
             if H != 8:
                 print("      product form without: epilogue %.4f | patch reads, transform, window DMA %.4f | filter DMA %.4f | transform (window DMA kept) %.4f | "
-                      "window DMA (transform kept) %.4f | barrier per chunk %.4f" % tuple(sorted(t for a, t in ts if a == ab)[1] for ab in (24, 31, 33, 35, 36, 40)), flush=True)
+                      "window DMA (transform kept) %.4f | barrier per chunk %.4f || with s_setprio around the MFMAs %.4f" % tuple(sorted(t for a, t in ts if a == ab)[1] for ab in (24, 31, 33, 35, 36, 40, 42)), flush=True)
