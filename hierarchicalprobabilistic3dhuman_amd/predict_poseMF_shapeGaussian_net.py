@@ -381,9 +381,14 @@ class InferencePipeline:
             if tr is not None:
                 tr["mesh1"].record(main)
 
-        return infer(self.net, self.smpl, None, num_samples=self.num_samples, use_mean_shape=self.use_mean_shape,
-                     sample_on_cpu=self.sample_on_cpu, seed=seed, image_offset=image_offset, input_feats=feats,
-                     _before_meshes=hook, _after_smpl=smpl_done, _run_net=run_net)
+        try:
+            return infer(self.net, self.smpl, None, num_samples=self.num_samples, use_mean_shape=self.use_mean_shape,
+                         sample_on_cpu=self.sample_on_cpu, seed=seed, image_offset=image_offset, input_feats=feats,
+                         _before_meshes=hook, _after_smpl=smpl_done, _run_net=run_net)
+        finally:
+            # an error between the two hooks (a failed launch in SMPL.forward) must not leave the caller on the encoder's stream
+            if torch.cuda.current_stream() != main:
+                torch.cuda.set_stream(main)
 
 
 _PREDICT_PIPELINES = weakref.WeakKeyDictionary()      # model -> (key, InferencePipeline, StagedUpload) of predict_poseMF_shapeGaussian_net

@@ -209,6 +209,33 @@ def test_mesh_kernel_on_the_encoder_stream_equals_the_separate_stream_schedule(d
     assert torch.equal(sums[True][0], sums[False][0]) and torch.equal(sums[True][0], sums[True][1])
 
 
+def test_an_error_inside_the_mesh_window_leaves_the_caller_on_its_own_stream(dev, net_gpu, smpl_gpu, monkeypatch):
+    """Between the pipeline's two hooks the current stream is the encoder's (inline_mesh); a launch that fails there must not leave it so."""
+    from hierarchicalprobabilistic3dhuman_amd import _capi
+    from hierarchicalprobabilistic3dhuman_amd.predict_poseMF_shapeGaussian_net import InferencePipeline
+    pipe = InferencePipeline(net_gpu, smpl_gpu, num_samples=20)
+    x = torch.rand(32, 18, 256, 256, device=dev)
+    main = torch.cuda.current_stream()
+    want = pipe.finish(pipe.submit(x, input_ready=False), seed=3)["verts_samples"].clone()
+    ticket = pipe.submit(x, input_ready=False)
+    real = _capi.call
+
+    def failing(name, *args):
+        if name.startswith("hps_smpl_mesh_fused"):
+            assert torch.cuda.current_stream() != main           # (the case under test: the kernel is queued on the encoder's stream)
+            raise _capi.HpsError("injected launch failure")
+        return real(name, *args)
+
+    monkeypatch.setattr(_capi, "call", failing)
+    with pytest.raises(_capi.HpsError):
+        pipe.finish(ticket, seed=3)
+    assert torch.cuda.current_stream() == main
+    monkeypatch.setattr(_capi, "call", real)
+    got = pipe.finish(pipe.submit(x, input_ready=False), seed=3)["verts_samples"]      # and the pipeline still works
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+
+
 def test_pipeline_from_host_rgb_equals_infer_on_the_proxy_representation(dev, net_gpu, smpl_gpu):
     """The reference's order of work (predict/...:61-104) as the pipelined loop runs it: page-locked host RGB crops + keypoints ->
     StagedUpload (copy stream, two device slots) -> submit(make_input=...) builds the proxy representation on the encoder's stream
