@@ -580,31 +580,43 @@ __global__ __launch_bounds__(256) void heatmap_argmax_kernel(const float* __rest
     const float* h = heat + (size_t)blockIdx.x * HW;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    // strided scan: each lane keeps its first maximum; eight of its elements are requested before the first is compared (same order)
+    auto take = [&](float v, int idx) {                       // the larger value; among equal values the lower index (torch.max's first maximum)
+        if (v > best || (v == best && idx < bi)) { best = v; bi = idx; }
+    };
+    // 16-byte loads, four per lane in flight (a 64 x 64 map is four of them per lane), then the tail one float at a time
+    const int n4 = ((HW & 3) == 0 && ((size_t)h & 15) == 0) ? HW >> 2 : 0;
+    const float4* h4 = reinterpret_cast<const float4*>(h);
     int i = threadIdx.x;
-    for (; i + 7 * 256 < HW; i += 8 * 256) {
-        float v[8];
+    for (; i + 3 * 256 < n4; i += 4 * 256) {
+        float4 v[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = h[i + q * 256];
+        for (int q = 0; q < 4; ++q) v[q] = h4[i + q * 256];
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (v[q] > best) { best = v[q]; bi = i + q * 256; }
-    }
-    for (; i < HW; i += 256) {
-        const float v = h[i];
-        if (v > best) { best = v; bi = i; }
-    }
-    __shared__ float sv[256];
-    __shared__ int si[256];
-    sv[threadIdx.x] = best; si[threadIdx.x] = bi;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) {
-            const float ov = sv[threadIdx.x + off];
-            const int oi = si[threadIdx.x + off];
-            if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+        for (int q = 0; q < 4; ++q) {
+            const int e = 4 * (i + q * 256);
+            take(v[q].x, e); take(v[q].y, e + 1); take(v[q].z, e + 2); take(v[q].w, e + 3);
         }
-        __syncthreads();
+    }
+    for (; i < n4; i += 256) {
+        const float4 v = h4[i];
+        take(v.x, 4 * i); take(v.y, 4 * i + 1); take(v.z, 4 * i + 2); take(v.w, 4 * i + 3);
+    }
+    for (int e = 4 * n4 + threadIdx.x; e < HW; e += 256) take(h[e], e);
+    // wavefront first (shuffles), then the four wavefronts through LDS
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_down(best, off);
+        const int oi = __shfl_down(bi, off);
+        take(ov, oi);
+    }
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) take(sv[w], si[w]);
+        sv[0] = best; si[0] = bi;
     }
     if (threadIdx.x == 0) {
         const bool vis = sv[0] > eps;
