@@ -366,10 +366,12 @@ class InferencePipeline:
                     u.record_stream(main)
             return outs
 
-        def smpl_done():
+        def smpl_done(mesh_end=None):
             if inline:
-                done_ev = torch.cuda.Event()
-                done_ev.record(self.enc_stream)
+                done_ev = mesh_end                       # SMPL.forward's own event behind the kernel, when it recorded one
+                if done_ev is None:
+                    done_ev = torch.cuda.Event()
+                    done_ev.record(self.enc_stream)
                 if tr is not None:
                     tr["mesh1"].record(self.enc_stream)
                 torch.cuda.set_stream(main)

@@ -243,7 +243,9 @@ class SMPL(nn.Module):
             ev[1].record()
             self.lbs_events.append((M, ev[0], ev[1]))
         if kwargs.get("_after_mesh") is not None:
-            kwargs["_after_mesh"]()
+            # (an event already recorded right behind the mesh kernel -- bench.py's timing event -- is handed to the hook, which may wait
+            # on it instead of recording one of its own: an event record costs the queue ~8 us)
+            kwargs["_after_mesh"](ev[1] if ev is not None else None)
             s = _capi.stream()                   # (the hook may have switched back to the caller's stream)
         if picked is not None:      # the regressor vertices lie side by side: same rows, same values, same sums
             _capi.call("hps_smpl_joints", P(picked), P(j_posed), _capi.iptr(self._csr_ptr), _capi.iptr(self._csr_slot),
