@@ -162,7 +162,12 @@ __device__ __forceinline__ void sw_transform(const float* rawp, const float* raw
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 const float* p = (g < 4 ? rawp + g * 4 : raws) + (b >> 1) * SW_PAIR + (b & 1) * SW_C + o[e];
-                ld[g & 1][b][e] = AB == 1 ? (v2f){(float)(unsigned)(size_t)p, 1.0f} : sw_ld2(p);
+                if (AB == 7) {       // profiling: the channel pair as two 4-byte reads (what a planar, NCHW-fed window would need)
+                    typedef const volatile __attribute__((address_space(3))) float* lds_f_t;
+                    const lds_f_t q = (lds_f_t)(const __attribute__((address_space(3))) float*)p;
+                    ld[g & 1][b][e] = (v2f){q[0], q[1]};
+                } else
+                    ld[g & 1][b][e] = AB == 1 ? (v2f){(float)(unsigned)(size_t)p, 1.0f} : sw_ld2(p);
             }
     };
     issue(0);
@@ -595,6 +600,7 @@ static int stem_wino_launch(const float* frames, const float* u, const float* sc
         case 4: launch(std::integral_constant<int, 4>()); break;
         case 5: launch(std::integral_constant<int, 5>()); break;
         case 6: launch(std::integral_constant<int, 6>()); break;
+        case 7: launch(std::integral_constant<int, 7>()); break;
 #endif
         default: return bad_arg("hps_stem_winograd: ablate");
     }
