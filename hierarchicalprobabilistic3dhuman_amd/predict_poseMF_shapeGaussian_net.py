@@ -167,20 +167,21 @@ class InferencePipeline:
         # B = 16, N = 100 the mesh kernel is a tenth of that and a partition would only slow the encoder down.  None = decide from
         # the work: 8 CUs per XCD when the batch is small enough to overlap at all AND carries at least 12 000 meshes, else 0.
         self.encoder_cus = None
-        # head_cus > 0 (exclusive schedule only): the head's chain of small dependent kernels runs on head_cus CUs of every XCD that the
-        # mesh kernel's stream does not use (the caller's stream becomes the partition of the other 32 - head_cus; the encoder keeps
-        # the whole chip).  Why: the head of batch i + 1 is ready when the mesh kernel of batch i starts, but beside that kernel's
-        # four workgroups per CU it only gets a slot when one retires, so most of its 11 launches slipped into the next encoder's stem
-        # and Winograd layers -- whose persistent one-per-CU workgroups cannot start on a CU a level kernel holds (kernel trace: level
-        # kernels 90-115 us instead of 45, layer1 convolutions 103-120 us instead of 93).  On CUs of its own the head finishes inside
-        # the mesh kernel's window.  None = decide from the batch (see _setup_streams).
+        # head_cus > 0 (exclusive schedule only; an experiment, default off): the head's chain of small dependent kernels runs on
+        # head_cus CUs of every XCD that the mesh kernel's stream does not use (the caller's stream becomes the partition of the other
+        # 32 - head_cus; the encoder keeps the whole chip).  The idea: the head of batch i + 1 is ready when the mesh kernel of batch i
+        # starts, but beside that kernel's four workgroups per CU it only gets a slot when one retires, so most of its 11 launches slip
+        # into the next encoder's stem and Winograd layers.  Measured (profiles/r05_experiments.txt item 7): with 1-4 CUs per XCD the
+        # encoder's time in the loop does not change and the mesh kernel loses its CUs in proportion -- 20.6-20.8 k against 21.0-21.1 k
+        # images/s.  None = 0.
         self.head_cus = None
         # inline_mesh (exclusive schedule): the chip-filling mesh kernel of batch i is enqueued ON THE ENCODER'S STREAM, behind encoder
         # i + 1 and in front of encoder i + 2, instead of on the caller's stream with an event on either side.  The two take turns
-        # anyway; as neighbours in one stream they start back to back, where each cross-stream hand-over (event record -> wait on
-        # another hardware queue) left the chip idle for ~25 us -- twice per step on the critical path (kernel trace: encoder end ->
-        # mesh kernel start 24-27 us, mesh kernel end -> next phase split 24-26 us).  Pose prep (before) and joints / uncertainty (after)
-        # stay on the caller's stream and meet the mesh kernel through events that are off the critical path.
+        # anyway; as neighbours in one queue they need no hand-over between hardware queues on the critical path (+0.7-1 % images/s,
+        # interleaved A/B, identical results).  Pose prep (before) and joints / uncertainty (after) stay on the caller's stream and
+        # meet the mesh kernel through two events; the kernel's operands are NOT registered with the encoder's stream -- the caller's
+        # stream waits for the kernel instead (SMPL.forward, "ordered"): record_stream would have the allocator put one event record
+        # per freed operand into the encoder's queue.
         self.inline_mesh = True
         # (measured and dropped: making the next encoder wait for the uncertainty pass as well -- B = 16, N = 1000: 3.15 -> 3.24 ms
         # per step; B = 64, N = 100: 3.53 -> 3.51)
