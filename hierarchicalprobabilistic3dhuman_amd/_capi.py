@@ -65,6 +65,8 @@ _PROTOTYPES = {
     "hps_stem_phase_split": [_P, _P, _I, _I, _I, _I, _P],
     "hps_proxy_rep_phase_frames": [_P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _P],
     "hps_stem_winograd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "hps_stem_pool_side_bytes": [_I, _I, _I],
+    "hps_stem_winograd_pooled": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "hps_sums_f64": [_P, _P, _P, _I, _c.c_double, _P, _P, _P],
     "hps_sizeof_enc_op": [],
     "hps_encoder_run": [_P, _I, _P],
@@ -101,7 +103,7 @@ _DEV_PROTOTYPES = {
     "hps_dev_mesh_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
 }
 _RESTYPES = {"hps_last_error": _c.c_char_p, "hps_query_workspace": _c.c_int64, "hps_conv3x3_winograd_workspace": _c.c_size_t,
-             "hps_stem_phase_frames_bytes": _c.c_size_t}
+             "hps_stem_phase_frames_bytes": _c.c_size_t, "hps_stem_pool_side_bytes": _c.c_size_t}
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
 DEV_EXPORTED_SYMBOLS = tuple(_DEV_PROTOTYPES)
@@ -119,6 +121,7 @@ class EncOp(_c.Structure):
 
 
 ENC_RELAYOUT, ENC_CONV, ENC_MAXPOOL, ENC_AVGPOOL, ENC_CONV_WINOGRAD, ENC_STEM_SPLIT, ENC_STEM_WINOGRAD, ENC_RELAYOUT_GENERIC = 0, 1, 2, 3, 4, 5, 6, 7
+ENC_STEM_WINOGRAD_POOLED = 8
 SVD_HOST, SVD_DEVICE, SVD_DEVICE_FMA = 0, 1, 2
 SVD_ROUNDING_REFERENCE, SVD_ROUNDING_FMA = 0, 1
 HEAD_WIDE_WORKGROUPS = 0x100

@@ -251,10 +251,19 @@ __device__ __forceinline__ void sw_gemm(const float* ub, const float* ub1, const
     Y[1][1] += e1 * t1;
 }
 
-template <int AB>
+// POOL: the 3 x 3 / 2 max pool that follows the stem (models/resnet.py:150, :206) is formed in the epilogue and only the pooled map is
+// written (the stem's full-resolution output has no other reader).  Pooled pixel (py, px) is the maximum over rows 2 py - 1 .. 2 py + 1
+// and columns 2 px - 1 .. 2 px + 1 of the stem's output, i.e. over tile (py, px) entirely, the bottom row of tile (py - 1, px), the right
+// column of tile (py, px - 1) and the corner pixel of tile (py - 1, px - 1): a lane owns a tile, so its left / upper neighbours are the
+// lanes il - 1 / il - 8 / il - 9 (shuffles), the wave above (through LDS) -- or another work item.  Those last terms are left out here:
+// the item writes the bottom row's and right column's contributions (bottom-row / right-column maxima and corner pixels of its tile
+// row 7 / tile column 7) to `side` ([item][bottom | right][8 tiles][2][64 channels]) and stem_pool_borders_kernel completes the 15
+// pooled pixels of every item that touch a neighbour.  Maxima of the same values in another order: identical to hps_maxpool3x3s2_pad
+// on the stem's output.  g.out_* / g.opad then describe the POOLED frame.
+template <int AB, bool POOL = false>
 __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict__ xf, const float* __restrict__ u,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           float* __restrict__ y, const StemGeom g) {
+                                                           float* __restrict__ y, float* __restrict__ side, const StemGeom g) {
     typedef __attribute__((address_space(3))) void* lptr_t;
     extern __shared__ __attribute__((aligned(16))) float smem[];     // raw[team][buf][SW_RAW_F] | filters[buf][SW_U_F]
 
@@ -387,6 +396,79 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
 #pragma unroll
                     for (int r = 0; r < 16; ++r) t += Y[a][bb][r];
             if (t == 12345.678f) y[0] = t;
+        } else if (POOL) {
+            const int co = wn * 32 + 4 * kl;
+            float4 sc[4], sh[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sc[q] = *reinterpret_cast<const float4*>(scale + co + 8 * q);
+                sh[q] = *reinterpret_cast<const float4*>(shift + co + 8 * q);
+            }
+            const int trow = il >> 3;                                    // the tile's row inside the wave's four
+            const bool has_left = tx > 0, up_in_wave = trow > 0;
+            // exchange buffer of the team: its window buffer 1 (phase 3's window, read for the last time before row 17's barrier; the next
+            // DMA into it is issued behind the next item's first barrier): [wn][kl][bottom maxima | corners][16 channels][8 tiles]
+            float* xb = smem + (team * 2 + 1) * SW_RAW_F + ((wn * 2 + kl) * 2) * 128;
+            float P[16], Bt[16], R[16], Cn[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = r >> 2, e = r & 3;
+                const float s1 = e == 0 ? sc[q].x : e == 1 ? sc[q].y : e == 2 ? sc[q].z : sc[q].w;
+                const float h1 = e == 0 ? sh[q].x : e == 1 ? sh[q].y : e == 2 ? sh[q].z : sh[q].w;
+                float v00 = Y[0][0][r] * s1 + h1, v01 = Y[0][1][r] * s1 + h1, v10 = Y[1][0][r] * s1 + h1, v11 = Y[1][1][r] * s1 + h1;
+                if (g.relu) { v00 = fmaxf(v00, 0.f); v01 = fmaxf(v01, 0.f); v10 = fmaxf(v10, 0.f); v11 = fmaxf(v11, 0.f); }
+                Bt[r] = fmaxf(v10, v11);
+                R[r] = fmaxf(v01, v11);
+                Cn[r] = v11;
+                P[r] = fmaxf(fmaxf(v00, v01), Bt[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float rl = __shfl_up(R[r], 1), bu = __shfl_up(Bt[r], 8), cu = __shfl_up(Cn[r], 9);
+                if (has_left) P[r] = fmaxf(P[r], rl);
+                if (up_in_wave) {
+                    P[r] = fmaxf(P[r], bu);
+                    if (has_left) P[r] = fmaxf(P[r], cu);
+                }
+            }
+            if (wm == 0 && trow == 3) {                                  // tile row 3 of the item: what tile row 4 (the wave below) needs
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    xb[r * 8 + tx] = Bt[r];
+                    xb[128 + r * 8 + tx] = Cn[r];
+                }
+            }
+            __syncthreads();
+            if (wm == 1 && trow == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    P[r] = fmaxf(P[r], xb[r * 8 + tx]);
+                    if (has_left) P[r] = fmaxf(P[r], xb[128 + r * 8 + tx - 1]);
+                }
+            }
+            if (live) {
+                const unsigned b = sw_div((unsigned)item, (unsigned)g.blocks_img, g.magic_img), rem = item - b * g.blocks_img;
+                const unsigned by = sw_div(rem, (unsigned)g.blocks_x, g.magic_x), bx = rem - by * g.blocks_x;
+                float* yp = y + (size_t)b * g.out_img + (size_t)(8 * by + ty + g.opad) * g.out_row + (size_t)(8 * bx + tx + g.opad) * SW_CO + co;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(yp + 8 * q) = make_float4(P[4 * q], P[4 * q + 1], P[4 * q + 2], P[4 * q + 3]);
+                float* sd = side + (size_t)item * 2048 + co;
+                if (ty == 7) {                                           // bottom edge: [tx][maxima | corners][64]
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        *reinterpret_cast<float4*>(sd + tx * 128 + 8 * q) = make_float4(Bt[4 * q], Bt[4 * q + 1], Bt[4 * q + 2], Bt[4 * q + 3]);
+                        *reinterpret_cast<float4*>(sd + tx * 128 + 64 + 8 * q) = make_float4(Cn[4 * q], Cn[4 * q + 1], Cn[4 * q + 2], Cn[4 * q + 3]);
+                    }
+                }
+                if (tx == 7) {                                           // right edge: [ty][maxima | corners][64]
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        *reinterpret_cast<float4*>(sd + 1024 + ty * 128 + 8 * q) = make_float4(R[4 * q], R[4 * q + 1], R[4 * q + 2], R[4 * q + 3]);
+                        *reinterpret_cast<float4*>(sd + 1024 + ty * 128 + 64 + 8 * q) = make_float4(Cn[4 * q], Cn[4 * q + 1], Cn[4 * q + 2], Cn[4 * q + 3]);
+                    }
+                }
+            }
         } else if (live) {
             const unsigned b = sw_div((unsigned)item, (unsigned)g.blocks_img, g.magic_img), rem = item - b * g.blocks_img;
             const unsigned by = sw_div(rem, (unsigned)g.blocks_x, g.magic_x), bx = rem - by * g.blocks_x;
@@ -524,6 +606,43 @@ __global__ __launch_bounds__(256) void proxy_rep_frames_kernel(const float* __re
     }
 }
 
+
+// Second pass of the pooled stem: the pooled pixels of an item that lie on its top row or left column (15 of 64) also see the neighbouring
+// items' bottom rows / right columns (`side`, written by stem_wino_kernel<., true>).  Thread = (item, one of the 15 pixels, four channels).
+__global__ __launch_bounds__(256) void stem_pool_borders_kernel(float* __restrict__ y, const float* __restrict__ side, const StemGeom g, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cq = (int)(i & 15);
+    long p = i >> 4;
+    const int j = (int)(p % 15);
+    const int item = (int)(p / 15);
+    const int ty = j < 8 ? 0 : j - 7, tx = j < 8 ? j : 0;
+    const unsigned b = sw_div((unsigned)item, (unsigned)g.blocks_img, g.magic_img), rem = item - b * g.blocks_img;
+    const unsigned by = sw_div(rem, (unsigned)g.blocks_x, g.magic_x), bx = rem - by * g.blocks_x;
+    if (by == 0 && bx == 0) return;                                      // nothing above, nothing to the left
+    float4* yp = reinterpret_cast<float4*>(y + (size_t)b * g.out_img + (size_t)(8 * by + ty + g.opad) * g.out_row +
+                                           (size_t)(8 * bx + tx + g.opad) * SW_CO + cq * 4);
+    float4 v = *yp;
+    auto take = [&](int it, int edge, int pos, int val) {
+        const float4 o = *reinterpret_cast<const float4*>(side + (size_t)it * 2048 + edge * 1024 + pos * 128 + val * 64 + cq * 4);
+        v = make_float4(fmaxf(v.x, o.x), fmaxf(v.y, o.y), fmaxf(v.z, o.z), fmaxf(v.w, o.w));
+    };
+    if (ty == 0) {
+        if (by > 0) {
+            take(item - g.blocks_x, 0, tx, 0);                           // bottom-row maxima of the tile above
+            if (tx > 0) take(item - g.blocks_x, 0, tx - 1, 1);           // corner pixel of the tile above and to the left
+        }
+        if (tx == 0 && bx > 0) {
+            take(item - 1, 1, 0, 0);                                     // right-column maxima of the tile to the left
+            if (by > 0) take(item - g.blocks_x - 1, 0, 7, 1);            // corner pixel of the diagonal item's last tile
+        }
+    } else if (bx > 0) {
+        take(item - 1, 1, ty, 0);
+        take(item - 1, 1, ty - 1, 1);
+    }
+    *yp = v;
+}
+
 }  // namespace hps
 
 using namespace hps;
@@ -561,7 +680,8 @@ extern "C" int hps_proxy_rep_phase_frames(const float* edge, const float* joints
 }
 
 static int stem_wino_launch(const float* frames, const float* u, const float* scale, const float* shift, float* y, int B, int H,
-                            int W, int opad, int relu, int ablate, hps_stream_t stream) {
+                            int W, int opad, int relu, int ablate, hps_stream_t stream, float* side = nullptr) {
+    const bool pool = side != nullptr;
     if (!frames || !u || !scale || !shift || !y) return bad_arg("hps_stem_winograd: null pointer");
     if (H <= 0 || W <= 0 || (H % 32) || (W % 32)) return bad_arg("hps_stem_winograd: H and W must be multiples of 32 (8 x 8 blocks of 2 x 2-pixel tiles at stride 2)");
     if (opad < 0) return bad_arg("hps_stem_winograd: opad");
@@ -574,8 +694,8 @@ static int stem_wino_launch(const float* frames, const float* u, const float* sc
     g.blocks_x = Wo / 16;
     g.blocks_img = (Ho / 16) * g.blocks_x;
     g.n_items = B * g.blocks_img;
-    g.out_row = (Wo + 2 * opad) * SW_CO;
-    g.out_img = (Ho + 2 * opad) * g.out_row;
+    g.out_row = ((pool ? Wo / 2 : Wo) + 2 * opad) * SW_CO;       // pool: the frame of the pooled map
+    g.out_img = ((pool ? Ho / 2 : Ho) + 2 * opad) * g.out_row;
     g.opad = opad;
     g.relu = relu;
     g.magic_img = sw_magic((unsigned)g.blocks_img);
@@ -589,8 +709,18 @@ static int stem_wino_launch(const float* frames, const float* u, const float* sc
         constexpr int ab = decltype(AB)::value;
         if ((rc = grant_lds<&stem_wino_kernel<ab>>((int)lds, "hps_stem_winograd")) != HPS_OK) return;
         hipLaunchKernelGGL((stem_wino_kernel<ab>), dim3((unsigned)(pairs < 256 ? pairs : 256)), dim3(512), lds, (hipStream_t)stream,
-                           frames, u, scale, shift, y, g);
+                           frames, u, scale, shift, y, (float*)nullptr, g);
     };
+    if (pool) {
+        if (ablate != 0) return bad_arg("hps_stem_winograd_pooled: no ablations");
+        if ((rc = grant_lds<&stem_wino_kernel<0, true>>((int)lds, "hps_stem_winograd_pooled")) != HPS_OK) return rc;
+        hipLaunchKernelGGL((stem_wino_kernel<0, true>), dim3((unsigned)(pairs < 256 ? pairs : 256)), dim3(512), lds, (hipStream_t)stream,
+                           frames, u, scale, shift, y, side, g);
+        if ((rc = check_launch("hps_stem_winograd_pooled")) != HPS_OK) return rc;
+        const long total = (long)g.n_items * 15 * 16;
+        hipLaunchKernelGGL(stem_pool_borders_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, side, g, total);
+        return check_launch("hps_stem_winograd_pooled (borders)");
+    }
     switch (ablate) {
         case 0: launch(std::integral_constant<int, 0>()); break;
 #ifdef HPS_DEV_BUILD
@@ -611,6 +741,17 @@ static int stem_wino_launch(const float* frames, const float* u, const float* sc
 extern "C" int hps_stem_winograd(const float* frames, const float* u, const float* scale, const float* shift, float* y, int B, int H,
                                  int W, int opad, int relu, hps_stream_t stream) {
     return stem_wino_launch(frames, u, scale, shift, y, B, H, W, opad, relu, 0, stream);
+}
+
+extern "C" size_t hps_stem_pool_side_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0 || (H % 32) || (W % 32)) return 0;
+    return (size_t)B * (H / 32) * (W / 32) * 2048 * sizeof(float);
+}
+
+extern "C" int hps_stem_winograd_pooled(const float* frames, const float* u, const float* scale, const float* shift, float* pooled, float* side,
+                                        int B, int H, int W, int opad, int relu, hps_stream_t stream) {
+    if (!side) return bad_arg("hps_stem_winograd_pooled: null pointer");
+    return stem_wino_launch(frames, u, scale, shift, pooled, B, H, W, opad, relu, 0, stream, side);
 }
 
 #ifdef HPS_DEV_BUILD

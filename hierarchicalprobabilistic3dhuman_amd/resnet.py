@@ -318,6 +318,9 @@ class ResNet(nn.Module):
         self._latency = False
         self.layout = "padded"    # "padded": halo-padded NHWC + scalar-base LDS-DMA kernel (product); "plain": the conv.hip kernels of libhps_dev.so (tests)
         self.composite = True     # padded layout: issue the launch list through hps_encoder_run (one call) instead of one by one
+        # Winograd stem: form the max pool in the stem kernel's epilogue (hps_stem_winograd_pooled: the full-resolution stem output is never
+        # written; identical values).  False: hps_stem_winograd + hps_maxpool3x3s2_pad (the cross-check of the tests)
+        self.fused_pool = True
         self._frames = _FrameCache()
         self.register_load_state_dict_post_hook(_invalidate_after_load)
 
@@ -393,7 +396,8 @@ class ResNet(nn.Module):
     def _frame_set(self, prep, B, C, H, W, device):
         stem = prep["stem"]
         stem_wino = stem.stem_winograd_ok(C, H, W)
-        key = (B, C, H, W, str(device), _capi.stream().value, stem_wino)
+        fused_pool = bool(stem_wino and self.fused_pool)
+        key = (B, C, H, W, str(device), _capi.stream().value, stem_wino, fused_pool)
         fs = self._frames.get(key)
         if fs is not None:
             return fs
@@ -411,7 +415,13 @@ class ResNet(nn.Module):
             fs = {"in": z(B, H + 6, wf + 6, cf)}
         fs["stem_wino"], fs["generic_in"] = stem_wino, (C, cf, W, wf) if generic else None
         h, w = stem.out_hw(H, W)
-        fs["stem"] = torch.empty(B, h, w, stem.cout, device=device, dtype=torch.float32)
+        fs["fused_pool"] = fused_pool
+        if fused_pool:       # the stem's full-resolution output is never materialised; scratch for the items' border contributions
+            fs["stem"] = None
+            fs["side"] = torch.empty(int(_capi.load(dev=_capi._use_dev).hps_stem_pool_side_bytes(B, H, W)) // 4, device=device, dtype=torch.float32)
+        else:
+            fs["stem"] = torch.empty(B, h, w, stem.cout, device=device, dtype=torch.float32)
+        h_stem, w_stem = h, w
         h, w = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
         fs["pool"] = z(B, h + 2, w + 2, stem.cout)
         fs["blocks"] = []
@@ -427,7 +437,12 @@ class ResNet(nn.Module):
             fs["blocks"].append(ent)
         fs["hw"] = (h, w)
         # the launch list of hps_encoder_run: every pointer but the input image and the feature output is fixed
-        if stem_wino:
+        if fused_pool:
+            first = [_capi.EncOp(kind=_capi.ENC_STEM_SPLIT, x=None, y=fs["in"].data_ptr(), B=B, Cin=C, H=H, W=W),
+                     _capi.EncOp(kind=_capi.ENC_STEM_WINOGRAD_POOLED, x=fs["in"].data_ptr(), w=stem.stem_u.data_ptr(), scale=stem.scale.data_ptr(),
+                                 shift=stem.shift.data_ptr(), y=fs["pool"].data_ptr(), splitk_ws=fs["side"].data_ptr(), B=B, H=H, W=W, Cin=C,
+                                 Cout=stem.cout, KH=7, KW=7, stride=2, pad=3, opad=1, relu=1)]
+        elif stem_wino:
             first = [_capi.EncOp(kind=_capi.ENC_STEM_SPLIT, x=None, y=fs["in"].data_ptr(), B=B, Cin=C, H=H, W=W),
                      _capi.EncOp(kind=_capi.ENC_STEM_WINOGRAD, x=fs["in"].data_ptr(), w=stem.stem_u.data_ptr(), scale=stem.scale.data_ptr(),
                                  shift=stem.shift.data_ptr(), y=fs["stem"].data_ptr(), B=B, H=H, W=W, Cin=C, Cout=stem.cout, KH=7, KW=7,
@@ -436,9 +451,8 @@ class ResNet(nn.Module):
             relayout = (_capi.EncOp(kind=_capi.ENC_RELAYOUT_GENERIC, x=None, y=fs["in"].data_ptr(), B=B, Cin=C, Cout=cf, H=H, W=W, KW=wf, opad=3)
                         if generic else _capi.EncOp(kind=_capi.ENC_RELAYOUT, x=None, y=fs["in"].data_ptr(), B=B, Cin=C, H=H, W=W, opad=3))
             first = [relayout, stem.enc_op(fs["in"], 3, fs["stem"], 0, relu=True)]
-        ops = first + [
-               _capi.EncOp(kind=_capi.ENC_MAXPOOL, x=fs["stem"].data_ptr(), y=fs["pool"].data_ptr(), B=B, H=fs["stem"].shape[1],
-                           W=fs["stem"].shape[2], Cin=stem.cout, opad=1)]
+        ops = first if fused_pool else first + [
+               _capi.EncOp(kind=_capi.ENC_MAXPOOL, x=fs["stem"].data_ptr(), y=fs["pool"].data_ptr(), B=B, H=h_stem, W=w_stem, Cin=stem.cout, opad=1)]
         y = fs["pool"]
         for (c1, c2, down), ent in zip(prep["blocks"], fs["blocks"]):      # BasicBlock.forward :62-78
             identity = y
@@ -518,7 +532,11 @@ class ResNet(nn.Module):
             if filled:
                 x.run_fill()
             y = fs["stem"]
-            _capi.call("hps_stem_winograd", P(fs["in"]), P(stem.stem_u), P(stem.scale), P(stem.shift), P(y), B, H, W, 0, 1, s)
+            if fs["fused_pool"]:
+                _capi.call("hps_stem_winograd_pooled", P(fs["in"]), P(stem.stem_u), P(stem.scale), P(stem.shift), P(fs["pool"]), P(fs["side"]),
+                           B, H, W, 1, 1, s)
+            else:
+                _capi.call("hps_stem_winograd", P(fs["in"]), P(stem.stem_u), P(stem.scale), P(stem.shift), P(y), B, H, W, 0, 1, s)
         else:
             if fs["generic_in"] is not None:
                 _, cf, _, wf = fs["generic_in"]
@@ -528,7 +546,8 @@ class ResNet(nn.Module):
             if gate is not None:
                 gate()
             y = stem.padded(fs["in"], 3, fs["stem"], 0, relu=True)         # conv1 + bn1 + relu
-        _capi.call("hps_maxpool3x3s2_pad", P(y), P(fs["pool"]), B, y.shape[1], y.shape[2], y.shape[3], 1, s)
+        if not fs["fused_pool"]:
+            _capi.call("hps_maxpool3x3s2_pad", P(y), P(fs["pool"]), B, y.shape[1], y.shape[2], y.shape[3], 1, s)
         y = fs["pool"]
         for (c1, c2, down), ent in zip(prep["blocks"], fs["blocks"]):      # BasicBlock.forward :62-78
             identity = down.padded(y, 1, ent["down"], 1, relu=False) if down is not None else y

@@ -375,16 +375,27 @@ int hps_proxy_rep_phase_frames(const float* edge, const float* joints2d, const f
                                int W, float std, hps_stream_t stream);
 int hps_stem_winograd(const float* frames, const float* u, const float* scale, const float* shift, float* y, int B, int H,
                       int W, int opad, int relu, hps_stream_t stream);
+/* The stem AND the 3x3 / 2 / pad 1 max pool behind it (models/resnet.py:150, :206: self.maxpool) in one call: frames -> the interior of
+ * the (B, H/4 + 2 opad, W/4 + 2 opad, 64) NHWC frame of the POOLED map; the stem's full-resolution output (which nothing else reads) is
+ * never written.  Every pooled pixel is the maximum of the same nine stem outputs hps_maxpool3x3s2_pad takes it over (formed tile by tile
+ * in the stem kernel's epilogue; the pixels of an 8 x 8 block of pooled pixels that also see a neighbouring block are completed by a
+ * small second kernel from `side`): identical values.  side: scratch of hps_stem_pool_side_bytes(B, H, W) bytes, written and read by
+ * this call only. */
+size_t hps_stem_pool_side_bytes(int B, int H, int W);
+int hps_stem_winograd_pooled(const float* frames, const float* u, const float* scale, const float* shift, float* pooled, float* side,
+                             int B, int H, int W, int opad, int relu, hps_stream_t stream);
 
 /* One launch of the encoder's operation list (hps_encoder_run).  kind: HPS_ENC_RELAYOUT = hps_nchw_to_padded_nhwc
  * (x, y, B, Cin = C, H, W, opad = P), HPS_ENC_CONV = hps_conv2d_bn_act_pad (all fields), HPS_ENC_MAXPOOL =
  * hps_maxpool3x3s2_pad (x, y, B, H, W, Cin = C, opad), HPS_ENC_AVGPOOL = hps_global_avgpool_pad (x, y, B, H, W,
  * Cin = C, ipad = P), HPS_ENC_CONV_WINOGRAD = hps_conv3x3_winograd (x, w = u, scale, shift, residual, y, B, H, W, ipad, Cin,
  * Cout, opad, relu, splitk_ws), HPS_ENC_STEM_SPLIT = hps_stem_phase_split (x, y = frames, B, Cin = C, H, W),
- * HPS_ENC_STEM_WINOGRAD = hps_stem_winograd (x = frames, w = u, scale, shift, y, B, H, W, opad, relu). */
+ * HPS_ENC_STEM_WINOGRAD = hps_stem_winograd (x = frames, w = u, scale, shift, y, B, H, W, opad, relu), HPS_ENC_STEM_WINOGRAD_POOLED =
+ * hps_stem_winograd_pooled (x = frames, w = u, scale, shift, y = pooled frame, splitk_ws = side, B, H, W, opad, relu). */
 enum { HPS_ENC_RELAYOUT = 0, HPS_ENC_CONV = 1, HPS_ENC_MAXPOOL = 2, HPS_ENC_AVGPOOL = 3, HPS_ENC_CONV_WINOGRAD = 4,
        HPS_ENC_STEM_SPLIT = 5, HPS_ENC_STEM_WINOGRAD = 6,
-       HPS_ENC_RELAYOUT_GENERIC = 7 /* hps_nchw_to_padded_nhwc_generic (x, y, B, Cin = C, Cout = CP, H, W, KW = WF, opad = P) */ };
+       HPS_ENC_RELAYOUT_GENERIC = 7 /* hps_nchw_to_padded_nhwc_generic (x, y, B, Cin = C, Cout = CP, H, W, KW = WF, opad = P) */,
+       HPS_ENC_STEM_WINOGRAD_POOLED = 8 };
 typedef struct hps_enc_op {
     int kind;
     const float* x;

@@ -540,6 +540,62 @@ def test_winograd_stem_kernel(cfg, dev):
         _capi.call("hps_stem_phase_split", P(xd), P(frames), B, 20, H, W, s)
 
 
+@pytest.mark.parametrize("cfg", [(3, 64, 64), (2, 96, 160), (5, 32, 64), (1, 32, 32), (64, 256, 256)])
+def test_stem_with_the_max_pool_in_its_epilogue(cfg, dev):
+    """hps_stem_winograd_pooled (stem + bn1 + relu + the 3x3 / 2 / pad 1 max pool of models/resnet.py:150 in one call: the pool is formed
+    from the tiles' registers, the full-resolution stem output is never written, a second kernel completes the pooled pixels that see a
+    neighbouring work item) against hps_stem_winograd followed by hps_maxpool3x3s2_pad: EQUAL, for odd item counts, one-item and
+    non-square maps and the bench shape; the halo of the pooled frame is never written; and against torch's max_pool2d on the stem output."""
+    B, H, W = cfg
+    torch.manual_seed(11 * B + H + W)
+    conv = torch.nn.Conv2d(18, 64, 7, 2, 3, bias=False)
+    bn = torch.nn.BatchNorm2d(64).eval()
+    bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2); bn.weight.data.normal_(); bn.bias.data.normal_()      # (negative scales too)
+    cb = _ConvBN(conv.to(dev), bn.to(dev), cin_pad=20)
+    P, s = _capi.ptr, _capi.stream()
+    x = torch.randn(B, 18, H, W, device=dev)
+    frames = torch.zeros(int(_capi.load().hps_stem_phase_frames_bytes(B, H, W)) // 4, device=dev)
+    _capi.call("hps_stem_phase_split", P(x), P(frames), B, 18, H, W, s)
+    Ho, Wo = H // 2, W // 2
+    full = torch.empty(B, Ho, Wo, 64, device=dev)
+    _capi.call("hps_stem_winograd", P(frames), P(cb.stem_u), P(cb.scale), P(cb.shift), P(full), B, H, W, 0, 1, s)
+    want = torch.full((B, Ho // 2 + 2, Wo // 2 + 2, 64), 7.0, device=dev)
+    _capi.call("hps_maxpool3x3s2_pad", P(full), P(want), B, Ho, Wo, 64, 1, s)
+    side_bytes = int(_capi.load().hps_stem_pool_side_bytes(B, H, W))
+    assert side_bytes == B * (H // 32) * (W // 32) * 2048 * 4
+    side = torch.full((side_bytes // 4,), float("nan"), device=dev)          # (every entry that is read has been written by the call)
+    got = torch.full((B, Ho // 2 + 2, Wo // 2 + 2, 64), 7.0, device=dev)
+    _capi.call("hps_stem_winograd_pooled", P(frames), P(cb.stem_u), P(cb.scale), P(cb.shift), P(got), P(side), B, H, W, 1, 1, s)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert float((got[:, 0] - 7).abs().max()) == 0 and float((got[:, :, -1] - 7).abs().max()) == 0
+    ref = F.max_pool2d(full.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(got[:, 1:-1, 1:-1], ref)
+    # without ReLU (negative values): the same maxima
+    _capi.call("hps_stem_winograd", P(frames), P(cb.stem_u), P(cb.scale), P(cb.shift), P(full), B, H, W, 0, 0, s)
+    _capi.call("hps_stem_winograd_pooled", P(frames), P(cb.stem_u), P(cb.scale), P(cb.shift), P(got), P(side), B, H, W, 1, 0, s)
+    assert torch.equal(got[:, 1:-1, 1:-1], F.max_pool2d(full.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1))
+    with pytest.raises(_capi.HpsError):
+        _capi.call("hps_stem_winograd_pooled", P(frames), P(cb.stem_u), P(cb.scale), P(cb.shift), P(got), None, B, H, W, 1, 1, s)
+
+
+def test_encoder_with_and_without_the_fused_pool_gives_the_same_features(dev, net_gpu, golden_input):
+    enc = net_gpu.image_encoder
+    x = torch.cat([golden_input.to(dev), torch.rand(3, 18, 256, 256, generator=torch.Generator().manual_seed(4)).to(dev)])
+    assert enc.fused_pool
+    fused = enc(x).clone()
+    try:
+        enc.fused_pool = False
+        two = enc(x).clone()
+        enc.composite = False
+        two_b = enc(x).clone()
+        enc.fused_pool = True
+        fused_b = enc(x).clone()
+    finally:
+        enc.fused_pool, enc.composite = True, True
+    assert torch.equal(fused, two) and torch.equal(fused, two_b) and torch.equal(fused, fused_b)
+
+
 def test_winograd_and_direct_encoders_agree_and_are_batch_invariant(dev, net_gpu, golden, golden_input):
     enc = net_gpu.image_encoder
     x = golden_input.to(dev)
