@@ -86,7 +86,7 @@ if os.path.exists(stats_p):
     enc_flop = 6.279e9 * B
     stem_flop = 2.0 * B * 128 * 128 * 64 * 49 * 18
     model = [   # (substring, what, bound, algorithmic quantity per launch, unit)
-        ("stem_wino_kernel", "stem 7x7/2 in Winograd form (direct-convolution FLOPs; the MFMA pipe does 81/196 of them)", "mfma", stem_flop, "flop"),
+        ("stem_wino_kernel", "stem 7x7/2 in Winograd form + the 3x3/2 max pool in its epilogue (direct-convolution FLOPs; the MFMA pipe does 81/196 of them)", "mfma", stem_flop, "flop"),
         ("conv_", "the other 19 ResNet-18 convolutions, direct + Winograd F(2x2,3x3) (all launches of a step together; direct-convolution FLOPs)", "mfma", enc_flop - stem_flop, "flop/step"),
         ("mesh_fused_kernel", "blend GEMM + LBS, fused", "mfma", 2.0 * 217 * 3 * V * M, "flop"),
         ("uncertainty_reg_kernel", "per-vertex sample uncertainty", "hbm", (B * N * V * 12.0 + B * V * 4.0), "bytes"),
@@ -95,12 +95,15 @@ if os.path.exists(stats_p):
         ("nchw_to_padded_nhwc", "input relayout", "hbm", 2.0 * B * 18 * 256 * 256 * 4, "bytes"),
         ("stem_phase_split_kernel", "input -> four phase frames per image", "hbm", 2.0 * B * 18 * 256 * 256 * 4, "bytes"),
         ("maxpool_pad_kernel", "3x3/2 max pool", "hbm", B * 64 * 4.0 * (128 * 128 + 64 * 64), "bytes"),
+        ("stem_pool_borders_kernel", "border pass of the max pool formed in the stem's epilogue (15 of 64 pooled pixels per item + the side buffer)", "hbm",
+         B * 64 * (2 * 15 * 64 * 4.0 + 2048 * 4.0), "bytes"),
         ("mf_sample_kernel", "matrix-Fisher rejection sampling", "alu", B * 23 * 8.0 * N, "proposals"),
         ("joint_level_kernel", "head: per-level MLPs + in-kernel SVD (8 launches per step)", "latency", None, ""),
         ("linear_kernel", "head: FC trunk (3 launches per step)", "latency", None, ""),
     ]
-    # encoder passes in the profiled run (timed steps + warm-up + the unfused-LBS repetitions behind the timed region): one max-pool each
-    steps = float(sum(int(r["Calls"]) for r in stats if "maxpool_pad_kernel" in r["Name"]) or 12)
+    # encoder passes in the profiled run (timed steps + warm-up + the unfused-LBS repetitions behind the timed region): one stem (or max-pool) launch each
+    steps = float(sum(int(r["Calls"]) for r in stats if "stem_wino_kernel" in r["Name"]) or
+                  sum(int(r["Calls"]) for r in stats if "maxpool_pad_kernel" in r["Name"]) or 12)
     for sub, what, bound, qty, unit in model:
         rs = [r for r in stats if sub in r["Name"]]
         if not rs:
