@@ -67,6 +67,7 @@ _PROTOTYPES = {
     "hps_stem_winograd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "hps_stem_pool_side_bytes": [_I, _I, _I],
     "hps_stem_winograd_pooled": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "hps_stem_winograd_pooled_nchw": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "hps_sums_f64": [_P, _P, _P, _I, _c.c_double, _P, _P, _P],
     "hps_sizeof_enc_op": [],
     "hps_encoder_run": [_P, _I, _P],
@@ -95,6 +96,7 @@ _DEV_PROTOTYPES = {
     "hps_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P],
     "hps_global_avgpool": [_P, _P, _I, _I, _I, _P],
     "hps_dev_stem_winograd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "hps_dev_stem_winograd_pooled_nchw": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hps_dev_conv3x3_winograd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "hps_dev_head_pose_levels_fused": [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _P, _I, _I, _I,
                                    _P, _P],
@@ -121,7 +123,7 @@ class EncOp(_c.Structure):
 
 
 ENC_RELAYOUT, ENC_CONV, ENC_MAXPOOL, ENC_AVGPOOL, ENC_CONV_WINOGRAD, ENC_STEM_SPLIT, ENC_STEM_WINOGRAD, ENC_RELAYOUT_GENERIC = 0, 1, 2, 3, 4, 5, 6, 7
-ENC_STEM_WINOGRAD_POOLED = 8
+ENC_STEM_WINOGRAD_POOLED, ENC_STEM_WINOGRAD_POOLED_NCHW = 8, 9
 SVD_HOST, SVD_DEVICE, SVD_DEVICE_FMA = 0, 1, 2
 SVD_ROUNDING_REFERENCE, SVD_ROUNDING_FMA = 0, 1
 HEAD_WIDE_WORKGROUPS = 0x100

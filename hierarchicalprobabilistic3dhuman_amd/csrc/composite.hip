@@ -45,6 +45,9 @@ extern "C" int hps_encoder_run(const hps_enc_op* ops, int n_ops, hps_stream_t st
             case HPS_ENC_STEM_WINOGRAD_POOLED:
                 rc = hps_stem_winograd_pooled(o.x, o.w, o.scale, o.shift, o.y, o.splitk_ws, o.B, o.H, o.W, o.opad, o.relu, stream);
                 break;
+            case HPS_ENC_STEM_WINOGRAD_POOLED_NCHW:
+                rc = hps_stem_winograd_pooled_nchw(o.x, o.w, o.scale, o.shift, o.y, o.splitk_ws, o.B, o.H, o.W, o.opad, o.relu, stream);
+                break;
             case HPS_ENC_MAXPOOL:
                 rc = hps_maxpool3x3s2_pad(o.x, o.y, o.B, o.H, o.W, o.Cin, o.opad, stream);
                 break;

@@ -100,6 +100,7 @@ struct StemGeom {
     int blocks_x, blocks_img, n_items;
     int out_row, out_img, opad, relu;     // output frame (B, Ho + 2 opad, Wo + 2 opad, 64)
     unsigned magic_img, magic_x;
+    int in_h, in_w;                       // NCHW-fed form: the input image (B, 18, in_h, in_w)
 };
 
 __device__ __forceinline__ unsigned sw_div(unsigned n, unsigned d, unsigned magic) {
@@ -260,7 +261,13 @@ __device__ __forceinline__ void sw_gemm(const float* ub, const float* ub1, const
 // row 7 / tile column 7) to `side` ([item][bottom | right][8 tiles][2][64 channels]) and stem_pool_borders_kernel completes the 15
 // pooled pixels of every item that touch a neighbour.  Maxima of the same values in another order: identical to hps_maxpool3x3s2_pad
 // on the stem's output.  g.out_* / g.opad then describe the POOLED frame.
-template <int AB, bool POOL = false>
+// NCHW: the raw phase windows are gathered from the (B, 18, H, W) network input itself -- hps_stem_phase_split and its four frames per image
+// disappear.  The LDS windows keep their layout (pixel pairs of 38 floats, channels in the lanes' order), so nothing downstream changes:
+// lane tt = 10 wi + pj (tt < 190) of a team owns pixel pair (wi, pj) of a window and moves it in four chunks (pixel, channel half) of 8 / 10
+// floats: global loads (exec-masked where the pixel lies outside the image: it stays zero) in one row's MFMA run, the 8-byte LDS stores at the
+// top of the next row.  Window p + 1 is stored during the first four rows of phase p (its first chunk is loaded in the last row of phase
+// p - 1, when the buffer's previous window has been read for the last time); xf is then the NCHW tensor.
+template <int AB, bool POOL = false, bool NCHW = false>
 __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict__ xf, const float* __restrict__ u,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            float* __restrict__ y, float* __restrict__ side, const StemGeom g) {
@@ -320,11 +327,82 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
     const float* frag0 = smem + 4 * SW_RAW_F + wn * 576 + kl * 128 + il * 4;      // filter fragment (k 0-7) of position 0, buffer 0
     const float* frag1 = smem + 4 * SW_RAW_F + wn * 576 + 512 + kl * 32 + il;     // ... (k 16-17)
 
+    // ---- NCHW gather role (see the template comment) ----
+    const int tt = tid & 255;
+    const int n_wi = tt / 10, n_pj = tt - 10 * n_wi;
+    const bool n_act = NCHW && tt < 190;
+    const unsigned n_goff = (unsigned)((2 * n_wi * g.in_w + 4 * n_pj) * 4);      // bytes from the (item, phase) origin to pixel 0 of the pair
+    const int n_lds = n_wi * SW_ROWF + n_pj * SW_PAIR;                            // the pair's float offset in a window buffer
+    const long n_plane = (long)g.in_h * g.in_w;
+    float lr[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // the chunk in flight: lr[2 s + e] = channel s of the chunk, pixel e of the pair
+    const float* nc_origin = xf; int nc_y0 = 0, nc_x0 = 0; bool nc_border = false;        // the current item
+    const float* nn_origin = xf; int nn_y0 = 0, nn_x0 = 0; bool nn_border = false;        // the next one
+    auto nchw_item = [&](int it, const float*& origin, int& y0, int& x0, bool& border) {
+        const unsigned b = sw_div((unsigned)it, (unsigned)g.blocks_img, g.magic_img), rem = it - b * g.blocks_img;
+        const unsigned by = sw_div(rem, (unsigned)g.blocks_x, g.magic_x), bx = rem - by * g.blocks_x;
+        y0 = 32 * (int)by - 3; x0 = 32 * (int)bx - 3;
+        origin = xf + (long)b * SW_C * n_plane + (long)y0 * g.in_w + x0;
+        border = by == 0 || bx == 0 || y0 + 38 > g.in_h || x0 + 38 > g.in_w;
+    };
+    const bool n_act1 = n_act && n_pj < 9;                                         // the pair's second pixel exists (19 pixels per window row)
+    const float* n_base = xf;                                                      // wave-uniform: pixel 0 of pair (0, 0), first channel of the chunk
+    bool n_ok0 = false, n_ok1 = false, n_zero = false;                             // the lane loads pixel 0 / 1; the chunk needs zeros where it does not
+    // chunk q = channels 4 q .. 4 q + 3 (q = 3: 12 .. 17) of BOTH pixels of the pair: the two loads of a channel are neighbours in the
+    // instruction stream and hit the same 128-byte lines (chunks split by pixel fetched every line twice: 0.72 against 0.69 ms)
+    auto nchw_aim = [&](bool next, int phase, int q) {
+        const float* origin = next ? nn_origin : nc_origin;
+        const bool border = next ? nn_border : nc_border;
+        n_base = origin + (long)(4 * q) * n_plane + (long)(phase >> 1) * g.in_w + (phase & 1);
+        n_ok0 = n_act; n_ok1 = n_act1;
+        n_zero = border;
+        if (border) {
+            const int yy = (next ? nn_y0 : nc_y0) + (phase >> 1) + 2 * n_wi, xx = (next ? nn_x0 : nc_x0) + (phase & 1) + 4 * n_pj;
+            const bool vy = (unsigned)yy < (unsigned)g.in_h;
+            n_ok0 = n_ok0 && vy && (unsigned)xx < (unsigned)g.in_w;
+            n_ok1 = n_ok1 && vy && (unsigned)(xx + 2) < (unsigned)g.in_w;
+        }
+    };
+    auto nchw_load2 = [&](int q, int sc) {                   // channel sc of the chunk aimed at, both pixels
+        if (sc < (q == 3 ? 6 : 4) && AB != 8) {             // (8: profiling, no gather loads)
+            if (n_zero) { lr[2 * sc] = 0.0f; lr[2 * sc + 1] = 0.0f; }
+            const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(n_base + sc * n_plane) + n_goff);
+            if (n_ok0) lr[2 * sc] = p[0];
+            if (n_ok1) lr[2 * sc + 1] = p[2];
+        }
+    };
+    auto nchw_store = [&](int phase, int q) {                // the chunk in lr -> the team's window buffer phase & 1 (slots: c c+2 | c+1 c+3 per four channels)
+        if (AB == 9) return;                                 // (9: profiling, no window stores)
+        float* d = smem + team * 2 * SW_RAW_F + (phase & 1) * SW_RAW_F + n_lds + 4 * q;
+        if (n_act) {
+            *reinterpret_cast<v2f*>(d + 0) = (v2f){lr[0], lr[4]};
+            *reinterpret_cast<v2f*>(d + 2) = (v2f){lr[2], lr[6]};
+            if (q == 3) *reinterpret_cast<v2f*>(d + 4) = (v2f){lr[8], lr[10]};       // channels 16, 17
+        }
+        if (n_act1) {
+            *reinterpret_cast<v2f*>(d + SW_C + 0) = (v2f){lr[1], lr[5]};
+            *reinterpret_cast<v2f*>(d + SW_C + 2) = (v2f){lr[3], lr[7]};
+            if (q == 3) *reinterpret_cast<v2f*>(d + SW_C + 4) = (v2f){lr[9], lr[11]};
+        }
+    };
+
     int pair = blockIdx.x;
     if (2 * pair >= g.n_items) return;
     int item = min(2 * pair + team, g.n_items - 1);
     bool live = 2 * pair + team < g.n_items;
-    dma_raw(item, 0);
+    if (NCHW) {
+        nchw_item(item, nc_origin, nc_y0, nc_x0, nc_border);
+        for (int q = 0; q < 4; ++q) {                        // the first window, chunk by chunk; then the first chunk of the second one
+            nchw_aim(false, 0, q);
+#pragma unroll
+            for (int sc = 0; sc < 6; ++sc) nchw_load2(q, sc);
+            nchw_store(0, q);
+        }
+        nchw_aim(false, 1, 0);
+#pragma unroll
+        for (int sc = 0; sc < 6; ++sc) nchw_load2(0, sc);
+    } else {
+        dma_raw(item, 0);
+    }
     dma_filters(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first row's transform reads the window in front of the row's barrier
     __syncthreads();
@@ -340,10 +418,24 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
         const int next_pair = pair + gridDim.x;
         const bool has_next = 2 * next_pair < g.n_items;
         const int next_item = min(2 * next_pair + team, g.n_items - 1);
+        if (NCHW && has_next) nchw_item(next_item, nn_origin, nn_y0, nn_x0, nn_border);
 
         for (int r = 0; r < SW_ROWS; ++r) {
             const StemRow& row = c_stem_rows[r];
             const int phase = row.phase;
+            // NCHW: row idx of its phase stores chunk idx of the NEXT window (loaded during the previous row) and loads chunk idx + 1; the
+            // phase's last row loads chunk 0 of the window after next
+            const int n_idx = r - (phase == 0 ? 0 : phase == 1 ? 5 : phase == 2 ? 10 : 14);
+            const bool n_last = r == SW_ROWS - 1 || c_stem_rows[r + 1].first;
+            int n_lq = -1;                                       // chunk to load in this row's MFMA run
+            if (NCHW) {
+                int l_phase = phase + 1;
+                bool l_next = false;
+                if (n_idx + 1 < 4) n_lq = n_idx + 1;
+                else if (n_last) { n_lq = 0; l_phase = phase + 2; }
+                if (l_phase > 3) { l_phase -= 4; l_next = true; if (!has_next) n_lq = -1; }
+                if (n_lq >= 0) nchw_aim(l_next, l_phase, n_lq);
+            }
             // ---- the row's VALU run: input transform (the window of its phase landed at least a row ago) ----
             const float* rawp = raw_team + (phase & 1) * SW_RAW_F + patch0 + 2 * kl;
             const float* raws = raw_team + (phase & 1) * SW_RAW_F + patch0 + 16;
@@ -358,6 +450,9 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
                 else if (row.ne == 3) sw_transform<4, 3, AB>(rawp, raws, row, odd, A);
                 else sw_transform<4, 2, AB>(rawp, raws, row, odd, A);
             }
+            // NCHW: the chunk loaded during the previous row's MFMA run goes to LDS here, behind the transform (its loads have had the
+            // transform's time to arrive; stored at the top of the row they were waited for) and in front of the row's barrier
+            if (NCHW && n_idx < 4 && (phase < 3 || has_next)) nchw_store(phase + 1, n_idx);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of row r's filters (and of the next phase window)
             if (AB != 4) __syncthreads();                        // ... everyone's; the other filter buffer and window buffer are free
             // The DMAs of the next row's filters (and, in the first row of a phase, of the next phase's window) are issued INSIDE the
@@ -365,7 +460,7 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
             // pieces) held the whole SIMD back while the MFMA pipe was idle.
             const int f_row = r + 1 < SW_ROWS ? r + 1 : (has_next ? 0 : -1);
             const int w_phase = phase < 3 ? phase + 1 : 0;
-            const bool w_fetch = row.first && (phase < 3 || has_next);
+            const bool w_fetch = !NCHW && row.first && (phase < 3 || has_next);
             const float* w_src = xf;
             if (w_fetch) w_src = window_src(phase < 3 ? item : next_item, w_phase);      // (four rows in eighteen: two divisions)
             // the filter row's source and piece count once per row, not per piece
@@ -375,6 +470,8 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
             auto spread = [&](int slot) {                        // slots 0-2: filter pieces, 3-9: window pieces
                 if (slot < 3) {
                     if (wave + 8 * slot < f_pieces) lds_dma16((unsigned)(lane * 16), f_src + slot * 8 * 256, f_dst + (unsigned)(slot * 8 * 1024));
+                } else if (NCHW) {
+                    if (n_lq >= 0 && slot < 9) nchw_load2(n_lq, slot - 3);       // (issued in a burst at the head of the run instead: 0.70 against 0.69 ms)
                 } else if (w_fetch) {
                     dma_raw_piece(w_src, w_phase, slot - 3);
                 }
@@ -446,6 +543,7 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
                     if (has_left) P[r] = fmaxf(P[r], xb[128 + r * 8 + tx - 1]);
                 }
             }
+            if (NCHW) __syncthreads();       // the next item's first row STORES into this buffer at once (the frame-fed form's DMA into it waits for a barrier)
             if (live) {
                 const unsigned b = sw_div((unsigned)item, (unsigned)g.blocks_img, g.magic_img), rem = item - b * g.blocks_img;
                 const unsigned by = sw_div(rem, (unsigned)g.blocks_x, g.magic_x), bx = rem - by * g.blocks_x;
@@ -496,6 +594,7 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
         if (!has_next) break;
         pair = next_pair;
         item = next_item;
+        nc_origin = nn_origin; nc_y0 = nn_y0; nc_x0 = nn_x0; nc_border = nn_border;
         live = 2 * pair + team < g.n_items;
     }
 }
@@ -680,7 +779,7 @@ extern "C" int hps_proxy_rep_phase_frames(const float* edge, const float* joints
 }
 
 static int stem_wino_launch(const float* frames, const float* u, const float* scale, const float* shift, float* y, int B, int H,
-                            int W, int opad, int relu, int ablate, hps_stream_t stream, float* side = nullptr) {
+                            int W, int opad, int relu, int ablate, hps_stream_t stream, float* side = nullptr, bool nchw = false) {
     const bool pool = side != nullptr;
     if (!frames || !u || !scale || !shift || !y) return bad_arg("hps_stem_winograd: null pointer");
     if (H <= 0 || W <= 0 || (H % 32) || (W % 32)) return bad_arg("hps_stem_winograd: H and W must be multiples of 32 (8 x 8 blocks of 2 x 2-pixel tiles at stride 2)");
@@ -700,6 +799,7 @@ static int stem_wino_launch(const float* frames, const float* u, const float* sc
     g.relu = relu;
     g.magic_img = sw_magic((unsigned)g.blocks_img);
     g.magic_x = sw_magic((unsigned)g.blocks_x);
+    g.in_h = H; g.in_w = W;
     if ((size_t)B * g.fr_imgf * 4 >= 0xffffffffull || (size_t)B * g.out_img * 4 >= 0xffffffffull)
         return bad_arg("hps_stem_winograd: tensor exceeds the 32-bit lane offsets");
     const size_t lds = (size_t)SW_LDS_F * sizeof(float);
@@ -712,10 +812,30 @@ static int stem_wino_launch(const float* frames, const float* u, const float* sc
                            frames, u, scale, shift, y, (float*)nullptr, g);
     };
     if (pool) {
-        if (ablate != 0) return bad_arg("hps_stem_winograd_pooled: no ablations");
-        if ((rc = grant_lds<&stem_wino_kernel<0, true>>((int)lds, "hps_stem_winograd_pooled")) != HPS_OK) return rc;
-        hipLaunchKernelGGL((stem_wino_kernel<0, true>), dim3((unsigned)(pairs < 256 ? pairs : 256)), dim3(512), lds, (hipStream_t)stream,
-                           frames, u, scale, shift, y, side, g);
+        if (ablate != 0 && !(nchw && (ablate == 8 || ablate == 9))) return bad_arg("hps_stem_winograd_pooled: no ablations");
+        if (nchw) {
+#ifdef HPS_DEV_BUILD
+            if (ablate == 8 || ablate == 9) {                // profiling: the gather without its loads / without its LDS stores (results are garbage)
+                if (ablate == 8) {
+                    if ((rc = grant_lds<&stem_wino_kernel<8, true, true>>((int)lds, "hps_dev_stem_winograd_pooled_nchw")) != HPS_OK) return rc;
+                    hipLaunchKernelGGL((stem_wino_kernel<8, true, true>), dim3((unsigned)(pairs < 256 ? pairs : 256)), dim3(512), lds, (hipStream_t)stream,
+                                       frames, u, scale, shift, y, side, g);
+                } else {
+                    if ((rc = grant_lds<&stem_wino_kernel<9, true, true>>((int)lds, "hps_dev_stem_winograd_pooled_nchw")) != HPS_OK) return rc;
+                    hipLaunchKernelGGL((stem_wino_kernel<9, true, true>), dim3((unsigned)(pairs < 256 ? pairs : 256)), dim3(512), lds, (hipStream_t)stream,
+                                       frames, u, scale, shift, y, side, g);
+                }
+                return check_launch("hps_dev_stem_winograd_pooled_nchw");
+            }
+#endif
+            if ((rc = grant_lds<&stem_wino_kernel<0, true, true>>((int)lds, "hps_stem_winograd_pooled_nchw")) != HPS_OK) return rc;
+            hipLaunchKernelGGL((stem_wino_kernel<0, true, true>), dim3((unsigned)(pairs < 256 ? pairs : 256)), dim3(512), lds, (hipStream_t)stream,
+                               frames, u, scale, shift, y, side, g);
+        } else {
+            if ((rc = grant_lds<&stem_wino_kernel<0, true>>((int)lds, "hps_stem_winograd_pooled")) != HPS_OK) return rc;
+            hipLaunchKernelGGL((stem_wino_kernel<0, true>), dim3((unsigned)(pairs < 256 ? pairs : 256)), dim3(512), lds, (hipStream_t)stream,
+                               frames, u, scale, shift, y, side, g);
+        }
         if ((rc = check_launch("hps_stem_winograd_pooled")) != HPS_OK) return rc;
         const long total = (long)g.n_items * 15 * 16;
         hipLaunchKernelGGL(stem_pool_borders_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, side, g, total);
@@ -754,7 +874,18 @@ extern "C" int hps_stem_winograd_pooled(const float* frames, const float* u, con
     return stem_wino_launch(frames, u, scale, shift, pooled, B, H, W, opad, relu, 0, stream, side);
 }
 
+extern "C" int hps_stem_winograd_pooled_nchw(const float* x, const float* u, const float* scale, const float* shift, float* pooled, float* side,
+                                             int B, int H, int W, int opad, int relu, hps_stream_t stream) {
+    if (!side) return bad_arg("hps_stem_winograd_pooled_nchw: null pointer");
+    if ((size_t)B * SW_C * H * W * 4 >= 0x7fffffffull * 4) return bad_arg("hps_stem_winograd_pooled_nchw: input too large");
+    return stem_wino_launch(x, u, scale, shift, pooled, B, H, W, opad, relu, 0, stream, side, true);
+}
+
 #ifdef HPS_DEV_BUILD
+extern "C" int hps_dev_stem_winograd_pooled_nchw(const float* x, const float* u, const float* scale, const float* shift, float* pooled, float* side,
+                                                 int B, int H, int W, int opad, int relu, int ablate, hps_stream_t stream) {
+    return stem_wino_launch(x, u, scale, shift, pooled, B, H, W, opad, relu, ablate, stream, side, true);
+}
 extern "C" int hps_dev_stem_winograd(const float* frames, const float* u, const float* scale, const float* shift, float* y, int B,
                                      int H, int W, int opad, int relu, int ablate, hps_stream_t stream) {
     return stem_wino_launch(frames, u, scale, shift, y, B, H, W, opad, relu, ablate, stream);

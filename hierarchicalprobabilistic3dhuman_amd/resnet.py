@@ -321,6 +321,9 @@ class ResNet(nn.Module):
         # Winograd stem: form the max pool in the stem kernel's epilogue (hps_stem_winograd_pooled: the full-resolution stem output is never
         # written; identical values).  False: hps_stem_winograd + hps_maxpool3x3s2_pad (the cross-check of the tests)
         self.fused_pool = True
+        # ... and gather its phase windows from the NCHW input itself (hps_stem_winograd_pooled_nchw: no hps_stem_phase_split, no phase frames;
+        # identical values).  Needs fused_pool; callers that fill the frames themselves (stem_frames) keep the frame-fed kernel.
+        self.stem_reads_nchw = True
         self._frames = _FrameCache()
         self.register_load_state_dict_post_hook(_invalidate_after_load)
 
@@ -393,11 +396,13 @@ class ResNet(nn.Module):
         return prep
 
     # ---- halo-padded activation frames: owned by the module, zeroed once, only interiors are ever written ----
-    def _frame_set(self, prep, B, C, H, W, device):
+    def _frame_set(self, prep, B, C, H, W, device, frames=False):
+        """``frames``: the caller fills the stem's phase frames itself (stem_frames / FilledStemFrames): the frame-fed stem kernel."""
         stem = prep["stem"]
         stem_wino = stem.stem_winograd_ok(C, H, W)
         fused_pool = bool(stem_wino and self.fused_pool)
-        key = (B, C, H, W, str(device), _capi.stream().value, stem_wino, fused_pool)
+        from_nchw = bool(fused_pool and self.stem_reads_nchw and not frames)
+        key = (B, C, H, W, str(device), _capi.stream().value, stem_wino, fused_pool, from_nchw)
         fs = self._frames.get(key)
         if fs is not None:
             return fs
@@ -409,13 +414,15 @@ class ResNet(nn.Module):
         cf = stem.row_c if stem.wn is None else stem.cin_p
         wf = W + (W & 1)
         generic = cf != C or wf != W or C not in (4, 18, 64)
-        if stem_wino:      # four phase frames per image (hps_stem_phase_split), out-of-image pixels zeroed here once
+        if from_nchw:      # the stem reads the NCHW input itself
+            fs = {"in": None}
+        elif stem_wino:    # four phase frames per image (hps_stem_phase_split), out-of-image pixels zeroed here once
             fs = {"in": z(int(_capi.load(dev=_capi._use_dev).hps_stem_phase_frames_bytes(B, H, W)) // 4)}
         else:
             fs = {"in": z(B, H + 6, wf + 6, cf)}
         fs["stem_wino"], fs["generic_in"] = stem_wino, (C, cf, W, wf) if generic else None
         h, w = stem.out_hw(H, W)
-        fs["fused_pool"] = fused_pool
+        fs["fused_pool"], fs["from_nchw"] = fused_pool, from_nchw
         if fused_pool:       # the stem's full-resolution output is never materialised; scratch for the items' border contributions
             fs["stem"] = None
             fs["side"] = torch.empty(int(_capi.load(dev=_capi._use_dev).hps_stem_pool_side_bytes(B, H, W)) // 4, device=device, dtype=torch.float32)
@@ -437,7 +444,11 @@ class ResNet(nn.Module):
             fs["blocks"].append(ent)
         fs["hw"] = (h, w)
         # the launch list of hps_encoder_run: every pointer but the input image and the feature output is fixed
-        if fused_pool:
+        if from_nchw:
+            first = [_capi.EncOp(kind=_capi.ENC_STEM_WINOGRAD_POOLED_NCHW, x=None, w=stem.stem_u.data_ptr(), scale=stem.scale.data_ptr(),
+                                 shift=stem.shift.data_ptr(), y=fs["pool"].data_ptr(), splitk_ws=fs["side"].data_ptr(), B=B, H=H, W=W, Cin=C,
+                                 Cout=stem.cout, KH=7, KW=7, stride=2, pad=3, opad=1, relu=1)]
+        elif fused_pool:
             first = [_capi.EncOp(kind=_capi.ENC_STEM_SPLIT, x=None, y=fs["in"].data_ptr(), B=B, Cin=C, H=H, W=W),
                      _capi.EncOp(kind=_capi.ENC_STEM_WINOGRAD_POOLED, x=fs["in"].data_ptr(), w=stem.stem_u.data_ptr(), scale=stem.scale.data_ptr(),
                                  shift=stem.shift.data_ptr(), y=fs["pool"].data_ptr(), splitk_ws=fs["side"].data_ptr(), B=B, H=H, W=W, Cin=C,
@@ -485,7 +496,7 @@ class ResNet(nn.Module):
         prep = self._prepared or self.prepare()
         if self.layout != "padded" or not prep["stem"].stem_winograd_ok(C, H, W):
             return None
-        fs = self._frame_set(prep, B, C, H, W, device)
+        fs = self._frame_set(prep, B, C, H, W, device, frames=True)
         return FilledStemFrames(fs["in"], (B, C, H, W), device) if fs["stem_wino"] else None
 
     def _forward_padded(self, prep, x, gate=None):
@@ -496,7 +507,7 @@ class ResNet(nn.Module):
         B, C, H, W = x.shape
         s = _capi.stream()
         P = _capi.ptr
-        fs = self._frame_set(prep, B, C, H, W, x.device)
+        fs = self._frame_set(prep, B, C, H, W, x.device, frames=filled)
         if filled and (not fs["stem_wino"] or fs["in"].data_ptr() != x.frames.data_ptr()):
             raise _capi.HpsError("FilledStemFrames belong to another stream / shape / kernel selection than this forward (fill the "
                                  "frames stem_frames() returned on the stream the encoder runs on)")
@@ -514,6 +525,9 @@ class ResNet(nn.Module):
                 _capi.call("hps_encoder_run", rest, len(ops) - 1, s)
                 return feats
             ops[0].x = x.data_ptr()
+            if fs["from_nchw"] and gate is not None:     # no relayout in front of the first convolution: the whole list waits
+                gate()
+                gate = None
             if gate is None:
                 _capi.call("hps_encoder_run", ops, len(ops), s)
             else:
@@ -524,7 +538,13 @@ class ResNet(nn.Module):
                 _capi.call("hps_encoder_run", rest, len(ops) - 1, s)
             return feats
         stem = prep["stem"]
-        if fs["stem_wino"]:
+        if fs["from_nchw"]:
+            if gate is not None:
+                gate()
+            y = None
+            _capi.call("hps_stem_winograd_pooled_nchw", P(x), P(stem.stem_u), P(stem.scale), P(stem.shift), P(fs["pool"]), P(fs["side"]),
+                       B, H, W, 1, 1, s)
+        elif fs["stem_wino"]:
             if not filled:
                 _capi.call("hps_stem_phase_split", P(x), P(fs["in"]), B, C, H, W, s)
             if gate is not None:

@@ -384,6 +384,11 @@ int hps_stem_winograd(const float* frames, const float* u, const float* scale, c
 size_t hps_stem_pool_side_bytes(int B, int H, int W);
 int hps_stem_winograd_pooled(const float* frames, const float* u, const float* scale, const float* shift, float* pooled, float* side,
                              int B, int H, int W, int opad, int relu, hps_stream_t stream);
+/* The same from the network input itself: x (B,18,H,W) NCHW fp32, exactly what models/resnet.py:202-206 receives.  The kernel gathers its
+ * phase windows from x (global loads, out-of-image pixels stay zero) into the LDS layout the frames would have given it:
+ * hps_stem_phase_split and the four frames per image are not needed.  Identical values to hps_stem_phase_split + hps_stem_winograd_pooled. */
+int hps_stem_winograd_pooled_nchw(const float* x, const float* u, const float* scale, const float* shift, float* pooled, float* side,
+                                  int B, int H, int W, int opad, int relu, hps_stream_t stream);
 
 /* One launch of the encoder's operation list (hps_encoder_run).  kind: HPS_ENC_RELAYOUT = hps_nchw_to_padded_nhwc
  * (x, y, B, Cin = C, H, W, opad = P), HPS_ENC_CONV = hps_conv2d_bn_act_pad (all fields), HPS_ENC_MAXPOOL =
@@ -391,11 +396,12 @@ int hps_stem_winograd_pooled(const float* frames, const float* u, const float* s
  * Cin = C, ipad = P), HPS_ENC_CONV_WINOGRAD = hps_conv3x3_winograd (x, w = u, scale, shift, residual, y, B, H, W, ipad, Cin,
  * Cout, opad, relu, splitk_ws), HPS_ENC_STEM_SPLIT = hps_stem_phase_split (x, y = frames, B, Cin = C, H, W),
  * HPS_ENC_STEM_WINOGRAD = hps_stem_winograd (x = frames, w = u, scale, shift, y, B, H, W, opad, relu), HPS_ENC_STEM_WINOGRAD_POOLED =
- * hps_stem_winograd_pooled (x = frames, w = u, scale, shift, y = pooled frame, splitk_ws = side, B, H, W, opad, relu). */
+ * hps_stem_winograd_pooled (x = frames, w = u, scale, shift, y = pooled frame, splitk_ws = side, B, H, W, opad, relu),
+ * HPS_ENC_STEM_WINOGRAD_POOLED_NCHW = hps_stem_winograd_pooled_nchw (the same fields with x = the NCHW input). */
 enum { HPS_ENC_RELAYOUT = 0, HPS_ENC_CONV = 1, HPS_ENC_MAXPOOL = 2, HPS_ENC_AVGPOOL = 3, HPS_ENC_CONV_WINOGRAD = 4,
        HPS_ENC_STEM_SPLIT = 5, HPS_ENC_STEM_WINOGRAD = 6,
        HPS_ENC_RELAYOUT_GENERIC = 7 /* hps_nchw_to_padded_nhwc_generic (x, y, B, Cin = C, Cout = CP, H, W, KW = WF, opad = P) */,
-       HPS_ENC_STEM_WINOGRAD_POOLED = 8 };
+       HPS_ENC_STEM_WINOGRAD_POOLED = 8, HPS_ENC_STEM_WINOGRAD_POOLED_NCHW = 9 };
 typedef struct hps_enc_op {
     int kind;
     const float* x;

@@ -104,6 +104,9 @@ int hps_dev_mesh_lds_floor(int bytes);
 /* Experiment hook: K slices of hps_conv3x3_winograd's 8 x 8 geometry (0 = the product rule: four when >= 32 chunks).  Also changes
  * hps_conv3x3_winograd_workspace's answer. */
 int hps_dev_wino_quad_ksplit(int ks);
+/* profiling: hps_stem_winograd_pooled_nchw with ablate = 8 (no gather loads) / 9 (no window stores); 0 = the product */
+int hps_dev_stem_winograd_pooled_nchw(const float* x, const float* u, const float* scale, const float* shift, float* pooled, float* side,
+                                      int B, int H, int W, int opad, int relu, int ablate, hps_stream_t stream);
 /* experiment: Winograd layer on half items (4 x 8 tiles), two four-wave workgroups per CU; u4 = the half-chunk packing of the filters */
 int hps_dev_conv3x3_winograd_half(const float* x, const float* u4, const float* scale, const float* shift, const float* residual,
                                   float* y, int B, int H, int W, int ipad, int Cin, int Cout, int opad, int relu, int ablate,

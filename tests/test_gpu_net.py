@@ -571,6 +571,12 @@ def test_stem_with_the_max_pool_in_its_epilogue(cfg, dev):
     assert float((got[:, 0] - 7).abs().max()) == 0 and float((got[:, :, -1] - 7).abs().max()) == 0
     ref = F.max_pool2d(full.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
     assert torch.equal(got[:, 1:-1, 1:-1], ref)
+    # ... and fed by the NCHW input itself (hps_stem_winograd_pooled_nchw gathers the phase windows: no phase split, no frames): equal again
+    direct = torch.full((B, Ho // 2 + 2, Wo // 2 + 2, 64), 7.0, device=dev)
+    side.fill_(float("nan"))
+    _capi.call("hps_stem_winograd_pooled_nchw", P(x), P(cb.stem_u), P(cb.scale), P(cb.shift), P(direct), P(side), B, H, W, 1, 1, s)
+    torch.cuda.synchronize()
+    assert torch.equal(direct, want)
     # without ReLU (negative values): the same maxima
     _capi.call("hps_stem_winograd", P(frames), P(cb.stem_u), P(cb.scale), P(cb.shift), P(full), B, H, W, 0, 0, s)
     _capi.call("hps_stem_winograd_pooled", P(frames), P(cb.stem_u), P(cb.scale), P(cb.shift), P(got), P(side), B, H, W, 1, 0, s)
@@ -582,18 +588,23 @@ def test_stem_with_the_max_pool_in_its_epilogue(cfg, dev):
 def test_encoder_with_and_without_the_fused_pool_gives_the_same_features(dev, net_gpu, golden_input):
     enc = net_gpu.image_encoder
     x = torch.cat([golden_input.to(dev), torch.rand(3, 18, 256, 256, generator=torch.Generator().manual_seed(4)).to(dev)])
-    assert enc.fused_pool
+    assert enc.fused_pool and enc.stem_reads_nchw
     fused = enc(x).clone()
     try:
-        enc.fused_pool = False
+        enc.stem_reads_nchw = False              # phase split + frame-fed stem with the pool
+        framed = enc(x).clone()
+        enc.fused_pool = False                   # ... + max pool as its own kernel
         two = enc(x).clone()
         enc.composite = False
         two_b = enc(x).clone()
         enc.fused_pool = True
+        framed_b = enc(x).clone()
+        enc.stem_reads_nchw = True
         fused_b = enc(x).clone()
     finally:
-        enc.fused_pool, enc.composite = True, True
-    assert torch.equal(fused, two) and torch.equal(fused, two_b) and torch.equal(fused, fused_b)
+        enc.fused_pool, enc.composite, enc.stem_reads_nchw = True, True, True
+    for other in (framed, two, two_b, framed_b, fused_b):
+        assert torch.equal(fused, other)
 
 
 def test_winograd_and_direct_encoders_agree_and_are_batch_invariant(dev, net_gpu, golden, golden_input):

@@ -16,8 +16,9 @@ from hierarchicalprobabilistic3dhuman_amd import _capi, configs  # noqa: E402
 from hierarchicalprobabilistic3dhuman_amd.poseMF_shapeGaussian_net import PoseMFShapeGaussianNet  # noqa: E402
 
 
-def op_names(enc, stem_wino=True, fused_pool=False):
-    names = (["phase split NCHW->4 phase frames", "conv1 7x7/2 18->64 + maxpool 3x3/2 (stem, winograd F(2x2, 4x4|4x3|3x4|3x3); pool in the epilogue + border pass)"]
+def op_names(enc, stem_wino=True, fused_pool=False, from_nchw=False):
+    names = (["conv1 7x7/2 18->64 + maxpool 3x3/2 (stem, winograd; windows gathered from the NCHW input, pool in the epilogue + border pass)"] if from_nchw else
+             ["phase split NCHW->4 phase frames", "conv1 7x7/2 18->64 + maxpool 3x3/2 (stem, winograd F(2x2, 4x4|4x3|3x4|3x3); pool in the epilogue + border pass)"]
              if fused_pool else
              ["phase split NCHW->4 phase frames", "conv1 7x7/2 18->64 (stem, winograd F(2x2, 4x4|4x3|3x4|3x3))", "maxpool 3x3/2"] if stem_wino
              else ["relayout NCHW->padded NHWC", "conv1 7x7/2 18->64 (stem, row mode)", "maxpool 3x3/2"])
@@ -42,13 +43,15 @@ def main():
         enc.set_winograd(False)
     if len(sys.argv) > 3 and sys.argv[3] == "unfused-pool":     # A/B: stem and max pool as two kernels
         enc.fused_pool = False
+    if len(sys.argv) > 3 and sys.argv[3] == "from-frames":      # A/B: phase split + frame-fed stem
+        enc.stem_reads_nchw = False
     x = torch.rand(B, 18, 256, 256, generator=torch.Generator().manual_seed(1)).to(dev)
     with torch.no_grad():
         feats = enc(x)                                    # builds the frames and the launch list
         torch.cuda.synchronize()
         fs = next(iter(enc._frames.values()))
         ops, n = fs["ops"], len(fs["ops"])
-        names = op_names(enc, fs["stem_wino"], fs.get("fused_pool", False))
+        names = op_names(enc, fs["stem_wino"], fs.get("fused_pool", False), fs.get("from_nchw", False))
         assert len(names) == n, (len(names), n)
         ops[0].x = x.data_ptr()
         ops[n - 1].y = feats.data_ptr()
@@ -83,10 +86,10 @@ def main():
                            algorithm=("winograd F(2x2,3x3), four images per item, K in 4 slices" if o.H == 8 else "winograd F(2x2,3x3)") if wino
                            else "direct implicit GEMM",
                            mfma_gflop=gflop / 2.25 if wino else gflop)
-            if o.kind in (_capi.ENC_STEM_WINOGRAD, _capi.ENC_STEM_WINOGRAD_POOLED):
+            if o.kind in (_capi.ENC_STEM_WINOGRAD, _capi.ENC_STEM_WINOGRAD_POOLED, _capi.ENC_STEM_WINOGRAD_POOLED_NCHW):
                 gflop = 2.0 * o.B * (o.H // 2) * (o.W // 2) * 64 * 49 * 18 / 1e9
                 row.update(gflop=gflop, tflops=gflop / ms, out_hw=[o.H // 2, o.W // 2], cin=18, cout=64, ksplit=1,
-                           launches=2 if o.kind == _capi.ENC_STEM_WINOGRAD_POOLED else 1,
+                           launches=2 if o.kind in (_capi.ENC_STEM_WINOGRAD_POOLED, _capi.ENC_STEM_WINOGRAD_POOLED_NCHW) else 1,
                            algorithm="winograd, four stride-1 phases F(2x2, r x s): 81 multiplications per tile instead of 196",
                            mfma_gflop=gflop * 81.0 / 196.0)
             rows.append(row)
