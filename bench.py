@@ -166,7 +166,7 @@ def main():
     ap.add_argument("--event-every", type=int, default=1,
                     help="record the HIP timing events around the mesh kernel / encoder on every n-th step only (0 = never: no roofline from this run)")
     ap.add_argument("--no-inline-mesh", action="store_true", help="A/B: the mesh kernel on the caller's stream with an event on either side (round 4) instead of on the encoder's stream")
-    ap.add_argument("--stem-from-frames", action="store_true", help="A/B: hps_stem_phase_split + the frame-fed stem kernel instead of the stem gathering its windows from the NCHW input")
+    ap.add_argument("--stem-from-nchw", action="store_true", help="A/B: the stem gathers its windows from the NCHW input itself (no phase split); see ResNet.stem_reads_nchw for why it is off")
     ap.add_argument("--unfused-pool", action="store_true", help="A/B: stem and max pool as two kernels (round 4) instead of the pool in the stem kernel's epilogue")
     ap.add_argument("--head-cus", type=int, default=None,
                     help="exclusive schedule: CUs per XCD reserved for the head's kernels (the mesh kernel runs on the others); 0 = shared CUs")
@@ -239,7 +239,7 @@ def main():
         pipe.head_cus = args.head_cus
     pipe.inline_mesh = not args.no_inline_mesh
     net.image_encoder.fused_pool = not args.unfused_pool
-    net.image_encoder.stem_reads_nchw = not args.stem_from_frames
+    net.image_encoder.stem_reads_nchw = args.stem_from_nchw
 
     step_marks = []
 

@@ -322,8 +322,12 @@ class ResNet(nn.Module):
         # written; identical values).  False: hps_stem_winograd + hps_maxpool3x3s2_pad (the cross-check of the tests)
         self.fused_pool = True
         # ... and gather its phase windows from the NCHW input itself (hps_stem_winograd_pooled_nchw: no hps_stem_phase_split, no phase frames;
-        # identical values).  Needs fused_pool; callers that fill the frames themselves (stem_frames) keep the frame-fed kernel.
-        self.stem_reads_nchw = True
+        # identical values; needs fused_pool).  OFF by default: alone the encoder is 0.03 ms faster, but in the pipelined loop its first
+        # kernel is then the persistent stem instead of the light phase split, and whether the previous batch's joint / uncertainty
+        # kernels get their CUs before it decides the step: +0.3-0.5 % with the bench's event records in the queue, -3 to -7 % without
+        # them (bench.py --stem-from-nchw [--event-every 0]).  Callers that fill the frames themselves (stem_frames)
+        # use the frame-fed kernel either way.
+        self.stem_reads_nchw = False
         self._frames = _FrameCache()
         self.register_load_state_dict_post_hook(_invalidate_after_load)
 

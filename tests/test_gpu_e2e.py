@@ -304,7 +304,7 @@ def test_front_end_writes_the_stems_phase_frames_directly(dev, net_gpu):
         for v in (vis.to(dev), None):
             proxy = proxy_representation(rgb, j2d.to(dev), v, det, cfg)
             assert torch.is_tensor(proxy) and proxy.shape == (B, 18, D, D)
-            want_feats = enc(proxy).clone()                                              # (the stem gathers from the NCHW tensor itself)
+            want_feats = enc(proxy).clone()
             filled_buf = enc.stem_frames(B, 18, D, D, dev)
             _capi.call("hps_stem_phase_split", _capi.ptr(proxy), _capi.ptr(filled_buf.frames), B, 18, D, D, _capi.stream())
             want_frames = filled_buf.frames.clone()                                      # as hps_stem_phase_split leaves them

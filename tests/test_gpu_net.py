@@ -588,22 +588,22 @@ def test_stem_with_the_max_pool_in_its_epilogue(cfg, dev):
 def test_encoder_with_and_without_the_fused_pool_gives_the_same_features(dev, net_gpu, golden_input):
     enc = net_gpu.image_encoder
     x = torch.cat([golden_input.to(dev), torch.rand(3, 18, 256, 256, generator=torch.Generator().manual_seed(4)).to(dev)])
-    assert enc.fused_pool and enc.stem_reads_nchw
-    fused = enc(x).clone()
+    assert enc.fused_pool and not enc.stem_reads_nchw
+    fused = enc(x).clone()                       # phase split + frame-fed stem with the pool (the default)
     try:
-        enc.stem_reads_nchw = False              # phase split + frame-fed stem with the pool
-        framed = enc(x).clone()
-        enc.fused_pool = False                   # ... + max pool as its own kernel
-        two = enc(x).clone()
+        enc.stem_reads_nchw = True               # the stem gathers its windows from the NCHW input
+        direct = enc(x).clone()
         enc.composite = False
-        two_b = enc(x).clone()
-        enc.fused_pool = True
+        direct_b = enc(x).clone()
+        enc.stem_reads_nchw = False
         framed_b = enc(x).clone()
-        enc.stem_reads_nchw = True
-        fused_b = enc(x).clone()
+        enc.fused_pool = False                   # ... and the max pool as its own kernel
+        two_b = enc(x).clone()
+        enc.composite = True
+        two = enc(x).clone()
     finally:
-        enc.fused_pool, enc.composite, enc.stem_reads_nchw = True, True, True
-    for other in (framed, two, two_b, framed_b, fused_b):
+        enc.fused_pool, enc.composite, enc.stem_reads_nchw = True, True, False
+    for other in (direct, direct_b, framed_b, two_b, two):
         assert torch.equal(fused, other)
 
 

@@ -43,8 +43,8 @@ def main():
         enc.set_winograd(False)
     if len(sys.argv) > 3 and sys.argv[3] == "unfused-pool":     # A/B: stem and max pool as two kernels
         enc.fused_pool = False
-    if len(sys.argv) > 3 and sys.argv[3] == "from-frames":      # A/B: phase split + frame-fed stem
-        enc.stem_reads_nchw = False
+    if len(sys.argv) > 3 and sys.argv[3] == "from-nchw":        # A/B: the stem gathers its windows from the NCHW input (no phase split)
+        enc.stem_reads_nchw = True
     x = torch.rand(B, 18, 256, 256, generator=torch.Generator().manual_seed(1)).to(dev)
     with torch.no_grad():
         feats = enc(x)                                    # builds the frames and the launch list
