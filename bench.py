@@ -50,7 +50,9 @@ def cpu_baseline(net_state, parents, num_samples, n_images):
     params = O.SMPLParams(model, smpl_data.load_extra_joint_regressors(None), configs.SMPLX_EXTRA_VERTEX_IDS)
     x = synthetic_inputs(0, n_images)
     default_threads = torch.get_num_threads()
-    cores = max(1, min(default_threads, sharding.effective_cpus()))     # do not oversubscribe a cgroup CPU quota
+    # every hardware thread this process may use (affinity / cgroup quota: never oversubscribed).  Under torch.distributed.run the
+    # default is ONE thread (OMP_NUM_THREADS=1); the other ranks are idle while rank 0 times the baseline, so it takes the host
+    cores = max(1, min(os.cpu_count() or 1, sharding.effective_cpus()))
     torch.set_num_threads(cores)
     with torch.no_grad():
         torch.manual_seed(0)
@@ -166,7 +168,12 @@ def main():
     ap.add_argument("--event-every", type=int, default=1,
                     help="record the HIP timing events around the mesh kernel / encoder on every n-th step only (0 = never: no roofline from this run)")
     ap.add_argument("--no-inline-mesh", action="store_true", help="A/B: the mesh kernel on the caller's stream with an event on either side (round 4) instead of on the encoder's stream")
-    ap.add_argument("--stem-from-nchw", action="store_true", help="A/B: the stem gathers its windows from the NCHW input itself (no phase split); see ResNet.stem_reads_nchw for why it is off")
+    ap.add_argument("--stem-route", choices=("default", "nchw", "frames"), default="default",
+                    help="A/B: 'nchw' = the stem gathers its windows from the NCHW input itself (no phase split), 'frames' = hps_stem_phase_split + "
+                         "the frame-fed stem (round 5); default: ResNet.stem_reads_nchw as the model sets it")
+    ap.add_argument("--side-on-caller-stream", action="store_true",
+                    help="A/B: joint regression + uncertainty pass on the caller's stream, racing the next encoder's first kernel (round 5), "
+                         "instead of behind the mesh kernel on the encoder's stream")
     ap.add_argument("--unfused-pool", action="store_true", help="A/B: stem and max pool as two kernels (round 4) instead of the pool in the stem kernel's epilogue")
     ap.add_argument("--head-cus", type=int, default=None,
                     help="exclusive schedule: CUs per XCD reserved for the head's kernels (the mesh kernel runs on the others); 0 = shared CUs")
@@ -239,7 +246,9 @@ def main():
         pipe.head_cus = args.head_cus
     pipe.inline_mesh = not args.no_inline_mesh
     net.image_encoder.fused_pool = not args.unfused_pool
-    net.image_encoder.stem_reads_nchw = args.stem_from_nchw
+    pipe.inline_side = not args.side_on_caller_stream
+    if args.stem_route != "default":
+        net.image_encoder.stem_reads_nchw = args.stem_route == "nchw"
 
     step_marks = []
 
@@ -280,11 +289,11 @@ def main():
     # no kernel is loaded for the first time inside the timed region
     warm_sums = torch.zeros(4, dtype=torch.float64, device=dev)
     if not args.no_pipeline:
-        run_steps(0, args.warmup, lambda r: warm_sums.add_(sharding.batch_metric_sums(r)))
+        run_steps(0, args.warmup, lambda r: sharding.batch_metric_sums(r, accumulate=warm_sums))
     else:
         for i in range(args.warmup):
-            warm_sums.add_(sharding.batch_metric_sums(
-                infer(net, smpl, xs[i % INPUT_SETS], num_samples=N, use_mean_shape=True, seed=1234 + i, image_offset=offset_of(i))))
+            sharding.batch_metric_sums(infer(net, smpl, xs[i % INPUT_SETS], num_samples=N, use_mean_shape=True, seed=1234 + i,
+                                             image_offset=offset_of(i)), accumulate=warm_sums)
     sharding.gather_metric_sums(warm_sums)
     torch.cuda.synchronize()
     smpl.lbs_events = ev_lists["lbs"] = []
@@ -297,7 +306,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     def accumulate(res):
-        sums.add_(sharding.batch_metric_sums(res))
+        sharding.batch_metric_sums(res, accumulate=sums)      # the running total is formed by the checksum's own second launch
 
     if not args.no_pipeline:
         run_steps(args.warmup, args.steps, accumulate)
@@ -419,7 +428,7 @@ def main():
             ticket = rgb_step(first)
             for i in range(count):
                 nxt = rgb_step(first + i + 1) if i + 1 < count else None
-                sink.add_(sharding.batch_metric_sums(pipe.finish(ticket, seed=777 + first + i, image_offset=lo, after=nxt)))
+                sharding.batch_metric_sums(pipe.finish(ticket, seed=777 + first + i, image_offset=lo, after=nxt), accumulate=sink)
                 ticket = nxt
 
         # warm-up = one whole untimed leg (at least 8 steps): both upload slots, both input sets, the page-locked buffers' first
@@ -618,11 +627,14 @@ def main():
             "backend": (torch.distributed.get_backend() if distributed else None),
             "image_range_rank0": [lo, hi],
         }
-        if world == 1 and args.cpu_images > 0:
+        if args.cpu_images > 0:
+            # every N (north_star: "images/sec at 1/2/4/8 GPUs reported against the CPU reference baseline"): rank 0 times the oracle on
+            # the host after the collective; the other ranks sleep in sharding.wait_for_rank0 below (no spinning: the host is rank 0's)
             out["cpu_baseline"] = cpu_baseline(net_state, configs.SMPL_PARENTS, N, args.cpu_images)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if distributed:
+        sharding.wait_for_rank0("bench_line_printed", timeout_s=1800)
         torch.distributed.destroy_process_group()
 
 

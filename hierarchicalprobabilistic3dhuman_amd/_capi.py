@@ -68,7 +68,7 @@ _PROTOTYPES = {
     "hps_stem_pool_side_bytes": [_I, _I, _I],
     "hps_stem_winograd_pooled": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "hps_stem_winograd_pooled_nchw": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "hps_sums_f64": [_P, _P, _P, _I, _c.c_double, _P, _P, _P],
+    "hps_sums_f64": [_P, _P, _P, _I, _c.c_double, _P, _P, _P, _P],
     "hps_sizeof_enc_op": [],
     "hps_encoder_run": [_P, _I, _P],
     "hps_head_pose_levels": [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _P, _P, _P,

@@ -959,7 +959,7 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
         hipLaunchKernelGGL((conv_wino_kernel<ab, q>), grid, dim3(256), lds, (hipStream_t)stream, x, u, scale, shift, quad ? nullptr : residual,
                            quad ? splitk_ws : y, g);
     };
-    auto launch8 = [&](auto Q, auto TRF, auto AB) {           // the eight-wave forms (the product: TRF = true)
+    auto launch8 = [&](auto Q, auto TRF, auto AB) {           // the eight-wave forms (the product: TRF = false; true = dev ablation 23, the lane-per-tile store form, 2-6 % slower)
         constexpr bool q = decltype(Q)::value, tr = decltype(TRF)::value;
         constexpr int ab = decltype(AB)::value;
         if ((grant_rc = grant_lds<&conv_wino_kernel<ab, q, true, tr>>(160 * 1024, "hps_conv3x3_winograd")) != HPS_OK) return;

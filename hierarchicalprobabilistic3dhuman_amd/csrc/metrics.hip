@@ -227,13 +227,18 @@ __global__ __launch_bounds__(256) void sums_partial_kernel(const SumJobs jobs, d
     if (threadIdx.x == 0) partial[j * SUM_BLOCKS + blockIdx.x] = red[0];
 }
 
-__global__ void sums_final_kernel(const double* __restrict__ partial, int count, double first, double* __restrict__ out) {
+__global__ void sums_final_kernel(const double* __restrict__ partial, int count, double first, double* __restrict__ out,
+                                  double* __restrict__ accumulate) {
     const int j = threadIdx.x;
-    if (j == 0) out[0] = first;
+    if (j == 0) {
+        out[0] = first;
+        if (accumulate) accumulate[0] += first;
+    }
     if (j < count) {
         double t = 0.0;
         for (int b = 0; b < SUM_BLOCKS; ++b) t += partial[j * SUM_BLOCKS + b];
         out[1 + j] = t;
+        if (accumulate) accumulate[1 + j] += t;       // one lane per entry: running total = total + this call's sum, as a caller's add would form it
     }
 }
 
@@ -242,7 +247,7 @@ __global__ void sums_final_kernel(const double* __restrict__ partial, int count,
 using namespace hps;
 
 extern "C" int hps_sums_f64(const float* const* xs, const int64_t* ns, const int32_t* take_abs, int count, double first,
-                            double* partial_ws, double* out, hps_stream_t stream) {
+                            double* partial_ws, double* out, double* accumulate, hps_stream_t stream) {
     if (!xs || !ns || !take_abs || !partial_ws || !out) return bad_arg("hps_sums_f64: null pointer");
     if (count < 1 || count > 4) return bad_arg("hps_sums_f64: 1..4 tensors");
     SumJobs jobs;
@@ -253,7 +258,7 @@ extern "C" int hps_sums_f64(const float* const* xs, const int64_t* ns, const int
         if (j < count && (!xs[j] || ns[j] < 0)) return bad_arg("hps_sums_f64: tensor");
     }
     hipLaunchKernelGGL(sums_partial_kernel, dim3(SUM_BLOCKS, count), dim3(256), 0, (hipStream_t)stream, jobs, partial_ws);
-    hipLaunchKernelGGL(sums_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, count, first, out);
+    hipLaunchKernelGGL(sums_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_ws, count, first, out, accumulate);
     return check_launch("hps_sums_f64");
 }
 

@@ -550,13 +550,16 @@ __global__ __launch_bounds__(UV * UG) void uncertainty_lds_kernel(const f3* __re
 // its samples s = g, g + 8, ... (SPT of them, 3 floats each) in registers, so the samples are read from HBM once, the
 // only LDS is the 3 KB reduction buffer, and many workgroups share a CU (the LDS-resident form allows one).
 // Same sample-to-group assignment, same summation order and reduction tree as uncertainty_lds_kernel: identical bits.
-template <int SPT>
+// REV (dev A/B, hps_dev_unc_mode 6): images fastest, vertex panels DESCENDING -- the mesh kernel walks the panels in ascending order, so
+// the panels written last (the ones most likely still in the memory-side cache) would be read first.
+template <int SPT, bool REV = false>
 __global__ __launch_bounds__(512) void uncertainty_reg_kernel(const f3* __restrict__ verts, float* __restrict__ unc,
                                                               int N, int V) {
     constexpr int RV = 64, H = UG / 2;
     __shared__ float sRed[H * 3 * RV];
     const int v = threadIdx.x & (RV - 1), g = threadIdx.x / RV;
-    const int vg = blockIdx.x * RV + v, b = blockIdx.y;
+    const int panel = REV ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.x;
+    const int vg = panel * RV + v, b = REV ? blockIdx.x : blockIdx.y;
     const bool live = vg < V;
     const f3* base = verts + (size_t)b * N * V + (live ? vg : V - 1);
     // Guard-free: a sample beyond N re-reads sample N - 1 and contributes +0 (x + 0 = x bit for bit; the sums start at +0 and
@@ -607,6 +610,13 @@ __global__ __launch_bounds__(512) void uncertainty_reg_kernel(const f3* __restri
 
 template <int SPT>
 static int launch_unc_reg(const float* verts, float* unc, int B, int N, int V, hipStream_t s) {
+#ifdef HPS_DEV_BUILD
+    if (g_unc_mode == 6) {
+        hipLaunchKernelGGL((uncertainty_reg_kernel<SPT, true>), dim3(B, ceil_div(V, 64)), dim3(512), 0, s, reinterpret_cast<const f3*>(verts),
+                           unc, N, V);
+        return check_launch("hps_vertex_uncertainty");
+    }
+#endif
     hipLaunchKernelGGL(uncertainty_reg_kernel<SPT>, dim3(ceil_div(V, 64), B), dim3(512), 0, s, reinterpret_cast<const f3*>(verts),
                        unc, N, V);
     return check_launch("hps_vertex_uncertainty");
@@ -857,7 +867,7 @@ extern "C" int hps_vertex_uncertainty(const float* verts, float* unc, int B, int
     auto lds_bytes = [&](int uv) { return ((size_t)N * 3 * uv + (size_t)(UG / 2) * 3 * uv) * sizeof(float); };
 #endif
     // N <= 128 samples: register-resident single pass (mode 4 forces it, modes 1-3 select the older kernels)
-    if ((g_unc_mode == 0 || g_unc_mode == 4) && N >= 8 && N <= 16 * UG) {
+    if ((g_unc_mode == 0 || g_unc_mode == 4 || g_unc_mode == 6) && N >= 8 && N <= 16 * UG) {
         const int spt = ceil_div(N, UG);
         hipStream_t st = (hipStream_t)stream;
         if (spt <= 2) return launch_unc_reg<2>(verts, unc, B, N, V, st);
@@ -867,7 +877,7 @@ extern "C" int hps_vertex_uncertainty(const float* verts, float* unc, int B, int
         return launch_unc_reg<16>(verts, unc, B, N, V, st);
     }
     // 128 < N <= 1024: one sweep, 16 vertices x 32 sample groups per workgroup (mode 1: the two-sweep kernel; mode 5: 32 vertices)
-    if ((g_unc_mode == 0 || g_unc_mode >= 5) && N > 16 * UG && N <= 32 * 32) {
+    if ((g_unc_mode == 0 || g_unc_mode == 5) && N > 16 * UG && N <= 32 * 32) {
         hipStream_t st = (hipStream_t)stream;
 #ifdef HPS_DEV_BUILD
         if (g_unc_mode == 5) return launch_unc_sweep1<32, 32, 32>(verts, unc, B, N, V, st);

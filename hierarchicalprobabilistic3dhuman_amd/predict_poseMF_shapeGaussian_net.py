@@ -23,7 +23,7 @@ from .resnet import FilledStemFrames
 @torch.no_grad()
 def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mean_shape=True,
           sample_on_cpu=False, seed=None, image_offset=0, input_feats=None, _before_meshes=None, _after_smpl=None,
-          _run_net=None):
+          _run_net=None, _after_unc=None):
     """predict/predict_poseMF_shapeGaussian_net.py:103-165 for a batch of B proxy representations.
 
     proxy_rep_input: (B,18,256,256) on the device.  Returns a dict of device tensors; every entry equals
@@ -68,12 +68,17 @@ def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mea
     # InferencePipeline: the chip-filling mesh kernel waits at _before_meshes and signals at _after_smpl; sampling, the input
     # assembly, pose prep (before) and the joint regression / uncertainty (after) are small or HBM-bound and may run beside the
     # neighbouring batches' encoders
+    # (the uncertainties are allocated HERE, on the caller's stream: a hook may move the launches between _before_meshes and
+    # _after_unc to another stream, and every result must come from the caller's pool -- see SMPL.forward, "ordered")
+    unc = torch.empty(B, smpl_model.num_verts, **f32)
     out = smpl_model(body_pose=body, global_orient=glob_all, betas=betas_all, pose2rot=False,
                      _before_mesh=_before_meshes, _after_mesh=_after_smpl)
     V = out.vertices.shape[1]
     verts_s = out.vertices[2 * B:].view(B, N, V, 3)
     joints_s = out.joints[2 * B:].view(B, N, -1, 3)
-    unc = vertex_uncertainty(verts_s)                                             # sampling_utils.py:189-190
+    vertex_uncertainty(verts_s, out=unc)                                          # sampling_utils.py:189-190
+    if _after_unc is not None:
+        _after_unc()
     return dict(pose_F=pose_F, pose_U=pose_U, pose_S=pose_S, pose_V=pose_V, pose_rotmats_mode=mode,
                 shape_loc=loc, shape_scale=shape_dist.scale, glob=glob, cam=cam,
                 glob_rotmats=glob_rotmats, verts_mode=out.vertices[:B], joints_mode=out.joints[:B],
@@ -149,6 +154,7 @@ class InferencePipeline:
         self.enc_stream = None        # created by the first submit (its kind depends on the batch size)
         self.mesh_stream = None
         self._smpl_done = None
+        self._enc_tail = None         # the event recorded last on the encoder's stream, while nothing has been queued behind it
         self._exclusive = True
         self.enc_events = None
         self.trace = None             # bench.py --trace-steps: list of per-batch dicts of timing events (head / mesh phases)
@@ -183,6 +189,14 @@ class InferencePipeline:
         # stream waits for the kernel instead (SMPL.forward, "ordered"): record_stream would have the allocator put one event record
         # per freed operand into the encoder's queue.
         self.inline_mesh = True
+        # inline_side (with inline_mesh): the joint regression and the uncertainty pass of batch i FOLLOW its mesh kernel on the encoder's
+        # stream, in front of encoder i + 2, instead of racing that encoder's first kernel from the caller's stream.  Left on the
+        # caller's stream the two become ready at the moment the mesh kernel ends -- exactly when the next encoder's first kernel is
+        # dispatched; a persistent first kernel (the NCHW-fed stem: every CU's LDS and registers for 0.6 ms) then decided the step by
+        # whether it or the side kernels won that race (round 5: -3 to -7 % when it won).  In stream order there is no race: the
+        # HBM-bound pass runs alone (0.09 ms against 0.14 ms beside an encoder; it reads vertices the mesh kernel has just written),
+        # and a step is the sum of its kernels' work either way.
+        self.inline_side = True
         # (measured and dropped: making the next encoder wait for the uncertainty pass as well -- B = 16, N = 1000: 3.15 -> 3.24 ms
         # per step; B = 64, N = 100: 3.53 -> 3.51)
 
@@ -261,6 +275,11 @@ class InferencePipeline:
             if proxy_rep_input is None:
                 raise _capi.HpsError("InferencePipeline: call caller_stream(batch) before the first submit(make_input=...)")
             self._setup_streams(proxy_rep_input.shape[0])
+        # (re-armed whenever the encoder's prepared weights are gone -- load_state_dict / invalidate() / .to(): the next forward runs the
+        # lazy prepare() on the ENCODER's stream and must not read parameters a device-to-device copy is still writing on the caller's;
+        # the head's weights are re-prepared on its stream the same way: ADVICE r5)
+        if getattr(self.net.image_encoder, "_prepared", True) is None or getattr(self.net, "_prepared", True) is None:
+            self._fresh_streams = True
         if getattr(self, "_fresh_streams", False):
             # ONE-TIME ordering of the side streams behind whatever the caller has queued so far: parameters still
             # being written by a device-to-device load_state_dict, BN folding of a preceding warm-up infer(), ... -- whatever
@@ -294,15 +313,23 @@ class InferencePipeline:
             self.enc_stream.wait_event(self._smpl_done)
         with torch.cuda.stream(self.enc_stream):
             ev = None
+            tail, self._enc_tail = self._enc_tail, None
             if self.enc_events is not None:      # bench.py: HIP events around the encoder, on its own stream
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record(self.enc_stream)
+                # (an event record is a marker packet of ~8 us in the queue: the mark behind the previous batch's last kernel on this
+                # stream, when it was recorded with timing and nothing has been queued since, is this encoder's start mark, and the
+                # end mark is the event the head waits for)
+                start = tail if (tail is not None and make_input is None and input_ready is False and gate is None) else None
+                ev = (start if start is not None else torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                if start is None:
+                    ev[0].record(self.enc_stream)
             feats = self.net.image_encoder(proxy_rep_input, _gate=gate)
             if ev is not None:
                 ev[1].record(self.enc_stream)
                 self.enc_events.append(ev)
-            done = torch.cuda.Event()
-            done.record(self.enc_stream)
+                done = ev[1]
+            else:
+                done = torch.cuda.Event()
+                done.record(self.enc_stream)
         proxy_rep_input.record_stream(self.enc_stream)
         return feats, done
 
@@ -367,7 +394,13 @@ class InferencePipeline:
                     u.record_stream(main)
             return outs
 
+        side = inline and self.inline_side
+
         def smpl_done(mesh_end=None):
+            if side:                                     # joints + uncertainty follow in stream order; side_done() hands back
+                if tr is not None:
+                    tr["mesh1"].record(self.enc_stream)
+                return
             if inline:
                 done_ev = mesh_end                       # SMPL.forward's own event behind the kernel, when it recorded one
                 if done_ev is None:
@@ -384,14 +417,30 @@ class InferencePipeline:
             if tr is not None:
                 tr["mesh1"].record(main)
 
+        def side_done():
+            if not side:
+                return
+            # one event behind the uncertainty pass: the caller's stream waits for it (every result of the batch is complete), and
+            # with the bench's timing on it doubles as the next encoder's start mark (nothing is queued between the two)
+            timing = self.enc_events is not None
+            done_ev = torch.cuda.Event(enable_timing=timing)
+            done_ev.record(self.enc_stream)
+            self._enc_tail = done_ev if timing else None
+            torch.cuda.set_stream(main)
+            main.wait_event(done_ev)
+            self._smpl_done = None                       # the next encoder follows in stream order
+
         try:
             return infer(self.net, self.smpl, None, num_samples=self.num_samples, use_mean_shape=self.use_mean_shape,
                          sample_on_cpu=self.sample_on_cpu, seed=seed, image_offset=image_offset, input_feats=feats,
-                         _before_meshes=hook, _after_smpl=smpl_done, _run_net=run_net)
+                         _before_meshes=hook, _after_smpl=smpl_done, _run_net=run_net, _after_unc=side_done)
         finally:
-            # an error between the two hooks (a failed launch in SMPL.forward) must not leave the caller on the encoder's stream
+            # an error between the hooks (a failed launch in SMPL.forward) must not leave the caller on the encoder's stream -- nor
+            # let it reuse operands a kernel already queued there still reads: on the error path the caller's stream waits for the
+            # encoder's (no cost in steady state)
             if torch.cuda.current_stream() != main:
                 torch.cuda.set_stream(main)
+                main.wait_stream(self.enc_stream)
 
 
 _PREDICT_PIPELINES = weakref.WeakKeyDictionary()      # model -> (key, InferencePipeline, StagedUpload) of predict_poseMF_shapeGaussian_net

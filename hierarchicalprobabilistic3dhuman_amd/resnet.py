@@ -241,9 +241,12 @@ class FilledStemFrames:
     been (or are about to be, on that stream) filled by the caller -- hps_proxy_rep_phase_frames -- instead of by
     hps_stem_phase_split from an NCHW tensor.  ``ResNet.forward(filled)`` then starts at the stem convolution."""
 
-    def __init__(self, frames, shape, device, fill=None):
+    def __init__(self, frames, shape, device, fill=None, owner=None, generation=0):
         self.frames, self.shape, self.device = frames, tuple(shape), device
         self.is_cuda = True
+        # the frame buffer is ONE per (shape, stream) and belongs to the encoder: this object is good for exactly one forward, the next
+        # stem_frames() / phase split on the same buffer bumps the owner's generation and forward() refuses a stale object (ADVICE r5)
+        self.owner, self.generation = owner, generation
         # ``fill``: the launch that writes the frames, deferred to forward() -- issued right in front of the stem convolution, where
         # hps_stem_phase_split would have run: the stem then reads frames that were just written (L2 / Infinity Cache), not frames
         # written before the previous batch's mesh kernel streamed 540 MB through the caches (measured: filling them early made the
@@ -322,12 +325,13 @@ class ResNet(nn.Module):
         # written; identical values).  False: hps_stem_winograd + hps_maxpool3x3s2_pad (the cross-check of the tests)
         self.fused_pool = True
         # ... and gather its phase windows from the NCHW input itself (hps_stem_winograd_pooled_nchw: no hps_stem_phase_split, no phase frames;
-        # identical values; needs fused_pool).  OFF by default: alone the encoder is 0.03 ms faster, but in the pipelined loop its first
-        # kernel is then the persistent stem instead of the light phase split, and whether the previous batch's joint / uncertainty
-        # kernels get their CUs before it decides the step: +0.3-0.5 % with the bench's event records in the queue, -3 to -7 % without
-        # them (bench.py --stem-from-nchw [--event-every 0]).  Callers that fill the frames themselves (stem_frames)
-        # use the frame-fed kernel either way.
-        self.stem_reads_nchw = False
+        # identical values; needs fused_pool): phase split 0.118 + frame-fed stem 0.61 -> 0.67 ms.  The default since round 6.  In round 5
+        # it was off: the persistent stem as the encoder's first kernel raced the previous batch's joint / uncertainty kernels on the
+        # caller's stream for the CUs, and lost or won 3-7 % of the step with the bench's event records; InferencePipeline.inline_side now
+        # queues those kernels in stream order behind the mesh kernel (no race: the rate is the same with and without the markers,
+        # profiles/r06_ab.txt).  False = phase split + frame-fed kernel (the cross-check of the tests; callers that fill the frames
+        # themselves -- stem_frames -- use the frame-fed kernel either way).
+        self.stem_reads_nchw = True
         self._frames = _FrameCache()
         self.register_load_state_dict_post_hook(_invalidate_after_load)
 
@@ -501,7 +505,10 @@ class ResNet(nn.Module):
         if self.layout != "padded" or not prep["stem"].stem_winograd_ok(C, H, W):
             return None
         fs = self._frame_set(prep, B, C, H, W, device, frames=True)
-        return FilledStemFrames(fs["in"], (B, C, H, W), device) if fs["stem_wino"] else None
+        if not fs["stem_wino"]:
+            return None
+        fs["generation"] = fs.get("generation", 0) + 1
+        return FilledStemFrames(fs["in"], (B, C, H, W), device, owner=fs, generation=fs["generation"])
 
     def _forward_padded(self, prep, x, gate=None):
         """``gate``: optional callable invoked after the input relayout has been enqueued and before the first convolution
@@ -515,6 +522,13 @@ class ResNet(nn.Module):
         if filled and (not fs["stem_wino"] or fs["in"].data_ptr() != x.frames.data_ptr()):
             raise _capi.HpsError("FilledStemFrames belong to another stream / shape / kernel selection than this forward (fill the "
                                  "frames stem_frames() returned on the stream the encoder runs on)")
+        if filled:
+            if x.owner is not fs or x.generation != fs.get("generation", 0):
+                raise _capi.HpsError("stale FilledStemFrames: the encoder's frame buffer has been handed out again (or consumed by a forward) "
+                                     "since stem_frames() returned this object; call stem_frames() once per forward")
+            fs["generation"] += 1                        # consumed: a second forward with the same object would read whatever the frames hold then
+        elif fs.get("in") is not None and fs["stem_wino"]:
+            fs["generation"] = fs.get("generation", 0) + 1      # the phase split below overwrites the frames
         if self.composite and fs["variants"] == self._variant_state(prep):
             # one call across the C ABI for the whole encoder (csrc/composite.hip); two when the list is gated
             feats = torch.empty(B, fs["blocks"][-1]["c2"].shape[3], device=x.device, dtype=torch.float32)

@@ -183,12 +183,14 @@ def check_sampling():
                              "are pose_S / pose_U / pose_V finite?" % (bad, _MAX_ROUNDS))
 
 
-def vertex_uncertainty(vertices_samples):
-    """utils/sampling_utils.py:189-190, batched: (B,N,V,3) -> (B,V)."""
+def vertex_uncertainty(vertices_samples, out=None):
+    """utils/sampling_utils.py:189-190, batched: (B,N,V,3) -> (B,V).  ``out``: optional contiguous (B,V) fp32 destination."""
     _capi.require_device(vertices_samples, "vertices_samples")
     v = _capi.f32c(vertices_samples)
     B, N, V = v.shape[:3]
-    unc = torch.empty(B, V, device=v.device, dtype=torch.float32)
+    if out is not None:
+        assert out.shape == (B, V) and out.is_contiguous() and out.dtype == torch.float32 and out.device == v.device
+    unc = out if out is not None else torch.empty(B, V, device=v.device, dtype=torch.float32)
     ev = None
     if unc_events is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

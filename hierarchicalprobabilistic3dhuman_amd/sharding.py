@@ -58,6 +58,25 @@ def barrier():
         dist.barrier()
 
 
+def wait_for_rank0(key, timeout_s=1800):
+    """Rank 0 signals ``key`` through the process group's key-value store; every other rank BLOCKS on the store until it appears
+    (or ``timeout_s`` passes) -- a hand-over for long host-side work on rank 0 (bench.py: the CPU baseline, 10-30 s on all host
+    threads) that must not race the ranks' teardown.  Not a collective: the waiting ranks neither spin a host thread nor occupy a
+    device queue, and no collective timeout applies.  No-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    import datetime
+    try:
+        store = dist.distributed_c10d._get_default_store()
+    except Exception:                     # a build without the accessor: fall back to the collective
+        barrier()
+        return
+    if dist.get_rank() == 0:
+        store.set("hps/" + key, "1")
+    else:
+        store.wait(["hps/" + key], datetime.timedelta(seconds=timeout_s))
+
+
 def all_reduce_max(value):
     """MAX over ranks of one Python float (bench.py: the slowest rank's wall time)."""
     if not (dist.is_available() and dist.is_initialized()):
@@ -163,10 +182,12 @@ def effective_cpus():
     return max(1, n)
 
 
-def batch_metric_sums(result):
+def batch_metric_sums(result, accumulate=None):
     """Accumulator of one ``infer`` result: [image count, sum of per-vertex uncertainty, sum |mode vertices|,
     sum |sample joints|] in float64 -- the checksum-of-checksums the scaling tests compare across world sizes.
-    Two small launches (hps_sums_f64: fixed summation order, no float64 temporaries) -- this runs inside bench.py's timed step."""
+    Two small launches (hps_sums_f64: fixed summation order, no float64 temporaries) -- this runs inside bench.py's timed step.
+    ``accumulate``: optional (4,) float64 device tensor, a loop's running total: the second launch adds this batch's sums to it
+    (the same values ``accumulate.add_(returned)`` would leave, without that launch)."""
     import ctypes
     from . import _capi
     ts = [_capi.f32c(result["unc"]), _capi.f32c(result["verts_mode"]), _capi.f32c(result["joints_samples"])]
@@ -179,5 +200,6 @@ def batch_metric_sums(result):
     xs = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
     ns = (ctypes.c_int64 * 3)(*[t.numel() for t in ts])
     ab = (ctypes.c_int32 * 3)(0, 1, 1)
-    _capi.call("hps_sums_f64", xs, ns, ab, 3, float(ts[0].shape[0]), _capi.ptr(ws, torch.float64), _capi.ptr(out, torch.float64), _capi.stream())
+    _capi.call("hps_sums_f64", xs, ns, ab, 3, float(ts[0].shape[0]), _capi.ptr(ws, torch.float64), _capi.ptr(out, torch.float64),
+               _capi.ptr(accumulate, torch.float64) if accumulate is not None else None, _capi.stream())
     return out

@@ -514,9 +514,11 @@ int hps_pointset_errors(const float* pred, const float* target, int S, int group
 
 /* Result checksums (bench.py / the sharding-invariance tests; no reference counterpart): out[0] = first, out[1 + j] =
  * sum of xs[j][0 .. ns[j]) (of |x| where take_abs[j]) accumulated in float64 in a fixed order, for count <= 4 float tensors
- * in two launches.  xs / ns / take_abs are HOST arrays; partial_ws: 4 * 128 doubles; out: 1 + count doubles (device). */
+ * in two launches.  xs / ns / take_abs are HOST arrays; partial_ws: 4 * 128 doubles; out: 1 + count doubles (device).
+ * accumulate (optional, 1 + count doubles, device): a running total, accumulate[k] += out[k] in the second launch (a loop's
+ * accumulator without a launch of its own). */
 int hps_sums_f64(const float* const* xs, const int64_t* ns, const int32_t* take_abs, int count, double first,
-                 double* partial_ws, double* out, hps_stream_t stream);
+                 double* partial_ws, double* out, double* accumulate, hps_stream_t stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -479,6 +479,12 @@ def sec_encoder_pad():
     print("encoder B=64: plain %.3f ms, padded %.3f ms (%.1f TFLOP/s on 6.279 GFLOP/img); feats diff %.2e (max |f| %.2e)" % (
         t0, t1, 64 * 6.279 / t1, err(f0, f1), float(f0.abs().max())))
     prep = enc._prepared
+    # this section times the DIRECT kernels layer by layer on a plain padded NHWC input frame and a materialised stem output: select the
+    # direct stem + separate max pool (with the product defaults -- Winograd stem, pool in its epilogue -- fs["stem"] is None and fs["in"]
+    # holds phase frames or nothing: ADVICE r5)
+    enc.fused_pool = False
+    enc.set_winograd(False)
+    prep = enc._prepared
     fs = enc._frame_set(prep, 64, 18, 256, 256, x.device)
     from hierarchicalprobabilistic3dhuman_amd import _capi
     P = _capi.ptr

@@ -189,9 +189,11 @@ def test_mesh_kernel_on_the_encoder_stream_equals_the_separate_stream_schedule(d
     torch.manual_seed(5)
     xs = [torch.rand(32, 18, 256, 256, device=dev) for _ in range(2)]
     sums = {}
-    for inline in (True, False, True):
+    # (inline_mesh, inline_side): mesh kernel + joints + uncertainty on the encoder's stream (the default), the mesh kernel alone there,
+    # everything on the caller's stream
+    for inline, side in ((True, True), (False, False), (True, False), (True, True)):
         pipe = InferencePipeline(net_gpu, smpl_gpu, num_samples=20)
-        pipe.inline_mesh = inline
+        pipe.inline_mesh, pipe.inline_side = inline, side
         acc = []
         t = pipe.submit(xs[0], input_ready=False)
         for i in range(6):
@@ -205,8 +207,9 @@ def test_mesh_kernel_on_the_encoder_stream_equals_the_separate_stream_schedule(d
         torch.cuda.synchronize()
         got = torch.stack(acc).cpu()
         assert torch.isfinite(got).all()
-        sums.setdefault(inline, []).append(got)
-    assert torch.equal(sums[True][0], sums[False][0]) and torch.equal(sums[True][0], sums[True][1])
+        sums.setdefault((inline, side), []).append(got)
+    first = sums[(True, True)][0]
+    assert all(torch.equal(first, g) for runs in sums.values() for g in runs)
 
 
 def test_an_error_inside_the_mesh_window_leaves_the_caller_on_its_own_stream(dev, net_gpu, smpl_gpu, monkeypatch):
@@ -319,6 +322,10 @@ def test_front_end_writes_the_stems_phase_frames_directly(dev, net_gpu):
             filled.frames.copy_(torch.where(touched, filled.frames, torch.zeros_like(filled.frames)))
             assert torch.equal(filled.frames, want_frames)
             assert torch.equal(enc(filled), want_feats)
+            with pytest.raises(_capi.HpsError, match="stale"):                           # one forward per stem_frames(): the buffer is shared
+                enc(filled)
+            with pytest.raises(_capi.HpsError, match="stale"):                           # ... and an object handed out earlier is stale too
+                enc(filled_buf)
     # a shape the Winograd stem does not take: the tensor route
     cfg.DATA.PROXY_REP_SIZE = 48
     rgb = torch.rand(2, 3, 48, 48).to(dev)

@@ -78,11 +78,21 @@ def test_bare_bench_command_starts_its_own_ranks(dev, single_rank_shards):
     itself and print rank 0's one JSON line.  Two ranks over gloo on the one device: same shards, bit for
     bit, as `--as-rank r 2`; and with the default backend (nccl = RCCL: one device per rank) on a one-GPU box it must refuse
     with one clear sentence and a non-zero status instead of a traceback."""
-    two = _bench(["--gpus", "2", "--backend", "gloo"])              # ranks=None: plain `python bench.py`
+    # (--cpu-images 2: the N > 1 line carries the CPU baseline too -- rank 0 times the oracle after the collective while rank 1
+    # blocks on the store, sharding.wait_for_rank0 -- on a two-image sample to keep the test short)
+    two = _bench(["--gpus", "2", "--backend", "gloo", "--cpu-images", "2"])              # ranks=None: plain `python bench.py`
     assert two["n_gpus"] == 2 and two["backend"] == "gloo" and two["config"]["global_batch"] == 128
+    assert len(two["metric_checksums_per_rank"]) == 2
     for r in range(2):
         assert two["metric_checksums_per_rank"][r] == single_rank_shards[r]["metric_checksums_per_rank"][0], r
     assert two["metric_checksums"]["images"] == 2 * 64 * 2
+    # the schema of every N: metric / unit / scaling, roofline from this run's own HIP events, cpu_baseline timed on this host
+    assert two["unit"] == "images/s" and two["scaling"] == "weak" and two["higher_is_better"] is True and two["vs_baseline"] is None
+    roof = two["roofline"]
+    assert roof["bound"] == "hbm" and roof["launches"] == 2 and roof["achieved"] > 0 and 0 < roof["frac"] < 1 and roof["peak"] == 8000.0
+    cpu = two["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["unit"] == "images/s" and cpu["value"] > 0 and cpu["cores"] >= 1 and "2 images" in cpu["sample"]
+    assert two["speedup_vs_cpu_baseline"] == pytest.approx(two["value"] / cpu["value"])
     if torch.cuda.device_count() < 2:
         env = dict(os.environ)
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):

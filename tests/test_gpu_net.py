@@ -588,23 +588,23 @@ def test_stem_with_the_max_pool_in_its_epilogue(cfg, dev):
 def test_encoder_with_and_without_the_fused_pool_gives_the_same_features(dev, net_gpu, golden_input):
     enc = net_gpu.image_encoder
     x = torch.cat([golden_input.to(dev), torch.rand(3, 18, 256, 256, generator=torch.Generator().manual_seed(4)).to(dev)])
-    assert enc.fused_pool and not enc.stem_reads_nchw
-    fused = enc(x).clone()                       # phase split + frame-fed stem with the pool (the default)
+    assert enc.fused_pool and enc.stem_reads_nchw
+    direct = enc(x).clone()                      # the default: the stem gathers its windows from the NCHW input, pool in its epilogue
     try:
-        enc.stem_reads_nchw = True               # the stem gathers its windows from the NCHW input
-        direct = enc(x).clone()
         enc.composite = False
         direct_b = enc(x).clone()
-        enc.stem_reads_nchw = False
+        enc.stem_reads_nchw = False              # phase split + frame-fed stem with the pool (round 5's default)
         framed_b = enc(x).clone()
-        enc.fused_pool = False                   # ... and the max pool as its own kernel
-        two_b = enc(x).clone()
         enc.composite = True
+        fused = enc(x).clone()
+        enc.fused_pool = False                   # ... and the max pool as its own kernel
         two = enc(x).clone()
+        enc.composite = False
+        two_b = enc(x).clone()
     finally:
-        enc.fused_pool, enc.composite, enc.stem_reads_nchw = True, True, False
-    for other in (direct, direct_b, framed_b, two_b, two):
-        assert torch.equal(fused, other)
+        enc.fused_pool, enc.composite, enc.stem_reads_nchw = True, True, True
+    for other in (direct_b, framed_b, fused, two_b, two):
+        assert torch.equal(direct, other)
 
 
 def test_winograd_and_direct_encoders_agree_and_are_batch_invariant(dev, net_gpu, golden, golden_input):

@@ -11,7 +11,7 @@ from oracle import ref_cpu as O
 from oracle.smpl_np64 import smpl_forward64, rodrigues64
 from hierarchicalprobabilistic3dhuman_amd import configs, _capi
 from hierarchicalprobabilistic3dhuman_amd import sampling_utils as su
-from conftest import maxerr
+from conftest import maxerr, smplx_golden_models
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
@@ -446,3 +446,27 @@ def test_mesh_kernel_side_output_feeds_the_joint_regression(M, dev, smpl_gpu):
         _capi.call("hps_smpl_mesh_fused_picks", P(xt), P(smpl_gpu._bmat_p), P(smpl_gpu._v_template_flat), P(a), _capi.iptr(smpl_gpu._w_idx),
                    P(smpl_gpu._w_val), 8, 24, None, P(verts), M, smpl_gpu.num_verts, smpl_gpu._k_used, mp, smpl_gpu._np_fused,
                    _capi.iptr(smpl_gpu._pick_slot), P(picked), smpl_gpu._n_picked, _capi.stream())
+
+
+def test_hip_smpl_matches_the_reference_class_on_smplx(dev, smplx_golden):
+    """A10 / A11 pinned on the device: SMPL.forward (pose prep, fused mesh kernel, joints) against models/smpl_official.py:27-41
+    running on the installed smplx (tests/golden/make_smpl_golden.py).  Skips where the fixture does not exist."""
+    from hierarchicalprobabilistic3dhuman_amd.smpl_official import SMPL
+    fix = smplx_golden
+    for tag, gender, model in smplx_golden_models(fix):
+        key = "%s_%s_" % (tag, gender)
+        smpl = SMPL(model, batch_size=1, gender=gender, num_betas=10).to(dev)
+        t = lambda name: torch.from_numpy(fix[key + name]).to(dev)
+        betas, aa, transl, R = t("betas"), t("aa"), t("transl"), t("rotmats")
+        M = betas.shape[0]
+        sel = torch.from_numpy(fix[key + "vertex_ids"]).to(dev) if key + "vertex_ids" in fix else None
+        outs = {
+            "rotmat": smpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=betas, pose2rot=False),
+            "aa": smpl(body_pose=aa[:, 1:].reshape(M, 69), global_orient=aa[:, 0], betas=betas),
+            "tpose": smpl(betas=betas[:1]),
+            "transl": smpl(body_pose=R[:, 1:], global_orient=R[:, :1], betas=betas, transl=transl, pose2rot=False),
+        }
+        for name, o in outs.items():
+            v = o.vertices if sel is None else o.vertices[:, sel]
+            assert maxerr(v, t(name + "_verts")) <= TOL, (key, name)
+            assert maxerr(o.joints, t(name + "_joints")) <= TOL, (key, name)

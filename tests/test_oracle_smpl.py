@@ -6,7 +6,7 @@ import torch
 from oracle import ref_cpu as O
 from oracle.smpl_np64 import smpl_forward64, rodrigues64
 from hierarchicalprobabilistic3dhuman_amd import configs
-from conftest import maxerr
+from conftest import maxerr, smplx_golden_models
 
 
 def _rand_pose(M, seed, scale=0.5):
@@ -85,3 +85,53 @@ def test_batched_infer_equals_looping_single_images(smpl_assets, net_cpu, golden
     singles = [O.infer(net_cpu[1], p, configs.SMPL_PARENTS, None, 3, feats=feats[i:i + 1]) for i in range(2)]
     for k in ("verts_mode", "R_samples", "verts_samples", "unc"):
         assert maxerr(both[k], torch.cat([s[k] for s in singles])) <= 5e-6, k   # BLAS blocking differs with batch size
+
+
+def test_model_pkl_writer_round_trips_through_the_loader(tmp_path):
+    """tests/golden/make_smpl_golden.py hands smplx the seeded synthetic models as SMPL_<GENDER>.pkl; the file it writes must be what
+    smpl_data.load_smpl_pkl (the mirror of smplx's own reader) turns back into the same arrays."""
+    import importlib.util
+    import os
+    from hierarchicalprobabilistic3dhuman_amd import smpl_data
+    spec = importlib.util.spec_from_file_location("make_smpl_golden", os.path.join(os.path.dirname(__file__), "golden", "make_smpl_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    model = smpl_data.synthetic_smpl_model(1)
+    path = gen.write_model_pkl(model, str(tmp_path / "SMPL_MALE.pkl"))
+    back = smpl_data.resolve_smpl_model(str(tmp_path), gender="male")
+    for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "weights"):
+        assert np.array_equal(np.asarray(model[k], np.float64), back[k]), k
+    assert smpl_data.parents_from_kintree(back["kintree_table"]).tolist() == configs.SMPL_PARENTS
+    betas, aa, transl = gen.seeded_inputs(0)
+    assert betas.shape == (8, 10) and aa.shape == (8, 24, 3) and transl.shape == (8, 3) and not aa[0].any()
+    assert os.path.getsize(path) > 0
+
+
+def test_oracle_smpl_matches_the_reference_class_on_smplx(smplx_golden):
+    """A10 / A11 pinned: oracle/ref_cpu.smpl_forward against models/smpl_official.py:27-41 running on the installed smplx
+    (fixture: tests/golden/make_smpl_golden.py).  Skips where the fixture does not exist."""
+    fix = smplx_golden
+    models = smplx_golden_models(fix)
+    assert models
+    for tag, gender, model in models:
+        key = "%s_%s_" % (tag, gender)
+        from hierarchicalprobabilistic3dhuman_amd import smpl_data
+        p = O.SMPLParams(model, smpl_data.load_extra_joint_regressors(None), configs.SMPLX_EXTRA_VERTEX_IDS)
+        t = lambda name: torch.from_numpy(fix[key + name])
+        betas, aa, transl, R = t("betas"), t("aa"), t("transl"), t("rotmats")
+        M = betas.shape[0]
+        sel = torch.from_numpy(fix[key + "vertex_ids"]) if key + "vertex_ids" in fix else None
+        assert fix[key + "parents"].tolist()[1:] == configs.SMPL_PARENTS[1:]
+        assert maxerr(O.batch_rodrigues(aa.reshape(-1, 3)).reshape(M, 24, 3, 3), R) <= 1e-6
+        outs = {
+            "rotmat": O.smpl_forward(p, betas=betas, body_pose=R[:, 1:], global_orient=R[:, :1], pose2rot=False),
+            "aa": O.smpl_forward(p, betas=betas, body_pose=aa[:, 1:].reshape(M, 69), global_orient=aa[:, 0]),
+            "tpose": O.smpl_forward(p, betas=betas[:1]),
+            "transl": O.smpl_forward(p, betas=betas, body_pose=R[:, 1:], global_orient=R[:, :1], pose2rot=False, transl=transl),
+        }
+        for name, o in outs.items():
+            v = o["vertices"] if sel is None else o["vertices"][:, sel]
+            assert maxerr(v, t(name + "_verts")) <= 2e-5, (key, name)
+            assert maxerr(o["joints"], t(name + "_joints")) <= 2e-5, (key, name)
+            s64 = o["vertices"].double().abs().sum(dim=(1, 2))
+            assert maxerr(s64, t(name + "_verts_sum64")) <= 1e-5 * float(s64.max()), (key, name)

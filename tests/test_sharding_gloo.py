@@ -118,6 +118,35 @@ def test_evaluation_sharding_and_reduction(world, tmp_path):
     assert saved.tolist() == [float(f + 1) for f in range(n_frames)]
 
 
+def _handover_worker(rank, world, port, q):
+    import time
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sharding.init_distributed("gloo")
+    t0 = time.perf_counter()
+    if rank == 0:
+        time.sleep(1.5)                               # rank 0's long host-side work (bench.py: the CPU baseline)
+    sharding.wait_for_rank0("test_handover", timeout_s=60)
+    q.put((rank, time.perf_counter() - t0))
+    dist.destroy_process_group()
+
+
+def test_ranks_wait_for_rank0s_host_work_without_a_collective():
+    """bench.py with N > 1: rank 0 times the CPU baseline after the run's one collective; the other ranks block on the store
+    (sharding.wait_for_rank0) until the line is printed, then everybody tears the group down."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_handover_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[1] >= 1.0                          # rank 1 really waited for rank 0's signal
+    sharding.wait_for_rank0("no_group")               # no process group: a no-op
+
+
 def test_shard_dataset_partitions_exactly():
     for world in (1, 2, 3, 4, 8):
         for n in (0, 1, 7, 8, 64, 513):
