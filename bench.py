@@ -174,10 +174,12 @@ def main():
     ap.add_argument("--side-on-caller-stream", action="store_true",
                     help="A/B: joint regression + uncertainty pass on the caller's stream, racing the next encoder's first kernel (round 5), "
                          "instead of behind the mesh kernel on the encoder's stream")
+    ap.add_argument("--separate-downsample", action="store_true", help="A/B: the 1x1/2 down-sample of layer2-4's first block as a launch of its own (round 5) instead of inside the block's 3x3/2 convolution's launch")
     ap.add_argument("--unfused-pool", action="store_true", help="A/B: stem and max pool as two kernels (round 4) instead of the pool in the stem kernel's epilogue")
     ap.add_argument("--head-cus", type=int, default=None,
                     help="exclusive schedule: CUs per XCD reserved for the head's kernels (the mesh kernel runs on the others); 0 = shared CUs")
     ap.add_argument("--gather-joints", action="store_true", help="A/B: the joint regression gathers its vertices from the meshes (round 4) instead of reading the mesh kernel's compact side output")
+    ap.add_argument("--per-mesh-shape-blend", action="store_true", help="A/B: the K = 217 form of the fused mesh kernel (shape blend inside the GEMM, once per mesh: round 5) instead of the shared-shape form (K = 207, shape blend once per image)")
     ap.add_argument("--unfused-mesh", action="store_true", help="blend GEMM + LBS as two kernels (the unfused definition) instead of the fused mesh kernel")
     ap.add_argument("--trace-steps", action="store_true", help="print host-side per-step times to stderr (debugging)")
     ap.add_argument("--cpu-images", type=int, default=64, help="images in the CPU-baseline sample (0 = skip); 64 = one full batch, SURVEY 8(d)")
@@ -224,6 +226,7 @@ def main():
     smpl = SMPL(smpl_data.synthetic_smpl_model(0), batch_size=1, gender="neutral", num_betas=10).to(dev)
     smpl.fused_mesh = not args.unfused_mesh
     smpl.picked_joints = not args.gather_joints
+    smpl.shared_shape = not args.per_mesh_shape_blend
 
     lo, hi = sharding.shard_range(B * shard_world, shard_rank, shard_world)   # weak scaling: B images per GPU
     # INPUT_SETS different global batches rotate through the steps (step i reads set i % INPUT_SETS: no step re-reads the
@@ -246,6 +249,7 @@ def main():
         pipe.head_cus = args.head_cus
     pipe.inline_mesh = not args.no_inline_mesh
     net.image_encoder.fused_pool = not args.unfused_pool
+    net.image_encoder.fold_downsample = not args.separate_downsample
     pipe.inline_side = not args.side_on_caller_stream
     if args.stem_route != "default":
         net.image_encoder.stem_reads_nchw = args.stem_route == "nchw"
@@ -550,7 +554,9 @@ def main():
                                 "unit": "matrix-Fisher proposals/s (8N per image and joint, Philox)"}
 
     fused = bool(getattr(smpl, "fused_mesh", False))
-    mesh_kernel = "hps::mesh_fused_kernel<4,0,24,false,5>" if fused else "hps::lbs_kernel<4,8,1>"
+    shared_shape = fused and bool(getattr(smpl, "shared_shape", False)) and smpl.picked_joints
+    mesh_kernel = ("hps::mesh_fused_kernel<4,0,24,false,8,2,true,true>" if shared_shape else "hps::mesh_fused_kernel<4,0,24,false,5>") if fused else "hps::lbs_kernel<4,8,1>"
+    k_required = 207 if shared_shape else 217            # K rows the launch has to multiply per mesh (the shared shape blend: once per IMAGE)
     # HBM traffic of the same kernel from the PMC counters: collected in separate rocprofv3 passes of this very
     # command (tools/collect_profiles.sh), corrected as MI355X_MICROARCH.md prescribes, committed under profiles/
     traffic = None
@@ -615,9 +621,16 @@ def main():
                                "peak": MFMA_FP32_PEAK_TF, "unit": "TFLOP/s",
                                "frac": BLEND_FLOP_PER_MESH * M / (lbs_avg_ms * 1e-3) / 1e12 / MFMA_FP32_PEAK_TF,
                                "algorithmic_flop_per_launch": BLEND_FLOP_PER_MESH * M,
-                               "note": "fp32 MFMA: the bound of the fused kernel (K = 217 algorithmic, 224 issued); fp32 VALU "
-                                       "work of the skinning epilogue does not overlap with fp32 MFMA on gfx950 "
-                                       "(tools/mfma_valu_overlap.hip)"} if fused and lbs_ms else None),
+                               "k_algorithmic": 217, "k_required": k_required, "k_issued": 208 if shared_shape else 218,
+                               "required_flop_per_launch": 2 * k_required * 3 * 6890 * M,
+                               "frac_of_required_flop": 2 * k_required * 3 * 6890 * M / (lbs_avg_ms * 1e-3) / 1e12 / MFMA_FP32_PEAK_TF,
+                               "note": "fp32 MFMA: the bound of the fused kernel.  achieved / frac use SURVEY 8(d)'s per-mesh figure "
+                                       "(K = 217: pose blend + shape blend per mesh).  With use_mean_shape the meshes of an image share "
+                                       "their betas and the shape blend is formed once per image (hps_smpl_v_shaped), so the launch "
+                                       "has to multiply k_required = 207 rows per mesh (k_issued incl. padding): frac_of_required_flop "
+                                       "is the fraction of the MFMA peak by the work the launch really does.  fp32 VALU work of the "
+                                       "skinning epilogue does not overlap with fp32 MFMA on gfx950 (tools/mfma_valu_overlap.hip)"}
+                              if fused and lbs_ms else None),
             "secondary": secondary,
             "metric_checksums": {"images": float(total[0]), "sum_unc": float(total[1]),
                                  "sum_abs_verts_mode": float(total[2]), "sum_abs_joints_samples": float(total[3])},

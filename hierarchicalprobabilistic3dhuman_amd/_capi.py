@@ -32,6 +32,8 @@ _PROTOTYPES = {
     "hps_smpl_lbs": [_P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
     "hps_smpl_mesh_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "hps_smpl_mesh_fused_picks": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P],
+    "hps_smpl_mesh_fused_shared_shape": [_P] * 8 + [_I, _I, _P] + [_I] * 5 + [_P, _P, _I, _P],
+    "hps_smpl_v_shaped": [_P, _I, _P, _I, _P, _P, _I, _I, _P],
     "hps_smpl_mesh_fused_np": [_I],
     "hps_smpl_joints": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
     "hps_vertex_uncertainty": [_P, _P, _I, _I, _I, _P],
@@ -59,6 +61,7 @@ _PROTOTYPES = {
     "hps_heatmaps_to_joints2d": [_P, _P, _P, _I, _I, _I, _c.c_float, _P],
     "hps_sample_joints2d_error": [_P, _P, _I, _P, _P, _P, _c.c_float, _P, _I, _I, _P],
     "hps_conv2d_bn_act_pad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "hps_conv2d_bn_act_pad_down": [_P] * 9 + [_I] * 14 + [_P, _P],
     "hps_conv3x3_winograd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "hps_conv3x3_winograd_workspace": [_I, _I, _I, _I, _I],
     "hps_stem_phase_frames_bytes": [_I, _I, _I],
@@ -119,11 +122,12 @@ class EncOp(_c.Structure):
     """include/hps.h: hps_enc_op."""
     _fields_ = [("kind", _I), ("x", _P), ("w", _P), ("scale", _P), ("shift", _P), ("residual", _P), ("y", _P),
                 ("splitk_ws", _P)] + [(n, _I) for n in ("B", "H", "W", "ipad", "Cin", "Cout", "KH", "KW", "stride", "pad", "opad",
-                                                       "relu", "row_mode", "variant", "ksplit")]
+                                                       "relu", "row_mode", "variant", "ksplit")] + [
+                    ("w_down", _P), ("scale_down", _P), ("shift_down", _P), ("y_down", _P)]
 
 
 ENC_RELAYOUT, ENC_CONV, ENC_MAXPOOL, ENC_AVGPOOL, ENC_CONV_WINOGRAD, ENC_STEM_SPLIT, ENC_STEM_WINOGRAD, ENC_RELAYOUT_GENERIC = 0, 1, 2, 3, 4, 5, 6, 7
-ENC_STEM_WINOGRAD_POOLED, ENC_STEM_WINOGRAD_POOLED_NCHW = 8, 9
+ENC_STEM_WINOGRAD_POOLED, ENC_STEM_WINOGRAD_POOLED_NCHW, ENC_CONV_DOWN = 8, 9, 10
 SVD_HOST, SVD_DEVICE, SVD_DEVICE_FMA = 0, 1, 2
 SVD_ROUNDING_REFERENCE, SVD_ROUNDING_FMA = 0, 1
 HEAD_WIDE_WORKGROUPS = 0x100

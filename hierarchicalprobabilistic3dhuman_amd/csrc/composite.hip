@@ -32,6 +32,11 @@ extern "C" int hps_encoder_run(const hps_enc_op* ops, int n_ops, hps_stream_t st
                                            o.KH, o.KW, o.stride, o.pad, o.opad, o.relu, o.row_mode, o.variant, o.ksplit,
                                            o.splitk_ws, stream);
                 break;
+            case HPS_ENC_CONV_DOWN:
+                rc = hps_conv2d_bn_act_pad_down(o.x, o.w, o.scale, o.shift, o.y, o.w_down, o.scale_down, o.shift_down, o.y_down, o.B, o.H,
+                                                o.W, o.ipad, o.Cin, o.Cout, o.KH, o.KW, o.stride, o.pad, o.opad, o.relu, o.variant, o.ksplit,
+                                                o.splitk_ws, stream);
+                break;
             case HPS_ENC_CONV_WINOGRAD:
                 rc = hps_conv3x3_winograd(o.x, o.w, o.scale, o.shift, o.residual, o.y, o.B, o.H, o.W, o.ipad, o.Cin, o.Cout, o.opad,
                                           o.relu, o.splitk_ws, stream);

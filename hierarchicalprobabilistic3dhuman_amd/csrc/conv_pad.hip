@@ -14,6 +14,8 @@
 // The stem (7x7 / 2, 18 channels) runs on the same kernel in "row mode": in NHWC one filter row of a window is
 // KW * C = 126 contiguous floats, so it is treated as one tap of 128 "channels" (the two extra floats meet zero
 // filter entries): K = 7 * 128 = 896 instead of 7 * 7 * 20 = 980, no channel padding of the image.
+#include <type_traits>
+
 #include "hps_common.h"
 
 namespace hps {
@@ -51,6 +53,23 @@ struct PadGeom {
     unsigned magic_howo, magic_wo;
     int ablate;                            // tuning only (hps_dev_conv_pad_ablate): 1 = no epilogue
 };
+// The 1x1 / stride-s down-sample convolution of a residual block's entry (models/resnet.py:71-72, 184-188) issued by EXTRA WORKGROUPS OF
+// THE SAME LAUNCH as the block's 3x3 / stride-s convolution (hps_conv2d_bn_act_pad_down): the pixel a 1x1 / s / 0 window reads is the centre
+// tap (pad, pad) of the 3x3 / s / pad window of the same output pixel, so both share the geometry (pixel -> input offset, output frame) and
+// differ in the filter, the K range (that tap's Cin channels only), BatchNorm constants, destination and ReLU.  Workgroups [0, blocks_main)
+// of the grid (x every K slice) are the main convolution's; the rest walk the centre tap with the down-sample's filter -- the same chunks
+// in the same order as the separate launch: identical bits.  As launches of their own the three down-samples ran at 0.24-0.32 MFMA-busy
+// (16-26 us for 1-2 us of MFMA work per CU: too few, too short workgroups); here they fill the tail of a launch that is there anyway.
+struct DownArgs {
+    const float* wn;                       // (Cout, Cin) n-major filter of the 1x1 convolution
+    const float* scale;
+    const float* shift;
+    float* y;                              // its output frame (the main convolution's geometry)
+    int blocks_main;
+    int tap_kh, tap_kw;                    // the main window's tap it reads
+};
+struct NoDown {};
+
 #ifdef HPS_DEV_BUILD
 static int g_pad_ablate = 0;               // dev library only (hps_dev_conv_pad_ablate)
 #else
@@ -70,11 +89,12 @@ __device__ __forceinline__ unsigned out_pixel_offset(unsigned m, const PadGeom& 
 // two / three chunks ahead -- at batch 1 a 64 x 64 tile's chunk is 16 MFMAs per wave (0.43 us) with ONE workgroup on the CU, and a
 // chunk fetched one ahead arrived ~0.6 us after it was needed: 1.0 us per chunk, 18.3 us for a layer1 convolution of 18 chunks
 // (three stages: 15.3 us).
-template <int BM, int BN, int WM, int WN, int ST = 2>
+template <int BM, int BN, int WM, int WN, int ST = 2, bool DOWN = false>
 __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__ x, const float* __restrict__ wn,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ residual, float* __restrict__ y,
-                                                       float* __restrict__ partial, const PadGeom g) {
+                                                       float* __restrict__ partial, const PadGeom g,
+                                                       const std::conditional_t<DOWN, DownArgs, NoDown> d) {
     constexpr int WAVES_N = BN / WN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int A_LD = BM / 32, B_LD = BN / 32;        // DMA pieces per wave per chunk
@@ -85,7 +105,20 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
     float* sA = smem;                                   // [ST][BM][32]
     float* sB = smem + ST * BM * PBK;                   // [ST][BN][32]
 
-    const int tile_n = blockIdx.x / g.tiles_m, tile_m = blockIdx.x % g.tiles_m;
+    int bx = blockIdx.x;
+    bool down = false;                                   // workgroup-uniform
+    if constexpr (DOWN) {
+        if (bx >= d.blocks_main) {                       // a workgroup of the 1x1 down-sample convolution (see DownArgs)
+            if (blockIdx.y != 0) return;                 // it is never split over K
+            down = true;
+            bx -= d.blocks_main;
+            wn = d.wn; scale = d.scale; shift = d.shift; y = d.y; residual = nullptr;
+        }
+    }
+    const int filter_kp = down ? g.cin_k : g.Kp;         // K extent (floats) of a filter row
+    const int ksplit = down ? 1 : g.ksplit;
+    const int relu = down ? 0 : g.relu;
+    const int tile_n = bx / g.tiles_m, tile_m = bx % g.tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
@@ -110,7 +143,7 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
             a_off[r] = (o + dquad) * 4u;
         }
 #pragma unroll
-        for (int r = 0; r < B_LD; ++r) b_off[r] = ((unsigned)(n0 + drow + 32 * r) * g.Kp + dquad) * 4u;
+        for (int r = 0; r < B_LD; ++r) b_off[r] = ((unsigned)(n0 + drow + 32 * r) * filter_kp + dquad) * 4u;
     }
 
     f32x16 acc[TM][TN];
@@ -123,13 +156,16 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
 
     // split-K: blockIdx.y owns the chunk range [c_begin, c_end) and writes raw partial sums (summed in slice order by
     // splitk_pad_epilogue_kernel: deterministic, no atomics)
-    const int chunks_total = g.Kp / PBK;
-    const int per_split = chunks_total / g.ksplit;
-    const int c_begin = blockIdx.y * per_split, c_end = c_begin + per_split;
+    const int chunks_total = filter_kp / PBK;
+    const int per_split = chunks_total / ksplit;
+    const int c_begin = down ? 0 : blockIdx.y * per_split, c_end = c_begin + per_split;
     // scalar walk over (kh, kw, ci0): the A base pointer advances by 32 floats per chunk and jumps at tap / row ends
     const int cpt = g.cin_k / PBK;
     int ci = c_begin % cpt, tap = c_begin / cpt;
     int kw = tap % g.kw, kh = tap / g.kw;
+    if constexpr (DOWN) {
+        if (down) { kh = d.tap_kh; kw = d.tap_kw; }      // the one tap the 1x1 window reads; ci = 0 .. cpt - 1
+    }
     const float* a_src = x + (size_t)kh * g.row_pitch + (size_t)kw * g.pix_pitch + (size_t)ci * PBK;
     const float* b_src = wn + (size_t)c_begin * PBK;
     const int tap_jump = g.pix_pitch - g.cin_k + PBK;                    // from the last chunk of a tap to the next tap
@@ -242,7 +278,7 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
     // The filter fragment is the MFMA's row operand and the pixel fragment its column operand (products commute, the
     // k order is unchanged), so a lane ends up with ONE pixel (column = lane & 31) and, per register quad q, four
     // consecutive output channels: row = (r & 3) + 8 q + 4 (lane >> 5)  ->  128-bit accesses along Cout.
-    if (g.ksplit > 1) {
+    if (ksplit > 1) {
         float* dst = partial + (size_t)blockIdx.y * g.Mtot * g.Cout;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -312,7 +348,7 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
                 for (int u = 0; u < U; ++u) {
                     float4 v = make_float4(a[u].x * sc.x + sh.x + res[u].x, a[u].y * sc.y + sh.y + res[u].y,
                                            a[u].z * sc.z + sh.z + res[u].z, a[u].w * sc.w + sh.w + res[u].w);
-                    if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     *reinterpret_cast<float4*>(y + po[u]) = v;
                 }
             } else {
@@ -321,7 +357,7 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
                     // "+ 0" as in the guarded path (residual absent = zero addend): the same bits
                     float4 v = make_float4(a[u].x * sc.x + sh.x + 0.f, a[u].y * sc.y + sh.y + 0.f, a[u].z * sc.z + sh.z + 0.f,
                                            a[u].w * sc.w + sh.w + 0.f);
-                    if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     *reinterpret_cast<float4*>(y + po[u]) = v;
                 }
             }
@@ -342,7 +378,7 @@ __global__ __launch_bounds__(256) void conv_pad_kernel(const float* __restrict__
             const float4 a = *reinterpret_cast<const float4*>(patch + (u * PPI + lane / LPP) * EP + c4);
             float4 v = make_float4(a.x * sc.x + sh.x + res[u].x, a.y * sc.y + sh.y + res[u].y, a.z * sc.z + sh.z + res[u].z,
                                    a.w * sc.w + sh.w + res[u].w);
-            if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             if (live[u]) *reinterpret_cast<float4*>(y + po[u]) = v;
         }
     }
@@ -496,14 +532,23 @@ __global__ __launch_bounds__(256) void avgpool_pad_kernel(const float* __restric
 
 template <int BM, int BN, int WM, int WN, int ST = 2>
 static int launch_conv_pad(const float* x, const float* wn, const float* scale, const float* shift, const float* residual,
-                           float* y, float* partial, PadGeom g, hipStream_t s) {
+                           float* y, float* partial, PadGeom g, hipStream_t s, const DownArgs* down = nullptr) {
     g.tiles_m = ceil_div(g.Mtot, BM);
     const int tiles_n = g.Cout / BN;
     const size_t lds = (size_t)ST * (BM + BN) * PBK * sizeof(float);
-    if (lds > 64 * 1024)
-        if (int rc = grant_lds<&conv_pad_kernel<BM, BN, WM, WN, ST>>((int)lds, "hps_conv2d_bn_act_pad")) return rc;
-    hipLaunchKernelGGL((conv_pad_kernel<BM, BN, WM, WN, ST>), dim3(g.tiles_m * tiles_n, g.ksplit), dim3(256), lds, s, x, wn, scale,
-                       shift, residual, y, partial, g);
+    if (down) {                 // the block's 1x1 down-sample rides in the same launch: as many workgroups again, one K slice
+        DownArgs d = *down;
+        d.blocks_main = g.tiles_m * tiles_n;
+        if (lds > 64 * 1024)
+            if (int rc = grant_lds<&conv_pad_kernel<BM, BN, WM, WN, ST, true>>((int)lds, "hps_conv2d_bn_act_pad_down")) return rc;
+        hipLaunchKernelGGL((conv_pad_kernel<BM, BN, WM, WN, ST, true>), dim3(2 * d.blocks_main, g.ksplit), dim3(256), lds, s, x, wn, scale,
+                           shift, residual, y, partial, g, d);
+    } else {
+        if (lds > 64 * 1024)
+            if (int rc = grant_lds<&conv_pad_kernel<BM, BN, WM, WN, ST>>((int)lds, "hps_conv2d_bn_act_pad")) return rc;
+        hipLaunchKernelGGL((conv_pad_kernel<BM, BN, WM, WN, ST>), dim3(g.tiles_m * tiles_n, g.ksplit), dim3(256), lds, s, x, wn, scale,
+                           shift, residual, y, partial, g, NoDown());
+    }
     if (g.ksplit > 1) {
         const long total4 = (long)g.Mtot * g.Cout / 4;
         hipLaunchKernelGGL(splitk_pad_epilogue_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, partial, scale,
@@ -516,10 +561,10 @@ static int launch_conv_pad(const float* x, const float* wn, const float* scale, 
 
 using namespace hps;
 
-extern "C" int hps_conv2d_bn_act_pad(const float* x, const float* wn, const float* scale, const float* shift,
-                                     const float* residual, float* y, int B, int H, int W, int ipad, int Cin, int Cout,
-                                     int KH, int KW, int stride, int pad, int opad, int relu, int row_mode, int variant,
-                                     int ksplit, float* splitk_ws, hps_stream_t stream) {
+static int conv_pad_entry(const float* x, const float* wn, const float* scale, const float* shift,
+                          const float* residual, float* y, int B, int H, int W, int ipad, int Cin, int Cout,
+                          int KH, int KW, int stride, int pad, int opad, int relu, int row_mode, int variant,
+                          int ksplit, float* splitk_ws, hps_stream_t stream, DownArgs* down) {
     if (!x || !wn || !scale || !shift || !y) return bad_arg("hps_conv2d_bn_act_pad: null pointer");
     if (ipad < pad || opad < 0) return bad_arg("hps_conv2d_bn_act_pad: the input halo must cover the convolution padding");
     if (Cout % 64 != 0) return bad_arg("hps_conv2d_bn_act_pad: Cout % 64 == 0 required");
@@ -570,6 +615,17 @@ extern "C" int hps_conv2d_bn_act_pad(const float* x, const float* wn, const floa
         else variant = 3;
     }
     if (variant == 1 && Cout % 128 != 0) variant = 2;
+    if (down) {
+        // the tile shapes a residual block's entry convolution takes (Cout >= 128): 128 x 128, 128 x 64, 64 x 64 (two- and four-stage)
+        switch (variant) {
+            case 1: return launch_conv_pad<128, 128, 64, 64>(x, wn, scale, shift, residual, y, splitk_ws, g, s, down);
+            case 2: return launch_conv_pad<128, 64, 64, 32>(x, wn, scale, shift, residual, y, splitk_ws, g, s, down);
+            case 3: return launch_conv_pad<64, 64, 32, 32>(x, wn, scale, shift, residual, y, splitk_ws, g, s, down);
+            case 5: return launch_conv_pad<64, 64, 32, 32, 4>(x, wn, scale, shift, residual, y, splitk_ws, g, s, down);
+            default: set_error("hps_conv2d_bn_act_pad_down: tile variant %d carries no down-sample (issue the two convolutions separately)", variant);
+                     return HPS_E_UNSUPPORTED;
+        }
+    }
     switch (variant) {
         case 1: return launch_conv_pad<128, 128, 64, 64>(x, wn, scale, shift, residual, y, splitk_ws, g, s);
         case 2: return launch_conv_pad<128, 64, 64, 32>(x, wn, scale, shift, residual, y, splitk_ws, g, s);
@@ -581,6 +637,29 @@ extern "C" int hps_conv2d_bn_act_pad(const float* x, const float* wn, const floa
 #endif
         default: return bad_arg("hps_conv2d_bn_act_pad: variant");
     }
+}
+
+extern "C" int hps_conv2d_bn_act_pad(const float* x, const float* wn, const float* scale, const float* shift,
+                                     const float* residual, float* y, int B, int H, int W, int ipad, int Cin, int Cout,
+                                     int KH, int KW, int stride, int pad, int opad, int relu, int row_mode, int variant,
+                                     int ksplit, float* splitk_ws, hps_stream_t stream) {
+    return conv_pad_entry(x, wn, scale, shift, residual, y, B, H, W, ipad, Cin, Cout, KH, KW, stride, pad, opad, relu, row_mode, variant,
+                          ksplit, splitk_ws, stream, nullptr);
+}
+
+extern "C" int hps_conv2d_bn_act_pad_down(const float* x, const float* wn, const float* scale, const float* shift, float* y,
+                                          const float* wn_down, const float* scale_down, const float* shift_down, float* y_down,
+                                          int B, int H, int W, int ipad, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                          int opad, int relu, int variant, int ksplit, float* splitk_ws, hps_stream_t stream) {
+    if (!wn_down || !scale_down || !shift_down || !y_down) return bad_arg("hps_conv2d_bn_act_pad_down: null pointer");
+    if (KH != KW || KH % 2 != 1 || pad != KH / 2 || stride < 1)
+        return bad_arg("hps_conv2d_bn_act_pad_down: the main convolution must be k x k / s / (k / 2) (its centre tap is the 1x1 / s / 0 window)");
+    DownArgs d;
+    d.wn = wn_down; d.scale = scale_down; d.shift = shift_down; d.y = y_down;
+    d.blocks_main = 0;
+    d.tap_kh = pad; d.tap_kw = pad;
+    return conv_pad_entry(x, wn, scale, shift, nullptr, y, B, H, W, ipad, Cin, Cout, KH, KW, stride, pad, opad, relu, 0, variant, ksplit,
+                          splitk_ws, stream, &d);
 }
 
 #ifdef HPS_DEV_BUILD

@@ -62,12 +62,21 @@ static_assert(F_XP == FW && F_BP % FW == 0, "DMA pieces must divide evenly over 
 // PICK (round 5): the vertices the joint regressors read (pick_slot[v] >= 0: 198 of SMPL's 6 890) are ALSO written to a compact
 // (M, n_picked, 3) array -- the lane that skins a vertex has it in registers, and hps_smpl_joints then reads 2.4 KB per mesh in one
 // place instead of gathering 276 scattered 12-byte records from the 83 KB mesh (60 us per 6 528 meshes, bound by the request rate).
-template <int K, int ABL, int JC, bool HAS_T, int TAIL = FBK / 2, int ST = 2, bool PICK = false>
+// VS (round 6): meshes SHARE their shape -- every mesh of an image has the image's betas (use_mean_shape, the reference's predict
+// default: utils/sampling_utils.py:178-179) -- so the shape blend is not part of the GEMM at all: ``v_template`` is then the (R, V, 3) array
+// of the R distinct shaped templates v_template + S beta_r (hps_smpl_v_shaped: smplx lbs step (1), once per image), ``xt`` / ``bmat_p`` hold
+// the 207 pose rows only (K = 207 -> kp = 208 = thirteen whole chunks: 312 MFMAs per wave instead of 327) and the lane adds its mesh's
+// shaped template where the plain form adds v_template: v_posed = v_shaped + P pf, in smplx's own order of the two additions.  A lane's 16
+// meshes lie in ONE group of 32 consecutive meshes; ``group_rows`` describes the group as (row A, row B, split): local mesh < split has
+// template row A, the others row B (a tile of sample meshes spans at most two images) -- both rows are fetched before the K loop;
+// split < 0 marks a group whose rows change more than once (the mode / T-pose meshes: one image each): its lanes fetch per mesh by ``mesh_row``.
+template <int K, int ABL, int JC, bool HAS_T, int TAIL = FBK / 2, int ST = 2, bool PICK = false, bool VS = false>
 __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
     const float* __restrict__ xt, const float* __restrict__ bmat_p, const float* __restrict__ v_template,
     const float* __restrict__ a, const int32_t* __restrict__ w_idx, const float* __restrict__ w_val, int J,
     const float* __restrict__ transl, f3* __restrict__ verts, int M, int V, int kp, int mp, int np, int tiles_m,
-    int tiles_m_per_xcd, const int32_t* __restrict__ pick_slot, f3* __restrict__ picked, int n_picked) {
+    int tiles_m_per_xcd, const int32_t* __restrict__ pick_slot, f3* __restrict__ picked, int n_picked,
+    const int32_t* __restrict__ mesh_row, const int32_t* __restrict__ group_rows) {
     typedef __attribute__((address_space(3))) void* lptr_t;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // union: ST operand chunks | A of 32 of the tile's meshes
 
@@ -95,7 +104,19 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
         idx[k] = w_idx[(size_t)vc * K + k] * 12;
         w[k] = w_val[(size_t)vc * K + k];
     }
-    const f3 vt = reinterpret_cast<const f3*>(v_template)[vc];
+    f3 vt, vtb;
+    int split = 32;
+    if (VS) {
+        const int32_t* gr = group_rows + 3 * __builtin_amdgcn_readfirstlane((m0 + wm * 32) >> 5);      // wave-uniform: scalar loads
+        const int row_a = gr[0], row_b = gr[1];
+        split = gr[2];
+        vt = reinterpret_cast<const f3*>(v_template)[(size_t)row_a * V + vc];
+        vtb = reinterpret_cast<const f3*>(v_template)[(size_t)row_b * V + vc];
+    } else {
+        vt = reinterpret_cast<const f3*>(v_template)[vc];
+        vtb = vt;
+    }
+    const int split_lane = split - 4 * kl;                    // local mesh 4 kl + dr < split  <=>  dr < split_lane
     const int pick = PICK && live_v ? pick_slot[vc] : -1;     // this lane's slot in the compact array of regressor vertices, or -1
 
     // LDS-DMA pieces (1 KiB each): a chunk is F_XP pieces of xt rows ([FBK][FM]) and F_BP of bmat_p rows ([FBK][FN]);
@@ -217,6 +238,14 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
     const unsigned voff = ((unsigned)(4 * kl) * (unsigned)V + (unsigned)v) * 12u;              // per lane
     char* const pbase = PICK ? reinterpret_cast<char*>(picked) + (size_t)(m0 + wm * 32) * n_picked * 12 : nullptr;
     const unsigned poff = PICK ? ((unsigned)(4 * kl) * (unsigned)n_picked + (unsigned)max(pick, 0)) * 12u : 0u;
+    // MANY (VS only): the wave's group of 32 meshes has more than two templates (split < 0: the mode / T-pose meshes, one image each --
+    // 4 of 204 groups at B = 64, N = 100) and every mesh fetches its own inside the loop.  That form is a COPY of the epilogue, chosen by one
+    // wave-uniform branch in front of it: a load -- or a branch around one -- inside the loop of the common form puts a vmcnt(0) there,
+    // which on gfx950 also waits for the previous mesh's store, and splits the loop body into blocks hipcc does not schedule across
+    // (measured: +7 us on the whole launch, more than the fifteen MFMAs per wave the K = 207 form saves).  Both copies pass the same
+    // barriers, so the waves of a workgroup may take different ones.
+    auto epilogue = [&](auto many_c) __attribute__((always_inline)) {
+    constexpr bool MANY = decltype(many_c)::value;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();                                   // operand chunks / the previous pass's transforms are dead
@@ -244,8 +273,14 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
                 const float* t = transl + (size_t)min(m, M - 1) * 3;
                 tx = t[0]; ty = t[1]; tz = t[2];
             }
+            f3 base = vt;
+            if (VS && !MANY) {                             // template A / B of the group by the split: three selects, no load
+                const bool first = dr < split_lane;
+                base.x = first ? vt.x : vtb.x; base.y = first ? vt.y : vtb.y; base.z = first ? vt.z : vtb.z;
+            }
+            if (VS && MANY) base = reinterpret_cast<const f3*>(v_template)[(size_t)mesh_row[min(m, M - 1)] * V + vc];
             f3 pv;
-            pv.x = vt.x + acc[0][r]; pv.y = vt.y + acc[1][r]; pv.z = vt.z + acc[2][r];
+            pv.x = base.x + acc[0][r]; pv.y = base.y + acc[1][r]; pv.z = base.z + acc[2][r];
             f3 o;
             if (ABL == 1) {
                 o = pv;
@@ -263,6 +298,9 @@ __global__ __launch_bounds__(FT, 4) void mesh_fused_kernel(
             if (PICK && pick >= 0 && m < M) *reinterpret_cast<f3*>(pbase + (size_t)dr * n_picked * 12 + poff) = o;
         }
     }
+    };
+    if (VS && split < 0) epilogue(std::true_type());
+    else epilogue(std::false_type());
 }
 
 #ifdef HPS_DEV_BUILD
@@ -273,7 +311,8 @@ static int g_mesh_stages = 0;              // hps_dev_mesh_stages: 2 = always th
 template <int K, int ABL, int JC, bool HAS_T>
 static int launch_fused_cfg(const float* xt, const float* bmat_p, const float* v_template, const float* a, const int32_t* w_idx,
                         const float* w_val, int J, const float* transl, float* verts, int M, int V, int kp, int mp, int np,
-                        hipStream_t s, const int32_t* pick_slot = nullptr, float* picked = nullptr, int n_picked = 0) {
+                        hipStream_t s, const int32_t* pick_slot = nullptr, float* picked = nullptr, int n_picked = 0,
+                        const int32_t* mesh_row = nullptr, const int32_t* group_rows = nullptr) {
     size_t lds = (size_t)4 * max(2 * F_CHUNK_FLOATS, 32 * J * 12);
 #ifdef HPS_DEV_BUILD
     if (g_mesh_lds_floor > lds) lds = g_mesh_lds_floor;     // experiment: fewer workgroups per CU (a larger LDS request, unused)
@@ -295,8 +334,28 @@ static int launch_fused_cfg(const float* xt, const float* bmat_p, const float* v
     do {                                                                                                                           \
         if (int rc = grant_lds<&mesh_fused_kernel<__VA_ARGS__>>(160 * 1024, "hps_smpl_mesh_fused")) return rc;                    \
         hipLaunchKernelGGL((mesh_fused_kernel<__VA_ARGS__>), grid, dim3(FT), lds, s, xt, bmat_p, v_template, a, w_idx, w_val, J,   \
-                           transl, reinterpret_cast<f3*>(verts), M, V, kp, mp, np, tiles_m, tiles_m_per_xcd, pick_slot, pk, n_picked); \
+                           transl, reinterpret_cast<f3*>(verts), M, V, kp, mp, np, tiles_m, tiles_m_per_xcd, pick_slot, pk, n_picked, \
+                           mesh_row, group_rows);                                                                                 \
     } while (0)
+    if constexpr (K == 4 && JC == 24 && ABL == 0 && !HAS_T) {     // shared shapes (VS): SMPL's 207 pose rows, thirteen whole chunks
+        if (group_rows) {
+            if (tail != 8 || !pick_slot || !mesh_row) {
+                set_error("hps_smpl_mesh_fused_shared_shape: exists for kp = 208 (SMPL's 207 pose rows) with the side output only");
+                return HPS_E_UNSUPPORTED;
+            }
+            if (few) {
+                lds = (size_t)4 * max(4 * F_CHUNK_FLOATS, 32 * J * 12);
+                HPS_MESH_LAUNCH(K, ABL, JC, HAS_T, 8, 4, true, true);
+            } else {
+                HPS_MESH_LAUNCH(K, ABL, JC, HAS_T, 8, 2, true, true);
+            }
+            return check_launch("hps_smpl_mesh_fused_shared_shape");
+        }
+    }
+    if (group_rows) {
+        set_error("hps_smpl_mesh_fused_shared_shape: exists for K = 4, 24 joints, no translation");
+        return HPS_E_UNSUPPORTED;
+    }
     if constexpr (K == 4 && JC == 24 && ABL == 0) {          // the product configuration (SMPL): tail, stages and the side output
         if (tail == 5) {
             if (few) {
@@ -322,8 +381,10 @@ static int launch_fused_cfg(const float* xt, const float* bmat_p, const float* v
 template <int K, int ABL = 0>
 static int launch_fused(const float* xt, const float* bmat_p, const float* v_template, const float* a, const int32_t* w_idx,
                         const float* w_val, int J, const float* transl, float* verts, int M, int V, int kp, int mp, int np,
-                        hipStream_t s, const int32_t* pick_slot = nullptr, float* picked = nullptr, int n_picked = 0) {
-    if (J == 24 && !transl) return launch_fused_cfg<K, ABL, 24, false>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s, pick_slot, picked, n_picked);
+                        hipStream_t s, const int32_t* pick_slot = nullptr, float* picked = nullptr, int n_picked = 0,
+                        const int32_t* mesh_row = nullptr, const int32_t* group_rows = nullptr) {
+    if (J == 24 && !transl) return launch_fused_cfg<K, ABL, 24, false>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s, pick_slot, picked, n_picked, mesh_row, group_rows);
+    if (group_rows) { set_error("hps_smpl_mesh_fused_shared_shape: 24 joints, no translation"); return HPS_E_UNSUPPORTED; }
     if (J == 24) return launch_fused_cfg<K, ABL, 24, true>(xt, bmat_p, v_template, a, w_idx, w_val, J, transl, verts, M, V, kp, mp, np, s, pick_slot, picked, n_picked);
     if (pick_slot) { set_error("hps_smpl_mesh_fused_picks: 24 joints only"); return HPS_E_UNSUPPORTED; }
     if constexpr (K == 4) {          // a run-time joint count costs registers: only the K = 4 instantiation stays free of scratch
@@ -379,6 +440,44 @@ extern "C" int hps_smpl_mesh_fused_picks(const float* xt, const float* bmat_p, c
     if (K != 4) { set_error("hps_smpl_mesh_fused_picks: K = %d (the side output exists for K = 4 only)", K); return HPS_E_UNSUPPORTED; }
     return launch_fused<4>(xt, bmat_p, v_template, a, w_idx, w_val, num_joints, transl, verts, M, V, kp, mp, np, (hipStream_t)stream,
                            pick_slot, picked, n_picked);
+}
+
+extern "C" int hps_smpl_mesh_fused_shared_shape(const float* xt_pose, const float* bmat_p_pose, const float* v_shaped,
+                                                const int32_t* mesh_row, const int32_t* group_rows, const float* a,
+                                                const int32_t* w_idx, const float* w_val, int K, int num_joints, float* verts, int M,
+                                                int V, int kp, int mp, int np, const int32_t* pick_slot, float* picked,
+                                                int n_picked, hps_stream_t stream) {
+    if (!mesh_row || !group_rows || !pick_slot || !picked || n_picked <= 0)
+        return bad_arg("hps_smpl_mesh_fused_shared_shape: mesh_row / group_rows / pick_slot / picked / n_picked");
+    const int rc = fused_check_args(xt_pose, bmat_p_pose, v_shaped, a, w_idx, w_val, verts, num_joints, M, V, kp, mp, np);
+    if (rc != HPS_OK) return rc > 0 ? HPS_OK : rc;
+    if (K != 4) { set_error("hps_smpl_mesh_fused_shared_shape: K = %d (exists for K = 4 only)", K); return HPS_E_UNSUPPORTED; }
+    return launch_fused<4>(xt_pose, bmat_p_pose, v_shaped, a, w_idx, w_val, num_joints, nullptr, verts, M, V, kp, mp, np,
+                           (hipStream_t)stream, pick_slot, picked, n_picked, mesh_row, group_rows);
+}
+
+// smplx lbs step (1) for R distinct shapes: v_shaped[r, n] = v_template[n] + sum_l betas[r, l] * shapedirs[l, n]  (n = 3 v + c; one fused
+// multiply-add chain over l ascending, the template added last -- smplx: v_template + blend_shapes(betas, shapedirs))
+namespace hps {
+__global__ __launch_bounds__(256) void v_shaped_kernel(const float* __restrict__ betas, int nb, const float* __restrict__ shape_rows, int ld,
+                                                       const float* __restrict__ v_template, float* __restrict__ v_shaped, int n3) {
+    const int n = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (n >= n3) return;
+    float acc = 0.0f;
+    for (int l = 0; l < nb; ++l) acc = __builtin_fmaf(betas[r * nb + l], shape_rows[(size_t)l * ld + n], acc);
+    v_shaped[(size_t)r * n3 + n] = v_template[n] + acc;
+}
+}  // namespace hps
+
+extern "C" int hps_smpl_v_shaped(const float* betas, int num_betas, const float* shape_rows, int ld, const float* v_template,
+                                 float* v_shaped, int R, int V, hps_stream_t stream) {
+    if (!betas || !shape_rows || !v_template || !v_shaped) return bad_arg("hps_smpl_v_shaped: null pointer");
+    if (num_betas < 0 || ld < 3 * V) return bad_arg("hps_smpl_v_shaped: num_betas >= 0 and ld >= 3 V required");
+    if (R <= 0 || V <= 0) return HPS_OK;
+    if (R > 65535) return bad_arg("hps_smpl_v_shaped: at most 65535 shapes per call");
+    hipLaunchKernelGGL(hps::v_shaped_kernel, dim3(ceil_div(3 * V, 256), R), dim3(256), 0, (hipStream_t)stream, betas, num_betas, shape_rows, ld,
+                       v_template, v_shaped, 3 * V);
+    return check_launch("hps_smpl_v_shaped");
 }
 
 #ifdef HPS_DEV_BUILD

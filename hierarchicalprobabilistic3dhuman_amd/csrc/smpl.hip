@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void uncertainty_kernel(const f3* __restrict__
 
 constexpr int UG = 8;             // sample groups of the single-pass uncertainty kernels
 #ifdef HPS_DEV_BUILD
-static int g_unc_mode = 0;        // hps_dev_unc_mode: 0 = automatic, 1 = two-sweep, 2 = LDS with 128 vertices, 3 = LDS with 64, 4 = registers
+static int g_unc_mode = 0;        // hps_dev_unc_mode: 0 = automatic, 1 = two-sweep, 2 = LDS with 128 vertices, 3 = LDS with 64, 4 = registers, 5 = one sweep with 32 vertices, 7 = registers in the earlier block order
 #else
 constexpr int g_unc_mode = 0;     // product library: no process-global switches
 #endif
@@ -550,16 +550,18 @@ __global__ __launch_bounds__(UV * UG) void uncertainty_lds_kernel(const f3* __re
 // its samples s = g, g + 8, ... (SPT of them, 3 floats each) in registers, so the samples are read from HBM once, the
 // only LDS is the 3 KB reduction buffer, and many workgroups share a CU (the LDS-resident form allows one).
 // Same sample-to-group assignment, same summation order and reduction tree as uncertainty_lds_kernel: identical bits.
-// REV (dev A/B, hps_dev_unc_mode 6): images fastest, vertex panels DESCENDING -- the mesh kernel walks the panels in ascending order, so
-// the panels written last (the ones most likely still in the memory-side cache) would be read first.
-template <int SPT, bool REV = false>
+// Block order (round 6): images fastest, vertex panels DESCENDING.  The pass follows the mesh kernel, which walks the panels in ascending
+// order: the panels written last -- the ones still in the memory-side cache -- are read first, and reading them does not push the older,
+// still dirty lines out through HBM.  Measured in the pipelined loop against panels-fastest / images-ascending (hps_dev_unc_mode 7, same
+// kernel): 22.23 k against 22.10-22.16 k images/s, three interleaved pairs (profiles/r06_ab.txt).  The order of the blocks changes no sum.
+template <int SPT, bool FWD = false>
 __global__ __launch_bounds__(512) void uncertainty_reg_kernel(const f3* __restrict__ verts, float* __restrict__ unc,
                                                               int N, int V) {
     constexpr int RV = 64, H = UG / 2;
     __shared__ float sRed[H * 3 * RV];
     const int v = threadIdx.x & (RV - 1), g = threadIdx.x / RV;
-    const int panel = REV ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.x;
-    const int vg = panel * RV + v, b = REV ? blockIdx.x : blockIdx.y;
+    const int panel = FWD ? (int)blockIdx.x : (int)(gridDim.y - 1 - blockIdx.y);
+    const int vg = panel * RV + v, b = FWD ? blockIdx.y : blockIdx.x;
     const bool live = vg < V;
     const f3* base = verts + (size_t)b * N * V + (live ? vg : V - 1);
     // Guard-free: a sample beyond N re-reads sample N - 1 and contributes +0 (x + 0 = x bit for bit; the sums start at +0 and
@@ -611,13 +613,13 @@ __global__ __launch_bounds__(512) void uncertainty_reg_kernel(const f3* __restri
 template <int SPT>
 static int launch_unc_reg(const float* verts, float* unc, int B, int N, int V, hipStream_t s) {
 #ifdef HPS_DEV_BUILD
-    if (g_unc_mode == 6) {
-        hipLaunchKernelGGL((uncertainty_reg_kernel<SPT, true>), dim3(B, ceil_div(V, 64)), dim3(512), 0, s, reinterpret_cast<const f3*>(verts),
+    if (g_unc_mode == 7) {      // A/B: the earlier block order (panels fastest, ascending)
+        hipLaunchKernelGGL((uncertainty_reg_kernel<SPT, true>), dim3(ceil_div(V, 64), B), dim3(512), 0, s, reinterpret_cast<const f3*>(verts),
                            unc, N, V);
         return check_launch("hps_vertex_uncertainty");
     }
 #endif
-    hipLaunchKernelGGL(uncertainty_reg_kernel<SPT>, dim3(ceil_div(V, 64), B), dim3(512), 0, s, reinterpret_cast<const f3*>(verts),
+    hipLaunchKernelGGL(uncertainty_reg_kernel<SPT>, dim3(B, ceil_div(V, 64)), dim3(512), 0, s, reinterpret_cast<const f3*>(verts),
                        unc, N, V);
     return check_launch("hps_vertex_uncertainty");
 }
@@ -867,7 +869,7 @@ extern "C" int hps_vertex_uncertainty(const float* verts, float* unc, int B, int
     auto lds_bytes = [&](int uv) { return ((size_t)N * 3 * uv + (size_t)(UG / 2) * 3 * uv) * sizeof(float); };
 #endif
     // N <= 128 samples: register-resident single pass (mode 4 forces it, modes 1-3 select the older kernels)
-    if ((g_unc_mode == 0 || g_unc_mode == 4 || g_unc_mode == 6) && N >= 8 && N <= 16 * UG) {
+    if ((g_unc_mode == 0 || g_unc_mode == 4 || g_unc_mode == 7) && N >= 8 && N <= 16 * UG) {
         const int spt = ceil_div(N, UG);
         hipStream_t st = (hipStream_t)stream;
         if (spt <= 2) return launch_unc_reg<2>(verts, unc, B, N, V, st);

@@ -20,6 +20,9 @@ from .label_conversions import make_proxy_representation
 from .resnet import FilledStemFrames
 
 
+_SHARED_SHAPE_TABLES = weakref.WeakKeyDictionary()      # smpl model -> ((B, N, device), mesh_row, group_rows) of the last infer() layout
+
+
 @torch.no_grad()
 def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mean_shape=True,
           sample_on_cpu=False, seed=None, image_offset=0, input_feats=None, _before_meshes=None, _after_smpl=None,
@@ -71,8 +74,18 @@ def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mea
     # (the uncertainties are allocated HERE, on the caller's stream: a hook may move the launches between _before_meshes and
     # _after_unc to another stream, and every result must come from the caller's pool -- see SMPL.forward, "ordered")
     unc = torch.empty(B, smpl_model.num_verts, **f32)
+    shared = None
+    if use_mean_shape and hasattr(smpl_model, "shared_shape_tables"):
+        # every mesh of image b has the betas loc[b]: the shape blend is formed once per image (hps_smpl_mesh_fused_shared_shape)
+        key = (B, N, dev)
+        tables = _SHARED_SHAPE_TABLES.get(smpl_model)
+        if tables is None or tables[0] != key:
+            rows = list(range(B)) + list(range(B)) + [b for b in range(B) for _ in range(N)]          # [mode | T-pose | samples]
+            tables = (key,) + smpl_model.shared_shape_tables(rows)
+            _SHARED_SHAPE_TABLES[smpl_model] = tables
+        shared = (loc, tables[1], tables[2])
     out = smpl_model(body_pose=body, global_orient=glob_all, betas=betas_all, pose2rot=False,
-                     _before_mesh=_before_meshes, _after_mesh=_after_smpl)
+                     _before_mesh=_before_meshes, _after_mesh=_after_smpl, _shared_shapes=shared)
     V = out.vertices.shape[1]
     verts_s = out.vertices[2 * B:].view(B, N, V, 3)
     joints_s = out.joints[2 * B:].view(B, N, -1, 3)

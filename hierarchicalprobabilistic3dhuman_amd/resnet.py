@@ -154,6 +154,49 @@ class _ConvBN:
                    ksplit, P(ws) if ksplit > 1 else None, _capi.stream())
         return out
 
+    def folds_down(self, down, H, W, ipad):
+        """This (a block's first convolution) can carry the block's 1x1 down-sample ``down`` in its own launch
+        (hps_conv2d_bn_act_pad_down): direct kernel, odd square filter with pad = k // 2 (its centre tap is the 1x1 / stride / 0
+        window), same stride and output channels -- a rule on the layer only."""
+        return (down is not None and self.wn is not None and down.wn is not None and not self.winograd_ok(H, W, ipad)
+                and self.kh == self.kw and self.kh % 2 == 1 and self.pad == self.kh // 2 and down.kh == down.kw == 1 and down.pad == 0
+                and down.stride == self.stride and down.cout == self.cout and down.cin_p == self.cin_p and self.cout >= 128)
+
+    def _down_variant(self, ksplit):
+        """Tile choice of the fused launch: the main convolution's; 0 (automatic) resolves to 128 x 128 or 64 x 64 tiles for Cout >= 128."""
+        return self._tile_variant(ksplit)
+
+    def padded_with_down(self, xp, ipad, out, opad, down, out_down, ws=None):
+        """padded(xp -> out, relu) and down.padded(xp -> out_down, no relu) in ONE launch (see folds_down); identical bits."""
+        B, Hp, Wp, C = xp.shape
+        H, W = Hp - 2 * ipad, Wp - 2 * ipad
+        assert self.folds_down(down, H, W, ipad) and C == self.cin_p
+        Ho, Wo = self.out_hw(H, W)
+        assert tuple(out.shape) == tuple(out_down.shape) == (B, Ho + 2 * opad, Wo + 2 * opad, self.cout)
+        ksplit = self.ksplit if self.ksplit > 0 else self._auto_ksplit(Ho * Wo)
+        if ksplit > 1 and ws is None:
+            ws = torch.empty(ksplit, B * Ho * Wo, self.cout, device=xp.device, dtype=torch.float32)
+        P = _capi.ptr
+        _capi.call("hps_conv2d_bn_act_pad_down", P(xp), P(self.wn), P(self.scale), P(self.shift), P(out), P(down.wn), P(down.scale),
+                   P(down.shift), P(out_down), B, H, W, ipad, C, self.cout, self.kh, self.kw, self.stride, self.pad, opad, 1,
+                   self._down_variant(ksplit), ksplit, P(ws) if ksplit > 1 else None, _capi.stream())
+        return out, out_down
+
+    def enc_op_with_down(self, xp, ipad, out, opad, down, out_down, ws=None):
+        """The hps_enc_op of ``padded_with_down(...)`` for hps_encoder_run."""
+        B, Hp, Wp, C = xp.shape
+        H, W = Hp - 2 * ipad, Wp - 2 * ipad
+        assert self.folds_down(down, H, W, ipad) and C == self.cin_p
+        Ho, Wo = self.out_hw(H, W)
+        assert tuple(out.shape) == tuple(out_down.shape) == (B, Ho + 2 * opad, Wo + 2 * opad, self.cout)
+        ksplit = self.ksplit if self.ksplit > 0 else self._auto_ksplit(Ho * Wo)
+        assert ksplit == 1 or ws is not None
+        return _capi.EncOp(kind=_capi.ENC_CONV_DOWN, x=xp.data_ptr(), w=self.wn.data_ptr(), scale=self.scale.data_ptr(),
+                           shift=self.shift.data_ptr(), residual=None, y=out.data_ptr(), splitk_ws=ws.data_ptr() if ksplit > 1 else None,
+                           B=B, H=H, W=W, ipad=ipad, Cin=C, Cout=self.cout, KH=self.kh, KW=self.kw, stride=self.stride, pad=self.pad,
+                           opad=opad, relu=1, row_mode=0, variant=self._down_variant(ksplit), ksplit=ksplit, w_down=down.wn.data_ptr(),
+                           scale_down=down.scale.data_ptr(), shift_down=down.shift.data_ptr(), y_down=out_down.data_ptr())
+
     def enc_op(self, xp, ipad, out, opad, residual=None, relu=True, ws=None):
         """The hps_enc_op of ``padded(...)`` for hps_encoder_run (same arguments, nothing is launched)."""
         B, Hp, Wp, C = xp.shape
@@ -324,6 +367,9 @@ class ResNet(nn.Module):
         # Winograd stem: form the max pool in the stem kernel's epilogue (hps_stem_winograd_pooled: the full-resolution stem output is never
         # written; identical values).  False: hps_stem_winograd + hps_maxpool3x3s2_pad (the cross-check of the tests)
         self.fused_pool = True
+        # the 1x1 / 2 down-sample of layer2-4's first block rides in the launch of the block's 3x3 / 2 convolution (hps_conv2d_bn_act_pad_down:
+        # three launches of 16-26 us at 0.24-0.32 MFMA-busy disappear; identical bits).  False: two launches per block (the cross-check of the tests)
+        self.fold_downsample = True
         # ... and gather its phase windows from the NCHW input itself (hps_stem_winograd_pooled_nchw: no hps_stem_phase_split, no phase frames;
         # identical values; needs fused_pool): phase split 0.118 + frame-fed stem 0.61 -> 0.67 ms.  The default since round 6.  In round 5
         # it was off: the persistent stem as the encoder's first kernel raced the previous batch's joint / uncertainty kernels on the
@@ -410,7 +456,7 @@ class ResNet(nn.Module):
         stem_wino = stem.stem_winograd_ok(C, H, W)
         fused_pool = bool(stem_wino and self.fused_pool)
         from_nchw = bool(fused_pool and self.stem_reads_nchw and not frames)
-        key = (B, C, H, W, str(device), _capi.stream().value, stem_wino, fused_pool, from_nchw)
+        key = (B, C, H, W, str(device), _capi.stream().value, stem_wino, fused_pool, from_nchw, bool(self.fold_downsample))
         fs = self._frames.get(key)
         if fs is not None:
             return fs
@@ -475,10 +521,15 @@ class ResNet(nn.Module):
         y = fs["pool"]
         for (c1, c2, down), ent in zip(prep["blocks"], fs["blocks"]):      # BasicBlock.forward :62-78
             identity = y
-            if down is not None:
-                ops.append(down.enc_op(y, 1, ent["down"], 1, relu=False))
+            hin, win = y.shape[1] - 2, y.shape[2] - 2
+            if down is not None and self.fold_downsample and c1.folds_down(down, hin, win, 1):
+                ops.append(c1.enc_op_with_down(y, 1, ent["c1"], 1, down, ent["down"], ws=ent["ws"]))
                 identity = ent["down"]
-            ops.append(c1.enc_op(y, 1, ent["c1"], 1, relu=True, ws=ent["ws"]))
+            else:
+                if down is not None:
+                    ops.append(down.enc_op(y, 1, ent["down"], 1, relu=False))
+                    identity = ent["down"]
+                ops.append(c1.enc_op(y, 1, ent["c1"], 1, relu=True, ws=ent["ws"]))
             ops.append(c2.enc_op(ent["c1"], 1, ent["c2"], 1, residual=identity, relu=True, ws=ent["ws"]))
             y = ent["c2"]
         ops.append(_capi.EncOp(kind=_capi.ENC_AVGPOOL, x=y.data_ptr(), y=None, B=B, H=h, W=w, Cin=y.shape[3], ipad=1))
@@ -588,8 +639,11 @@ class ResNet(nn.Module):
             _capi.call("hps_maxpool3x3s2_pad", P(y), P(fs["pool"]), B, y.shape[1], y.shape[2], y.shape[3], 1, s)
         y = fs["pool"]
         for (c1, c2, down), ent in zip(prep["blocks"], fs["blocks"]):      # BasicBlock.forward :62-78
-            identity = down.padded(y, 1, ent["down"], 1, relu=False) if down is not None else y
-            out = c1.padded(y, 1, ent["c1"], 1, relu=True, ws=ent["ws"])
+            if down is not None and self.fold_downsample and c1.folds_down(down, y.shape[1] - 2, y.shape[2] - 2, 1):
+                out, identity = c1.padded_with_down(y, 1, ent["c1"], 1, down, ent["down"], ws=ent["ws"])
+            else:
+                identity = down.padded(y, 1, ent["down"], 1, relu=False) if down is not None else y
+                out = c1.padded(y, 1, ent["c1"], 1, relu=True, ws=ent["ws"])
             y = c2.padded(out, 1, ent["c2"], 1, residual=identity, relu=True, ws=ent["ws"])
         h, w = fs["hw"]
         feats = torch.empty(B, y.shape[3], device=x.device, dtype=torch.float32)

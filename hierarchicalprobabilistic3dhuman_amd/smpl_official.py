@@ -54,6 +54,10 @@ class SMPL(nn.Module):
         self.lbs_events = None
         self.pad_v_posed = True
         self.fused_mesh = True
+        # meshes that share their shape (infer(use_mean_shape=True): every mesh of an image has the image's betas) take the K = 207 form of
+        # the fused kernel (hps_smpl_mesh_fused_shared_shape: the shape blend once per image, not once per mesh).  False: the K = 217 form
+        # for every call (the bit-level partner of the unfused pair).
+        self.shared_shape = True
 
         f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
         v_template = np.asarray(model["v_template"], np.float64)
@@ -148,6 +152,26 @@ class SMPL(nn.Module):
         self.register_buffer("_csr_col", torch.tensor(col_, dtype=torch.int32), persistent=False)
         self.register_buffer("_csr_val", torch.tensor(val_, dtype=torch.float32), persistent=False)
 
+    def shared_shape_tables(self, mesh_rows):
+        """The (mesh_row, group_rows) tables of hps_smpl_mesh_fused_shared_shape for meshes whose shapes are rows of a small table:
+        ``mesh_rows`` (M,) host integers, mesh m has shape row mesh_rows[m].  Device int32 tensors, padded to the kernel's mesh count."""
+        rows = np.asarray(mesh_rows, np.int32).reshape(-1)
+        M = rows.shape[0]
+        mp = _capi.query_workspace(_capi.WS_SMPL_MP, M)
+        full = np.concatenate([rows, np.full(mp - M, rows[-1] if M else 0, np.int32)])
+        groups = np.zeros((mp // 32, 3), np.int32)
+        for g in range(mp // 32):
+            r = full[32 * g:32 * g + 32]
+            change = np.nonzero(r[1:] != r[:-1])[0]
+            if change.size == 0:
+                groups[g] = (r[0], r[0], 32)
+            elif change.size == 1:
+                groups[g] = (r[0], r[-1], change[0] + 1)
+            else:
+                groups[g] = (r[0], r[0], -1)
+        dev = self.v_template.device
+        return torch.from_numpy(full).to(dev), torch.from_numpy(groups.reshape(-1)).to(dev)
+
     # ------------------------------------------------------------------------------------------
     def forward(self, betas=None, body_pose=None, global_orient=None, transl=None, pose2rot=True,
                 return_verts=True, return_full_pose=False, **kwargs):
@@ -194,6 +218,15 @@ class SMPL(nn.Module):
         use_picks = (self.fused_mesh and self._fused_ok and self.picked_joints and self._lbs_k == 4 and J == 24 and self._k_used == 218
                      and self._n_picked > 0)
         picked = torch.empty(M, self._n_picked, 3, **f32) if use_picks else None
+        # ``_shared_shapes = (shape_betas (R, num_betas), mesh_row, group_rows)``: betas[m] == shape_betas[mesh_row[m]] (the caller's
+        # promise -- infer(use_mean_shape=True)): the shape blend once per distinct shape, the GEMM over the pose rows only
+        shared = kwargs.get("_shared_shapes") if (self.shared_shape and use_picks and tr is None) else None
+        v_shaped = None
+        if shared is not None:
+            sb = _capi.f32c(shared[0])
+            v_shaped = torch.empty(sb.shape[0], V, 3, **f32)
+            _capi.call("hps_smpl_v_shaped", P(sb), self.num_betas, P(self._bmat), self._np, P(self._v_template_flat), P(v_shaped),
+                       sb.shape[0], V, s)
         _capi.call("hps_smpl_pose_prep", P(g), P(b), is_rotmat, P(be), self.num_betas, P(self._j_template),
                    P(self._j_shapedirs), _capi.iptr(self._parents_i32), _capi.iptr(self._depth_i32), J, P(xt),
                    self._kp, mp, P(a), P(j_posed), None, M, s)
@@ -211,7 +244,7 @@ class SMPL(nn.Module):
                 # the tensors are registered with the other stream -- which costs an event record ON THAT STREAM for each of them
                 # when they are freed (seven markers of ~6 us in front of the next encoder, measured: profiles/r05_experiments.txt).
                 if ordered != "ordered":
-                    for t in (xt, a, verts, picked, be, g, b):
+                    for t in (xt, a, verts, picked, be, g, b, v_shaped):
                         if t is not None:
                             t.record_stream(now)
         ev = None
@@ -222,7 +255,12 @@ class SMPL(nn.Module):
         if self.fused_mesh and self._fused_ok:
             if ev is not None:
                 ev[0].record()
-            if use_picks:
+            if shared is not None:
+                nb = self.num_betas
+                _capi.call("hps_smpl_mesh_fused_shared_shape", _capi._P(xt.data_ptr() + 4 * nb * mp), _capi._P(self._bmat_p.data_ptr() + 4 * nb * self._np_fused),
+                           P(v_shaped), _capi.iptr(shared[1]), _capi.iptr(shared[2]), P(a), _capi.iptr(self._w_idx), P(self._w_val), self._lbs_k, J,
+                           P(verts), M, V, self._k_used - nb, mp, self._np_fused, _capi.iptr(self._pick_slot), P(picked), self._n_picked, s)
+            elif use_picks:
                 _capi.call("hps_smpl_mesh_fused_picks", P(xt), P(self._bmat_p), P(self._v_template_flat), P(a),
                            _capi.iptr(self._w_idx), P(self._w_val), self._lbs_k, J, trp, P(verts), M, V, self._k_used, mp,
                            self._np_fused, _capi.iptr(self._pick_slot), P(picked), self._n_picked, s)

@@ -161,6 +161,26 @@ int hps_smpl_mesh_fused_picks(const float* xt, const float* bmat_p, const float*
                               const int32_t* w_idx, const float* w_val, int K, int num_joints, const float* transl,
                               float* verts, int M, int V, int kp, int mp, int np, const int32_t* pick_slot, float* picked,
                               int n_picked, hps_stream_t stream);
+/* The fused mesh kernel for meshes that SHARE their shape (round 6): every mesh of an image carries the image's betas
+ * (use_mean_shape = True, the reference's predict default: utils/sampling_utils.py:178-179, predict/...:157-165).  smplx lbs step (1),
+ * v_shaped = v_template + blend_shapes(betas), is then formed ONCE per distinct shape (hps_smpl_v_shaped: R = images, not meshes) and
+ * the GEMM keeps the 207 pose rows only: xt_pose / bmat_p_pose = the operands of hps_smpl_mesh_fused advanced by num_betas rows, kp =
+ * 208 (thirteen whole K chunks: 312 MFMAs per wave against 327), v_posed = v_shaped[row of the mesh] + pose blend -- smplx's own
+ * order of the two additions (v_posed = v_shaped + pose_offsets).  The K = 217 form adds template, shape and pose terms in one MFMA
+ * chain, so the two agree to rounding, not bit for bit (both within 2e-5 m of the oracle).
+ *   v_shaped (R, V, 3); mesh_row (mp,) int32: the row of v_shaped of every mesh (padding meshes: any valid row);
+ *   group_rows (mp / 32, 3) int32 per group of 32 consecutive meshes: (row A, row B, split) -- local mesh < split has row A, the
+ *   others row B; split = -1: more than two rows in the group, its lanes fetch per mesh through mesh_row.
+ * Exists for the SMPL configuration with the side output (K = 4, 24 joints, kp = 208, no translation); HPS_E_UNSUPPORTED otherwise. */
+int hps_smpl_mesh_fused_shared_shape(const float* xt_pose, const float* bmat_p_pose, const float* v_shaped,
+                                     const int32_t* mesh_row, const int32_t* group_rows, const float* a,
+                                     const int32_t* w_idx, const float* w_val, int K, int num_joints, float* verts, int M,
+                                     int V, int kp, int mp, int np, const int32_t* pick_slot, float* picked,
+                                     int n_picked, hps_stream_t stream);
+/* smplx lbs step (1) for R distinct shapes: v_shaped[r, n] = v_template[n] + sum_l betas[r, l] * shape_rows[l * ld + n], n = 3 v + c
+ * (shape_rows: the first num_betas rows of the blend matrix of hps_smpl_blend, row pitch ld >= 3 V floats). */
+int hps_smpl_v_shaped(const float* betas, int num_betas, const float* shape_rows, int ld, const float* v_template,
+                      float* v_shaped, int R, int V, hps_stream_t stream);
 /* Column count of bmat_p for a model with V vertices (192 per started panel of 64 vertices). */
 int hps_smpl_mesh_fused_np(int V);
 
@@ -331,6 +351,17 @@ int hps_conv2d_bn_act_pad(const float* x, const float* wn, const float* scale, c
                           int KH, int KW, int stride, int pad, int opad, int relu, int row_mode, int variant,
                           int ksplit, float* splitk_ws, hps_stream_t stream);
 
+/* BasicBlock entry with a down-sample branch (models/resnet.py:62-78 with :71-72 `identity = self.downsample(x)`, built at
+ * :184-188): the block's k x k / stride / pad = k/2 convolution + BatchNorm (+ ReLU) -> y AND its 1x1 / stride / 0 down-sample
+ * convolution + BatchNorm -> y_down, both from the same input frame, in ONE launch (extra workgroups walk the main window's centre
+ * tap with the down-sample's filter).  wn_down: (Cout, Cin) n-major; y_down: a frame of y's geometry.  Every output has the bits of
+ * hps_conv2d_bn_act_pad called once per convolution (same chunks, same order; tile shapes do not change a summation order).
+ * variant 1, 2, 3, 5 or 0 (automatic) as above; ksplit applies to the main convolution only.  Cin % 32 == 0. */
+int hps_conv2d_bn_act_pad_down(const float* x, const float* wn, const float* scale, const float* shift, float* y,
+                               const float* wn_down, const float* scale_down, const float* shift_down, float* y_down,
+                               int B, int H, int W, int ipad, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                               int opad, int relu, int variant, int ksplit, float* splitk_ws, hps_stream_t stream);
+
 /* 3x3 / stride 1 / pad 1 convolution + BatchNorm (+ residual) (+ ReLU) by Winograd F(2x2, 3x3) on the fp32 MFMA pipe
  * (csrc/conv_wino.hip): 16 multiplications per 2x2 output tile and (cin, cout) pair instead of 36 -- the stride-1 3x3
  * layers of the BasicBlocks (models/resnet.py:62-78).  x / y / residual are halo-padded NHWC frames as for
@@ -401,7 +432,8 @@ int hps_stem_winograd_pooled_nchw(const float* x, const float* u, const float* s
 enum { HPS_ENC_RELAYOUT = 0, HPS_ENC_CONV = 1, HPS_ENC_MAXPOOL = 2, HPS_ENC_AVGPOOL = 3, HPS_ENC_CONV_WINOGRAD = 4,
        HPS_ENC_STEM_SPLIT = 5, HPS_ENC_STEM_WINOGRAD = 6,
        HPS_ENC_RELAYOUT_GENERIC = 7 /* hps_nchw_to_padded_nhwc_generic (x, y, B, Cin = C, Cout = CP, H, W, KW = WF, opad = P) */,
-       HPS_ENC_STEM_WINOGRAD_POOLED = 8, HPS_ENC_STEM_WINOGRAD_POOLED_NCHW = 9 };
+       HPS_ENC_STEM_WINOGRAD_POOLED = 8, HPS_ENC_STEM_WINOGRAD_POOLED_NCHW = 9,
+       HPS_ENC_CONV_DOWN = 10 /* hps_conv2d_bn_act_pad_down: the HPS_ENC_CONV fields + w_down / scale_down / shift_down / y_down */ };
 typedef struct hps_enc_op {
     int kind;
     const float* x;
@@ -412,6 +444,10 @@ typedef struct hps_enc_op {
     float* y;
     float* splitk_ws;
     int B, H, W, ipad, Cin, Cout, KH, KW, stride, pad, opad, relu, row_mode, variant, ksplit;
+    const float* w_down;       /* HPS_ENC_CONV_DOWN only (NULL otherwise) */
+    const float* scale_down;
+    const float* shift_down;
+    float* y_down;
 } hps_enc_op;
 
 /* sizeof(hps_enc_op) as compiled into the library: lets a hand-written mirror of the struct check itself. */

@@ -170,6 +170,76 @@ def test_padded_conv_kernel(cfg, dev):
     cb.latency, cb.variant, cb.ksplit = False, 0, 0
 
 
+@pytest.mark.parametrize("cfg", [            # (B, H, Cin, Cout, k): the three block entries of ResNet-18 at the bench batch, small / ragged maps, k = 5
+    (64, 64, 64, 128, 3), (64, 32, 128, 256, 3), (64, 16, 256, 512, 3), (1, 64, 64, 128, 3), (3, 18, 64, 128, 3), (2, 16, 256, 512, 3),
+    (5, 10, 32, 128, 5)])
+def test_down_sample_rides_in_the_blocks_first_convolution(cfg, dev):
+    """hps_conv2d_bn_act_pad_down (models/resnet.py:62-78 with the down-sample branch of :71-72, :184-188): the block's k x k / 2 convolution
+    + bn + relu and its 1 x 1 / 2 down-sample + bn from one launch -- each output equal, BIT FOR BIT, to its own hps_conv2d_bn_act_pad launch
+    (and to torch within the tolerance), for every tile variant the entry takes, with K slices, in latency mode, and the halo untouched."""
+    B, H, Cin, Cout, k = cfg
+    torch.manual_seed(sum(cfg))
+    conv = torch.nn.Conv2d(Cin, Cout, k, 2, k // 2, bias=False)
+    dconv = torch.nn.Conv2d(Cin, Cout, 1, 2, 0, bias=False)
+    bns = []
+    for _ in range(2):
+        bn = torch.nn.BatchNorm2d(Cout).eval()
+        bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_()
+        bns.append(bn)
+    x = torch.randn(B, Cin, H, H)
+    with torch.no_grad():
+        want, want_d = F.relu(bns[0](conv(x))), bns[1](dconv(x))
+    Ho = want.shape[2]
+    assert want_d.shape == want.shape
+    c1, down = _ConvBN(conv.to(dev), bns[0].to(dev)), _ConvBN(dconv.to(dev), bns[1].to(dev))
+    ipad = k // 2                                   # the input halo covers the main convolution's padding
+    xp = _frame(x.to(dev).permute(0, 2, 3, 1).contiguous(), ipad)
+    assert c1.folds_down(down, H, H, ipad)
+    chunks = k * k * Cin // 32
+    settings = [(0, 0, False), (1, 0, False), (3, 0, False), (0, 0, True)] + [(0, ks, False) for ks in (2, 4) if chunks % ks == 0] + \
+               [(3, ks, False) for ks in (3,) if chunks % ks == 0] + [(0, ks, True) for ks in (9,) if chunks % ks == 0]
+    for variant, ks, latency in settings:
+        for c in (c1, down):
+            c.variant, c.latency = variant, latency
+        c1.ksplit = ks
+        sep, sep_d = torch.full((B, Ho + 2, Ho + 2, Cout), 7.0, device=dev), torch.full((B, Ho + 2, Ho + 2, Cout), 7.0, device=dev)
+        c1.padded(xp, ipad, sep, 1, relu=True)
+        down.padded(xp, ipad, sep_d, 1, relu=False)
+        got, got_d = torch.full_like(sep, 7.0), torch.full_like(sep, 7.0)
+        c1.padded_with_down(xp, ipad, got, 1, down, got_d)
+        assert torch.equal(got, sep) and torch.equal(got_d, sep_d), (variant, ks, latency)
+        assert float((got[:, 0] - 7).abs().max()) == 0 and float((got_d[:, :, -1] - 7).abs().max()) == 0        # the halo is never written
+        tol = 1e-4 * max(1.0, float(want.abs().max()))
+        assert maxerr(got[:, 1:-1, 1:-1].permute(0, 3, 1, 2), want) <= tol and maxerr(got_d[:, 1:-1, 1:-1].permute(0, 3, 1, 2), want_d) <= tol
+    c1.ksplit = 0
+    # what does not fold: a stride-1 entry, other channel counts on the branch, a Winograd layer
+    other = _ConvBN(torch.nn.Conv2d(Cin, Cout, 1, 1, 0, bias=False).to(dev), bns[1])
+    assert not c1.folds_down(other, H, H, ipad) and not c1.folds_down(None, H, H, ipad)
+
+
+def test_encoder_with_and_without_the_folded_down_samples_gives_the_same_features(dev, net_gpu, golden_input):
+    enc = net_gpu.image_encoder
+    x = torch.cat([golden_input.to(dev), torch.rand(3, 18, 256, 256, generator=torch.Generator().manual_seed(9)).to(dev)])
+    assert enc.fold_downsample
+    folded = enc(x).clone()
+    try:
+        enc.composite = False
+        folded_b = enc(x).clone()
+        enc.fold_downsample = False
+        two_b = enc(x).clone()
+        enc.composite = True
+        two = enc(x).clone()
+        net_gpu.set_latency_mode(True)               # latency mode: 64 x 64 four-stage tiles, K slices on the main convolution
+        lat_two = enc(x[:1]).clone()
+        enc.fold_downsample = True
+        lat_folded = enc(x[:1]).clone()
+    finally:
+        net_gpu.set_latency_mode(False)
+        enc.fold_downsample, enc.composite = True, True
+    assert torch.equal(folded, folded_b) and torch.equal(folded, two) and torch.equal(folded, two_b)
+    assert torch.equal(lat_folded, lat_two)
+
+
 def test_padded_and_plain_encoders_agree(dev, net_gpu, golden, golden_input):
     enc = net_gpu.image_encoder
     x = golden_input.to(dev)

@@ -470,3 +470,47 @@ def test_hip_smpl_matches_the_reference_class_on_smplx(dev, smplx_golden):
             v = o.vertices if sel is None else o.vertices[:, sel]
             assert maxerr(v, t(name + "_verts")) <= TOL, (key, name)
             assert maxerr(o.joints, t(name + "_joints")) <= TOL, (key, name)
+
+
+@pytest.mark.parametrize("B,N", [(1, 1), (1, 50), (3, 7), (2, 100), (17, 33), (64, 100)])
+def test_shared_shape_form_of_the_mesh_kernel(B, N, dev, smpl_gpu, smpl_assets):
+    """hps_smpl_mesh_fused_shared_shape (K = 207: the shape blend once per image, smplx's v_posed = v_shaped + pose_offsets) on infer()'s
+    mesh layout [mode | T-pose | samples]: vertices and joints within the stated 2e-5 m of the oracle, within rounding of the K = 217 form
+    (one MFMA chain over template, shape and pose terms), and the group table covers tiles with one, two and many images."""
+    p = smpl_assets[2]
+    g = torch.Generator().manual_seed(1000 * B + N)
+    loc = torch.randn(B, 10, generator=g)
+    rows = list(range(B)) + list(range(B)) + [b for b in range(B) for _ in range(N)]
+    M = len(rows)
+    aa = torch.randn(M, 24, 3, generator=g) * 0.5
+    aa[B:2 * B] = 0.0                                            # the T-pose meshes
+    R = O.batch_rodrigues(aa.view(-1, 3)).view(M, 24, 3, 3)
+    betas = loc[torch.tensor(rows)]
+    mesh_row, group_rows = smpl_gpu.shared_shape_tables(rows)
+    gr = group_rows.view(-1, 3).cpu()
+    assert mesh_row.shape[0] % 64 == 0 and mesh_row[:M].cpu().tolist() == rows and gr.shape[0] == mesh_row.shape[0] // 32
+    for gi in range(gr.shape[0]):                                # the table says what the rows are
+        r = mesh_row[32 * gi:32 * gi + 32].cpu()
+        a, b_, split = gr[gi].tolist()
+        if split >= 0:
+            assert (r[:split] == a).all() and (r[split:] == b_).all()
+        else:
+            assert int((r[1:] != r[:-1]).sum()) > 1                 # more than one change of row inside the group
+    args = dict(betas=betas.to(dev), body_pose=R[:, 1:].to(dev), global_orient=R[:, :1].to(dev), pose2rot=False)
+    shared = smpl_gpu(_shared_shapes=(loc.to(dev), mesh_row, group_rows), **args)
+    plain = smpl_gpu(**args)                                     # K = 217: template + shape + pose in one chain
+    assert maxerr(shared.vertices, plain.vertices) <= 4e-6 and maxerr(shared.joints, plain.joints) <= 4e-6
+    if M <= 700:
+        ref = O.smpl_forward(p, betas=betas, body_pose=R[:, 1:], global_orient=R[:, :1], pose2rot=False)
+        assert maxerr(shared.vertices, ref["vertices"]) <= TOL and maxerr(shared.joints, ref["joints"]) <= TOL
+    else:                                                        # full size: the oracle on a slice of every region
+        pick = torch.cat([torch.arange(0, 3), torch.arange(B, B + 3), torch.arange(2 * B, 2 * B + 70), torch.arange(M - 40, M)])
+        ref = O.smpl_forward(p, betas=betas[pick], body_pose=R[pick, 1:], global_orient=R[pick, :1], pose2rot=False)
+        assert maxerr(shared.vertices[pick.to(dev)], ref["vertices"]) <= TOL and maxerr(shared.joints[pick.to(dev)], ref["joints"]) <= TOL
+    # the T-pose meshes are the shaped template itself (identity rotations: A = identity up to the rest-pose subtraction)
+    smpl_gpu.shared_shape = False
+    try:
+        off = smpl_gpu(_shared_shapes=(loc.to(dev), mesh_row, group_rows), **args)      # the switch: the K = 217 form again
+    finally:
+        smpl_gpu.shared_shape = True
+    assert torch.equal(off.vertices, plain.vertices)

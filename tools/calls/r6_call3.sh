@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round 6, call 3: the down-sample fold -- its tests, then A/B in the bench, interleaved
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+OUT=$R/gpurun_out/r6_call3; rm -rf $OUT; mkdir -p $OUT
+timeout 900 python -m pytest tests/test_gpu_net.py -m gpu -x -q -k "down or folded or padded_conv or encoder" > $OUT/pytest.txt 2>&1; echo "pytest exit $?"; tail -15 $OUT/pytest.txt
+Q="--cpu-images 0 --from-rgb-steps 0 --stress-steps 0 --latency-reps 0 --lbs-unfused-reps 0 --steps 40 --warmup 10"
+{
+for rep in 1 2 3; do
+  for v in "" "--separate-downsample"; do
+    python bench.py $Q $v 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('[%-22s] %6d images/s  %.3f ms/step  encoder %.3f mesh %.3f' % ('$v', d['value'], d['ms_per_step'], d['secondary']['encoder']['avg_ms'], d['roofline']['avg_launch_ms']))"
+  done
+done
+} > $OUT/fold_ab.txt 2>&1
+cat $OUT/fold_ab.txt
+python tools/encoder_layers.py time 2>&1 | tail -40

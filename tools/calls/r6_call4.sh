@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round 6, call 4: shared-shape mesh kernel (K = 207) -- tests, then A/B in the bench; the down-sample fold's last test
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+OUT=$R/gpurun_out/r6_call4; rm -rf $OUT; mkdir -p $OUT
+timeout 1500 python -m pytest tests/test_gpu_smpl.py tests/test_gpu_e2e.py tests/test_gpu_net.py -m gpu -x -q > $OUT/pytest.txt 2>&1; echo "pytest exit $?"; tail -15 $OUT/pytest.txt
+Q="--cpu-images 0 --from-rgb-steps 0 --stress-steps 0 --latency-reps 0 --lbs-unfused-reps 0 --steps 40 --warmup 10"
+{
+for rep in 1 2 3; do
+  for v in "" "--per-mesh-shape-blend"; do
+    python bench.py $Q $v 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('[%-24s] %6d images/s  %.3f ms/step  encoder %.3f mesh %.4f  mfma frac %.3f / required %.3f' % ('$v', d['value'], d['ms_per_step'], d['secondary']['encoder']['avg_ms'], d['roofline']['avg_launch_ms'], d['roofline_mfma']['frac'], d['roofline_mfma']['frac_of_required_flop']))"
+  done
+done
+} > $OUT/shape_ab.txt 2>&1
+cat $OUT/shape_ab.txt

@@ -16,7 +16,7 @@ from hierarchicalprobabilistic3dhuman_amd import _capi, configs  # noqa: E402
 from hierarchicalprobabilistic3dhuman_amd.poseMF_shapeGaussian_net import PoseMFShapeGaussianNet  # noqa: E402
 
 
-def op_names(enc, stem_wino=True, fused_pool=False, from_nchw=False):
+def op_names(enc, stem_wino=True, fused_pool=False, from_nchw=False, fold=False):
     names = (["conv1 7x7/2 18->64 + maxpool 3x3/2 (stem, winograd; windows gathered from the NCHW input, pool in the epilogue + border pass)"] if from_nchw else
              ["phase split NCHW->4 phase frames", "conv1 7x7/2 18->64 + maxpool 3x3/2 (stem, winograd F(2x2, 4x4|4x3|3x4|3x3); pool in the epilogue + border pass)"]
              if fused_pool else
@@ -24,9 +24,12 @@ def op_names(enc, stem_wino=True, fused_pool=False, from_nchw=False):
              else ["relayout NCHW->padded NHWC", "conv1 7x7/2 18->64 (stem, row mode)", "maxpool 3x3/2"])
     for li, layer in enumerate((enc.layer1, enc.layer2, enc.layer3, enc.layer4), 1):
         for bi, blk in enumerate(layer):
-            if blk.downsample is not None:
-                names.append("layer%d.%d.downsample 1x1/2" % (li, bi))
-            names.append("layer%d.%d.conv1 3x3%s" % (li, bi, "/2" if blk.stride == 2 else ""))
+            if blk.downsample is not None and fold:
+                names.append("layer%d.%d.conv1 3x3/2 + downsample 1x1/2 (one launch)" % (li, bi))
+            else:
+                if blk.downsample is not None:
+                    names.append("layer%d.%d.downsample 1x1/2" % (li, bi))
+                names.append("layer%d.%d.conv1 3x3%s" % (li, bi, "/2" if blk.stride == 2 else ""))
             names.append("layer%d.%d.conv2 3x3" % (li, bi))
     names.append("global avgpool")
     return names
@@ -43,15 +46,18 @@ def main():
         enc.set_winograd(False)
     if len(sys.argv) > 3 and sys.argv[3] == "unfused-pool":     # A/B: stem and max pool as two kernels
         enc.fused_pool = False
-    if len(sys.argv) > 3 and sys.argv[3] == "from-nchw":        # A/B: the stem gathers its windows from the NCHW input (no phase split)
-        enc.stem_reads_nchw = True
+    if len(sys.argv) > 3 and sys.argv[3] == "frames":           # A/B: phase split + frame-fed stem (round 5's default)
+        enc.stem_reads_nchw = False
+    if len(sys.argv) > 3 and sys.argv[3] == "separate-downsample":     # A/B: the 1x1/2 down-samples as launches of their own (round 5)
+        enc.fold_downsample = False
     x = torch.rand(B, 18, 256, 256, generator=torch.Generator().manual_seed(1)).to(dev)
     with torch.no_grad():
         feats = enc(x)                                    # builds the frames and the launch list
         torch.cuda.synchronize()
         fs = next(iter(enc._frames.values()))
         ops, n = fs["ops"], len(fs["ops"])
-        names = op_names(enc, fs["stem_wino"], fs.get("fused_pool", False), fs.get("from_nchw", False))
+        names = op_names(enc, fs["stem_wino"], fs.get("fused_pool", False), fs.get("from_nchw", False),
+                         fold=any(o.kind == _capi.ENC_CONV_DOWN for o in ops))
         assert len(names) == n, (len(names), n)
         ops[0].x = x.data_ptr()
         ops[n - 1].y = feats.data_ptr()
@@ -75,11 +81,11 @@ def main():
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 20
             row = {"op": names[i], "ms_alone": ms}
-            if o.kind in (_capi.ENC_CONV, _capi.ENC_CONV_WINOGRAD):
+            if o.kind in (_capi.ENC_CONV, _capi.ENC_CONV_WINOGRAD, _capi.ENC_CONV_DOWN):
                 Ho = (o.H + 2 * o.pad - o.KH) // o.stride + 1
                 Wo = (o.W + 2 * o.pad - o.KW) // o.stride + 1
                 cin = 18 if o.row_mode else o.Cin
-                gflop = 2.0 * o.B * Ho * Wo * o.Cout * o.KH * o.KW * cin / 1e9
+                gflop = 2.0 * o.B * Ho * Wo * o.Cout * (o.KH * o.KW + (1 if o.kind == _capi.ENC_CONV_DOWN else 0)) * cin / 1e9
                 wino = o.kind == _capi.ENC_CONV_WINOGRAD
                 row.update(gflop=gflop, tflops=gflop / ms, out_hw=[Ho, Wo], cin=cin, cout=o.Cout, ksplit=o.ksplit,
                            launches=2 if (o.ksplit > 1 or (wino and o.H == 8 and o.W == 8)) else 1,
