@@ -81,37 +81,10 @@ _PROTOTYPES = {
     "hps_maxpool3x3s2_pad": [_P, _P, _I, _I, _I, _I, _I, _P],
     "hps_global_avgpool_pad": [_P, _P, _I, _I, _I, _I, _I, _P],
 }
-# extra entry points of libhps_dev.so (include/hps_dev.h)
-_DEV_PROTOTYPES = {
-    "hps_dev_lbs_variant": [_P, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P],
-    "hps_conv2d_bn_act": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "hps_conv2d_bn_act_v2": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "hps_conv2d_bn_act_v3": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
-    "hps_dev_conv_pad_ablate": [_I],
-    "hps_dev_wino_quad_ksplit": [_I],
-    "hps_dev_wino_stamps": [_P, _I],
-    "hps_dev_conv3x3_winograd_half": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "hps_dev_unc_mode": [_I],
-    "hps_dev_mesh_lds_floor": [_I],
-    "hps_dev_mesh_stages": [_I],
-    "hps_dev_blend_mode": [_I],
-    "hps_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
-    "hps_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P],
-    "hps_global_avgpool": [_P, _P, _I, _I, _I, _P],
-    "hps_dev_stem_winograd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "hps_dev_stem_winograd_pooled_nchw": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "hps_dev_conv3x3_winograd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
-    "hps_dev_head_pose_levels_fused": [_P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _P, _P, _P, _P, _I, _I, _I,
-                                   _P, _P],
-    "hps_dev_smpl_pose_prep_v1": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P],
-    "hps_dev_smpl_joints_v1": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
-    "hps_dev_mesh_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-}
 _RESTYPES = {"hps_last_error": _c.c_char_p, "hps_query_workspace": _c.c_int64, "hps_conv3x3_winograd_workspace": _c.c_size_t,
              "hps_stem_phase_frames_bytes": _c.c_size_t, "hps_stem_pool_side_bytes": _c.c_size_t}
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
-DEV_EXPORTED_SYMBOLS = tuple(_DEV_PROTOTYPES)
 
 _lib = None
 _dev_lib = None
@@ -159,11 +132,25 @@ def load(dev=False):
     global _lib, _dev_lib
     if dev:
         if _dev_lib is None:
-            _dev_lib = _open(DEV_LIB_PATH, dict(_PROTOTYPES, **_DEV_PROTOTYPES), "libhps_dev.so")
+            _dev_lib = _open(DEV_LIB_PATH, dict(_PROTOTYPES, **_dev_prototypes()), "libhps_dev.so")
         return _dev_lib
     if _lib is None:
         _lib = _open(LIB_PATH, _PROTOTYPES, "libhps.so")
     return _lib
+
+
+def _dev_prototypes():
+    """ctypes prototypes of the dev library's extra entry points (include/hps_dev.h).  They are test infrastructure and live on the
+    tests' side of the tree -- tests/devlib.py, loaded here by path -- together with the helpers that call them; the package itself
+    names no hps_dev_* symbol."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(_PKG_DIR), "tests", "devlib.py")
+    if not os.path.exists(path):
+        raise HpsError("libhps_dev.so is test infrastructure: its prototypes live in tests/devlib.py, which is missing (%s)" % path)
+    spec = importlib.util.spec_from_file_location("hps_tests_devlib_prototypes", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.DEV_PROTOTYPES
 
 
 @contextlib.contextmanager
@@ -254,7 +241,7 @@ def call(name, *args):
         raise HpsError("%s failed (code %d): %s" % (name, rc, msg.decode() if msg else ""))
 
 
-WS_CONV_SPLITK, WS_SMPL_MP, WS_SMPL_XT, WS_SMPL_A, WS_SMPL_VPOSED, WS_HEAD_F, WS_HEAD_USV, WS_HEAD_SYNC = range(8)
+WS_CONV_SPLITK, WS_SMPL_MP, WS_SMPL_XT, WS_SMPL_A, WS_SMPL_VPOSED, WS_HEAD_F, WS_HEAD_USV = range(7)
 
 
 def query_workspace(what, d0=0, d1=0, d2=0):

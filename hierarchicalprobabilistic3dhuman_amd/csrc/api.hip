@@ -28,7 +28,9 @@ extern "C" int64_t hps_query_workspace(int what, int64_t d0, int64_t d1, int64_t
         case HPS_WS_SMPL_VPOSED: return d0 * up(3 * d1, 128) * f;
         case HPS_WS_HEAD_F: return d0 * d1 * 9 * f;
         case HPS_WS_HEAD_USV: return d0 * d1 * 21 * f;
-        case HPS_WS_HEAD_SYNC: return ((d0 + 3) / 4) * (HPS_HEAD_MAX_LEVELS + 1) * (int64_t)sizeof(int32_t);
+#ifdef HPS_DEV_BUILD
+        case HPS_DEV_WS_HEAD_SYNC: return ((d0 + 3) / 4) * (HPS_HEAD_MAX_LEVELS + 1) * (int64_t)sizeof(int32_t);
+#endif
         default: hps::set_error("hps_query_workspace: unknown item %d", what); return -1;
     }
 }

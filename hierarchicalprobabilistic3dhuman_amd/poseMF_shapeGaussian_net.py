@@ -104,7 +104,6 @@ class PoseMFShapeGaussianNet(nn.Module):
         self.svd_mode = "device"       # "device": in-kernel gesdd-faithful SVD; "host": MKL sgesdd round trip (the routine itself)
         self.svd_flavor = None         # None: the rounding flavour of this host's MKL (calibrated); 0 / 1 force one
         self.latency_mode = False      # set_latency_mode(): encoder on direct kernels with many K slices, joint MLPs on wide workgroups
-        self.fused_levels = False      # experiment (tests / tools, dev library): all kinematic levels in ONE launch -- measured slower than eight launches
 
     def set_latency_mode(self, on=True):
         """One switch for one-image-at-a-time deployments (the reference's run_predict operating point): the encoder's latency mode
@@ -180,27 +179,19 @@ class PoseMFShapeGaussianNet(nn.Module):
         p["levels"] = [torch.tensor(l, dtype=torch.int32, device=dev) for l in self.levels]
         p["level_joints"] = torch.tensor([j for l in self.levels for j in l], dtype=torch.int32, device=dev)
         p["level_sizes_host"] = torch.tensor([len(l) for l in self.levels], dtype=torch.int32)
+        p["max_level_size"] = max(len(l) for l in self.levels)
         self._prepared = p
         return p
 
     # ------------------------------------------------------------------------------------------
-    def forward(self, input, input_feats=None):
-        """models/poseMF_shapeGaussian_net.py:85-162.  input: (B,C,D,D); ``input_feats`` skips the encoder."""
-        if input_feats is None:
-            input_feats = self.image_encoder(input)
-        _capi.require_device(input_feats, "input_feats")
-        p = self._prepared or self.prepare()
-        feats = _capi.f32c(input_feats)
-        B = feats.shape[0]
-        dev = feats.device
-        nj = self.num_joints
+    def _trunk(self, feats, p):
+        """:95-110: fc1 / ELU, the Gaussian over the betas, glob, cam, the embedding -- three launches (hps_head_trunk); the Gaussian's
+        mean / exp(log std), glob and cam come out contiguous: no concatenation buffer, no torch.exp, no clones on the head's stream."""
+        B, dev = feats.shape[0], feats.device
         nsh, ng, nc = self.num_shape_params * 2, self.num_glob_params, self.num_cam_params
         embed_dim = self.config.MODEL.EMBED_DIM
         P, s = _capi.ptr, _capi.stream()
         f32 = dict(device=dev, dtype=torch.float32)
-
-        # trunk (:95-110): three launches (hps_head_trunk); the Gaussian's mean / exp(log std), glob and cam come out contiguous --
-        # no concatenation buffer, no torch.exp, no clones on the head's stream
         nf = feats.shape[1]
         hidden = p["fc1_wt"].shape[1]
         x = torch.empty(B, hidden, **f32)
@@ -213,18 +204,34 @@ class PoseMFShapeGaussianNet(nn.Module):
         _capi.call("hps_head_trunk", P(feats), nf, P(p["fc1_wt"]), P(p["fc1_b"]), P(p["sgc_wt"]), P(p["sgc_b"]), P(p["sgc_add"]),
                    P(p["embed_wt"]), P(p["embed_b"]), P(x), P(sgc), P(embed), P(shape_mean), P(shape_scale), P(glob), P(cam), B, nf,
                    hidden, self.num_shape_params, ng, nc, embed_dim, s)
-        shape_dist = Normal(loc=shape_mean, scale=shape_scale, validate_args=False)
+        return embed, Normal(loc=shape_mean, scale=shape_scale, validate_args=False), glob, cam
+
+    def _pose_buffers(self, B, dev):
+        """pose_F, pose_U, pose_S, pose_V, U_proper, S_proper, mode: every joint is in exactly one level and ancestors come from earlier
+        levels, so all entries are written before they are read -- no zero fill (seven launches less on the head's stream)."""
+        f32 = dict(device=dev, dtype=torch.float32)
+        nj = self.num_joints
+        return (torch.empty(B, nj, 3, 3, **f32), torch.empty(B, nj, 3, 3, **f32), torch.empty(B, nj, 3, **f32),
+                torch.empty(B, nj, 3, 3, **f32), torch.empty(B, nj, 3, 3, **f32), torch.empty(B, nj, 3, **f32),
+                torch.empty(B, nj, 3, 3, **f32))
+
+    def forward(self, input, input_feats=None):
+        """models/poseMF_shapeGaussian_net.py:85-162.  input: (B,C,D,D); ``input_feats`` skips the encoder."""
+        if input_feats is None:
+            input_feats = self.image_encoder(input)
+        _capi.require_device(input_feats, "input_feats")
+        p = self._prepared or self.prepare()
+        feats = _capi.f32c(input_feats)
+        B = feats.shape[0]
+        dev = feats.device
+        nj = self.num_joints
+        embed_dim = self.config.MODEL.EMBED_DIM
+        P, s = _capi.ptr, _capi.stream()
+        f32 = dict(device=dev, dtype=torch.float32)
+        embed, shape_dist, glob, cam = self._trunk(feats, p)
 
         # hierarchical pose prediction (:121-160), one kinematic level at a time
-        # every joint is in exactly one level and ancestors come from earlier levels: all entries are written before
-        # they are read, no zero fill needed (seven launches less on the head's stream)
-        pose_F = torch.empty(B, nj, 3, 3, **f32)
-        pose_U = torch.empty(B, nj, 3, 3, **f32)
-        pose_S = torch.empty(B, nj, 3, **f32)
-        pose_V = torch.empty(B, nj, 3, 3, **f32)
-        U_proper = torch.empty(B, nj, 3, 3, **f32)
-        S_proper = torch.empty(B, nj, 3, **f32)
-        mode = torch.empty(B, nj, 3, 3, **f32)
+        pose_F, pose_U, pose_S, pose_V, U_proper, S_proper, mode = self._pose_buffers(B, dev)
         delta = float(self.config.MODEL.DELTA_I_WEIGHT) if self.config.MODEL.DELTA_I else 0.0
         stream = torch.cuda.current_stream()
         if self.svd_mode not in ("device", "host"):
@@ -233,24 +240,8 @@ class PoseMFShapeGaussianNet(nn.Module):
         if self.composite_head:
             # the whole joint loop in one call across the C ABI (csrc/composite.hip: same launches, same order)
             sizes = p["level_sizes_host"]
-            max_n = int(sizes.max())
+            max_n = p["max_level_size"]
             VP = _capi._P
-            if device_svd and self.latency_mode and self.fused_levels and len(p["levels"]) <= 32 and \
-                    max_n * ((B + 3) // 4) <= torch.cuda.get_device_properties(dev).multi_processor_count:
-                # EXPERIMENT (dev library; measured slower than the eight launches, csrc/head.hip): one launch for the whole joint
-                # loop -- the workgroups of an image tile hand their level's results to each other through counters in a small
-                # zeroed workspace (one per stream: two forwards in flight must not share counters)
-                key = ("sync", torch.cuda.current_stream().cuda_stream, (B + 3) // 4)
-                sync = p.get(key)
-                if sync is None:
-                    sync = p[key] = torch.zeros(_capi.query_workspace(_capi.WS_HEAD_SYNC, B) // 4, dtype=torch.int32, device=dev)
-                with _capi.dev_library():
-                    _capi.call("hps_dev_head_pose_levels_fused", P(embed), embed_dim, embed_dim // 2, _capi.iptr(p["level_joints"]),
-                               VP(sizes.data_ptr()), len(p["levels"]), _capi.iptr(p["anc_ptr"]), _capi.iptr(p["anc_idx"]),
-                               VP(p["w1t_ptrs"].data_ptr()), VP(p["b1_ptrs"].data_ptr()), VP(p["w2_ptrs"].data_ptr()),
-                               VP(p["b2_ptrs"].data_ptr()), P(U_proper), P(S_proper), P(mode), delta, P(pose_F), P(pose_U), P(pose_S),
-                               P(pose_V), B, nj, self._flavor() | _capi.HEAD_WIDE_WORKGROUPS, _capi.iptr(sync), s)
-                return pose_F, pose_U, pose_S, pose_V, mode, shape_dist, glob, cam
             if device_svd:
                 f_dev = usv_dev = None
                 fh = uh = None

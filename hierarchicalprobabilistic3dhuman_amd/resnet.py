@@ -70,7 +70,6 @@ class _ConvBN:
             self.stem_u = _stem_winograd_filters(w).to(w.device).contiguous()
         self.use_winograd = True
         self.latency = False      # ResNet.set_latency_mode: direct kernels with many K slices (see _auto_ksplit)
-        self.kernel = "v3"        # "v3" direct global->LDS (default), "v2" register-staged, "v1" generic (any Cin % 4 == 0)
         self.variant = 0          # tile choice of the v2 / v3 kernels (0 = automatic)
         self.ksplit = 0           # split-K slices of the v3 kernel (0 = automatic, 1 = off)
         self.zeros = torch.zeros(64, device=w.device, dtype=torch.float32)
@@ -223,36 +222,6 @@ class _ConvBN:
     def out_hw(self, H, W):
         return (H + 2 * self.pad - self.kh) // self.stride + 1, (W + 2 * self.pad - self.kw) // self.stride + 1
 
-    def __call__(self, x, residual=None, relu=True):
-        """The un-padded kernel generations (csrc/conv.hip): cross-check only, they live in libhps_dev.so."""
-        with _capi.dev_library():
-            return self._call_plain(x, residual, relu)
-
-    def _call_plain(self, x, residual=None, relu=True):
-        B, H, W, C = x.shape
-        assert C == self.cin_p
-        Ho = (H + 2 * self.pad - self.kh) // self.stride + 1
-        Wo = (W + 2 * self.pad - self.kw) // self.stride + 1
-        y = torch.empty(B, Ho, Wo, self.cout, device=x.device, dtype=torch.float32)
-        P = _capi.ptr
-        if self.wn is not None and self.kernel == "v3":
-            ksplit = self.ksplit if self.ksplit > 0 else self._auto_ksplit(Ho * Wo)
-            ws = torch.empty(ksplit, B * Ho * Wo, self.cout, device=x.device, dtype=torch.float32) if ksplit > 1 else None
-            _capi.call("hps_conv2d_bn_act_v3", P(x), P(self.wn), P(self.zeros), P(self.scale), P(self.shift),
-                       P(residual) if residual is not None else None, P(y), B, H, W, C, self.cout, self.kh, self.kw,
-                       self.stride, self.pad, 1 if relu else 0, self.variant if ksplit <= 1 else 1, ksplit,
-                       P(ws) if ws is not None else None, _capi.stream())
-            return y
-        if self.wn is not None and self.kernel == "v2":
-            _capi.call("hps_conv2d_bn_act_v2", P(x), P(self.wn), P(self.scale), P(self.shift),
-                       P(residual) if residual is not None else None, P(y), B, H, W, C, self.cout, self.kh, self.kw,
-                       self.stride, self.pad, 1 if relu else 0, self.variant, _capi.stream())
-            return y
-        _capi.call("hps_conv2d_bn_act", P(x), P(self.wk), P(self.scale), P(self.shift),
-                   P(residual) if residual is not None else None, P(y), B, H, W, C, self.cout, self.kh, self.kw,
-                   self.stride, self.pad, 1 if relu else 0, _capi.stream())
-        return y
-
 
 _STEM_G4 = [[0.5, 0, 0, 0], [-0.5, -0.5, -0.5, -0.5], [-1 / 6, 1 / 6, -1 / 6, 1 / 6], [1 / 6, 1 / 3, 2 / 3, 4 / 3], [0, 0, 0, 1]]
 _STEM_G3 = [[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]]
@@ -362,7 +331,6 @@ class ResNet(nn.Module):
         # prepare() re-applies them to the rebuilt _ConvBN objects
         self._winograd = True
         self._latency = False
-        self.layout = "padded"    # "padded": halo-padded NHWC + scalar-base LDS-DMA kernel (product); "plain": the conv.hip kernels of libhps_dev.so (tests)
         self.composite = True     # padded layout: issue the launch list through hps_encoder_run (one call) instead of one by one
         # Winograd stem: form the max pool in the stem kernel's epilogue (hps_stem_winograd_pooled: the full-resolution stem output is never
         # written; identical values).  False: hps_stem_winograd + hps_maxpool3x3s2_pad (the cross-check of the tests)
@@ -543,17 +511,12 @@ class ResNet(nn.Module):
         convs = [prep["stem"]] + [c for blk in prep["blocks"] for c in blk if c is not None]
         return tuple((c.variant, c.ksplit, c.use_winograd, c.latency) for c in convs)
 
-    def _padded_ok(self, C, H, W):
-        # every (C, H, W) runs on the product kernels: shapes the stem's fast paths do not take get a channel-padded, even-width
-        # input frame (hps_nchw_to_padded_nhwc_generic) in front of the row-mode / direct stem
-        return self.layout == "padded"
-
     def stem_frames(self, B, C, H, W, device):
         """The phase-frame buffer the Winograd stem will read for a (B, C, H, W) input on the CURRENT stream, wrapped as a
         FilledStemFrames for the caller to fill (hps_proxy_rep_phase_frames) and hand to forward(); None when this shape does not
         take the Winograd stem (then build the NCHW tensor as usual)."""
         prep = self._prepared or self.prepare()
-        if self.layout != "padded" or not prep["stem"].stem_winograd_ok(C, H, W):
+        if not prep["stem"].stem_winograd_ok(C, H, W):
             return None
         fs = self._frame_set(prep, B, C, H, W, device, frames=True)
         if not fs["stem_wino"]:
@@ -658,36 +621,9 @@ class ResNet(nn.Module):
         if isinstance(x, FilledStemFrames):
             return self._forward_padded(prep, x, gate=_gate)
         _capi.require_device(x, "encoder input")
-        x = _capi.f32c(x)
-        B, C, H, W = x.shape
-        if self._padded_ok(C, H, W):
-            return self._forward_padded(prep, x, gate=_gate)
-        with _capi.dev_library():          # earlier kernel generation: cross-check only, lives in libhps_dev.so
-            return self._forward_plain(prep, x)
-
-    def _forward_plain(self, prep, x):
-        B, C, H, W = x.shape
-        s = _capi.stream()
-        P = _capi.ptr
-        cp = self._cin_pad
-        if cp not in (4, 20, 64):
-            raise _capi.HpsError("in_channels=%d unsupported by hps_nchw_to_nhwc (padded %d)" % (C, cp))
-        xh = torch.empty(B, H, W, cp, device=x.device, dtype=torch.float32)
-        _capi.call("hps_nchw_to_nhwc", P(x), P(xh), B, C, H, W, cp, s)
-        y = prep["stem"](xh, relu=True)                                    # conv1 + bn1 + relu
-        Bh, Hh, Wh, Ch = y.shape
-        Hp, Wp = (Hh + 2 - 3) // 2 + 1, (Wh + 2 - 3) // 2 + 1
-        yp = torch.empty(B, Hp, Wp, Ch, device=x.device, dtype=torch.float32)
-        _capi.call("hps_maxpool3x3s2", P(y), P(yp), B, Hh, Wh, Ch, s)
-        y = yp
-        for c1, c2, down in prep["blocks"]:                                # BasicBlock.forward :62-78
-            identity = down(y, relu=False) if down is not None else y
-            out = c1(y, relu=True)
-            y = c2(out, residual=identity, relu=True)
-        Bq, Hq, Wq, Cq = y.shape
-        feats = torch.empty(B, Cq, device=x.device, dtype=torch.float32)
-        _capi.call("hps_global_avgpool", P(y), P(feats), B, Hq * Wq, Cq, s)
-        return feats
+        # every (C, H, W) runs on the product kernels: shapes the stem's fast paths do not take get a channel-padded, even-width input
+        # frame (hps_nchw_to_padded_nhwc_generic) in front of the row-mode / direct stem
+        return self._forward_padded(prep, _capi.f32c(x), gate=_gate)
 
 
 def resnet18(in_channels, pretrained=False, progress=True, **kwargs):

@@ -35,6 +35,21 @@ extern "C" {
 
 typedef void* hps_stream_t; /* hipStream_t */
 
+/* Entry points the package's own inference path no longer calls (round 6).  They stay exported, tested on every GPU run and
+ * supported -- each is the bit-level partner or the general form of the one that replaced it -- but a new caller should start
+ * from the replacement:
+ *   hps_stem_winograd + hps_maxpool3x3s2_pad      -> hps_stem_winograd_pooled_nchw (max pool in the stem's epilogue, windows gathered
+ *                                                    from the NCHW input); hps_stem_phase_split + hps_stem_winograd_pooled remain the
+ *                                                    route of callers that write the phase frames themselves (hps_proxy_rep_phase_frames)
+ *   hps_smpl_mesh_fused (no side output)          -> hps_smpl_mesh_fused_picks; with shared shapes (use_mean_shape)
+ *                                                    hps_smpl_v_shaped + hps_smpl_mesh_fused_shared_shape
+ *   hps_smpl_blend + hps_smpl_lbs                 -> the fused forms (the pair remains SURVEY 8(d)'s definition of the LBS kernel and the
+ *                                                    route for skinning weights with more than 12 influences)
+ *   one hps_conv2d_bn_act_pad call for a block's
+ *   1x1/2 down-sample                             -> hps_conv2d_bn_act_pad_down (rides in the 3x3/2 convolution's launch)
+ *   hps_nchw_to_padded_nhwc (+ row-mode stem)     -> the Winograd stem for the released model's shapes; the relayout + direct stem remain
+ *                                                    the route of every other (C, H, W) and of the latency mode */
+
 #define HPS_OK 0
 #define HPS_E_BADARG (-1)      /* null pointer / size out of range */
 #define HPS_E_UNSUPPORTED (-2) /* shape not implemented by this build */
@@ -56,7 +71,6 @@ typedef void* hps_stream_t; /* hipStream_t */
  * layer's partial sums are then added in another order: results differ in the last bits, so this is a property of the model
  * (PoseMFShapeGaussianNet.set_latency_mode), never of the batch. */
 #define HPS_HEAD_WIDE_WORKGROUPS 0x100
-#define HPS_HEAD_MAX_LEVELS 32 /* kinematic depth levels the single-launch experiment of the dev library handles (the body tree has 8) */
 
 #define HPS_ACT_NONE 0
 #define HPS_ACT_ELU 1
@@ -82,10 +96,9 @@ int hps_stream_destroy(hps_stream_t stream);
  *   HPS_WS_SMPL_VPOSED (d0 = M, d1 = V)                         v_posed of the unfused hps_smpl_blend with 128-byte aligned rows
  *   HPS_WS_HEAD_F      (d0 = B, d1 = largest level size)        f_level_dev / f_host_pinned of hps_head_pose_levels
  *   HPS_WS_HEAD_USV    (d0 = B, d1 = largest level size)        usv_level_dev / usv_host_pinned of hps_head_pose_levels
- *   HPS_WS_HEAD_SYNC   (d0 = B)                                 sync_ws of the dev library's hps_dev_head_pose_levels_fused (ZERO before its first use)
  * Unused dims are ignored.  Returns -1 (and sets hps_last_error) for an unknown `what` or negative dims. */
 enum { HPS_WS_CONV_SPLITK = 0, HPS_WS_SMPL_MP = 1, HPS_WS_SMPL_XT = 2, HPS_WS_SMPL_A = 3, HPS_WS_SMPL_VPOSED = 4,
-       HPS_WS_HEAD_F = 5, HPS_WS_HEAD_USV = 6, HPS_WS_HEAD_SYNC = 7 };
+       HPS_WS_HEAD_F = 5, HPS_WS_HEAD_USV = 6 };
 int64_t hps_query_workspace(int what, int64_t d0, int64_t d1, int64_t d2);
 
 /* ------------------------------------------------------------------------------------------

@@ -3,10 +3,10 @@
  *
  * NOT part of the product ABI: libhps.so exports none of these.  The dev library contains the product code plus
  *   - the earlier, un-padded convolution generations (csrc/conv.hip: v1 / v2 / v3) and their relayout / pool kernels,
- *     kept as a bit-level cross-check of the halo-padded product kernels (tests, layout = "plain");
+ *     kept as a bit-level cross-check of the halo-padded product kernels (tests/devlib.py: plain_conv, plain_forward);
  *   - alternate kernel variants (stationary-A blend GEMM, LDS-resident uncertainty kernels, LBS launch geometries);
  *   - process-global tuning switches (hps_dev_*) and ablation launches for profiling.
- * Only tests/ and tests/dev/ load it (_capi.dev_library()).
+ * Only tests/ and tests/dev/ load it (_capi.dev_library(); the ctypes prototypes of these entry points live in tests/devlib.py).
  */
 #ifndef HPS_DEV_H_
 #define HPS_DEV_H_
@@ -19,6 +19,11 @@ extern "C" {
 /* The libraries are built with -fvisibility=hidden: what is declared between this push and the pop at the end of the header is
  * the complete dynamic symbol table of the shared object (tests/test_capi_symbols.py compares it with `nm -D`). */
 #pragma GCC visibility push(default)
+
+/* Kinematic depth levels the single-launch head experiment (hps_dev_head_pose_levels_fused) handles (the body tree has 8), and the
+ * hps_query_workspace item -- of the DEV build only -- that sizes its counter workspace: d0 = B -> bytes (ZERO before its first use). */
+#define HPS_HEAD_MAX_LEVELS 32
+#define HPS_DEV_WS_HEAD_SYNC 7
 
 /* Development / tuning entry: hps_smpl_lbs with an explicit kernel variant (0..4: meshes per barrier G and
  * vertices per lane VPT = (4,1) (8,1) (4,2) (2,2) (2,1)) and resident-workgroup target. Same results. */
@@ -74,7 +79,7 @@ int hps_dev_smpl_joints_v1(const float* verts, const float* j_posed, const int32
  * one hps_head_joint_level_svd launch per kinematic level (level_joints: the levels' joint ids back to back, level_sizes_host: HOST
  * array of the n_levels <= HPS_HEAD_MAX_LEVELS level sizes), with the same per-joint code -- identical bits.  Workgroup (slot, tile)
  * walks the levels for its four images; the <= widest-level workgroups of a tile meet between levels at counters in sync_ws
- * (hps_query_workspace(HPS_WS_HEAD_SYNC, B) bytes; ZERO before the first use, the kernel leaves it zero).  For latency-bound calls
+ * (hps_query_workspace(HPS_DEV_WS_HEAD_SYNC, B) bytes -- dev build only; ZERO before the first use, the kernel leaves it zero).  For latency-bound calls
  * on one or a few images: eight dispatches become one, and the branchy LAPACK-faithful SVD runs from a warm instruction cache from
  * the second level on.  Returns HPS_E_UNSUPPORTED when widest level x ceil(B / 4) workgroups exceed the device's CU count (the
  * waiting workgroups must all be schedulable at once): use hps_head_pose_levels then. */

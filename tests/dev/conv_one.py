@@ -5,6 +5,11 @@ import os
 import sys
 
 import torch
+import os as _os, sys as _sys
+_sys.path[:0] = [_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), _os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))]          # tests/ (devlib) and the repository root
+import devlib
+devlib.enable_plain_call()          # cb(x) = the un-padded kernel generation of libhps_dev.so (tests/devlib.py)
+
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -12,6 +12,7 @@ from oracle import ref_cpu as O
 from hierarchicalprobabilistic3dhuman_amd import configs, _capi
 from hierarchicalprobabilistic3dhuman_amd.resnet import _ConvBN
 from conftest import maxerr
+from devlib import plain_conv, plain_forward, head_levels_fused, sync_workspaces
 
 pytestmark = pytest.mark.gpu
 
@@ -69,25 +70,25 @@ def test_conv_bn_relu_kernel(cfg, dev):
         want_nores = bn(conv(x))
     cb = _ConvBN(conv.to(dev), bn.to(dev))
     xh = x.to(dev).permute(0, 2, 3, 1).contiguous()
-    got = cb(xh, residual=res.to(dev).permute(0, 2, 3, 1).contiguous(), relu=True)
+    got = plain_conv(cb, xh, residual=res.to(dev).permute(0, 2, 3, 1).contiguous(), relu=True)
     assert maxerr(got.permute(0, 3, 1, 2), want) <= 1e-4 * max(1.0, float(want.abs().max()))
-    got2 = cb(xh, relu=False)
+    got2 = plain_conv(cb, xh, relu=False)
     assert maxerr(got2.permute(0, 3, 1, 2), want_nores) <= 1e-4 * max(1.0, float(want_nores.abs().max()))
     # every kernel generation / tile shape that supports this layer gives the same answer
     kernels = [("v1", 0)] + ([(kern, v) for kern in ("v2", "v3") for v in (1, 2, 3)] if Cin % 32 == 0 else [])
     for kern, v in kernels:
-        cb.kernel, cb.variant = kern, v
-        alt = cb(xh, residual=res.to(dev).permute(0, 2, 3, 1).contiguous(), relu=True)
+        cb.variant = v
+        alt = plain_conv(cb, xh, residual=res.to(dev).permute(0, 2, 3, 1).contiguous(), relu=True, kernel=kern)
         assert maxerr(alt, got) <= 1e-4 * max(1.0, float(want.abs().max())), (kern, v)
     # split-K (two-pass, deterministic) where the shape allows it
     if Cin % 32 == 0 and Cout % 128 == 0:
         chunks = k * k * Cin // 32
         for ks in (2, 4):
             if chunks % ks == 0:
-                cb.kernel, cb.variant, cb.ksplit = "v3", 0, ks
-                alt = cb(xh, residual=res.to(dev).permute(0, 2, 3, 1).contiguous(), relu=True)
+                cb.variant, cb.ksplit = 0, ks
+                alt = plain_conv(cb, xh, residual=res.to(dev).permute(0, 2, 3, 1).contiguous(), relu=True)
                 assert maxerr(alt, got) <= 1e-4 * max(1.0, float(want.abs().max())), ("split-K", ks)
-                assert torch.equal(alt, cb(xh, residual=res.to(dev).permute(0, 2, 3, 1).contiguous(), relu=True))
+                assert torch.equal(alt, plain_conv(cb, xh, residual=res.to(dev).permute(0, 2, 3, 1).contiguous(), relu=True))
 
 
 def _frame(t_nhwc, pad):
@@ -135,7 +136,7 @@ def test_padded_conv_kernel(cfg, dev):
             if v == 4 and Cout != 64:
                 continue
             cb.variant = v
-            plain = cb(xh, residual=resh, relu=True)        # same tile / split-K rule on both sides
+            plain = plain_conv(cb, xh, residual=resh, relu=True)        # same tile / split-K rule on both sides
             out = torch.zeros(B, Ho + 2, Ho + 2, Cout, device=dev)
             cb.padded(xp, ipad, out, 1, residual=_frame(resh, 1), relu=True)
             assert torch.equal(out[:, 1:-1, 1:-1], plain), v
@@ -145,7 +146,7 @@ def test_padded_conv_kernel(cfg, dev):
             for ks in (2, 4):
                 if chunks % ks == 0:
                     cb.ksplit = ks
-                    plain_k = cb(xh, residual=resh, relu=True)
+                    plain_k = plain_conv(cb, xh, residual=resh, relu=True)
                     out = torch.zeros(B, Ho + 2, Ho + 2, Cout, device=dev)
                     cb.padded(xp, ipad, out, 1, residual=_frame(resh, 1), relu=True)
                     assert torch.equal(out[:, 1:-1, 1:-1], plain_k), ("split-K", ks)
@@ -243,11 +244,7 @@ def test_encoder_with_and_without_the_folded_down_samples_gives_the_same_feature
 def test_padded_and_plain_encoders_agree(dev, net_gpu, golden, golden_input):
     enc = net_gpu.image_encoder
     x = golden_input.to(dev)
-    try:
-        enc.layout = "plain"
-        plain = enc(x)
-    finally:
-        enc.layout = "padded"
+    plain = plain_forward(enc, x)                           # the un-padded kernel generation (libhps_dev.so, tests/devlib.py)
     padded = enc(x)
     again = enc(x)
     assert torch.equal(padded, again)                       # frames are reused: nothing stale leaks between calls
@@ -777,7 +774,7 @@ def test_latency_mode_of_the_whole_net(dev, net_gpu, net_cpu, golden, golden_inp
 @pytest.mark.gpu
 def test_all_levels_in_one_launch_equal_the_per_level_launches(dev, net_gpu):
     """VERDICT r4 item 6, the experiment that was measured and not adopted (dev library: hps_dev_head_pose_levels_fused, switched
-    on by net.fused_levels): the eight kinematic levels as ONE launch -- workgroups of an image tile hand their level's results to
+    driven by tests/devlib.py head_levels_fused): the eight kinematic levels as ONE launch -- workgroups of an image tile hand their level's results to
     each other through counters in global memory.  It stays as a cross-check of "images are independent through the head" and of the
     per-joint code: all eight outputs bit for bit against the eight launches, for batches that leave ragged tiles, for many calls in a row (the counters reset
     themselves), on two streams at once (a workspace per stream), and the fall-back to per-level launches when the grid would not
@@ -785,8 +782,10 @@ def test_all_levels_in_one_launch_equal_the_per_level_launches(dev, net_gpu):
     feats = {B: (torch.rand(B, 512, generator=torch.Generator().manual_seed(70 + B)) * 2).to(dev) for B in (1, 2, 3, 4, 5, 17, 64, 204, 300)}
 
     def run(B, fused):
-        net_gpu.fused_levels = fused
-        out = net_gpu(None, input_feats=feats[B])
+        out = head_levels_fused(net_gpu, feats[B]) if fused else net_gpu(None, input_feats=feats[B])
+        if out is None:                          # the single launch's grid would not fit the chip at once: the per-level path is the only one
+            assert fused and B == 300
+            out = net_gpu(None, input_feats=feats[B])
         return [t.clone() for t in out[:5]] + [out[5].loc.clone(), out[5].scale.clone(), out[6].clone(), out[7].clone()]
 
     try:
@@ -798,20 +797,18 @@ def test_all_levels_in_one_launch_equal_the_per_level_launches(dev, net_gpu):
                 for i, (a, b) in enumerate(zip(want, got)):
                     assert torch.equal(a, b), (B, rep, i, float((a - b).abs().max()))
         # the workspace is left zero (self-resetting counters), whatever the batch
-        p = net_gpu._prepared
-        syncs = [v for k, v in p.items() if isinstance(k, tuple) and k[0] == "sync"]
-        assert syncs and all(int(v.abs().sum()) == 0 for v in syncs)
-        assert not any(k[2] == (300 + 3) // 4 for k in p if isinstance(k, tuple) and k[0] == "sync")     # 5 x 75 workgroups > 256 CUs: per-level launches
+        syncs = sync_workspaces(net_gpu)
+        assert syncs and all(int(v.abs().sum()) == 0 for v in syncs.values())
+        assert not any(k[2] == (300 + 3) // 4 for k in syncs)     # 5 x 75 workgroups > 256 CUs: per-level launches
         # two streams in flight at once
         want = {B: run(B, False) for B in (1, 5)}
-        net_gpu.fused_levels = True
         s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
         torch.cuda.synchronize()
         outs = {1: [], 5: []}
         for rep in range(10):
             for st, B in ((s1, 1), (s2, 5)):
                 with torch.cuda.stream(st):
-                    o = net_gpu(None, input_feats=feats[B])
+                    o = head_levels_fused(net_gpu, feats[B])
                     outs[B].append([o[0], o[1], o[2], o[3], o[4]])
         torch.cuda.synchronize()
         for B in (1, 5):
@@ -819,6 +816,5 @@ def test_all_levels_in_one_launch_equal_the_per_level_launches(dev, net_gpu):
                 for a, b in zip(want[B][:5], o):
                     assert torch.equal(a, b), B
     finally:
-        net_gpu.fused_levels = False
         net_gpu.set_latency_mode(False)
 

@@ -1,7 +1,7 @@
 """Batch-1 latency of infer() (the reference's run_predict operating point: one image, num_samples = 50): wall clock per call, and --
 under `rocprofv3 --kernel-trace` -- the kernel timeline of one call (tools/latency_b1.py analyse <kernel_trace.csv>).
 
-    python tools/latency_b1.py [reps] [--direct | --latency [--per-level]]   # ResNet.set_winograd(False) / set_latency_mode(True)
+    python tools/latency_b1.py [reps] [--direct | --latency]   # ResNet.set_winograd(False) / set_latency_mode(True)
     python tools/latency_b1.py analyse <kernel_trace.csv>
 """
 import os
@@ -59,8 +59,6 @@ def main():
         net.image_encoder.set_winograd(False)
     if "--latency" in sys.argv:
         net.set_latency_mode(True)
-    if "--per-level" in sys.argv:
-        net.fused_levels = False            # the eight kinematic levels as eight launches (A/B against hps_head_pose_levels_fused)
     smpl = SMPL(smpl_data.synthetic_smpl_model(0)).to(dev)
     x = torch.rand(1, 18, 256, 256, generator=torch.Generator().manual_seed(1)).to(dev)
     lat, host = [], []
@@ -74,7 +72,7 @@ def main():
         host.append((t1 - t0) * 1e3)
     lat, host = sorted(lat[5:]), sorted(host[5:])
     print("batch 1, N = 50%s: latency median %.3f ms (min %.3f max %.3f); host enqueue median %.3f ms" % (
-        " (direct convolutions)" if "--direct" in sys.argv else ((" (latency mode%s)" % (", per-level head launches" if "--per-level" in sys.argv else "")) if "--latency" in sys.argv else ""), lat[len(lat) // 2], lat[0], lat[-1], host[len(host) // 2]))
+        " (direct convolutions)" if "--direct" in sys.argv else (" (latency mode)" if "--latency" in sys.argv else ""), lat[len(lat) // 2], lat[0], lat[-1], host[len(host) // 2]))
 
 
 if __name__ == "__main__":
