@@ -387,13 +387,36 @@ def main():
         finally:
             net.set_latency_mode(False)
         st2 = spread(lat2[5:])
+        # ... and the same calls replayed from a hipGraph (GraphedInfer: what predict_poseMF_shapeGaussian_net does for batch_size <= 2):
+        # one graph launch per image instead of ~50 kernel launches; same kernels, same bits
+        from hierarchicalprobabilistic3dhuman_amd.predict_poseMF_shapeGaussian_net import GraphedInfer
+        graph_ms = {}
+        for mode_name, on in (("latency", True), ("throughput", False)):
+            net.set_latency_mode(on)
+            try:
+                g1 = GraphedInfer(net, smpl, batch=1, num_samples=n1, slots=1)
+                tl = []
+                for i in range(args.latency_reps + 5):
+                    torch.cuda.synchronize()
+                    t_a = time.perf_counter()
+                    g1(x1, seed=99 + i, image_offset=lo)
+                    torch.cuda.synchronize()
+                    tl.append((time.perf_counter() - t_a) * 1e3)
+                graph_ms[mode_name] = spread(tl[5:])
+                del g1
+            finally:
+                net.set_latency_mode(False)
         latency_b1 = {"median_ms": st2["median_ms"], "min_ms": st2["min_ms"], "max_ms": st2["max_ms"], "reps": st2["launches"],
                       "images_per_s": 1e3 / st2["median_ms"], "batch": 1, "num_samples": n1,
                       "model_mode": "latency (PoseMFShapeGaussianNet.set_latency_mode(True): direct kernels with many K slices, wide head workgroups)",
                       "throughput_mode_median_ms": st["median_ms"],
+                      "graph_median_ms": graph_ms["latency"]["median_ms"], "graph_min_ms": graph_ms["latency"]["min_ms"],
+                      "throughput_mode_graph_median_ms": graph_ms["throughput"]["median_ms"],
                       "note": "one image per call, host wall clock from issue to completion (torch.cuda.synchronize), input resident "
                               "in HBM; the reference's run_predict operating point.  median_ms: encoder in latency mode (what a "
-                              "batch-1 deployment selects); throughput_mode_median_ms: the default kernels of the headline"}
+                              "batch-1 deployment selects), launches issued one by one; throughput_mode_median_ms: the default kernels "
+                              "of the headline; graph_*: the same call replayed from a hipGraph (GraphedInfer, one slot: includes the "
+                              "input's copy into the graph's static buffer)"}
     # The path from where the REFERENCE starts (predict/predict_poseMF_shapeGaussian_net.py:61-100): RGB crops (3 x 256 x 256) and
     # 17 keypoints per image in page-locked HOST memory -> staged non-blocking H2D copy on a copy stream (786 KB per image
     # instead of the 4.7 MB of a finished proxy representation) -> Canny edge map + Gaussian heat-maps on the device

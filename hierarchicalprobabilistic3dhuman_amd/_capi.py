@@ -39,7 +39,7 @@ _PROTOTYPES = {
     "hps_vertex_uncertainty": [_P, _P, _I, _I, _I, _P],
     "hps_query_workspace": [_I, _c.c_int64, _c.c_int64, _c.c_int64],
     "hps_mf_sample": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _c.c_float, _P, _P, _P, _c.c_uint64,
-                      _c.c_int64, _I, _P, _P, _P, _P],
+                      _c.c_int64, _P, _I, _P, _P, _P, _P],
     "hps_infer_assemble": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hps_quat_to_rotmat": [_P, _P, _I, _P],
     "hps_rot6d_to_rotmat": [_P, _P, _I, _P],

@@ -50,8 +50,8 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
 __global__ __launch_bounds__(512) void mf_sample_kernel(
     const float* __restrict__ pose_u, const float* __restrict__ pose_s, const float* __restrict__ pose_v,
     const float* __restrict__ bingham_a, const float* __restrict__ acg_override, int nj, int N, int n_prop, float b, float m_star, const float* __restrict__ eps, const float* __restrict__ wun,
-    const int32_t* __restrict__ draw_idx, uint64_t seed, int64_t call_offset, int max_rounds, int count_all,
-    float* __restrict__ r_out, float* __restrict__ quat_out, int32_t* __restrict__ accepted) {
+    const int32_t* __restrict__ draw_idx, uint64_t seed, int64_t call_offset, const uint64_t* __restrict__ seed_dev, int max_rounds,
+    int count_all, float* __restrict__ r_out, float* __restrict__ quat_out, int32_t* __restrict__ accepted) {
     __shared__ int sCnt[2][8];
     const int c = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
@@ -93,6 +93,10 @@ __global__ __launch_bounds__(512) void mf_sample_kernel(
         const size_t d = (size_t)draw_idx[c];
         eps_c = eps + d * (size_t)n_prop * 4;
         w_c = wun + d * (size_t)n_prop;
+    }
+    if (seed_dev) {             // the Philox key from device memory (a launch captured in a hipGraph must not bake the seed in)
+        seed = seed_dev[0];
+        call_offset = (int64_t)seed_dev[1];
     }
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     const uint64_t gcall = (uint64_t)(call_offset + c);
@@ -266,7 +270,7 @@ extern "C" int hps_infer_assemble(const float* mode, const float* glob_rotmats, 
 
 extern "C" int hps_mf_sample(const float* pose_u, const float* pose_s, const float* pose_v, const float* bingham_a,
                              const float* acg_override, int C, int num_joints, int num_samples, int n_prop, float b, float m_star, const float* eps, const float* w,
-                             const int32_t* draw_idx, uint64_t seed, int64_t call_offset, int max_rounds,
+                             const int32_t* draw_idx, uint64_t seed, int64_t call_offset, const uint64_t* seed_dev, int max_rounds,
                              float* r_out, float* quat_out, int32_t* accepted, hps_stream_t stream) {
     if (!pose_u || !pose_s || !pose_v || !r_out || !accepted) return bad_arg("hps_mf_sample: null pointer");
     if ((eps != nullptr) != (w != nullptr) || (eps && !draw_idx)) return bad_arg("hps_mf_sample: eps, w and draw_idx go together");
@@ -280,8 +284,8 @@ extern "C" int hps_mf_sample(const float* pose_u, const float* pose_s, const flo
     waves = waves < 1 ? 1 : (waves > 8 ? 8 : waves);
     const int count_all = quat_out != nullptr;      // the Bingham entry point reports the round's total (accept_ratio, :67)
     hipLaunchKernelGGL(mf_sample_kernel, dim3(C), dim3(64 * waves), 0, (hipStream_t)stream, pose_u, pose_s, pose_v,
-                       bingham_a, acg_override, num_joints, num_samples, n_prop, b, m_star, eps, w, draw_idx, seed, call_offset, max_rounds,
-                       count_all, r_out, quat_out, accepted);
+                       bingham_a, acg_override, num_joints, num_samples, n_prop, b, m_star, eps, w, draw_idx, seed, call_offset, seed_dev,
+                       max_rounds, count_all, r_out, quat_out, accepted);
     return check_launch("hps_mf_sample");
 }
 

@@ -26,7 +26,7 @@ _SHARED_SHAPE_TABLES = weakref.WeakKeyDictionary()      # smpl model -> ((B, N, 
 @torch.no_grad()
 def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mean_shape=True,
           sample_on_cpu=False, seed=None, image_offset=0, input_feats=None, _before_meshes=None, _after_smpl=None,
-          _run_net=None, _after_unc=None):
+          _run_net=None, _after_unc=None, _seed_dev=None):
     """predict/predict_poseMF_shapeGaussian_net.py:103-165 for a batch of B proxy representations.
 
     proxy_rep_input: (B,18,256,256) on the device.  Returns a dict of device tensors; every entry equals
@@ -53,7 +53,8 @@ def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mea
     f32 = dict(device=dev, dtype=torch.float32)
     body = torch.empty(M, nj, 3, 3, **f32)
     R = pose_matrix_fisher_sampling_torch(pose_U, pose_S, pose_V, N, b=1.5, oversampling_ratio=8, sample_on_cpu=sample_on_cpu,
-                                          seed=seed, image_offset=image_offset, out=body[2 * B:].view(B, N, nj, 3, 3))
+                                          seed=seed, image_offset=image_offset, out=body[2 * B:].view(B, N, nj, 3, 3),
+                                          seed_dev=_seed_dev)
     loc = _capi.f32c(shape_dist.loc)
     nb = loc.shape[1]
     betas_s = None
@@ -456,6 +457,106 @@ class InferencePipeline:
                 main.wait_stream(self.enc_stream)
 
 
+class GraphedInfer:
+    """``infer`` for ONE fixed (batch, num_samples) captured in hipGraphs: a call costs the host one graph launch instead of the ~50
+    kernel launches of the eager path (batch 1: 0.34 ms of host time for 0.53 ms of device time -- at the reference's own operating
+    point, one image per call (predict/predict_poseMF_shapeGaussian_net.py:58-59), the host was what bounded a loop of calls).
+
+        g = GraphedInfer(net, smpl, batch=1, num_samples=50)
+        out = g(x, seed=7)                  # same dict as infer(net, smpl, x, num_samples=50, seed=7): same kernels, same order, same bits
+
+    ``slots`` graphs with their own static buffers and streams alternate: call k + 1 may be issued (and, the chip being mostly idle at
+    batch 1, may run) while call k is still in flight.  The returned tensors are the slot's STATIC output buffers: they are valid
+    until the same slot is used again, ``slots`` calls later -- consume or clone them before that (the predict loop hands them to
+    ``result_fn`` / saves them at once).  The Philox key is read from device memory at run time (hps_mf_sample seed_dev), so replays
+    draw new samples; ``seed`` / ``image_offset`` mean what they mean for infer().  Philox sampling only (the reference's
+    seed-reproducible host-noise route draws on the host per call and cannot be captured)."""
+
+    def __init__(self, pose_shape_model, smpl_model, batch, num_samples=50, use_mean_shape=True, slots=2, input_shape=(18, 256, 256)):
+        self.net, self.smpl = pose_shape_model, smpl_model
+        self.batch, self.num_samples, self.use_mean_shape = int(batch), int(num_samples), bool(use_mean_shape)
+        self.input_shape = tuple(input_shape)
+        self._slots = [None] * max(1, int(slots))
+        self._k = 0
+        self._net_key = None
+
+    def _capture(self, dev):
+        stream = torch.cuda.Stream()
+        x = torch.zeros((self.batch,) + self.input_shape, device=dev, dtype=torch.float32)
+        key_dev = torch.zeros(2, dtype=torch.int64, device=dev)
+        key_host = torch.zeros(2, dtype=torch.int64).pin_memory()
+        run = lambda: infer(self.net, self.smpl, x, num_samples=self.num_samples, use_mean_shape=self.use_mean_shape, _seed_dev=key_dev)
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            for _ in range(2):                   # eager warm-up on the capture stream: weight preparation, frame buffers, LDS grants
+                run()
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            out = run()
+        from . import sampling_utils
+        accepted = sampling_utils.last_accepted[0]
+        return dict(stream=stream, x=x, key_dev=key_dev, key_host=key_host, graph=graph, out=out, accepted=accepted,
+                    copied=None, done=None)
+
+    @torch.no_grad()
+    def __call__(self, proxy_rep_input, seed=None, image_offset=0, wait=True):
+        """``proxy_rep_input``: (batch, 18, D, D) device or page-locked host tensor, or a list of ``batch`` (1, 18, D, D) items (copied
+        row by row into the slot's static input: no concatenation).  ``wait=False``: the caller's stream is NOT made to wait for the
+        replay -- returns (out, done_event) and the caller waits for the event before it reads ``out`` (the predict loop issues call
+        k + 1 first, so that two replays overlap)."""
+        from .sampling_utils import _philox_seed
+        items = proxy_rep_input if isinstance(proxy_rep_input, (list, tuple)) else None
+        shape = ((len(items),) + tuple(items[0].shape[1:])) if items is not None else tuple(proxy_rep_input.shape)
+        if shape != (self.batch,) + self.input_shape:
+            raise _capi.HpsError("GraphedInfer was captured for inputs of shape %s, got %s" % ((self.batch,) + self.input_shape, shape))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        net_key = (id(getattr(self.net.image_encoder, "_prepared", None)), id(getattr(self.net, "_prepared", None)),
+                   bool(getattr(self.net, "latency_mode", False)))
+        if self._net_key != net_key and any(s is not None for s in self._slots):
+            self._slots = [None] * len(self._slots)            # weights re-prepared / mode switched: the graphs hold the old pointers
+        i = self._k % len(self._slots)
+        self._k += 1
+        if self._slots[i] is None:
+            self._slots[i] = self._capture(dev)
+            self._net_key = (id(getattr(self.net.image_encoder, "_prepared", None)), id(getattr(self.net, "_prepared", None)),
+                             bool(getattr(self.net, "latency_mode", False)))
+        s = self._slots[i]
+        if s["copied"] is not None:
+            s["copied"].synchronize()            # the key copy that last used the page-locked pair (``slots`` calls ago) has run
+        s["key_host"][0] = _philox_seed(seed) & 0x7FFFFFFFFFFFFFFF
+        s["key_host"][1] = int(image_offset) * self.net.num_joints
+        caller = torch.cuda.current_stream()
+        st = s["stream"]
+        st.wait_stream(caller)                   # the input's producer (and whoever still reads the slot's previous outputs)
+        with torch.cuda.stream(st):
+            if items is not None:
+                for r, it in enumerate(items):
+                    s["x"][r:r + 1].copy_(it, non_blocking=True)
+            else:
+                s["x"].copy_(proxy_rep_input, non_blocking=True)
+            s["key_dev"].copy_(s["key_host"], non_blocking=True)
+            s["copied"] = torch.cuda.Event()
+            s["copied"].record(st)
+            s["graph"].replay()
+            done = torch.cuda.Event()
+            done.record(st)
+        if not wait:
+            return s["out"], done
+        caller.wait_event(done)
+        return s["out"]
+
+    def check_sampling(self):
+        """Raise if a (image, joint) call of any slot's LAST replay never reached N accepted proposals (synchronises)."""
+        bad = 0
+        for s in self._slots:
+            if s is not None:
+                s["stream"].synchronize()
+                bad += int((s["accepted"] < self.num_samples).sum().item())
+        if bad:
+            raise _capi.HpsError("matrix-Fisher sampling failed for %d (image, joint) calls (are pose_S / pose_U / pose_V finite?)" % bad)
+
+
 _PREDICT_PIPELINES = weakref.WeakKeyDictionary()      # model -> (key, InferencePipeline, StagedUpload) of predict_poseMF_shapeGaussian_net
 
 
@@ -554,6 +655,56 @@ def predict_poseMF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mode
     groups = [image_fnames[i0:i0 + batch_size] for i0 in range(0, len(image_fnames), batch_size)]
     if not groups:
         return
+
+    def deliver(names, res):
+        cols = {key: val.unbind(0) for key, val in res.items()}      # per-image views, made once per key (not 17 x B index calls)
+        for k, n in enumerate(names):
+            item = {key: col[k] for key, col in cols.items()}
+            if result_fn is not None:
+                result_fn(n, item)
+            else:
+                keep = ("verts_mode", "joints_mode", "verts_tpose", "unc", "cam", "glob_rotmats")
+                torch.save({key: item[key].cpu() for key in keep},
+                           os.path.join(save_dir, os.path.splitext(n)[0] + ".pt"))
+
+    if batch_size <= 2 and device.type == "cuda":
+        # The reference's own operating point -- one image per call (:58-59) -- is latency-bound: ~50 launches of a few microseconds
+        # each, and the host needs longer to issue them than the device to run them.  Each (batch, num_samples) is captured ONCE in
+        # hipGraphs (GraphedInfer, two slots on two streams); the loop issues image k + 1 before it waits for image k, so two replays
+        # overlap on the mostly idle chip.  Same kernels, same order, same bits as infer().
+        key = ("graph", id(smpl_model), num_samples, batch_size, torch.cuda.current_device())
+        cached = _PREDICT_PIPELINES.get(pose_shape_model)
+        if cached is None or cached[0] != key:
+            cached = (key, GraphedInfer(weakref.proxy(pose_shape_model), smpl_model, batch_size, num_samples, use_mean_shape=True, slots=2), None)
+            _PREDICT_PIPELINES[pose_shape_model] = cached
+        graphed = cached[1]
+        caller = torch.cuda.current_stream()
+        pending = None
+
+        def finish_pending(p):
+            names_p, res_p, done = p
+            if done is not None:
+                caller.wait_event(done)
+                # a replay's outputs are the slot's static buffers, overwritten two calls later: result_fn gets tensors of its own
+                # (the reference hands each image's results on before the next image, and a callback may keep them)
+                res_p = {key: (val.clone() if torch.is_tensor(val) else val) for key, val in res_p.items()}
+            deliver(names_p, res_p)
+        for gi, names in enumerate(groups):
+            items = [proxy_rep_fn(os.path.join(image_dir, n)).float() for n in names]
+            if len(items) == batch_size and tuple(items[0].shape[1:]) == graphed.input_shape:
+                nxt = (names,) + graphed(items, wait=False)
+            else:                                        # a last, smaller group / another image size: the eager path
+                x = torch.cat([t.to(device) for t in items], dim=0)
+                nxt = (names, infer(pose_shape_model, smpl_model, x, num_samples=num_samples, use_mean_shape=True), None)
+            if pending is not None:
+                finish_pending(pending)
+            pending = nxt
+            if gi % 256 == 255:
+                graphed.check_sampling()
+        finish_pending(pending)
+        graphed.check_sampling()
+        check_sampling()
+        return
     # the pipeline (its streams, the encoder's frame buffers bound to them, the upload slots) is kept between calls, per model (weakly
     # referenced side table: nothing is attached to the module, so copies / pickles of it are unaffected)
     key = (id(smpl_model), num_samples, batch_size, torch.cuda.current_device())
@@ -583,15 +734,7 @@ def predict_poseMF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mode
             ticket = nxt
             if result_fn is None or gi % 64 == 63:
                 check_sampling()                         # synchronises; with a result_fn the check is deferred (below) so the loop stays pipelined
-            cols = {key: val.unbind(0) for key, val in res.items()}      # per-image views, made once per key (not 17 x B index calls)
-            for k, n in enumerate(names):
-                item = {key: col[k] for key, col in cols.items()}
-                if result_fn is not None:
-                    result_fn(n, item)
-                else:
-                    keep = ("verts_mode", "joints_mode", "verts_tpose", "unc", "cam", "glob_rotmats")
-                    torch.save({key: item[key].cpu() for key in keep},
-                               os.path.join(save_dir, os.path.splitext(n)[0] + ".pt"))
+            deliver(names, res)
         check_sampling()
     torch.cuda.current_stream().wait_stream(pipe.caller_stream(batch_size))
 

@@ -33,7 +33,7 @@ def _m_star(b):
 
 
 def _launch(pose_U, pose_S, pose_V, num_samples, n_prop, b, eps=None, w=None, draw_idx=None, seed=0,
-            call_offset=0, bingham_a=None, want_quat=False, acg_override=None, m_star=None, out=None):
+            call_offset=0, bingham_a=None, want_quat=False, acg_override=None, m_star=None, out=None, seed_dev=None):
     B, nj = pose_U.shape[:2]
     C = B * nj
     dev = pose_U.device
@@ -52,7 +52,8 @@ def _launch(pose_U, pose_S, pose_V, num_samples, n_prop, b, eps=None, w=None, dr
                C, nj, num_samples, n_prop, float(b), _m_star(b) if m_star is None else float(m_star),
                P(eps) if eps is not None else None, P(w) if w is not None else None,
                _capi.iptr(draw_idx) if draw_idx is not None else None,
-               int(seed) & 0xFFFFFFFFFFFFFFFF, int(call_offset), _MAX_ROUNDS,
+               int(seed) & 0xFFFFFFFFFFFFFFFF, int(call_offset),
+               _capi.ptr(seed_dev, torch.int64) if seed_dev is not None else None, _MAX_ROUNDS,
                P(R), P(quat) if quat is not None else None, _capi.iptr(accepted), _capi.stream())
     if ev is not None:
         ev[1].record()
@@ -126,11 +127,14 @@ def bingham_sampling_for_matrix_fisher_torch(A, num_samples, Omega=None, Gaussia
 
 
 def pose_matrix_fisher_sampling_torch(pose_U, pose_S, pose_V, num_samples, b=1.5, oversampling_ratio=8,
-                                      sample_on_cpu=False, seed=None, image_offset=0, out=None):
+                                      sample_on_cpu=False, seed=None, image_offset=0, out=None, seed_dev=None):
     """utils/sampling_utils.py:74-143: (B,23,3,3), (B,23,3), (B,23,3,3) -> R_samples (B,N,23,3,3).
 
     ``image_offset``: global index of the first image of this batch (multi-GPU sharding); only used by
-    the Philox route.  ``out``: optional contiguous (B,N,23,3,3) destination the kernel writes into."""
+    the Philox route.  ``out``: optional contiguous (B,N,23,3,3) destination the kernel writes into.
+    ``seed_dev``: optional (2,) int64 DEVICE tensor [seed, first call = image_offset * 23] read by the kernel at run time instead of
+    ``seed`` / ``image_offset`` (GraphedInfer: a launch captured in a hipGraph must not bake the key in); such launches are not
+    recorded for check_sampling() -- the caller reads ``last_accepted`` itself."""
     for t, name in ((pose_U, "pose_U"), (pose_S, "pose_S"), (pose_V, "pose_V")):
         _capi.require_device(t, name)
     U, S, V = _capi.f32c(pose_U), _capi.f32c(pose_S), _capi.f32c(pose_V)
@@ -139,8 +143,8 @@ def pose_matrix_fisher_sampling_torch(pose_U, pose_S, pose_V, num_samples, b=1.5
         R, _, _ = _host_stream_sampling(U, S, V, num_samples, n_prop, b, out=out)
     else:
         nj = U.shape[1]
-        R, _, accepted = _launch(U, S, V, num_samples, n_prop, b, seed=_philox_seed(seed), call_offset=image_offset * nj,
-                                 out=out)
+        R, _, accepted = _launch(U, S, V, num_samples, n_prop, b, seed=0 if seed_dev is not None else _philox_seed(seed),
+                                 call_offset=image_offset * nj, out=out, seed_dev=seed_dev)
         # A call that does not reach N accepts within _MAX_ROUNDS rounds (NaN / Inf pose_S from a bad checkpoint) gets NaN
         # rotations from the kernel -- loud downstream.  The counts stay on the device (no sync on the hot path);
         # check_sampling() is the deferred test the harnesses run per batch.
@@ -149,6 +153,8 @@ def pose_matrix_fisher_sampling_torch(pose_U, pose_S, pose_V, num_samples, b=1.5
         # The tensors stay referenced here until then, so the caching allocator cannot hand their blocks to another stream.
         global last_accepted
         last_accepted = (accepted, num_samples)
+        if seed_dev is not None:        # (an event recorded during stream capture cannot be waited for outside the graph)
+            return R
         ev = torch.cuda.Event()
         ev.record()
         _pending.append((accepted, num_samples, ev))

@@ -239,12 +239,14 @@ int hps_vertex_uncertainty(const float* verts, float* unc, int B, int N, int V, 
  *                   round, proposal) so results do not depend on how images are sharded over GPUs;
  *                   rounds are redrawn in-kernel until N proposals are accepted; a call that exhausts
  *                   max_rounds (non-finite concentrations) gets NaN outputs and accepted[c] < N.
+ *                   seed_dev (optional, device, two uint64: seed, call_offset) overrides the by-value pair: a launch captured in
+ *                   a hipGraph reads its key at run time, so every replay draws new samples.
  */
 int hps_mf_sample(const float* pose_u, const float* pose_s, const float* pose_v,
                   const float* bingham_a, const float* acg_override, int C, int num_joints, int num_samples, int n_prop,
                   float b, float m_star,
                   const float* eps, const float* w, const int32_t* draw_idx, uint64_t seed,
-                  int64_t call_offset, int max_rounds, float* r_out, float* quat_out,
+                  int64_t call_offset, const uint64_t* seed_dev, int max_rounds, float* r_out, float* quat_out,
                   int32_t* accepted, hps_stream_t stream);
 
 /* Inputs of ONE flattened SMPL call over the M = B (N + 2) meshes [mode (B) | T-pose (B) | samples (B N)] of the inference

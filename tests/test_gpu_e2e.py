@@ -366,6 +366,72 @@ def test_predict_loop_from_host_proxies_equals_infer(dev, net_gpu, smpl_gpu, tmp
                     assert torch.equal(got[n][key], want[key][k]), (pinned, n, key)
 
 
+@pytest.mark.parametrize("batch_size", [1, 2])
+def test_predict_loop_one_image_at_a_time_runs_on_graphs_and_equals_infer(batch_size, dev, net_gpu, smpl_gpu, tmp_path):
+    """The reference's own operating point (predict/...:58-59: one image per call): predict_poseMF_shapeGaussian_net with batch_size 1 / 2
+    replays hipGraphs (GraphedInfer, two slots) -- every image's outputs are those of infer() with the same seed, bit for bit, the
+    callback's tensors stay valid after later replays, a smaller last group takes the eager path, in both encoder modes."""
+    import os
+    from hierarchicalprobabilistic3dhuman_amd import configs
+    from hierarchicalprobabilistic3dhuman_amd.predict_poseMF_shapeGaussian_net import predict_poseMF_shapeGaussian_net
+    cfg = configs.get_cfg_defaults()
+    names = ["img_%02d.png" % i for i in range(5)]
+    image_dir = tmp_path / "images"
+    os.makedirs(image_dir)
+    for n in names:
+        open(image_dir / n, "wb").close()
+    proxies = {n: torch.rand(1, 18, 256, 256, generator=torch.Generator().manual_seed(900 + i)).pin_memory() for i, n in enumerate(names)}
+    keys = ("pose_F", "R_samples", "verts_mode", "verts_samples", "joints_samples", "unc")
+    try:
+        for latency in (False, True):
+            net_gpu.set_latency_mode(latency)
+            got = {}
+            torch.manual_seed(31)
+            predict_poseMF_shapeGaussian_net(net_gpu, cfg, smpl_gpu, None, None, None, dev, str(image_dir), str(tmp_path / "out"),
+                                             proxy_rep_fn=lambda path: proxies[os.path.basename(path)], num_samples=6, batch_size=batch_size,
+                                             result_fn=lambda name, item: got.__setitem__(name, {k: item[k] for k in keys}))      # kept, NOT cloned
+            torch.cuda.synchronize()
+            assert sorted(got) == names
+            torch.manual_seed(31)
+            for i0 in range(0, len(names), batch_size):
+                batch = names[i0:i0 + batch_size]
+                want = infer(net_gpu, smpl_gpu, torch.cat([proxies[n] for n in batch]).to(dev), num_samples=6)
+                for k, n in enumerate(batch):
+                    for key in keys:
+                        assert torch.equal(got[n][key], want[key][k]), (latency, n, key)
+    finally:
+        net_gpu.set_latency_mode(False)
+
+
+def test_graphed_infer_equals_infer_and_draws_new_samples_on_every_replay(dev, net_gpu, smpl_gpu, golden_input):
+    """GraphedInfer: the captured launches are infer()'s (same bits for the same seed / image offset), the Philox key is read at run time
+    (other seeds -> other samples, the same seed -> the same samples, replay after replay), slots alternate, and a wrong input shape is
+    refused."""
+    from hierarchicalprobabilistic3dhuman_amd.predict_poseMF_shapeGaussian_net import GraphedInfer
+    x = golden_input.to(dev)
+    g = GraphedInfer(net_gpu, smpl_gpu, batch=2, num_samples=7, slots=2)
+    keys = ("pose_F", "pose_rotmats_mode", "R_samples", "verts_mode", "verts_tpose", "verts_samples", "joints_samples", "unc", "cam")
+    outs = []
+    for seed, off in ((5, 0), (6, 0), (5, 0), (5, 64), (6, 0)):
+        want = infer(net_gpu, smpl_gpu, x, num_samples=7, seed=seed, image_offset=off)
+        got = g(x, seed=seed, image_offset=off)
+        for k in keys:
+            assert torch.equal(got[k], want[k]), (seed, off, k)
+        outs.append(got["R_samples"].clone())
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[4])
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[3])
+    g.check_sampling()
+    with pytest.raises(_capi.HpsError, match="captured for inputs"):
+        g(x[:1])
+    # two replays in flight: issue both, then wait
+    (o1, d1), (o2, d2) = g(x, seed=11, wait=False), g(x.flip(0).contiguous(), seed=12, wait=False)
+    cur = torch.cuda.current_stream()
+    cur.wait_event(d1); cur.wait_event(d2)
+    w1 = infer(net_gpu, smpl_gpu, x, num_samples=7, seed=11)
+    w2 = infer(net_gpu, smpl_gpu, x.flip(0).contiguous(), num_samples=7, seed=12)
+    assert torch.equal(o1["verts_samples"], w1["verts_samples"]) and torch.equal(o2["verts_samples"], w2["verts_samples"])
+
+
 def test_bench_line_has_every_leg(dev):
     """The line the driver records: one short run of bench.py with all of its legs on (headline, lbs_unfused, latency_b1,
     from_rgb), every field the contract names present and consistent."""
@@ -392,6 +458,8 @@ def test_bench_line_has_every_leg(dev):
     assert r["traffic"] is None or r["traffic_imported"] is True
     sec = d["secondary"]
     assert sec["latency_b1"]["median_ms"] > 0 and sec["latency_b1"]["throughput_mode_median_ms"] > 0
+    assert 0 < sec["latency_b1"]["graph_median_ms"] <= 1.2 * sec["latency_b1"]["median_ms"]          # a replay is not slower than issuing the launches
+    assert sec["latency_b1"]["throughput_mode_graph_median_ms"] > 0
     assert sec["from_rgb"]["images_per_s"] > 0 and len(sec["from_rgb"]["legs_images_per_s"]) == 3
     assert sec["from_rgb"]["checksum_images"] == 64 * 8
     # the three legs of the PCIe-inclusive loop must agree: a leg that is still warming is not a measurement

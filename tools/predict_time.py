@@ -2,7 +2,7 @@
 image-dependent front end replaced by stored proxy representations (proxy_rep_fn) and a no-op result_fn: the loop the host layer adds
 around infer().
 
-    python tools/predict_time.py [images] [batch] [samples] [--pageable]
+    python tools/predict_time.py [images] [batch] [samples] [--pageable] [--latency]
 """
 import os
 import sys
@@ -29,6 +29,8 @@ def main():
     cfg = configs.get_cfg_defaults()
     torch.manual_seed(0)
     net = PoseMFShapeGaussianNet(configs.SMPL_PARENTS, cfg).eval().to(dev)
+    if "--latency" in sys.argv:              # the per-model switch for one-image-at-a-time deployments (direct kernels with many K slices)
+        net.set_latency_mode(True)
     smpl = SMPL(smpl_data.synthetic_smpl_model(0)).to(dev)
     g = torch.Generator().manual_seed(1)
     pinned = "--pageable" not in sys.argv
@@ -47,7 +49,8 @@ def main():
         predict_poseMF_shapeGaussian_net(net, cfg, smpl, None, None, None, dev, d, os.path.join(d, "out"), **kw)
         torch.cuda.synchronize()
         dt = time.time() - t0
-    print("predict loop (%s host tensors): %d images, batch %d, %d samples: %.3f s = %.0f images/s (%.2f ms per image)" % ("page-locked" if pinned else "pageable", n, batch, samples, dt, n / dt, 1e3 * dt / n))
+    print("predict loop (%s host tensors%s): %d images, batch %d, %d samples: %.3f s = %.0f images/s (%.3f ms per image)" % (
+        "page-locked" if pinned else "pageable", ", latency mode" if "--latency" in sys.argv else "", n, batch, samples, dt, n / dt, 1e3 * dt / n))
 
 
 if __name__ == "__main__":
