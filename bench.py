@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--head-cus", type=int, default=None,
                     help="exclusive schedule: CUs per XCD reserved for the head's kernels (the mesh kernel runs on the others); 0 = shared CUs")
     ap.add_argument("--gather-joints", action="store_true", help="A/B: the joint regression gathers its vertices from the meshes (round 4) instead of reading the mesh kernel's compact side output")
+    ap.add_argument("--separate-joints", action="store_true", help="A/B: joint regression and uncertainty pass as two launches (round 5) instead of one (hps_joints_and_uncertainty)")
     ap.add_argument("--per-mesh-shape-blend", action="store_true", help="A/B: the K = 217 form of the fused mesh kernel (shape blend inside the GEMM, once per mesh: round 5) instead of the shared-shape form (K = 207, shape blend once per image)")
     ap.add_argument("--unfused-mesh", action="store_true", help="blend GEMM + LBS as two kernels (the unfused definition) instead of the fused mesh kernel")
     ap.add_argument("--trace-steps", action="store_true", help="print host-side per-step times to stderr (debugging)")
@@ -227,6 +228,9 @@ def main():
     smpl.fused_mesh = not args.unfused_mesh
     smpl.picked_joints = not args.gather_joints
     smpl.shared_shape = not args.per_mesh_shape_blend
+    if args.separate_joints:
+        from hierarchicalprobabilistic3dhuman_amd import predict_poseMF_shapeGaussian_net as _pm
+        _pm.FUSE_JOINTS_AND_UNCERTAINTY = False
 
     lo, hi = sharding.shard_range(B * shard_world, shard_rank, shard_world)   # weak scaling: B images per GPU
     # INPUT_SETS different global batches rotate through the steps (step i reads set i % INPUT_SETS: no step re-reads the

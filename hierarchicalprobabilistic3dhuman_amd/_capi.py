@@ -37,6 +37,7 @@ _PROTOTYPES = {
     "hps_smpl_mesh_fused_np": [_I],
     "hps_smpl_joints": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
     "hps_vertex_uncertainty": [_P, _P, _I, _I, _I, _P],
+    "hps_joints_and_uncertainty": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _I, _I, _I, _P],
     "hps_query_workspace": [_I, _c.c_int64, _c.c_int64, _c.c_int64],
     "hps_mf_sample": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _c.c_float, _c.c_float, _P, _P, _P, _c.c_uint64,
                       _c.c_int64, _P, _I, _P, _P, _P, _P],

@@ -391,16 +391,16 @@ __global__ __launch_bounds__(128) void joints_kernel_v1(const float* __restrict_
 // more: it runs beside the next batch's encoder, whose persistent kernels leave a CU almost no LDS or registers (the LDS form
 // averaged 69 us in the loop where this one takes 45).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void joints_kernel(const float* __restrict__ verts, const float* __restrict__ j_posed,
-                                                     const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_col,
-                                                     const float* __restrict__ csr_val, int n_rows, int J,
-                                                     const float* __restrict__ transl, float* __restrict__ joints, int V) {
-    const int m = blockIdx.x;
+// the rows of mesh m, row r = t, t + 128, ... (t < 128: the lane's index in the mesh's group of 128)
+__device__ __forceinline__ void joints_of_mesh(int m, int t, const float* __restrict__ verts, const float* __restrict__ j_posed,
+                                               const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_col,
+                                               const float* __restrict__ csr_val, int n_rows, int J,
+                                               const float* __restrict__ transl, float* __restrict__ joints, int V) {
     const int n_out = J + n_rows;
     float tx = 0.f, ty = 0.f, tz = 0.f;
     if (transl) { tx = transl[m * 3 + 0]; ty = transl[m * 3 + 1]; tz = transl[m * 3 + 2]; }
     const float* vm = verts + (size_t)m * V * 3;  // verts already include transl
-    for (int r = threadIdx.x; r < n_out; r += blockDim.x) {
+    for (int r = t; r < n_out; r += 128) {
         float x, y, z;
         if (r < J) {
             const float* s = j_posed + ((size_t)m * J + r) * 3;
@@ -432,6 +432,13 @@ __global__ __launch_bounds__(128) void joints_kernel(const float* __restrict__ v
         float* d = joints + ((size_t)m * n_out + r) * 3;
         d[0] = x; d[1] = y; d[2] = z;
     }
+}
+
+__global__ __launch_bounds__(128) void joints_kernel(const float* __restrict__ verts, const float* __restrict__ j_posed,
+                                                     const int32_t* __restrict__ csr_ptr, const int32_t* __restrict__ csr_col,
+                                                     const float* __restrict__ csr_val, int n_rows, int J,
+                                                     const float* __restrict__ transl, float* __restrict__ joints, int V) {
+    joints_of_mesh(blockIdx.x, threadIdx.x, verts, j_posed, csr_ptr, csr_col, csr_val, n_rows, J, transl, joints, V);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -554,14 +561,13 @@ __global__ __launch_bounds__(UV * UG) void uncertainty_lds_kernel(const f3* __re
 // order: the panels written last -- the ones still in the memory-side cache -- are read first, and reading them does not push the older,
 // still dirty lines out through HBM.  Measured in the pipelined loop against panels-fastest / images-ascending (hps_dev_unc_mode 7, same
 // kernel): 22.23 k against 22.10-22.16 k images/s, three interleaved pairs (profiles/r06_ab.txt).  The order of the blocks changes no sum.
-template <int SPT, bool FWD = false>
-__global__ __launch_bounds__(512) void uncertainty_reg_kernel(const f3* __restrict__ verts, float* __restrict__ unc,
-                                                              int N, int V) {
+template <int SPT>
+__device__ __forceinline__ void uncertainty_reg_body(const f3* __restrict__ verts, float* __restrict__ unc, int N, int V, int panel,
+                                                     int b) {
     constexpr int RV = 64, H = UG / 2;
     __shared__ float sRed[H * 3 * RV];
     const int v = threadIdx.x & (RV - 1), g = threadIdx.x / RV;
-    const int panel = FWD ? (int)blockIdx.x : (int)(gridDim.y - 1 - blockIdx.y);
-    const int vg = panel * RV + v, b = FWD ? blockIdx.y : blockIdx.x;
+    const int vg = panel * RV + v;
     const bool live = vg < V;
     const f3* base = verts + (size_t)b * N * V + (live ? vg : V - 1);
     // Guard-free: a sample beyond N re-reads sample N - 1 and contributes +0 (x + 0 = x bit for bit; the sums start at +0 and
@@ -608,6 +614,44 @@ __global__ __launch_bounds__(512) void uncertainty_reg_kernel(const f3* __restri
         for (int q = 0; q < H; ++q) t += sRed[q * RV + v];
         unc[(size_t)b * V + vg] = t / N;
     }
+}
+
+template <int SPT, bool FWD = false>
+__global__ __launch_bounds__(512) void uncertainty_reg_kernel(const f3* __restrict__ verts, float* __restrict__ unc,
+                                                              int N, int V) {
+    if (FWD) uncertainty_reg_body<SPT>(verts, unc, N, V, (int)blockIdx.x, (int)blockIdx.y);
+    else uncertainty_reg_body<SPT>(verts, unc, N, V, (int)(gridDim.y - 1 - blockIdx.y), (int)blockIdx.x);
+}
+
+// The joint regression of ALL meshes of a call and the uncertainty pass over its sample meshes in ONE launch (round 6): both read what
+// the mesh kernel has just written and neither depends on the other, but as two launches on one stream they ran one after the other --
+// 18 us of joint regression (6 528 x 128 threads: a fraction of the chip) plus a launch boundary in front of the HBM-bound pass.
+// Grid (B, joint rows + panels): rows y < jrows are the joint regression's, four meshes per 512-thread workgroup (each 128 lanes are
+// one joints_kernel workgroup: the same sums), the rest is uncertainty_reg_kernel's grid.  Identical bits to the two launches.
+struct JointArgs {
+    const float* picked; const float* j_posed; const int32_t* csr_ptr; const int32_t* csr_slot; const float* csr_val;
+    const float* transl; float* joints;
+    int n_rows, J, M, n_picked, jrows;
+};
+template <int SPT>
+__global__ __launch_bounds__(512) void uncertainty_joints_kernel(const f3* __restrict__ verts, float* __restrict__ unc, int N, int V,
+                                                                 const JointArgs ja) {
+    if ((int)blockIdx.y < ja.jrows) {                                  // (workgroup-uniform)
+        const int m = 4 * ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) + (int)(threadIdx.x >> 7);
+        if (m < ja.M)
+            joints_of_mesh(m, threadIdx.x & 127, ja.picked, ja.j_posed, ja.csr_ptr, ja.csr_slot, ja.csr_val, ja.n_rows, ja.J, ja.transl,
+                           ja.joints, ja.n_picked);
+        return;
+    }
+    uncertainty_reg_body<SPT>(verts, unc, N, V, (int)(gridDim.y - 1 - blockIdx.y), (int)blockIdx.x);
+}
+
+template <int SPT>
+static int launch_unc_joints(const float* verts, float* unc, int B, int N, int V, JointArgs ja, hipStream_t s) {
+    ja.jrows = ceil_div(ceil_div(ja.M, 4), B);
+    hipLaunchKernelGGL(uncertainty_joints_kernel<SPT>, dim3(B, ja.jrows + ceil_div(V, 64)), dim3(512), 0, s,
+                       reinterpret_cast<const f3*>(verts), unc, N, V, ja);
+    return check_launch("hps_joints_and_uncertainty");
 }
 
 template <int SPT>
@@ -861,6 +905,29 @@ extern "C" int hps_dev_unc_mode(int mode) {
     return HPS_OK;
 }
 #endif
+
+extern "C" int hps_joints_and_uncertainty(const float* picked, const float* j_posed, const int32_t* csr_ptr, const int32_t* csr_slot,
+                                          const float* csr_val, int n_rows, int num_joints, const float* transl, float* joints, int M,
+                                          int n_picked, const float* verts_samples, float* unc, int B, int N, int V,
+                                          hps_stream_t stream) {
+    if (!picked || !j_posed || !csr_ptr || !csr_slot || !csr_val || !joints || !verts_samples || !unc)
+        return bad_arg("hps_joints_and_uncertainty: null pointer");
+    if (num_joints < 0 || n_rows < 0 || M <= 0 || B <= 0 || V <= 0) return bad_arg("hps_joints_and_uncertainty: sizes");
+    if (N < 8 || N > 16 * UG) {
+        set_error("hps_joints_and_uncertainty: exists for 8 <= num_samples <= %d (call hps_smpl_joints and hps_vertex_uncertainty)", 16 * UG);
+        return HPS_E_UNSUPPORTED;
+    }
+    JointArgs ja;
+    ja.picked = picked; ja.j_posed = j_posed; ja.csr_ptr = csr_ptr; ja.csr_slot = csr_slot; ja.csr_val = csr_val; ja.transl = transl;
+    ja.joints = joints; ja.n_rows = n_rows; ja.J = num_joints; ja.M = M; ja.n_picked = n_picked; ja.jrows = 0;
+    const int spt = ceil_div(N, UG);
+    hipStream_t st = (hipStream_t)stream;
+    if (spt <= 2) return launch_unc_joints<2>(verts_samples, unc, B, N, V, ja, st);
+    if (spt <= 4) return launch_unc_joints<4>(verts_samples, unc, B, N, V, ja, st);
+    if (spt <= 8) return launch_unc_joints<8>(verts_samples, unc, B, N, V, ja, st);
+    if (spt <= 13) return launch_unc_joints<13>(verts_samples, unc, B, N, V, ja, st);
+    return launch_unc_joints<16>(verts_samples, unc, B, N, V, ja, st);
+}
 
 extern "C" int hps_vertex_uncertainty(const float* verts, float* unc, int B, int N, int V, hps_stream_t stream) {
     if (!verts || !unc) return bad_arg("hps_vertex_uncertainty: null pointer");

@@ -20,6 +20,7 @@ from .label_conversions import make_proxy_representation
 from .resnet import FilledStemFrames
 
 
+FUSE_JOINTS_AND_UNCERTAINTY = True     # False: hps_smpl_joints and hps_vertex_uncertainty as two launches (the cross-check of the tests; same bits)
 _SHARED_SHAPE_TABLES = weakref.WeakKeyDictionary()      # smpl model -> ((B, N, device), mesh_row, group_rows) of the last infer() layout
 
 
@@ -85,12 +86,22 @@ def infer(pose_shape_model, smpl_model, proxy_rep_input, num_samples=50, use_mea
             tables = (key,) + smpl_model.shared_shape_tables(rows)
             _SHARED_SHAPE_TABLES[smpl_model] = tables
         shared = (loc, tables[1], tables[2])
+    # the joint regression of the call's meshes and the uncertainty pass read what the mesh kernel has just written and do not depend
+    # on each other: one launch (hps_joints_and_uncertainty) when the sample count takes the register-resident pass
+    deferred = {}
     out = smpl_model(body_pose=body, global_orient=glob_all, betas=betas_all, pose2rot=False,
-                     _before_mesh=_before_meshes, _after_mesh=_after_smpl, _shared_shapes=shared)
+                     _before_mesh=_before_meshes, _after_mesh=_after_smpl, _shared_shapes=shared,
+                     _defer_joints=deferred.update if (FUSE_JOINTS_AND_UNCERTAINTY and 8 <= N <= 128) else None)
     V = out.vertices.shape[1]
     verts_s = out.vertices[2 * B:].view(B, N, V, 3)
     joints_s = out.joints[2 * B:].view(B, N, -1, 3)
-    vertex_uncertainty(verts_s, out=unc)                                          # sampling_utils.py:189-190
+    if deferred:
+        d = deferred
+        _capi.call("hps_joints_and_uncertainty", P(d["picked"]), P(d["j_posed"]), _capi.iptr(d["csr_ptr"]), _capi.iptr(d["csr_slot"]),
+                   P(d["csr_val"]), d["n_rows"], d["J"], P(d["transl"]) if d["transl"] is not None else None, P(d["joints"]), d["M"],
+                   d["n_picked"], P(verts_s), P(unc), B, N, V, _capi.stream())
+    else:
+        vertex_uncertainty(verts_s, out=unc)                                      # sampling_utils.py:189-190
     if _after_unc is not None:
         _after_unc()
     return dict(pose_F=pose_F, pose_U=pose_U, pose_S=pose_S, pose_V=pose_V, pose_rotmats_mode=mode,

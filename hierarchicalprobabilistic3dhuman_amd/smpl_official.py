@@ -285,7 +285,12 @@ class SMPL(nn.Module):
             # on it instead of recording one of its own: an event record costs the queue ~8 us)
             kwargs["_after_mesh"](ev[1] if ev is not None else None)
             s = _capi.stream()                   # (the hook may have switched back to the caller's stream)
-        if picked is not None:      # the regressor vertices lie side by side: same rows, same values, same sums
+        if picked is not None and kwargs.get("_defer_joints") is not None:
+            # infer(): the joint regression rides in the launch of the uncertainty pass (hps_joints_and_uncertainty); the caller gets the
+            # launch's joint arguments and fills ``joints`` itself
+            kwargs["_defer_joints"](dict(picked=picked, j_posed=j_posed, csr_ptr=self._csr_ptr, csr_slot=self._csr_slot, csr_val=self._csr_val,
+                                         n_rows=self._n_joint_rows, J=J, transl=tr, joints=joints, M=M, n_picked=self._n_picked))
+        elif picked is not None:      # the regressor vertices lie side by side: same rows, same values, same sums
             _capi.call("hps_smpl_joints", P(picked), P(j_posed), _capi.iptr(self._csr_ptr), _capi.iptr(self._csr_slot),
                        P(self._csr_val), self._n_joint_rows, J, P(tr) if tr is not None else None, P(joints), M, self._n_picked, s)
         else:

@@ -197,6 +197,14 @@ int hps_smpl_v_shaped(const float* betas, int num_betas, const float* shape_rows
 /* Column count of bmat_p for a model with V vertices (192 per started panel of 64 vertices). */
 int hps_smpl_mesh_fused_np(int V);
 
+/* hps_smpl_joints on the compact side output of hps_smpl_mesh_fused_picks / _shared_shape (picked (M, n_picked, 3), csr_slot = the
+ * entries' slots) AND hps_vertex_uncertainty on the call's sample meshes (verts_samples (B, N, V, 3), 8 <= N <= 128) in ONE launch:
+ * the two read what the mesh kernel has just written and do not depend on each other (predict/...:112-165: the joints of every mesh,
+ * utils/sampling_utils.py:189-190: the per-vertex uncertainty).  Identical bits to the two calls; HPS_E_UNSUPPORTED for other N. */
+int hps_joints_and_uncertainty(const float* picked, const float* j_posed, const int32_t* csr_ptr, const int32_t* csr_slot,
+                               const float* csr_val, int n_rows, int num_joints, const float* transl, float* joints, int M,
+                               int n_picked, const float* verts_samples, float* unc, int B, int N, int V, hps_stream_t stream);
+
 /* Joints: out[m, 0:J] = j_posed[m] ; out[m, J + r] = sum_e csr_val[e] * verts[m, csr_col[e]]
  * for CSR rows r = 0..n_rows-1 (the 21 smplx vertex picks as 1-entry rows, then the extra / cocoplus /
  * h36m regressors of models/smpl_official.py:30-34), each row summed as one chain of fused multiply-adds in entry order.
