@@ -203,7 +203,27 @@ def cu_partition_stream(first_cu, num_cus):
     The stream lives as long as the process (a handful are ever created: one pair per InferencePipeline)."""
     s = _P()
     call("hps_stream_create_cu_partition", int(first_cu), int(num_cus), _c.byref(s))
+    if not _partition_streams:
+        import atexit
+        atexit.register(_destroy_partition_streams)
+    _partition_streams.append(s.value)
     return torch.cuda.ExternalStream(s.value)
+
+
+_partition_streams = []
+
+
+def _destroy_partition_streams():
+    """At interpreter exit: drain and destroy the CU-partition streams this process created (a tool that hooks the runtime's teardown --
+    rocprofv3 -- otherwise finds live streams it never saw created by hipStreamCreate and crashes in its own finaliser)."""
+    try:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        lib = load()
+        while _partition_streams:
+            lib.hps_stream_destroy(_P(_partition_streams.pop()))
+    except Exception:
+        pass
 
 
 _svd_flavor = None

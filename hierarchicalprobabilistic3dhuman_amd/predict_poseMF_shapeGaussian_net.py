@@ -554,7 +554,10 @@ class GraphedInfer:
             done.record(st)
         if not wait:
             return s["out"], done
-        caller.wait_event(done)
+        # the HOST waits (the call's contract is "one image, results ready on return").  Making the caller's STREAM wait for the event
+        # instead -- a barrier packet that polls for the whole replay -- was measured to slow the replay's own kernels down by up to 2x
+        # once a high-priority queue exists in the process (tests/dev/graph_time.py --pipeline --bisect: 1.08 -> 1.94 ms)
+        done.synchronize()
         return s["out"]
 
     def check_sampling(self):
@@ -689,13 +692,12 @@ def predict_poseMF_shapeGaussian_net(pose_shape_model, pose_shape_cfg, smpl_mode
             cached = (key, GraphedInfer(weakref.proxy(pose_shape_model), smpl_model, batch_size, num_samples, use_mean_shape=True, slots=2), None)
             _PREDICT_PIPELINES[pose_shape_model] = cached
         graphed = cached[1]
-        caller = torch.cuda.current_stream()
         pending = None
 
         def finish_pending(p):
             names_p, res_p, done = p
             if done is not None:
-                caller.wait_event(done)
+                done.synchronize()                       # host wait (a stream-side wait polls beside the next replay: see GraphedInfer.__call__)
                 # a replay's outputs are the slot's static buffers, overwritten two calls later: result_fn gets tensors of its own
                 # (the reference hands each image's results on before the next image, and a callback may keep them)
                 res_p = {key: (val.clone() if torch.is_tensor(val) else val) for key, val in res_p.items()}

@@ -453,8 +453,7 @@ def test_graphed_infer_equals_infer_and_draws_new_samples_on_every_replay(dev, n
         g(x[:1])
     # two replays in flight: issue both, then wait
     (o1, d1), (o2, d2) = g(x, seed=11, wait=False), g(x.flip(0).contiguous(), seed=12, wait=False)
-    cur = torch.cuda.current_stream()
-    cur.wait_event(d1); cur.wait_event(d2)
+    d1.synchronize(); d2.synchronize()
     w1 = infer(net_gpu, smpl_gpu, x, num_samples=7, seed=11)
     w2 = infer(net_gpu, smpl_gpu, x.flip(0).contiguous(), num_samples=7, seed=12)
     assert torch.equal(o1["verts_samples"], w1["verts_samples"]) and torch.equal(o2["verts_samples"], w2["verts_samples"])

@@ -19,7 +19,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "$MESH" --output-format csv -d $OUT -o mesh_$c -- python $R/bench.py --steps 3 --warmup 1 --cpu-images 0 --from-rgb-steps 0 --latency-reps 0 --stress-steps 0 --lbs-unfused-reps 0 > $OUT/pmc_$c.log 2>&1
   echo "pmc $c exit $?"
 done
-for k in uncertainty_reg_kernel mf_sample_kernel; do
+for k in uncertainty_joints_kernel mf_sample_kernel; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "$k" --output-format csv -d $OUT -o ${k}_$c -- python $R/bench.py --steps 3 --warmup 1 --cpu-images 0 --from-rgb-steps 0 --latency-reps 0 --stress-steps 0 --lbs-unfused-reps 0 --no-pipeline > $OUT/pmc_${k}_$c.log 2>&1
     echo "pmc $k $c exit $?"
@@ -50,6 +50,6 @@ timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT -o lat -- pytho
 python $R/tools/latency_b1.py analyse $(find $OUT -name "lat_kernel_trace.csv" | head -1) > $OUT/latency_b1_timeline.txt 2>&1
 # the widened rows and the predict loop
 timeout 200 python $R/tools/next_rows_time.py > $OUT/next_rows.txt 2>&1
-for a in "4096 64 50" "2048 16 50" "1024 1 50" "2048 64 50 --pageable"; do timeout 200 python $R/tools/predict_time.py $a 2>&1 | tail -1 >> $OUT/predict_time.txt; done
+for a in "4096 64 50" "2048 16 50" "1024 1 50" "1024 1 50 --latency" "1024 2 50 --latency" "2048 64 50 --pageable"; do timeout 200 python $R/tools/predict_time.py $a 2>&1 | tail -1 >> $OUT/predict_time.txt; done
 # SQ / LDS counters of the fused mesh kernel
 bash $R/tools/mesh_pmc_lds.sh > $OUT/mesh_pmc_lds.txt 2>&1

@@ -88,9 +88,12 @@ if os.path.exists(stats_p):
     model = [   # (substring, what, bound, algorithmic quantity per launch, unit)
         ("stem_wino_kernel", "stem 7x7/2 in Winograd form + the 3x3/2 max pool in its epilogue (direct-convolution FLOPs; the MFMA pipe does 81/196 of them)", "mfma", stem_flop, "flop"),
         ("conv_", "the other 19 ResNet-18 convolutions, direct + Winograd F(2x2,3x3) (all launches of a step together; direct-convolution FLOPs)", "mfma", enc_flop - stem_flop, "flop/step"),
-        ("mesh_fused_kernel", "blend GEMM + LBS, fused", "mfma", 2.0 * 217 * 3 * V * M, "flop"),
+        ("mesh_fused_kernel", "blend GEMM + LBS, fused (FLOPs by SURVEY 8(d)'s K = 217 per mesh; the shared-shape form multiplies 207 rows per mesh)", "mfma", 2.0 * 217 * 3 * V * M, "flop"),
+        ("uncertainty_joints_kernel", "per-vertex sample uncertainty + the joint regression of every mesh, one launch (bytes: sample vertices read once + uncertainties + the compact regressor vertices + joints)", "hbm",
+         (B * N * V * 12.0 + B * V * 4.0) + M * (198 * 12.0 + 90 * 12.0 + 24 * 12.0), "bytes"),
         ("uncertainty_reg_kernel", "per-vertex sample uncertainty", "hbm", (B * N * V * 12.0 + B * V * 4.0), "bytes"),
-        ("joints_kernel", "90 joints per mesh (CSR rows on the vertices)", "hbm", M * (276 * 12.0 + 90 * 12.0), "bytes (gathered)"),
+        ("::joints_kernel", "90 joints per mesh (CSR rows on the compact regressor vertices)", "hbm", M * (198 * 12.0 + 90 * 12.0 + 24 * 12.0), "bytes"),
+        ("v_shaped_kernel", "shape blend once per image (smplx lbs step 1 for the shared-shape mesh kernel)", "hbm", B * 3.0 * V * 4 * 2 + 10.0 * 3 * V * 4, "bytes"),
         ("pose_prep_kernel", "Rodrigues / FK / blend operand", "hbm", M * (24 * 9 * 4.0 + 224 * 4.0 + 24 * 12 * 4.0 + 24 * 3 * 4.0 + 40.0), "bytes"),
         ("nchw_to_padded_nhwc", "input relayout", "hbm", 2.0 * B * 18 * 256 * 256 * 4, "bytes"),
         ("stem_phase_split_kernel", "input -> four phase frames per image", "hbm", 2.0 * B * 18 * 256 * 256 * 4, "bytes"),
@@ -141,5 +144,7 @@ if os.path.exists(stats_p):
 # ---- round-4 additions: the driver-flag bench line, batch-1 latency (+ kernel timeline), widened rows, predict loop, mesh-kernel SQ / LDS counters
 for a, b in (("bench_driver_flags.json", "_bench_driver_flags.json"), ("latency_b1.txt", "_latency_b1.txt"),
              ("latency_b1_timeline.txt", "_latency_b1_timeline.txt"), ("next_rows.txt", "_next_rows.txt"),
-             ("predict_time.txt", "_predict_time.txt"), ("mesh_pmc_lds.txt", "_mesh_pmc_lds.txt")):
+             ("predict_time.txt", "_predict_time.txt"), ("mesh_pmc_lds.txt", "_mesh_pmc_lds.txt"), ("ab.txt", "_ab.txt"),
+             ("step_launches.txt", "_step_launches.txt"), ("step_timeline.txt", "_step_timeline.txt"),
+             ("next_rows_stats.log", "_next_rows_kernels.txt"), ("bench_nographlat.json", "_bench_nographlat.json")):
     copy(a, tag + b)
