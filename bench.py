@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--head-cus", type=int, default=None,
                     help="exclusive schedule: CUs per XCD reserved for the head's kernels (the mesh kernel runs on the others); 0 = shared CUs")
     ap.add_argument("--gather-joints", action="store_true", help="A/B: the joint regression gathers its vertices from the meshes (round 4) instead of reading the mesh kernel's compact side output")
+    ap.add_argument("--head-high-priority", action="store_true", help="A/B: the head's stream at high priority (rounds 3-5) instead of normal priority")
     ap.add_argument("--separate-joints", action="store_true", help="A/B: joint regression and uncertainty pass as two launches (round 5) instead of one (hps_joints_and_uncertainty)")
     ap.add_argument("--per-mesh-shape-blend", action="store_true", help="A/B: the K = 217 form of the fused mesh kernel (shape blend inside the GEMM, once per mesh: round 5) instead of the shared-shape form (K = 207, shape blend once per image)")
     ap.add_argument("--unfused-mesh", action="store_true", help="blend GEMM + LBS as two kernels (the unfused definition) instead of the fused mesh kernel")
@@ -255,6 +256,8 @@ def main():
     net.image_encoder.fused_pool = not args.unfused_pool
     net.image_encoder.fold_downsample = not args.separate_downsample
     pipe.inline_side = not args.side_on_caller_stream
+    if args.head_high_priority:
+        pipe.head_stream = torch.cuda.Stream(priority=-1)
     if args.stem_route != "default":
         net.image_encoder.stem_reads_nchw = args.stem_route == "nchw"
 

@@ -152,7 +152,8 @@ __device__ __forceinline__ f32x16 sw_mfma(float a, float b, f32x16 c) {
 // keeps 17).  NXP: positions of the row, NE: window rows in its vertical combination.
 // AB: profiling ablations (dev library only; the product instantiates AB = 0): 1 = patch pixels not read (constants), 2 = no MFMAs,
 // 3 = no output transform, 4 = no barriers (races), 5 = no filter fragment reads, 6 = no stores
-template <int NXP, int NE, int AB>
+// G0, G1 (profiling, AB = 12 / 13): only the channel groups [G0, G1) are transformed, the other operands stay constants
+template <int NXP, int NE, int AB, int G0 = 0, int G1 = 5>
 __device__ __forceinline__ void sw_transform(const float* rawp, const float* raws, const StemRow& row, bool odd, float (&A)[5][9]) {
     const int o[4] = {row.aoff[0], row.aoff[1], row.aoff[2], row.aoff[3]};
     const float k[4] = {row.coef[0], row.coef[1], row.coef[2], row.coef[3]};
@@ -171,10 +172,16 @@ __device__ __forceinline__ void sw_transform(const float* rawp, const float* raw
                     ld[g & 1][b][e] = AB == 1 ? (v2f){(float)(unsigned)(size_t)p, 1.0f} : sw_ld2(p);
             }
     };
-    issue(0);
+    if (G0 > 0 || G1 < 5) {
 #pragma unroll
-    for (int g = 0; g < 5; ++g) {
-        if (g + 1 < 5) issue(g + 1);
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int m = 0; m < 9; ++m) A[j][m] = (float)(j + m);
+    }
+    issue(G0);
+#pragma unroll
+    for (int g = G0; g < G1; ++g) {
+        if (g + 1 < G1) issue(g + 1);
         v2f c[5];
 #pragma unroll
         for (int b = 0; b < NXP; ++b) {
@@ -441,6 +448,40 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
             const float* raws = raw_team + (phase & 1) * SW_RAW_F + patch0 + 16;
             const bool odd = kl != 0;
             float A[5][9];
+            // Profiling (dev library; results are garbage): what removing the DUPLICATE input transform could buy at most.  The waves of a
+            // channel-half pair (wn = 0 / 1) transform the same tiles.  AB = 10: the wn = 1 waves skip the transform outright (operands =
+            // constants) -- the upper bound, a hand-over that costs nothing.  AB = 11: they read their 45 operands from LDS instead (the
+            // team's window buffer as a stand-in for an exchange buffer: 45 four-byte reads per lane) behind one more barrier per row --
+            // the cheapest hand-over there could be (the wn = 0 waves' 45 stores are NOT charged).
+            // AB = 12 / 13: the SPLIT form -- each wave of the pair transforms about half of the channels (wn = 0: channel pairs 0-3 of
+            // the even / odd parity = groups 0, 1; wn = 1: groups 2, 3 and the singles) and would get the other half from its partner.
+            // 12: no exchange at all (the upper bound of the split); 13: + 23 LDS stores, 23 LDS reads per lane and row and a second barrier
+            // (stand-ins in the team's window buffer: the cheapest exchange there could be, its 2 x 23 KB of LDS not even found yet).
+            if (AB == 12 || AB == 13) {
+                if (row.nxp == 5) {
+                    if (wn == 0) { if (row.ne == 4) sw_transform<5, 4, AB, 0, 2>(rawp, raws, row, odd, A); else if (row.ne == 3) sw_transform<5, 3, AB, 0, 2>(rawp, raws, row, odd, A); else sw_transform<5, 2, AB, 0, 2>(rawp, raws, row, odd, A); }
+                    else { if (row.ne == 4) sw_transform<5, 4, AB, 2, 5>(rawp, raws, row, odd, A); else if (row.ne == 3) sw_transform<5, 3, AB, 2, 5>(rawp, raws, row, odd, A); else sw_transform<5, 2, AB, 2, 5>(rawp, raws, row, odd, A); }
+                } else {
+                    if (wn == 0) { if (row.ne == 4) sw_transform<4, 4, AB, 0, 2>(rawp, raws, row, odd, A); else if (row.ne == 3) sw_transform<4, 3, AB, 0, 2>(rawp, raws, row, odd, A); else sw_transform<4, 2, AB, 0, 2>(rawp, raws, row, odd, A); }
+                    else { if (row.ne == 4) sw_transform<4, 4, AB, 2, 5>(rawp, raws, row, odd, A); else if (row.ne == 3) sw_transform<4, 3, AB, 2, 5>(rawp, raws, row, odd, A); else sw_transform<4, 2, AB, 2, 5>(rawp, raws, row, odd, A); }
+                }
+                if (AB == 13) {
+                    float* xq = const_cast<float*>(raw_team) + (phase & 1) * SW_RAW_F + (w4 * 23) * 64 + lane;
+                    if (wn) {
+#pragma unroll
+                        for (int e = 0; e < 23; ++e) xq[e * 64] = A[e / 9 + 2][e % 9];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 23; ++e) xq[e * 64] = A[e / 9][e % 9];
+                    }
+                }
+            } else
+            if ((AB == 10 || AB == 11) && wn == 1) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+#pragma unroll
+                    for (int m = 0; m < 9; ++m) A[j][m] = AB == 10 ? (float)(j + m) : raw_team[(phase & 1) * SW_RAW_F + (j * 9 + m) * 64 + lane];
+            } else
             if (row.nxp == 5) {
                 if (row.ne == 4) sw_transform<5, 4, AB>(rawp, raws, row, odd, A);
                 else if (row.ne == 3) sw_transform<5, 3, AB>(rawp, raws, row, odd, A);
@@ -455,6 +496,18 @@ __global__ __launch_bounds__(512) void stem_wino_kernel(const float* __restrict_
             if (NCHW && n_idx < 4 && (phase < 3 || has_next)) nchw_store(phase + 1, n_idx);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of row r's filters (and of the next phase window)
             if (AB != 4) __syncthreads();                        // ... everyone's; the other filter buffer and window buffer are free
+            if (AB == 11) __syncthreads();                       // (profiling: the hand-over's second barrier)
+            if (AB == 13) {                                      // (profiling: the exchange's second half -- read the partner's 23 operands, one more barrier)
+                const float* xq = raw_team + (phase & 1) * SW_RAW_F + ((w4 ^ 1) * 23) * 64 + lane;
+                if (wn) {
+#pragma unroll
+                    for (int e = 0; e < 23; ++e) A[e / 9][e % 9] = xq[e * 64];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 23; ++e) A[e / 9 + 2][e % 9] = xq[e * 64];
+                }
+                __syncthreads();
+            }
             // The DMAs of the next row's filters (and, in the first row of a phase, of the next phase's window) are issued INSIDE the
             // MFMA run, two pieces behind each position's MFMAs: in front of the run their issue (about 50 cycles a piece, up to ten
             // pieces) held the whole SIMD back while the MFMA pipe was idle.
@@ -812,9 +865,33 @@ static int stem_wino_launch(const float* frames, const float* u, const float* sc
                            frames, u, scale, shift, y, (float*)nullptr, g);
     };
     if (pool) {
-        if (ablate != 0 && !(nchw && (ablate == 8 || ablate == 9))) return bad_arg("hps_stem_winograd_pooled: no ablations");
+        if (ablate != 0 && !(nchw && ablate >= 8 && ablate <= 13)) return bad_arg("hps_stem_winograd_pooled: no ablations");
         if (nchw) {
 #ifdef HPS_DEV_BUILD
+            if (ablate == 12 || ablate == 13) {              // profiling: the input transform SPLIT between the waves of a channel-half pair
+                if (ablate == 12) {
+                    if ((rc = grant_lds<&stem_wino_kernel<12, true, true>>((int)lds, "hps_dev_stem_winograd_pooled_nchw")) != HPS_OK) return rc;
+                    hipLaunchKernelGGL((stem_wino_kernel<12, true, true>), dim3((unsigned)(pairs < 256 ? pairs : 256)), dim3(512), lds, (hipStream_t)stream,
+                                       frames, u, scale, shift, y, side, g);
+                } else {
+                    if ((rc = grant_lds<&stem_wino_kernel<13, true, true>>((int)lds, "hps_dev_stem_winograd_pooled_nchw")) != HPS_OK) return rc;
+                    hipLaunchKernelGGL((stem_wino_kernel<13, true, true>), dim3((unsigned)(pairs < 256 ? pairs : 256)), dim3(512), lds, (hipStream_t)stream,
+                                       frames, u, scale, shift, y, side, g);
+                }
+                return check_launch("hps_dev_stem_winograd_pooled_nchw");
+            }
+            if (ablate == 10 || ablate == 11) {              // profiling: the duplicate input transform removed (see the kernel)
+                if (ablate == 10) {
+                    if ((rc = grant_lds<&stem_wino_kernel<10, true, true>>((int)lds, "hps_dev_stem_winograd_pooled_nchw")) != HPS_OK) return rc;
+                    hipLaunchKernelGGL((stem_wino_kernel<10, true, true>), dim3((unsigned)(pairs < 256 ? pairs : 256)), dim3(512), lds, (hipStream_t)stream,
+                                       frames, u, scale, shift, y, side, g);
+                } else {
+                    if ((rc = grant_lds<&stem_wino_kernel<11, true, true>>((int)lds, "hps_dev_stem_winograd_pooled_nchw")) != HPS_OK) return rc;
+                    hipLaunchKernelGGL((stem_wino_kernel<11, true, true>), dim3((unsigned)(pairs < 256 ? pairs : 256)), dim3(512), lds, (hipStream_t)stream,
+                                       frames, u, scale, shift, y, side, g);
+                }
+                return check_launch("hps_dev_stem_winograd_pooled_nchw");
+            }
             if (ablate == 8 || ablate == 9) {                // profiling: the gather without its loads / without its LDS stores (results are garbage)
                 if (ablate == 8) {
                     if ((rc = grant_lds<&stem_wino_kernel<8, true, true>>((int)lds, "hps_dev_stem_winograd_pooled_nchw")) != HPS_OK) return rc;

@@ -172,10 +172,13 @@ class InferencePipeline:
     def __init__(self, pose_shape_model, smpl_model, num_samples=50, use_mean_shape=True, sample_on_cpu=False):
         self.net, self.smpl = pose_shape_model, smpl_model
         self.num_samples, self.use_mean_shape, self.sample_on_cpu = num_samples, use_mean_shape, sample_on_cpu
-        # The head is a chain of small dependent kernels; next to kernels that keep every CU's LDS / registers full each of
-        # them would otherwise queue behind the pending workgroups.  A high-priority stream lets its few (small: 256 threads,
-        # 18 KiB) workgroups take the next free slots.
-        self.head_stream = torch.cuda.Stream(priority=-1)
+        # The head is a chain of small dependent kernels on a stream of its own: it depends on its batch's encoder only, not on what is
+        # queued on the caller's stream.  (Rounds 3-5 made this a HIGH-priority stream so that its workgroups would take the next free
+        # slots beside kernels that fill every CU.  With the side kernels in stream order behind the mesh kernel it no longer changes
+        # the rate at any batch size -- 22.48-22.56 k against 22.53-22.58 k images/s at B = 64, equal at B = 8 / 16 and N = 50 / 100 /
+        # 1000, profiles/r06_ab.txt -- and a high-priority queue in the process has a side effect on every OTHER queue: a stream-side
+        # wait that polls beside a chain of small kernels doubled that chain's time, tests/dev/graph_time.py.  Normal priority.)
+        self.head_stream = torch.cuda.Stream()
         self.enc_stream = None        # created by the first submit (its kind depends on the batch size)
         self.mesh_stream = None
         self._smpl_done = None

@@ -27,6 +27,10 @@ with _capi.dev_library():
         "NCHW-fed stem + pool": lambda: _capi.call("hps_dev_stem_winograd_pooled_nchw", P(x), P(cb.stem_u), P(cb.scale), P(cb.shift), P(y), P(side), B, H, W, 1, 1, 0, s),
         "  without the gather's loads": lambda: _capi.call("hps_dev_stem_winograd_pooled_nchw", P(x), P(cb.stem_u), P(cb.scale), P(cb.shift), P(y), P(side), B, H, W, 1, 1, 8, s),
         "  without its LDS stores": lambda: _capi.call("hps_dev_stem_winograd_pooled_nchw", P(x), P(cb.stem_u), P(cb.scale), P(cb.shift), P(y), P(side), B, H, W, 1, 1, 9, s),
+        "  duplicate input transform skipped (upper bound of removing it)": lambda: _capi.call("hps_dev_stem_winograd_pooled_nchw", P(x), P(cb.stem_u), P(cb.scale), P(cb.shift), P(y), P(side), B, H, W, 1, 1, 10, s),
+        "  transform SPLIT between the pair's waves, no exchange (upper bound)": lambda: _capi.call("hps_dev_stem_winograd_pooled_nchw", P(x), P(cb.stem_u), P(cb.scale), P(cb.shift), P(y), P(side), B, H, W, 1, 1, 12, s),
+        "  ... + 23 LDS stores, 23 reads per lane and row and a second barrier": lambda: _capi.call("hps_dev_stem_winograd_pooled_nchw", P(x), P(cb.stem_u), P(cb.scale), P(cb.shift), P(y), P(side), B, H, W, 1, 1, 13, s),
+        "  ... replaced by 45 LDS reads per lane and row + a second barrier": lambda: _capi.call("hps_dev_stem_winograd_pooled_nchw", P(x), P(cb.stem_u), P(cb.scale), P(cb.shift), P(y), P(side), B, H, W, 1, 1, 11, s),
     }
     for f in fns.values():
         f()
@@ -42,4 +46,4 @@ with _capi.dev_library():
             ts[k].append(e0.elapsed_time(e1) / 10)
     for k in fns:
         t = sorted(ts[k])
-        print("%-32s median %.4f ms (min %.4f max %.4f)" % (k, t[len(t) // 2], t[0], t[-1]))
+        print("%-70s median %.4f ms (min %.4f max %.4f)" % (k, t[len(t) // 2], t[0], t[-1]))
