@@ -99,6 +99,53 @@ def cpu_baseline(net_state, parents, num_samples, n_images):
                               "sample": "%d images, num_samples=%d (%.2f s)" % (n1, num_samples, dt1)}}
 
 
+def live_traffic(kernel_regex, n_steps=3):
+    """HBM-side bytes per launch of the mesh kernel, MEASURED IN THIS RUN: two short rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do
+    not fit one pass) over a three-step sub-run of this very script, on this GPU, after the timed region; corrected as
+    MI355X_MICROARCH.md prescribes for gfx950 (values in KB; fabric reads = 2 x FETCH_SIZE).  None when rocprofv3 is not on the PATH or a
+    pass fails (the caller then falls back to the committed summary and says so)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    out = tempfile.mkdtemp(prefix="hps_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    kb = {}
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = ["rocprofv3", "--pmc", c, "--kernel-trace", "--kernel-include-regex", kernel_regex, "--output-format", "csv", "-d", out,
+                   "-o", "pass_" + c, "--", sys.executable, os.path.abspath(__file__), "--steps", str(n_steps), "--warmup", "1",
+                   "--cpu-images", "0", "--from-rgb-steps", "0", "--latency-reps", "0", "--stress-steps", "0", "--lbs-unfused-reps", "0",
+                   "--live-traffic", "off"]
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180)
+            path = None
+            for root_, _, files in os.walk(out):
+                for f in files:
+                    if f.endswith("pass_%s_counter_collection.csv" % c):
+                        path = os.path.join(root_, f)
+            if path is None:
+                return None
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if r["Counter_Name"] == c]
+            vals = vals[1:] if len(vals) > 1 else vals            # the first launch of the sub-run is its warm-up step
+            if not vals:
+                return None
+            kb[c] = (sum(vals) / len(vals), len(vals))
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError):
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    return {"hbm_bytes_per_launch": (2.0 * kb["FETCH_SIZE"][0] + kb["WRITE_SIZE"][0]) * 1024.0,
+            "FETCH_SIZE_KB_per_launch": kb["FETCH_SIZE"][0], "WRITE_SIZE_KB_per_launch": kb["WRITE_SIZE"][0],
+            "launches": min(kb["FETCH_SIZE"][1], kb["WRITE_SIZE"][1]),
+            "method": "rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE} --kernel-trace --kernel-include-regex %s, two passes of a %d-step sub-run of "
+                      "bench.py on this GPU after the timed region; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB (the gfx950 correction of "
+                      "MI355X_MICROARCH.md)" % (kernel_regex, n_steps)}
+
+
 def workload_name(B, N, world):
     """Which BASELINE.json configuration the arguments select (the label is derived, never hard-coded)."""
     if B == 64 and N == 100:
@@ -202,6 +249,9 @@ def main():
     ap.add_argument("--stress-steps", type=int, default=8,
                     help="after the timed region (one GPU only): pipelined steps of BASELINE configs[4] (batch 16, num_samples 1000) "
                          "for secondary.stress_n1000 (0 = skip)")
+    ap.add_argument("--live-traffic", choices=("auto", "off"), default="auto",
+                    help="auto (one GPU only): measure roofline.traffic in this run with two rocprofv3 --pmc passes over a three-step sub-run "
+                         "(~15 s); off / unavailable: read it from the committed PMC summary under profiles/ and flag it traffic_imported")
     ap.add_argument("--lbs-unfused-reps", type=int, default=12,
                     help="after the timed region: launches of the unfused blend + LBS pair timed for secondary.lbs_unfused (0 = skip)")
     args = ap.parse_args()
@@ -589,15 +639,22 @@ def main():
     k_required = 207 if shared_shape else 217            # K rows the launch has to multiply per mesh (the shared shape blend: once per IMAGE)
     # HBM traffic of the same kernel from the PMC counters: collected in separate rocprofv3 passes of this very
     # command (tools/collect_profiles.sh), corrected as MI355X_MICROARCH.md prescribes, committed under profiles/
-    traffic = None
+    traffic, traffic_imported, traffic_detail = None, None, None
     pmc_name = "mesh_fused_pmc_latest.json" if fused else "lbs_pmc_latest.json"
     pmc_path = os.path.join(ROOT, "profiles", pmc_name)
     traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % pmc_name
-    if os.path.exists(pmc_path):
+    if args.live_traffic == "auto" and world == 1 and rank == 0 and args.as_rank is None and (B, N) == (64, 100) and not args.no_pipeline:
+        torch.cuda.synchronize()
+        traffic_detail = live_traffic("mesh_fused_kernel" if fused else "lbs_kernel")
+        if traffic_detail is not None:
+            traffic, traffic_imported = traffic_detail["hbm_bytes_per_launch"], False
+            traffic_source = traffic_detail["method"]
+    if traffic is None and os.path.exists(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)
         if pmc.get("meshes_per_launch", M) == M:
             traffic = pmc.get("hbm_bytes_per_launch")
+            traffic_imported = True
 
     if args.trace_steps and rank == 0 and pipe.trace and enc_ms:
         # device-side schedule of a few steady-state batches from HIP events (no profiler): batch j's encoder was the j-th
@@ -640,8 +697,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": mesh_kernel, "fused": fused,
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "traffic_imported": True if traffic else None,      # NOT measured in this run: read from the committed PMC summary
+                         "traffic_imported": traffic_imported,      # False: measured in this run (live_traffic); True: read from the committed PMC summary
                          "traffic_source": traffic_source if traffic else None,
+                         "traffic_detail": traffic_detail,
                          "avg_launch_ms": lbs_avg_ms, "launches": len(lbs_ms), "launch_spread": spread(lbs_ms),
                          "algorithmic_bytes_per_launch": LBS_BYTES_PER_MESH * M,
                          "note": ("fused kernel: the launch time covers blend GEMM + skinning; the bytes are SURVEY 8(d)'s "

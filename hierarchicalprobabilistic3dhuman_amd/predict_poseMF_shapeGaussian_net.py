@@ -487,8 +487,12 @@ class GraphedInfer:
     seed-reproducible host-noise route draws on the host per call and cannot be captured)."""
 
     def __init__(self, pose_shape_model, smpl_model, batch, num_samples=50, use_mean_shape=True, slots=2, input_shape=(18, 256, 256)):
+        if not use_mean_shape:
+            # (sampled shapes draw from torch's device generator inside infer(): a captured draw would need the generator's graph-safe
+            # offset bookkeeping, which nothing here has exercised -- the predict path, the one this class serves, uses the mean shape)
+            raise ValueError("GraphedInfer captures the use_mean_shape=True form of infer() only")
         self.net, self.smpl = pose_shape_model, smpl_model
-        self.batch, self.num_samples, self.use_mean_shape = int(batch), int(num_samples), bool(use_mean_shape)
+        self.batch, self.num_samples, self.use_mean_shape = int(batch), int(num_samples), True
         self.input_shape = tuple(input_shape)
         self._slots = [None] * max(1, int(slots))
         self._k = 0

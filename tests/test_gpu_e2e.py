@@ -482,7 +482,13 @@ def test_bench_line_has_every_leg(dev):
     assert abs(d["value"] - 64 * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["fused"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert r["traffic"] is None or r["traffic_imported"] is True
+    # roofline.traffic is MEASURED IN THIS RUN where rocprofv3 exists (two --pmc passes of a three-step sub-run, bench.live_traffic), else
+    # read from the committed PMC summary and flagged; either way it is the fused kernel's fabric-side bytes: at least the vertices it
+    # writes (540 MB at 6 528 meshes), well below twice the unfused LBS definition's bytes
+    import shutil
+    if shutil.which("rocprofv3") is not None:
+        assert r["traffic_imported"] is False and r["traffic_detail"]["launches"] >= 2, (r["traffic_imported"], r["traffic_source"])
+    assert r["traffic"] is None or (r["traffic_imported"] in (True, False) and 5.3e8 <= r["traffic"] <= 2 * r["algorithmic_bytes_per_launch"])
     sec = d["secondary"]
     assert sec["latency_b1"]["median_ms"] > 0 and sec["latency_b1"]["throughput_mode_median_ms"] > 0
     assert 0 < sec["latency_b1"]["graph_median_ms"] <= 1.2 * sec["latency_b1"]["median_ms"]          # a replay is not slower than issuing the launches

@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON = ["--steps", "2", "--warmup", "1", "--cpu-images", "0", "--lbs-unfused-reps", "0", "--latency-reps", "0", "--from-rgb-steps", "0",
-          "--stress-steps", "0"]
+          "--stress-steps", "0", "--live-traffic", "off"]
 
 
 def _free_port():

@@ -16,7 +16,7 @@ T=$(find $OUT -name "steptrace_kernel_trace.csv" | head -1)
 python tools/inloop_vs_alone.py $T > $OUT/step_timeline.txt 2>&1
 rm -f $T
 # round-6 A/Bs, interleaved on this box: the default against each round-5 setting it replaced, and against its own run without the bench's timing events
-Q="--steps 40 --warmup 10 --cpu-images 0 --from-rgb-steps 0 --stress-steps 0 --latency-reps 0 --lbs-unfused-reps 0"
+Q="--steps 40 --warmup 10 --cpu-images 0 --from-rgb-steps 0 --stress-steps 0 --latency-reps 0 --lbs-unfused-reps 0 --live-traffic off"
 one() { python bench.py $Q "$@" 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); e=d['secondary'].get('encoder',{}); r=d['roofline']; print('%-64s %6d images/s  %.3f ms/step  encoder %s  mesh %s' % ('[$*]', d['value'], d['ms_per_step'], ('%.3f' % e['avg_ms']) if e else '  -  ', ('%.4f' % r['avg_launch_ms']) if r['launches'] else '  -  '))"; }
 {

@@ -5,7 +5,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 OUT=$R/gpurun_out/r6_sched; rm -rf $OUT; mkdir -p $OUT
-Q="--cpu-images 0 --from-rgb-steps 0 --stress-steps 0 --latency-reps 0 --lbs-unfused-reps 0"
+Q="--cpu-images 0 --from-rgb-steps 0 --stress-steps 0 --latency-reps 0 --lbs-unfused-reps 0 --live-traffic off"
 one() { python bench.py --steps 40 --warmup 10 $Q "$@" 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); e=d['secondary'].get('encoder',{}); print('%-62s %6d images/s  %.3f ms/step  encoder %s  mesh %s' % ('[$*]', d['value'], d['ms_per_step'], ('%.3f' % e['avg_ms']) if e else '  -  ', ('%.3f' % d['roofline']['avg_launch_ms']) if d['roofline']['launches'] else '  -  '))"; }
 {

@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 OUT=$R/gpurun_out/r6_trace; rm -rf $OUT; mkdir -p $OUT
-Q="--cpu-images 0 --from-rgb-steps 0 --stress-steps 0 --latency-reps 0 --lbs-unfused-reps 0"
+Q="--cpu-images 0 --from-rgb-steps 0 --stress-steps 0 --latency-reps 0 --lbs-unfused-reps 0 --live-traffic off"
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python $R/bench.py --steps 12 --warmup 4 $Q "$@" > $OUT/trace_log.txt 2>&1
 cd $R

@@ -12,29 +12,29 @@ OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 MESH="mesh_fused_kernel"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python $R/bench.py --steps 10 --warmup 2 --cpu-images 0 --from-rgb-steps 0 --latency-reps 0 --stress-steps 0 > $OUT/bench_stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python $R/bench.py --live-traffic off --steps 10 --warmup 2 --cpu-images 0 --from-rgb-steps 0 --latency-reps 0 --stress-steps 0 > $OUT/bench_stats.log 2>&1
 echo "kernel stats exit $?"
 grep -h '^{' $OUT/bench_stats.log | tail -1 > $OUT/bench_under_rocprof.json
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "$MESH" --output-format csv -d $OUT -o mesh_$c -- python $R/bench.py --steps 3 --warmup 1 --cpu-images 0 --from-rgb-steps 0 --latency-reps 0 --stress-steps 0 --lbs-unfused-reps 0 > $OUT/pmc_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "$MESH" --output-format csv -d $OUT -o mesh_$c -- python $R/bench.py --live-traffic off --steps 3 --warmup 1 --cpu-images 0 --from-rgb-steps 0 --latency-reps 0 --stress-steps 0 --lbs-unfused-reps 0 > $OUT/pmc_$c.log 2>&1
   echo "pmc $c exit $?"
 done
 for k in uncertainty_joints_kernel mf_sample_kernel; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "$k" --output-format csv -d $OUT -o ${k}_$c -- python $R/bench.py --steps 3 --warmup 1 --cpu-images 0 --from-rgb-steps 0 --latency-reps 0 --stress-steps 0 --lbs-unfused-reps 0 --no-pipeline > $OUT/pmc_${k}_$c.log 2>&1
+    timeout 300 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "$k" --output-format csv -d $OUT -o ${k}_$c -- python $R/bench.py --live-traffic off --steps 3 --warmup 1 --cpu-images 0 --from-rgb-steps 0 --latency-reps 0 --stress-steps 0 --lbs-unfused-reps 0 --no-pipeline > $OUT/pmc_${k}_$c.log 2>&1
     echo "pmc $k $c exit $?"
   done
 done
 # the stress configuration (BASELINE configs[4]): bench line + kernel stats
-timeout 300 python $R/bench.py --batch 16 --num-samples 1000 --steps 10 --warmup 3 --cpu-images 0 --latency-reps 0 --stress-steps 0 > $OUT/bench_n1000.log 2>&1
+timeout 300 python $R/bench.py --live-traffic off --batch 16 --num-samples 1000 --steps 10 --warmup 3 --cpu-images 0 --latency-reps 0 --stress-steps 0 > $OUT/bench_n1000.log 2>&1
 echo "configs[4] bench exit $?"
 grep -h '^{' $OUT/bench_n1000.log | tail -1 > $OUT/bench_n1000.json
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o n1000 -- python $R/bench.py --batch 16 --num-samples 1000 --steps 6 --warmup 2 --cpu-images 0 --from-rgb-steps 0 --latency-reps 0 --stress-steps 0 > $OUT/n1000_stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o n1000 -- python $R/bench.py --live-traffic off --batch 16 --num-samples 1000 --steps 6 --warmup 2 --cpu-images 0 --from-rgb-steps 0 --latency-reps 0 --stress-steps 0 > $OUT/n1000_stats.log 2>&1
 echo "configs[4] kernel stats exit $?"
 # the unfused definition (blend GEMM + LBS as two kernels) for comparison, and the non-pipelined loop
-timeout 300 python $R/bench.py --steps 20 --warmup 5 --cpu-images 0 --from-rgb-steps 0 --latency-reps 0 --stress-steps 0 --unfused-mesh > $OUT/bench_unfused.log 2>&1
+timeout 300 python $R/bench.py --live-traffic off --steps 20 --warmup 5 --cpu-images 0 --from-rgb-steps 0 --latency-reps 0 --stress-steps 0 --unfused-mesh > $OUT/bench_unfused.log 2>&1
 grep -h '^{' $OUT/bench_unfused.log | tail -1 > $OUT/bench_unfused.json
-timeout 300 python $R/bench.py --steps 20 --warmup 5 --cpu-images 0 --from-rgb-steps 0 --latency-reps 0 --stress-steps 0 --no-pipeline > $OUT/bench_nopipe.log 2>&1
+timeout 300 python $R/bench.py --live-traffic off --steps 20 --warmup 5 --cpu-images 0 --from-rgb-steps 0 --latency-reps 0 --stress-steps 0 --no-pipeline > $OUT/bench_nopipe.log 2>&1
 grep -h '^{' $OUT/bench_nopipe.log | tail -1 > $OUT/bench_nopipe.json
 # the default command, un-profiled, with the CPU baseline: the line the driver will measure
 timeout 600 python $R/bench.py > $OUT/bench_default.log 2>&1
