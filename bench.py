@@ -99,7 +99,7 @@ def cpu_baseline(net_state, parents, num_samples, n_images):
                               "sample": "%d images, num_samples=%d (%.2f s)" % (n1, num_samples, dt1)}}
 
 
-def live_traffic(kernel_regex, n_steps=3):
+def live_traffic(kernel_regex, n_steps=3, extra=()):
     """HBM-side bytes per launch of the mesh kernel, MEASURED IN THIS RUN: two short rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do
     not fit one pass) over a three-step sub-run of this very script, on this GPU, after the timed region; corrected as
     MI355X_MICROARCH.md prescribes for gfx950 (values in KB; fabric reads = 2 x FETCH_SIZE).  None when rocprofv3 is not on the PATH or a
@@ -120,7 +120,7 @@ def live_traffic(kernel_regex, n_steps=3):
             cmd = ["rocprofv3", "--pmc", c, "--kernel-trace", "--kernel-include-regex", kernel_regex, "--output-format", "csv", "-d", out,
                    "-o", "pass_" + c, "--", sys.executable, os.path.abspath(__file__), "--steps", str(n_steps), "--warmup", "1",
                    "--cpu-images", "0", "--from-rgb-steps", "0", "--latency-reps", "0", "--stress-steps", "0", "--lbs-unfused-reps", "0",
-                   "--live-traffic", "off"]
+                   "--live-traffic", "off", "--split-steps", "0"] + list(extra)
             p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180)
             path = None
             for root_, _, files in os.walk(out):
@@ -144,6 +144,11 @@ def live_traffic(kernel_regex, n_steps=3):
             "method": "rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE} --kernel-trace --kernel-include-regex %s, two passes of a %d-step sub-run of "
                       "bench.py on this GPU after the timed region; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB (the gfx950 correction of "
                       "MI355X_MICROARCH.md)" % (kernel_regex, n_steps)}
+
+
+def fused_path_ok(smpl):
+    """The shared-shape fused mesh kernel is what infer(use_mean_shape=True) runs (the bf16x3 arithmetic exists for that form only)."""
+    return bool(smpl.fused_mesh and smpl.shared_shape and smpl.picked_joints)
 
 
 def workload_name(B, N, world):
@@ -229,6 +234,12 @@ def main():
     ap.add_argument("--head-high-priority", action="store_true", help="A/B: the head's stream at high priority (rounds 3-5) instead of normal priority")
     ap.add_argument("--separate-joints", action="store_true", help="A/B: joint regression and uncertainty pass as two launches (round 5) instead of one (hps_joints_and_uncertainty)")
     ap.add_argument("--per-mesh-shape-blend", action="store_true", help="A/B: the K = 217 form of the fused mesh kernel (shape blend inside the GEMM, once per mesh: round 5) instead of the shared-shape form (K = 207, shape blend once per image)")
+    ap.add_argument("--mesh-arith", choices=("f32", "bf16x3"), default="f32",
+                    help="arithmetic of the shared-shape mesh kernel's pose blend GEMM in the HEADLINE run: f32 = v_mfma_f32_32x32x2_f32 (default, the "
+                         "reference's arithmetic type in every instruction); bf16x3 = fp32 operands as three bf16 pieces, six exact piece products on the "
+                         "bf16 matrix pipe, fp32 accumulation (fp32 accuracy, other bits; SMPL.mesh_arith)")
+    ap.add_argument("--split-steps", type=int, default=16,
+                    help="after the timed region: pipelined steps with SMPL.mesh_arith = 'bf16x3' for secondary.mesh_bf16x3 (0 = skip)")
     ap.add_argument("--unfused-mesh", action="store_true", help="blend GEMM + LBS as two kernels (the unfused definition) instead of the fused mesh kernel")
     ap.add_argument("--trace-steps", action="store_true", help="print host-side per-step times to stderr (debugging)")
     ap.add_argument("--cpu-images", type=int, default=64, help="images in the CPU-baseline sample (0 = skip); 64 = one full batch, SURVEY 8(d)")
@@ -279,6 +290,7 @@ def main():
     smpl.fused_mesh = not args.unfused_mesh
     smpl.picked_joints = not args.gather_joints
     smpl.shared_shape = not args.per_mesh_shape_blend
+    smpl.mesh_arith = args.mesh_arith
     if args.separate_joints:
         from hierarchicalprobabilistic3dhuman_amd import predict_poseMF_shapeGaussian_net as _pm
         _pm.FUSE_JOINTS_AND_UNCERTAINTY = False
@@ -614,7 +626,48 @@ def main():
                   "lbs_unfused": ({"median_ms": lbs_ms_s, "bound": "hbm", "achieved": LBS_BYTES_PER_MESH * Ms / (lbs_ms_s * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": LBS_BYTES_PER_MESH * Ms / (lbs_ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "note": "hps_smpl_lbs alone at %d meshes (not on the product path)" % Ms} if lbs_ms_s else None)}
+    # The opt-in arithmetic of the mesh kernel under the same clock: the same pipelined steps with SMPL.mesh_arith = "bf16x3" (the pose blend
+    # GEMM on the bf16 matrix pipe at fp32 accuracy: csrc/mesh_split.hip), a few steps after the timed region, wall clock + the kernel's
+    # own HIP events; and how far its vertices are from the fp32-MFMA kernel's on one batch (same seed, same samples).
+    mesh_bf16x3 = None
+    if args.split_steps > 0 and world == 1 and not args.no_pipeline and args.mesh_arith == "f32" and fused_path_ok(smpl):
+        ref = infer(net, smpl, x, num_samples=N, use_mean_shape=True, seed=31337, image_offset=lo)
+        smpl.mesh_arith = "bf16x3"
+        try:
+            alt = infer(net, smpl, x, num_samples=N, use_mean_shape=True, seed=31337, image_offset=lo)
+            dv = float((alt["verts_samples"] - ref["verts_samples"]).abs().max()) if "verts_samples" in alt else None
+            dm = float((alt["verts_mode"] - ref["verts_mode"]).abs().max())
+            du = float((alt["unc"] - ref["unc"]).abs().max())
+            del ref, alt
+            run_steps(0, 4)
+            torch.cuda.synchronize()
+            smpl.lbs_events = ev_lists["lbs"] = []
+            pipe.enc_events = ev_lists["enc"] = []
+            t_a = time.perf_counter()
+            run_steps(4, args.split_steps)
+            torch.cuda.synchronize()
+            dt_b = time.perf_counter() - t_a
+            b_mesh = [e0.elapsed_time(e1) for (m, e0, e1) in ev_lists["lbs"] if m == M]
+            b_enc = [e0.elapsed_time(e1) for (e0, e1) in ev_lists["enc"]]
+        finally:
+            smpl.mesh_arith = "f32"
+            smpl.lbs_events = pipe.enc_events = None
+            ev_lists["lbs"] = ev_lists["enc"] = None
+        bm = spread(b_mesh)
+        mesh_bf16x3 = {"images_per_s": B * args.split_steps / dt_b, "ms_per_step": dt_b / args.split_steps * 1e3, "steps": args.split_steps,
+                       "vs_headline": (B * args.split_steps / dt_b) / (B * world * args.steps / dt),
+                       "mesh_kernel": "hps::mesh_split_kernel<4,24,4,0>", "mesh_kernel_ms": bm, "encoder_avg_ms": sum(b_enc) / max(1, len(b_enc)),
+                       "max_abs_diff_vs_f32_m": {"verts_samples": dv, "verts_mode": dm, "vertex_uncertainty": du},
+                       "blend_tflops_fp32_equivalent": (2 * 207 * 3 * 6890 * M / (bm["median_ms"] * 1e-3) / 1e12) if bm else None,
+                       "issued_bf16_tflops": (6 * 2 * 208 * 3 * 6912 * M / (bm["median_ms"] * 1e-3) / 1e12) if bm else None,
+                       "note": "opt-in (SMPL.mesh_arith = 'bf16x3', bench.py --mesh-arith bf16x3 makes it the headline's kernel): every fp32 operand of "
+                               "the pose blend GEMM as three bf16 pieces (exact split), six exact piece products per product on "
+                               "v_mfma_f32_32x32x16_bf16, fp32 accumulation -- as close to the float64 twin as the fp32-MFMA kernel "
+                               "(tests/test_gpu_smpl.py::test_split_bf16_form_of_the_mesh_kernel), not the same bits.  The default keeps "
+                               "the reference's arithmetic type in every instruction."}
     secondary = {}
+    if mesh_bf16x3:
+        secondary["mesh_bf16x3"] = mesh_bf16x3
     if stress:
         secondary["stress_n1000"] = stress
     if from_rgb:
@@ -635,7 +688,8 @@ def main():
 
     fused = bool(getattr(smpl, "fused_mesh", False))
     shared_shape = fused and bool(getattr(smpl, "shared_shape", False)) and smpl.picked_joints
-    mesh_kernel = ("hps::mesh_fused_kernel<4,0,24,false,8,2,true,true>" if shared_shape else "hps::mesh_fused_kernel<4,0,24,false,5>") if fused else "hps::lbs_kernel<4,8,1>"
+    split_arith = shared_shape and smpl.mesh_arith == "bf16x3"
+    mesh_kernel = "hps::mesh_split_kernel<4,24,4,0>" if split_arith else ("hps::mesh_fused_kernel<4,0,24,false,8,2,true,true>" if shared_shape else "hps::mesh_fused_kernel<4,0,24,false,5>") if fused else "hps::lbs_kernel<4,8,1>"
     k_required = 207 if shared_shape else 217            # K rows the launch has to multiply per mesh (the shared shape blend: once per IMAGE)
     # HBM traffic of the same kernel from the PMC counters: collected in separate rocprofv3 passes of this very
     # command (tools/collect_profiles.sh), corrected as MI355X_MICROARCH.md prescribes, committed under profiles/
@@ -645,11 +699,12 @@ def main():
     traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % pmc_name
     if args.live_traffic == "auto" and world == 1 and rank == 0 and args.as_rank is None and (B, N) == (64, 100) and not args.no_pipeline:
         torch.cuda.synchronize()
-        traffic_detail = live_traffic("mesh_fused_kernel" if fused else "lbs_kernel")
+        traffic_detail = live_traffic(("mesh_split_kernel" if split_arith else "mesh_fused_kernel") if fused else "lbs_kernel",
+                                      extra=["--mesh-arith", args.mesh_arith])
         if traffic_detail is not None:
             traffic, traffic_imported = traffic_detail["hbm_bytes_per_launch"], False
             traffic_source = traffic_detail["method"]
-    if traffic is None and os.path.exists(pmc_path):
+    if traffic is None and os.path.exists(pmc_path) and not split_arith:       # (the committed summary is the fp32 kernel's)
         with open(pmc_path) as f:
             pmc = json.load(f)
         if pmc.get("meshes_per_launch", M) == M:
@@ -684,6 +739,7 @@ def main():
                        "images_per_gpu": B, "global_batch": B * world, "num_samples": N,
                        "meshes_per_step_per_gpu": M, "parallelism": "images sharded over %d GPU(s)" % world,
                        "mesh_kernel": "fused blend GEMM + LBS" if fused else "blend GEMM, then LBS",
+                       "mesh_arith": smpl.mesh_arith if shared_shape else "f32",
                        "step_pipelining": "none" if args.no_pipeline else (
                            ("encoder of step i+1 (own stream) overlaps the latency-bound head of step i (high-priority stream); the mesh kernels (pose prep / blend + LBS / joints) of a batch run alone"
                             + ("; the head on %d CUs of every XCD, the caller's stream (sampling, mesh kernels, uncertainty) on the other %d" % (32 - _capi_mesh_cus(pipe), _capi_mesh_cus(pipe))

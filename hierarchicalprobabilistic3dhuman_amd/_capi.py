@@ -33,6 +33,10 @@ _PROTOTYPES = {
     "hps_smpl_mesh_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "hps_smpl_mesh_fused_picks": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "hps_smpl_mesh_fused_shared_shape": [_P] * 8 + [_I, _I, _P] + [_I] * 5 + [_P, _P, _I, _P],
+    "hps_smpl_split_bf16x3_bytes": [_I, _I],
+    "hps_smpl_split_bf16x3_mesh_tile": [],
+    "hps_smpl_split_bf16x3": [_P, _I, _I, _I, _I, _P, _P],
+    "hps_smpl_mesh_fused_shared_shape_bf16x3": [_P] * 8 + [_I, _I, _P] + [_I] * 4 + [_P, _P, _I, _P],
     "hps_smpl_v_shaped": [_P, _I, _P, _I, _P, _P, _I, _I, _P],
     "hps_smpl_mesh_fused_np": [_I],
     "hps_smpl_joints": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
@@ -82,7 +86,7 @@ _PROTOTYPES = {
     "hps_maxpool3x3s2_pad": [_P, _P, _I, _I, _I, _I, _I, _P],
     "hps_global_avgpool_pad": [_P, _P, _I, _I, _I, _I, _I, _P],
 }
-_RESTYPES = {"hps_last_error": _c.c_char_p, "hps_query_workspace": _c.c_int64, "hps_conv3x3_winograd_workspace": _c.c_size_t,
+_RESTYPES = {"hps_last_error": _c.c_char_p, "hps_smpl_split_bf16x3_bytes": _c.c_size_t, "hps_query_workspace": _c.c_int64, "hps_conv3x3_winograd_workspace": _c.c_size_t,
              "hps_stem_phase_frames_bytes": _c.c_size_t, "hps_stem_pool_side_bytes": _c.c_size_t}
 
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

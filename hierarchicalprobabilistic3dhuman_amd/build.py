@@ -18,7 +18,7 @@ INCLUDE = os.path.join(REPO_ROOT, "include")
 LIB_PATH = os.path.join(PKG_DIR, "libhps.so")
 DEV_LIB_PATH = os.path.join(PKG_DIR, "libhps_dev.so")
 
-SOURCES = ["api.hip", "smpl.hip", "blend_gemm.hip", "mesh_fused.hip", "mf_sample.hip", "head.hip", "conv_pad.hip", "conv_wino.hip", "stem_wino.hip", "composite.hip",
+SOURCES = ["api.hip", "smpl.hip", "blend_gemm.hip", "mesh_fused.hip", "mesh_split.hip", "mf_sample.hip", "head.hip", "conv_pad.hip", "conv_wino.hip", "stem_wino.hip", "composite.hip",
            "host_svd.hip", "frontend.hip", "metrics.hip"]
 DEV_ONLY_SOURCES = ["conv.hip"]
 # per-file flags.  mesh_fused.hip: hipcc's SLP vectoriser turns the skinning epilogue into v_pk_fma_f32 plus one v_mov
@@ -30,7 +30,7 @@ DEV_ONLY_SOURCES = ["conv.hip"]
 # dependent FMAs into one accumulator; a wave alone on its SIMD issues a dependent v_fma_f32 every 8.25 cycles and an independent
 # one every 5.0 (tools/valu_dep_probe.hip; two waves per SIMD together: one per 2.5).  Interleaved chains: edge map 0.031 -> 0.029 ms.  (Tried on stem_wino.hip and mesh_fused.hip:
 # no change -- 0.603 / 0.574 ms; conv_wino.hip goes to scratch with it.)
-FILE_FLAGS = {"mesh_fused.hip": ["-fno-slp-vectorize"],
+FILE_FLAGS = {"mesh_fused.hip": ["-fno-slp-vectorize"], "mesh_split.hip": ["-fno-slp-vectorize"],
               "frontend.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]

@@ -14,7 +14,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace hps
 
-extern "C" int hps_version(void) { return 501; }  // 0.5.1: + hps_stem_winograd_pooled (0.5.0: second-generation pose-prep / joint kernels)
+extern "C" int hps_version(void) { return 502; }  // 0.5.2: + hps_smpl_*_bf16x3; 0.5.1: + hps_stem_winograd_pooled (0.5.0: second-generation pose-prep / joint kernels)
 
 extern "C" int64_t hps_query_workspace(int what, int64_t d0, int64_t d1, int64_t d2) {
     if (d0 < 0 || d1 < 0 || d2 < 0) { hps::set_error("hps_query_workspace: negative dimension"); return -1; }

@@ -58,6 +58,12 @@ class SMPL(nn.Module):
         # the fused kernel (hps_smpl_mesh_fused_shared_shape: the shape blend once per image, not once per mesh).  False: the K = 217 form
         # for every call (the bit-level partner of the unfused pair).
         self.shared_shape = True
+        # arithmetic of the shared-shape form's pose blend GEMM.  "f32": v_mfma_f32_32x32x2_f32, the reference's own arithmetic type in every
+        # instruction (default).  "bf16x3": every fp32 operand as three bf16 pieces, six exact piece products per product on the bf16 matrix
+        # pipe, fp32 accumulation -- fp32 accuracy (as close to the float64 twin as "f32"), not the same bits (include/hps.h:
+        # hps_smpl_mesh_fused_shared_shape_bf16x3).  Applies where the shared-shape form applies; every other call is "f32".
+        self.mesh_arith = "f32"
+        self._bsplit = None
 
         f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
         v_template = np.asarray(model["v_template"], np.float64)
@@ -89,6 +95,7 @@ class SMPL(nn.Module):
         nb = num_betas
         n_pose = posedirs_v3k.shape[-1]
         self._N = 3 * V
+        self._n_pose = n_pose
         self._kp = _round_up(nb + n_pose, 16)
         self._k_used = _round_up(nb + n_pose, 2)          # rows the fused kernel multiplies (the rest of the 16-row padding is zero)
         self._np = _round_up(self._N, 128)
@@ -172,6 +179,18 @@ class SMPL(nn.Module):
         dev = self.v_template.device
         return torch.from_numpy(full).to(dev), torch.from_numpy(groups.reshape(-1)).to(dev)
 
+    def _blend_matrix_split(self):
+        """The pose rows of the panel-permuted blend matrix as bf16 piece planes in MFMA fragment order (once per model and device)."""
+        dev = self._bmat_p.device
+        if self._bsplit is None or self._bsplit.device != dev:
+            nb, rows = self.num_betas, self._n_pose
+            n = _capi.load().hps_smpl_split_bf16x3_bytes(rows, self._np_fused)
+            buf = torch.empty(n, dtype=torch.uint8, device=dev)
+            _capi.call("hps_smpl_split_bf16x3", _capi._P(self._bmat_p.data_ptr() + 4 * nb * self._np_fused), rows, self._np_fused,
+                       self._np_fused, 192, _capi._P(buf.data_ptr()), _capi.stream())
+            self._bsplit = buf
+        return self._bsplit
+
     # ------------------------------------------------------------------------------------------
     def forward(self, betas=None, body_pose=None, global_orient=None, transl=None, pose2rot=True,
                 return_verts=True, return_full_pose=False, **kwargs):
@@ -222,6 +241,10 @@ class SMPL(nn.Module):
         # promise -- infer(use_mean_shape=True)): the shape blend once per distinct shape, the GEMM over the pose rows only
         shared = kwargs.get("_shared_shapes") if (self.shared_shape and use_picks and tr is None) else None
         v_shaped = None
+        if self.mesh_arith not in ("f32", "bf16x3"):
+            raise ValueError("mesh_arith must be 'f32' or 'bf16x3', got %r" % (self.mesh_arith,))
+        split = shared is not None and self.mesh_arith == "bf16x3"
+        xsplit = bsplit = None
         if shared is not None:
             sb = _capi.f32c(shared[0])
             v_shaped = torch.empty(sb.shape[0], V, 3, **f32)
@@ -230,6 +253,11 @@ class SMPL(nn.Module):
         _capi.call("hps_smpl_pose_prep", P(g), P(b), is_rotmat, P(be), self.num_betas, P(self._j_template),
                    P(self._j_shapedirs), _capi.iptr(self._parents_i32), _capi.iptr(self._depth_i32), J, P(xt),
                    self._kp, mp, P(a), P(j_posed), None, M, s)
+        if split:
+            bsplit = self._blend_matrix_split()
+            xsplit = torch.empty(_capi.load().hps_smpl_split_bf16x3_bytes(self._n_pose, mp), dtype=torch.uint8, device=dev)
+            _capi.call("hps_smpl_split_bf16x3", _capi._P(xt.data_ptr() + 4 * self.num_betas * mp), self._n_pose, mp, mp,
+                       _capi.load(dev=_capi._use_dev).hps_smpl_split_bf16x3_mesh_tile(), _capi._P(xsplit.data_ptr()), s)
         # InferencePipeline: only the chip-filling mesh kernel(s) run alone; pose prep (before) and the joint regression (after)
         # may share the GPU with the neighbouring batches' encoders
         if kwargs.get("_before_mesh") is not None:
@@ -244,7 +272,7 @@ class SMPL(nn.Module):
                 # the tensors are registered with the other stream -- which costs an event record ON THAT STREAM for each of them
                 # when they are freed (seven markers of ~6 us in front of the next encoder, measured: profiles/r05_experiments.txt).
                 if ordered != "ordered":
-                    for t in (xt, a, verts, picked, be, g, b, v_shaped):
+                    for t in (xt, a, verts, picked, be, g, b, v_shaped, xsplit):
                         if t is not None:
                             t.record_stream(now)
         ev = None
@@ -255,7 +283,11 @@ class SMPL(nn.Module):
         if self.fused_mesh and self._fused_ok:
             if ev is not None:
                 ev[0].record()
-            if shared is not None:
+            if split:
+                _capi.call("hps_smpl_mesh_fused_shared_shape_bf16x3", _capi._P(xsplit.data_ptr()), _capi._P(bsplit.data_ptr()), P(v_shaped),
+                           _capi.iptr(shared[1]), _capi.iptr(shared[2]), P(a), _capi.iptr(self._w_idx), P(self._w_val), self._lbs_k, J,
+                           P(verts), M, V, self._n_pose, mp, _capi.iptr(self._pick_slot), P(picked), self._n_picked, s)
+            elif shared is not None:
                 nb = self.num_betas
                 _capi.call("hps_smpl_mesh_fused_shared_shape", _capi._P(xt.data_ptr() + 4 * nb * mp), _capi._P(self._bmat_p.data_ptr() + 4 * nb * self._np_fused),
                            P(v_shaped), _capi.iptr(shared[1]), _capi.iptr(shared[2]), P(a), _capi.iptr(self._w_idx), P(self._w_val), self._lbs_k, J,

@@ -194,6 +194,26 @@ int hps_smpl_mesh_fused_shared_shape(const float* xt_pose, const float* bmat_p_p
  * (shape_rows: the first num_betas rows of the blend matrix of hps_smpl_blend, row pitch ld >= 3 V floats). */
 int hps_smpl_v_shaped(const float* betas, int num_betas, const float* shape_rows, int ld, const float* v_template,
                       float* v_shaped, int R, int V, hps_stream_t stream);
+/* The shared-shape mesh kernel with its pose blend GEMM on the bf16 matrix pipe AT FP32 ACCURACY ("bf16x3", round 6, opt-in:
+ * SMPL.mesh_arith).  Every fp32 operand x is carried as three bf16 pieces x = x1 + x2 + x3 (x1 = RN(x), x2 = RN(x - x1), x3 = RN(x - x1 -
+ * x2): 3 x 8 significand bits = fp32's 24, the sum is exact) and a product is formed as the six piece products of weight >= 2^-16 of
+ * the leading one, each exact in the fp32 accumulator; the dropped part is < 2^-23 |a b| -- one fp32 rounding.  Same tile, mapping,
+ * skinning arithmetic, side output and HBM traffic as hps_smpl_mesh_fused_shared_shape; the vertices agree with it to rounding (<= 4e-6
+ * m asserted; both within 2e-5 m of the oracle and equally close to the float64 twin).  Why it exists: v_mfma_f32_32x32x2_f32 runs at
+ * the fp32 vector rate on gfx950 and excludes fp32 VALU work, v_mfma_f32_32x32x16_bf16 is 16 x faster and does not.
+ *   hps_smpl_split_bf16x3: src (rows, ld) fp32 k-major (rows behind `rows` up to the next multiple of 16 are written as zeros), its
+ *     first `cols` columns in tiles of tile_cols (hps_smpl_split_bf16x3_mesh_tile(): the mesh operand xt of hps_smpl_pose_prep advanced by num_betas rows; 192: bmat_p
+ *     advanced likewise) -> dst[tile][16-row chunk][piece][k half][column][8 bf16], hps_smpl_split_bf16x3_bytes(rows, cols) bytes.
+ *     The blend matrix is split once per model, the mesh operand once per call.
+ *   hps_smpl_mesh_fused_shared_shape_bf16x3: xsplit / bsplit from the above (rows = 207 for SMPL); everything else as for
+ *     hps_smpl_mesh_fused_shared_shape.  K = 4, 24 joints; HPS_E_UNSUPPORTED otherwise. */
+size_t hps_smpl_split_bf16x3_bytes(int rows, int cols);
+int hps_smpl_split_bf16x3_mesh_tile(void);   /* tile_cols of the mesh operand = meshes per workgroup tile of the kernel (128) */
+int hps_smpl_split_bf16x3(const float* src, int rows, int ld, int cols, int tile_cols, void* dst, hps_stream_t stream);
+int hps_smpl_mesh_fused_shared_shape_bf16x3(const void* xsplit, const void* bsplit, const float* v_shaped, const int32_t* mesh_row,
+                                            const int32_t* group_rows, const float* a, const int32_t* w_idx, const float* w_val,
+                                            int K, int num_joints, float* verts, int M, int V, int rows, int mp,
+                                            const int32_t* pick_slot, float* picked, int n_picked, hps_stream_t stream);
 /* Column count of bmat_p for a model with V vertices (192 per started panel of 64 vertices). */
 int hps_smpl_mesh_fused_np(int V);
 

@@ -101,6 +101,13 @@ int hps_dev_unc_mode(int mode);
 /* Cross-check hook: 2 = hps_smpl_mesh_fused always runs its two-stage K loop (calls of at most two mesh tiles otherwise take the
  * four-stage form: same bits), 0 = the product rule. */
 int hps_dev_mesh_stages(int stages);
+/* hps_smpl_mesh_fused_shared_shape_bf16x3: mg = 2 selects the 64-mesh tile (four waves, three workgroups per CU) for A/B runs; any other
+ * value = the product's 128-mesh tile.  hps_smpl_split_bf16x3_mesh_tile() follows the switch. */
+int hps_dev_mesh_split_groups(int mg);
+/* timing ablations of the bf16x3 mesh kernel (results garbage): 1 = K loop only, 2 = skinning only, 3 = operand stream without MFMAs */
+int hps_dev_mesh_split_ablate(int ablate);   /* ... 4 = the next chunk's DMA pieces in one burst (results valid) */
+/* start delay of the second resident workgroup of every CU, in units of ~1.5 us (< 0: the product's value) */
+int hps_dev_mesh_split_stagger(int units);
 
 /* Experiment: request at least `bytes` of dynamic LDS for the fused mesh kernel (unused space), i.e. cap its workgroups per CU
  * (36 KiB -> 4, 52 KiB -> 3, 72 KiB -> 2, 150 KiB -> 1).  0 restores the product value. */

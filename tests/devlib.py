@@ -24,6 +24,9 @@ DEV_PROTOTYPES = {
     "hps_dev_unc_mode": [_I],
     "hps_dev_mesh_lds_floor": [_I],
     "hps_dev_mesh_stages": [_I],
+    "hps_dev_mesh_split_groups": [_I],
+    "hps_dev_mesh_split_ablate": [_I],
+    "hps_dev_mesh_split_stagger": [_I],
     "hps_dev_blend_mode": [_I],
     "hps_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "hps_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P],

@@ -50,7 +50,7 @@ def test_dev_library_is_separate_and_exports_the_dev_header():
 
 def test_version_and_error_string():
     lib = _capi.load()
-    assert lib.hps_version() == 501
+    assert lib.hps_version() == 502
     assert isinstance(lib.hps_last_error(), bytes)
 
 

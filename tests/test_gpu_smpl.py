@@ -514,3 +514,82 @@ def test_shared_shape_form_of_the_mesh_kernel(B, N, dev, smpl_gpu, smpl_assets):
     finally:
         smpl_gpu.shared_shape = True
     assert torch.equal(off.vertices, plain.vertices)
+
+
+def _split_reference(x):
+    """x = x1 + x2 + x3 in bf16 pieces, round-to-nearest-even each (torch's own conversion)."""
+    x1 = x.bfloat16()
+    r1 = x - x1.float()
+    x2 = r1.bfloat16()
+    x3 = (r1 - x2.float()).bfloat16()
+    return x1, x2, x3
+
+
+@pytest.mark.parametrize("rows,cols,W", [(207, 128, 64), (16, 64, 64), (5, 192, 192), (207, 384, 192), (33, 320, 64), (207, 256, 128)])
+def test_split_bf16x3_operand_layout_and_exactness(rows, cols, W, dev):
+    """hps_smpl_split_bf16x3: the three pieces are torch's round-to-nearest-even bf16 conversions of x, x - x1, x - x1 - x2, they lie in
+    [tile][16-row chunk][piece][k half][column][8] order, rows behind `rows` are zero, and x1 + x2 + x3 == x EXACTLY."""
+    g = torch.Generator().manual_seed(rows * 1000 + cols)
+    ld = cols + 64
+    src = (torch.randn(rows, ld, generator=g) * torch.logspace(-6, 1, ld)[None]).to(dev)
+    lib = _capi.load()
+    nbytes = lib.hps_smpl_split_bf16x3_bytes(rows, cols)
+    nchunks = -(-rows // 16)
+    assert nbytes == nchunks * 16 * cols * 6
+    dst = torch.full((nbytes,), 0x55, dtype=torch.uint8, device=dev)
+    _capi.call("hps_smpl_split_bf16x3", _capi.ptr(src), rows, ld, cols, W, _capi._P(dst.data_ptr()), _capi.stream())
+    got = dst.view(torch.bfloat16).view(cols // W, nchunks, 3, 2, W, 8)
+    x = torch.zeros(nchunks * 16, cols, device=dev)
+    x[:rows] = src[:, :cols]
+    pieces = _split_reference(x)
+    want = torch.stack([p.view(nchunks, 2, 8, cols // W, W).permute(3, 0, 1, 4, 2) for p in pieces], dim=2)   # (tile, chunk, piece, kl, w, j)
+    assert torch.equal(got.view(torch.int16), want.contiguous().view(torch.int16))
+    total = got[:, :, 0].double() + got[:, :, 1].double() + got[:, :, 2].double()
+    back = total.permute(1, 2, 4, 0, 3).reshape(nchunks * 16, cols)
+    assert torch.equal(back, x.double())
+    with pytest.raises(_capi.HpsError):
+        _capi.call("hps_smpl_split_bf16x3", _capi.ptr(src), rows, ld, cols, 100, _capi._P(dst.data_ptr()), _capi.stream())
+
+
+@pytest.mark.parametrize("B,N", [(1, 1), (1, 50), (3, 7), (2, 100), (17, 33), (64, 100)])
+def test_split_bf16_form_of_the_mesh_kernel(B, N, dev, smpl_gpu, smpl_assets):
+    """SMPL.mesh_arith = "bf16x3" (hps_smpl_mesh_fused_shared_shape_bf16x3: the pose blend GEMM as six exact bf16 piece products per
+    product, fp32 accumulation) on infer()'s mesh layout: within rounding of the fp32-MFMA form (4e-6 m), within the stated 2e-5 m of the
+    oracle, and NO FURTHER from the float64 twin than the fp32-MFMA form is (fp32 accuracy, not fp32 bits); the joints follow from the
+    side output.  Calls the shared-shape form does not cover keep the fp32 kernel whatever the switch says."""
+    model, extra, p = smpl_assets
+    g = torch.Generator().manual_seed(7000 * B + N)
+    loc = torch.randn(B, 10, generator=g)
+    rows = list(range(B)) + list(range(B)) + [b for b in range(B) for _ in range(N)]
+    M = len(rows)
+    aa = torch.randn(M, 24, 3, generator=g) * 0.5
+    aa[B:2 * B] = 0.0
+    R = O.batch_rodrigues(aa.view(-1, 3)).view(M, 24, 3, 3)
+    betas = loc[torch.tensor(rows)]
+    mesh_row, group_rows = smpl_gpu.shared_shape_tables(rows)
+    args = dict(betas=betas.to(dev), body_pose=R[:, 1:].to(dev), global_orient=R[:, :1].to(dev), pose2rot=False)
+    f32 = smpl_gpu(_shared_shapes=(loc.to(dev), mesh_row, group_rows), **args)
+    smpl_gpu.mesh_arith = "bf16x3"
+    try:
+        sp = smpl_gpu(_shared_shapes=(loc.to(dev), mesh_row, group_rows), **args)
+        sp2 = smpl_gpu(_shared_shapes=(loc.to(dev), mesh_row, group_rows), **args)
+        plain = smpl_gpu(**args)                                  # no shared shapes: the fp32 K = 217 form
+    finally:
+        smpl_gpu.mesh_arith = "f32"
+    assert torch.equal(sp.vertices, sp2.vertices) and torch.equal(sp.joints, sp2.joints)           # deterministic
+    assert maxerr(sp.vertices, f32.vertices) <= 4e-6 and maxerr(sp.joints, f32.joints) <= 4e-6
+    assert maxerr(plain.vertices, f32.vertices) <= 4e-6
+    pick = torch.arange(M) if M <= 300 else torch.cat([torch.arange(0, 3), torch.arange(B, B + 3), torch.arange(2 * B, 2 * B + 70),
+                                                         torch.arange(M - 40, M)])
+    ref = O.smpl_forward(p, betas=betas[pick], body_pose=R[pick, 1:], global_orient=R[pick, :1], pose2rot=False)
+    assert maxerr(sp.vertices[pick.to(dev)], ref["vertices"]) <= TOL and maxerr(sp.joints[pick.to(dev)], ref["joints"]) <= TOL
+    v64, j64 = smpl_forward64(model, extra, configs.SMPLX_EXTRA_VERTEX_IDS, betas[pick].double().numpy(), R[pick].double().numpy())
+    e_sp = np.abs(sp.vertices[pick.to(dev)].cpu().numpy() - v64)
+    e_f32 = np.abs(f32.vertices[pick.to(dev)].cpu().numpy() - v64)
+    assert e_sp.max() <= max(1.25 * e_f32.max(), 1e-6) and e_sp.mean() <= 1.1 * e_f32.mean() + 1e-9, (e_sp.max(), e_f32.max(), e_sp.mean(), e_f32.mean())
+    with pytest.raises(ValueError):
+        smpl_gpu.mesh_arith = "bf16"
+        try:
+            smpl_gpu(_shared_shapes=(loc.to(dev), mesh_row, group_rows), **args)
+        finally:
+            smpl_gpu.mesh_arith = "f32"
