@@ -596,6 +596,23 @@ def main():
             s_unc = [e0.elapsed_time(e1) for (b_, n_, e0, e1) in sampling_utils.unc_events if (b_, n_) == (Bs, Ns)]
             spipe.enc_events, smpl.lbs_events, sampling_utils.launch_events, sampling_utils.unc_events = None, None, None, None
             finite = bool(torch.isfinite(r_last["unc"]).all())
+            # ... and the same steps with the opt-in bf16x3 arithmetic of the mesh kernel (this configuration is the one the mesh kernel dominates)
+            s_split = None
+            if args.split_steps > 0 and args.mesh_arith == "f32" and fused_path_ok(smpl):
+                smpl.mesh_arith = "bf16x3"
+                try:
+                    stress_steps(0, 3)
+                    torch.cuda.synchronize()
+                    smpl.lbs_events = []
+                    t_b = time.perf_counter()
+                    stress_steps(3, args.stress_steps)
+                    torch.cuda.synchronize()
+                    dt_sb = time.perf_counter() - t_b
+                    sb_mesh = [e0.elapsed_time(e1) for (m, e0, e1) in smpl.lbs_events if m == Ms]
+                finally:
+                    smpl.mesh_arith, smpl.lbs_events = "f32", None
+                s_split = {"images_per_s": Bs * args.stress_steps / dt_sb, "ms_per_step": dt_sb / args.stress_steps * 1e3,
+                           "mesh_kernel_median_ms": spread(sb_mesh)["median_ms"] if sb_mesh else None}
             # the unfused LBS kernel at this size (SURVEY 8(d)'s definition), a few sequential calls on the same stream
             smpl.fused_mesh, smpl.lbs_events = False, []
             for i in range(5):
@@ -610,6 +627,7 @@ def main():
         stress = {"workload": "BASELINE configs[4]: batch=%d, num_samples=%d (%d meshes per step), 1 GPU" % (Bs, Ns, Ms),
                   "images_per_s": Bs * args.stress_steps / dt_s, "ms_per_step": dt_s / args.stress_steps * 1e3, "steps": args.stress_steps,
                   "results_finite": finite,
+                  "mesh_bf16x3": s_split,
                   "schedule": ("encoder on %d of the 32 CUs of every XCD, mesh kernels on the other %d" % (32 - _capi_mesh_cus(spipe), _capi_mesh_cus(spipe))
                                if spipe.mesh_stream is not None else "shared CUs"),
                   "encoder_avg_ms": sum(s_enc) / max(1, len(s_enc)),

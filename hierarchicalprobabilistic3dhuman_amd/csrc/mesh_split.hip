@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
     }
 }
 
-// ABL (dev library only): 1 = K loop only (no skinning), 2 = skinning only (no K loop), 3 = K loop without its MFMAs (operand stream only)
+// ABL (dev library only): 1 = K loop only (no skinning), 2 = skinning only (no K loop), 3 = K loop without its MFMAs (operand stream only),
+// 4 = DMA pieces in a burst, 5 = operands one chunk ahead (the fp32 kernel's scheme); 4 and 5 give valid results; 6 = K loop only WITHOUT the operand stream after the first two chunks
+// (MFMAs, fragment reads, one barrier per chunk), 7 = 6 with the second barrier
 template <int K, int JC, int MG, int ABL = 0>
 __global__ __launch_bounds__(SplitCfg<MG>::THREADS, SplitCfg<MG>::WAVES_PER_SIMD) void mesh_split_kernel(
     const char* __restrict__ xsplit, const char* __restrict__ bsplit, const float* __restrict__ v_shaped, const float* __restrict__ a,
@@ -154,14 +156,27 @@ __global__ __launch_bounds__(SplitCfg<MG>::THREADS, SplitCfg<MG>::WAVES_PER_SIMD
     const char* const sbytes = reinterpret_cast<const char*>(smem);
     const int a_frag = kl * (SM * 16) + (wm * 32 + il) * 16;                     // + s * 2 SM 16
     const int b_frag = S_XB + kl * (SN * 16) + (wn * 32 + il) * 16;              // + s * 2 SN 16 + t * 64 * 16
-    // (the last chunk is its own copy of the body: a run-time "is another chunk fetched" inside the MFMA run is a branch per piece)
-    auto do_chunk = [&](auto more_c, int c) __attribute__((always_inline)) {
-        constexpr bool more = decltype(more_c)::value;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c has landed
-        __syncthreads();                                   // ... for everyone; and everyone is done with the stage refilled below
-        const char* nx = x_src + (size_t)(c + 1) * S_XB;
-        const char* nb = b_src + (size_t)(c + 1) * S_BB;
-        const int nbuf = (c + 1) & 1;
+    // K loop, operands fetched TWO chunks ahead through two stages: a chunk's fragments are complete in registers before its first MFMA,
+    // so its stage is free as soon as every wave has read -- a second barrier behind the reads, and the DMA of chunk c + 2 goes into the
+    // stage chunk c was just read from, with the MFMAs of chunks c and c + 1 to land under.  (One chunk ahead -- the fp32 kernel's scheme,
+    // ABL = 5 -- left the MFMA pipe idle half the time: at the bf16 rate a chunk's MFMAs are 0.24 us per wave, shorter than a loaded
+    // L2 -> LDS round trip.)  YOUNGER: chunk c + 1's pieces are in flight at the top of the iteration; ISSUE: chunk c + 2 exists.
+    // The body is instantiated for the three cases: a run-time test inside the MFMA run would be a branch per piece.
+    constexpr bool AHEAD2 = ABL != 5;
+    const bool full_wave = C::NPIECES % SW == 0 || wave + SW * (C::PER_WAVE - 1) < C::NPIECES;      // this wave has PER_WAVE pieces per chunk
+    auto do_chunk = [&](auto younger_c, auto issue_c, int c) __attribute__((always_inline)) {
+        constexpr bool younger = decltype(younger_c)::value && ABL != 6 && ABL != 7, issue = decltype(issue_c)::value && ABL != 6 && ABL != 7;
+        if (AHEAD2 && younger) {                           // chunk c has landed; chunk c + 1 (issued later) may still be in flight
+            if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PER_WAVE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PER_WAVE - 1) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                   // ... for everyone
+        const int ahead = AHEAD2 ? 2 : 1;
+        const char* nx = x_src + (size_t)(c + ahead) * S_XB;
+        const char* nb = b_src + (size_t)(c + ahead) * S_BB;
+        const int nbuf = (c + ahead) & 1;
         const char* stage = sbytes + (c & 1) * S_STAGE;
         bf16x8 af[3], bf[3][3];
 #pragma unroll
@@ -171,7 +186,11 @@ __global__ __launch_bounds__(SplitCfg<MG>::THREADS, SplitCfg<MG>::WAVES_PER_SIMD
 #pragma unroll
             for (int s = 0; s < 3; ++s)
                 bf[t][s] = *reinterpret_cast<const bf16x8*>(stage + b_frag + s * (2 * SN * 16) + t * (SV * 16));
-        if (more && ABL == 4) {                            // dev: the next chunk's pieces in one burst in front of the MFMAs
+        if (AHEAD2 && (issue || ABL == 7)) {               // every wave holds its fragments: the stage may be refilled
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (issue && ABL == 4) {                           // dev: the pieces in one burst in front of the MFMAs
 #pragma unroll
             for (int j = 0; j < C::PER_WAVE; ++j) dma_piece(j, nbuf, nx, nb);
         }
@@ -186,20 +205,29 @@ __global__ __launch_bounds__(SplitCfg<MG>::THREADS, SplitCfg<MG>::WAVES_PER_SIMD
                 if (ABL == 3) { acc[t][p] += (float)af[PA[p]][0] * (float)bf[t][PB[p]][0]; continue; }
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[p]], bf[t][PB[p]], acc[t], 0, 0, 0);
             }
-            if (more && p < C::PER_WAVE && ABL != 4) {     // the next chunk's pieces go out between the MFMAs, not in a burst
+            if (issue && p < C::PER_WAVE && ABL != 4) {    // the pieces go out between the MFMAs, not in a burst
                 __builtin_amdgcn_sched_barrier(0);
                 dma_piece(p, nbuf, nx, nb);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
-    if (ABL != 2) {
-        for (int c = 0; c + 1 < nchunks; ++c) do_chunk(std::true_type(), c);
-        do_chunk(std::false_type(), nchunks - 1);
-    } else {
+    if (ABL == 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (AHEAD2) {
+        if (nchunks > 1) {
+#pragma unroll
+            for (int j = 0; j < C::PER_WAVE; ++j) dma_piece(j, 1, x_src + S_XB, b_src + S_BB);
+        }
+        int c = 0;
+        for (; c + 2 < nchunks; ++c) do_chunk(std::true_type(), std::true_type(), c);
+        if (nchunks > 1) do_chunk(std::true_type(), std::false_type(), c++);
+        do_chunk(std::false_type(), std::false_type(), c);
+    } else {
+        for (int c = 0; c + 1 < nchunks; ++c) do_chunk(std::false_type(), std::true_type(), c);
+        do_chunk(std::false_type(), std::false_type(), nchunks - 1);
     }
-    if (ABL == 1 || ABL == 3) {                            // K loop only: one never-taken store keeps the accumulators alive
+    if (ABL == 1 || ABL == 3 || ABL == 6 || ABL == 7) {                            // K loop only: one never-taken store keeps the accumulators alive
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += acc[0][r] + acc[1][r] + acc[2][r];
@@ -356,6 +384,9 @@ extern "C" int hps_smpl_mesh_fused_shared_shape_bf16x3(const void* xsplit, const
     if (mg == 4 && g_split_abl == 2) return launch_split<4, 2>(HPS_SPLIT_ARGS);
     if (mg == 4 && g_split_abl == 3) return launch_split<4, 3>(HPS_SPLIT_ARGS);
     if (mg == 4 && g_split_abl == 4) return launch_split<4, 4>(HPS_SPLIT_ARGS);
+    if (mg == 4 && g_split_abl == 5) return launch_split<4, 5>(HPS_SPLIT_ARGS);
+    if (mg == 4 && g_split_abl == 6) return launch_split<4, 6>(HPS_SPLIT_ARGS);
+    if (mg == 4 && g_split_abl == 7) return launch_split<4, 7>(HPS_SPLIT_ARGS);
 #undef HPS_SPLIT_ARGS
     if (mg == 2) return launch_split<2>(xsplit, bsplit, v_shaped, mesh_row, group_rows, a, w_idx, w_val, verts, M, V, rows, pick_slot, picked, n_picked, (hipStream_t)stream);
 #endif

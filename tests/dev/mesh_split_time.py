@@ -52,7 +52,7 @@ def run(arith):
 
 
 ARITHS = ("f32", "bf16x3", "bf16x3-mg2")
-for arith in ARITHS + ("bf16x3-abl1", "bf16x3-abl2", "bf16x3-abl3", "bf16x3-abl4") + tuple("bf16x3-stag%d" % k for k in (2, 4, 6, 8, 10, 12, 16, 20)):
+for arith in ARITHS + ("bf16x3-abl1", "bf16x3-abl6", "bf16x3-abl7", "bf16x3-abl3", "bf16x3-abl1", "bf16x3-abl6", "bf16x3-abl7", "bf16x3-abl3", "bf16x3-abl2"):
     smpl.mesh_arith = arith.split("-")[0]
     if "stag" in arith:
         with _capi.dev_library() as lib:

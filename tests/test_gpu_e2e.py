@@ -503,6 +503,11 @@ def test_bench_line_has_every_leg(dev):
     assert st["workload"].startswith("BASELINE configs[4]") and st["images_per_s"] > 0 and st["results_finite"]
     assert st["sampler"]["proposals_per_s"] > 0 and 0 < st["mesh_kernel"]["frac"] < 1
     assert 0 < st["uncertainty_sweep1"]["frac"] < 1 and 0 < st["lbs_unfused"]["frac"] < 1
+    # the opt-in bf16x3 arithmetic of the mesh kernel under the same clock: faster kernel, vertices within rounding of the fp32-MFMA kernel's
+    mb = sec["mesh_bf16x3"]
+    assert mb["images_per_s"] > 0 and mb["mesh_kernel_ms"]["median_ms"] < r["avg_launch_ms"]
+    assert 0 < mb["max_abs_diff_vs_f32_m"]["verts_samples"] <= 4e-6 and mb["max_abs_diff_vs_f32_m"]["vertex_uncertainty"] <= 4e-6
+    assert st["mesh_bf16x3"]["images_per_s"] > 0 and d["config"]["mesh_arith"] == "f32"
     cl = d["cpu_baseline"]["latency_b1"]
     assert cl["all_threads"]["median_ms"] > 0 and cl["single_thread"]["cores"] == 1
     assert sec["lbs_unfused"]["frac"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["metric_checksums"]["images"] == 64 * 3
@@ -573,3 +578,42 @@ def test_result_checksums_match_float64_sums(dev):
     want = torch.stack([torch.tensor(5.0, dtype=torch.float64, device=dev), res["unc"].double().sum(),
                         res["verts_mode"].double().abs().sum(), res["joints_samples"].double().abs().sum()])
     assert maxerr(a, want) <= 1e-12 * float(want.abs().max())
+
+
+def test_bf16x3_mesh_arithmetic_end_to_end(dev, net_gpu, net_cpu, smpl_gpu, smpl_assets, golden_input):
+    """SMPL.mesh_arith = "bf16x3" through infer(), InferencePipeline and GraphedInfer: the three agree bit for bit among themselves, the
+    vertices stay within rounding (4e-6 m) of the default fp32-MFMA arithmetic and within the stated 1e-4 m of the oracle end to end, and
+    everything in front of the mesh kernel (head, samples) is untouched."""
+    from hierarchicalprobabilistic3dhuman_amd.predict_poseMF_shapeGaussian_net import InferencePipeline, GraphedInfer
+    x = golden_input.to(dev)
+    keys = ("pose_F", "R_samples", "verts_mode", "verts_tpose", "verts_samples", "joints_samples", "unc", "cam")
+    ref32 = infer(net_gpu, smpl_gpu, x, num_samples=9, seed=3)
+    smpl_gpu.mesh_arith = "bf16x3"
+    try:
+        a = infer(net_gpu, smpl_gpu, x, num_samples=9, seed=3)
+        pipe = InferencePipeline(net_gpu, smpl_gpu, num_samples=9)
+        b = pipe.finish(pipe.submit(x), seed=3)
+        g = GraphedInfer(net_gpu, smpl_gpu, batch=2, num_samples=9, slots=1)
+        c = g(x, seed=3)
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
+        del pipe, g
+    finally:
+        smpl_gpu.mesh_arith = "f32"
+    for k in ("pose_F", "R_samples", "cam"):
+        assert torch.equal(a[k], ref32[k]), k
+    for k in ("verts_mode", "verts_tpose", "verts_samples", "joints_samples", "unc"):
+        assert 0 <= maxerr(a[k], ref32[k]) <= 4e-6, k
+    assert not torch.equal(a["verts_samples"], ref32["verts_samples"])          # (the switch did select the other kernel)
+    # against the oracle on the reference's seed-reproducible route (the host noise stream), as test_infer_matches_oracle does for "f32"
+    torch.manual_seed(11)
+    ref = O.infer(net_cpu[1], smpl_assets[2], configs.SMPL_PARENTS, golden_input, 4)
+    smpl_gpu.mesh_arith = "bf16x3"
+    try:
+        torch.manual_seed(11)
+        out = infer(net_gpu, smpl_gpu, x, num_samples=4, sample_on_cpu=True)
+    finally:
+        smpl_gpu.mesh_arith = "f32"
+    for k in KEYS:
+        assert maxerr(out[k], ref[k]) <= 1e-4, k
