@@ -165,19 +165,20 @@ __global__ __launch_bounds__(SplitCfg<MG>::THREADS, SplitCfg<MG>::WAVES_PER_SIMD
     constexpr bool AHEAD2 = ABL != 5;
     const bool full_wave = C::NPIECES % SW == 0 || wave + SW * (C::PER_WAVE - 1) < C::NPIECES;      // this wave has PER_WAVE pieces per chunk
     auto do_chunk = [&](auto younger_c, auto issue_c, int c) __attribute__((always_inline)) {
-        constexpr bool younger = decltype(younger_c)::value && ABL != 6 && ABL != 7, issue = decltype(issue_c)::value && ABL != 6 && ABL != 7;
+        constexpr bool nostream = ABL == 6 || ABL == 7 || ABL == 8 || ABL == 9;
+        constexpr bool younger = decltype(younger_c)::value && !nostream, issue = decltype(issue_c)::value && !nostream;
         if (AHEAD2 && younger) {                           // chunk c has landed; chunk c + 1 (issued later) may still be in flight
             if (full_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PER_WAVE) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PER_WAVE - 1) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __syncthreads();                                   // ... for everyone
+        if (ABL != 8 && ABL != 9) __syncthreads();         // ... for everyone
         const int ahead = AHEAD2 ? 2 : 1;
         const char* nx = x_src + (size_t)(c + ahead) * S_XB;
         const char* nb = b_src + (size_t)(c + ahead) * S_BB;
         const int nbuf = (c + ahead) & 1;
-        const char* stage = sbytes + (c & 1) * S_STAGE;
+        const char* stage = sbytes + (ABL == 9 ? 0 : (c & 1)) * S_STAGE;
         bf16x8 af[3], bf[3][3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) af[s] = *reinterpret_cast<const bf16x8*>(stage + a_frag + s * (2 * SM * 16));
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(SplitCfg<MG>::THREADS, SplitCfg<MG>::WAVES_PER_SIMD
         for (int c = 0; c + 1 < nchunks; ++c) do_chunk(std::false_type(), std::true_type(), c);
         do_chunk(std::false_type(), std::false_type(), nchunks - 1);
     }
-    if (ABL == 1 || ABL == 3 || ABL == 6 || ABL == 7) {                            // K loop only: one never-taken store keeps the accumulators alive
+    if (ABL == 1 || ABL == 3 || (ABL >= 6 && ABL <= 9)) {                            // K loop only: one never-taken store keeps the accumulators alive
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += acc[0][r] + acc[1][r] + acc[2][r];
@@ -387,6 +388,8 @@ extern "C" int hps_smpl_mesh_fused_shared_shape_bf16x3(const void* xsplit, const
     if (mg == 4 && g_split_abl == 5) return launch_split<4, 5>(HPS_SPLIT_ARGS);
     if (mg == 4 && g_split_abl == 6) return launch_split<4, 6>(HPS_SPLIT_ARGS);
     if (mg == 4 && g_split_abl == 7) return launch_split<4, 7>(HPS_SPLIT_ARGS);
+    if (mg == 4 && g_split_abl == 8) return launch_split<4, 8>(HPS_SPLIT_ARGS);
+    if (mg == 4 && g_split_abl == 9) return launch_split<4, 9>(HPS_SPLIT_ARGS);
 #undef HPS_SPLIT_ARGS
     if (mg == 2) return launch_split<2>(xsplit, bsplit, v_shaped, mesh_row, group_rows, a, w_idx, w_val, verts, M, V, rows, pick_slot, picked, n_picked, (hipStream_t)stream);
 #endif

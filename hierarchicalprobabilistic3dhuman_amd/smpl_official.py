@@ -179,17 +179,30 @@ class SMPL(nn.Module):
         dev = self.v_template.device
         return torch.from_numpy(full).to(dev), torch.from_numpy(groups.reshape(-1)).to(dev)
 
-    def _blend_matrix_split(self):
-        """The pose rows of the panel-permuted blend matrix as bf16 piece planes in MFMA fragment order (once per model and device)."""
+    def _blend_matrix_split(self, with_shape_rows=False):
+        """The panel-permuted blend matrix as bf16 piece planes in MFMA fragment order (once per model and device): the 207 pose rows
+        (shared shapes) or, ``with_shape_rows``, all num_betas + 207 rows (the shape blend inside the GEMM)."""
         dev = self._bmat_p.device
-        if self._bsplit is None or self._bsplit.device != dev:
-            nb, rows = self.num_betas, self._n_pose
-            n = _capi.load().hps_smpl_split_bf16x3_bytes(rows, self._np_fused)
+        if self._bsplit is None or self._bsplit[0] != dev:
+            self._bsplit = (dev, {})
+        cache = self._bsplit[1]
+        if with_shape_rows not in cache:
+            first, rows = (0, self.num_betas + self._n_pose) if with_shape_rows else (self.num_betas, self._n_pose)
+            n = _capi.load(dev=_capi._use_dev).hps_smpl_split_bf16x3_bytes(rows, self._np_fused)
             buf = torch.empty(n, dtype=torch.uint8, device=dev)
-            _capi.call("hps_smpl_split_bf16x3", _capi._P(self._bmat_p.data_ptr() + 4 * nb * self._np_fused), rows, self._np_fused,
+            _capi.call("hps_smpl_split_bf16x3", _capi._P(self._bmat_p.data_ptr() + 4 * first * self._np_fused), rows, self._np_fused,
                        self._np_fused, 192, _capi._P(buf.data_ptr()), _capi.stream())
-            self._bsplit = buf
-        return self._bsplit
+            cache[with_shape_rows] = buf
+        return cache[with_shape_rows]
+
+    def _one_shape_tables(self, mp):
+        """(mesh_row, group_rows) of the bf16x3 kernel for a call whose meshes do NOT share shapes: one template row (v_template) for all."""
+        dev = self.v_template.device
+        key = (dev, mp)
+        if getattr(self, "_one_shape", (None,))[0] != key:
+            groups = torch.tensor([0, 0, 32], dtype=torch.int32).repeat(mp // 32)
+            self._one_shape = (key, torch.zeros(mp, dtype=torch.int32, device=dev), groups.to(dev))
+        return self._one_shape[1], self._one_shape[2]
 
     # ------------------------------------------------------------------------------------------
     def forward(self, betas=None, body_pose=None, global_orient=None, transl=None, pose2rot=True,
@@ -243,7 +256,10 @@ class SMPL(nn.Module):
         v_shaped = None
         if self.mesh_arith not in ("f32", "bf16x3"):
             raise ValueError("mesh_arith must be 'f32' or 'bf16x3', got %r" % (self.mesh_arith,))
-        split = shared is not None and self.mesh_arith == "bf16x3"
+        # bf16x3: the shared-shape form (207 pose rows), or -- no shared shapes, SMPL configuration, no translation -- the same kernel over
+        # all 217 rows with v_template as the one "shaped template" (the shape blend inside the GEMM, as in the fp32 K = 217 form)
+        split = self.mesh_arith == "bf16x3" and use_picks and tr is None and self.fused_mesh
+        split_rows = (self.num_betas, self._n_pose) if shared is not None else (0, self.num_betas + self._n_pose)      # (first row, rows)
         xsplit = bsplit = None
         if shared is not None:
             sb = _capi.f32c(shared[0])
@@ -254,10 +270,11 @@ class SMPL(nn.Module):
                    P(self._j_shapedirs), _capi.iptr(self._parents_i32), _capi.iptr(self._depth_i32), J, P(xt),
                    self._kp, mp, P(a), P(j_posed), None, M, s)
         if split:
-            bsplit = self._blend_matrix_split()
-            xsplit = torch.empty(_capi.load().hps_smpl_split_bf16x3_bytes(self._n_pose, mp), dtype=torch.uint8, device=dev)
-            _capi.call("hps_smpl_split_bf16x3", _capi._P(xt.data_ptr() + 4 * self.num_betas * mp), self._n_pose, mp, mp,
-                       _capi.load(dev=_capi._use_dev).hps_smpl_split_bf16x3_mesh_tile(), _capi._P(xsplit.data_ptr()), s)
+            lib = _capi.load(dev=_capi._use_dev)
+            bsplit = self._blend_matrix_split(with_shape_rows=shared is None)
+            xsplit = torch.empty(lib.hps_smpl_split_bf16x3_bytes(split_rows[1], mp), dtype=torch.uint8, device=dev)
+            _capi.call("hps_smpl_split_bf16x3", _capi._P(xt.data_ptr() + 4 * split_rows[0] * mp), split_rows[1], mp, mp,
+                       lib.hps_smpl_split_bf16x3_mesh_tile(), _capi._P(xsplit.data_ptr()), s)
         # InferencePipeline: only the chip-filling mesh kernel(s) run alone; pose prep (before) and the joint regression (after)
         # may share the GPU with the neighbouring batches' encoders
         if kwargs.get("_before_mesh") is not None:
@@ -284,9 +301,11 @@ class SMPL(nn.Module):
             if ev is not None:
                 ev[0].record()
             if split:
-                _capi.call("hps_smpl_mesh_fused_shared_shape_bf16x3", _capi._P(xsplit.data_ptr()), _capi._P(bsplit.data_ptr()), P(v_shaped),
-                           _capi.iptr(shared[1]), _capi.iptr(shared[2]), P(a), _capi.iptr(self._w_idx), P(self._w_val), self._lbs_k, J,
-                           P(verts), M, V, self._n_pose, mp, _capi.iptr(self._pick_slot), P(picked), self._n_picked, s)
+                rows_t, groups_t = (shared[1], shared[2]) if shared is not None else self._one_shape_tables(mp)
+                _capi.call("hps_smpl_mesh_fused_shared_shape_bf16x3", _capi._P(xsplit.data_ptr()), _capi._P(bsplit.data_ptr()),
+                           P(v_shaped) if shared is not None else P(self._v_template_flat), _capi.iptr(rows_t), _capi.iptr(groups_t), P(a),
+                           _capi.iptr(self._w_idx), P(self._w_val), self._lbs_k, J, P(verts), M, V, split_rows[1], mp,
+                           _capi.iptr(self._pick_slot), P(picked), self._n_picked, s)
             elif shared is not None:
                 nb = self.num_betas
                 _capi.call("hps_smpl_mesh_fused_shared_shape", _capi._P(xt.data_ptr() + 4 * nb * mp), _capi._P(self._bmat_p.data_ptr() + 4 * nb * self._np_fused),

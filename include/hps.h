@@ -206,7 +206,9 @@ int hps_smpl_v_shaped(const float* betas, int num_betas, const float* shape_rows
  *     advanced likewise) -> dst[tile][16-row chunk][piece][k half][column][8 bf16], hps_smpl_split_bf16x3_bytes(rows, cols) bytes.
  *     The blend matrix is split once per model, the mesh operand once per call.
  *   hps_smpl_mesh_fused_shared_shape_bf16x3: xsplit / bsplit from the above (rows = 207 for SMPL); everything else as for
- *     hps_smpl_mesh_fused_shared_shape.  K = 4, 24 joints; HPS_E_UNSUPPORTED otherwise. */
+ *     hps_smpl_mesh_fused_shared_shape.  K = 4, 24 joints; HPS_E_UNSUPPORTED otherwise.  Meshes that do NOT share shapes take the same
+ *     entry point with the operands split from row 0 (rows = num_betas + 207: the shape blend inside the GEMM, as in
+ *     hps_smpl_mesh_fused), v_shaped = v_template (one row), mesh_row all 0 and every group (0, 0, 32) -- what SMPL.forward does. */
 size_t hps_smpl_split_bf16x3_bytes(int rows, int cols);
 int hps_smpl_split_bf16x3_mesh_tile(void);   /* tile_cols of the mesh operand = meshes per workgroup tile of the kernel (128) */
 int hps_smpl_split_bf16x3(const float* src, int rows, int ld, int cols, int tile_cols, void* dst, hps_stream_t stream);

@@ -52,7 +52,7 @@ def run(arith):
 
 
 ARITHS = ("f32", "bf16x3", "bf16x3-mg2")
-for arith in ARITHS + ("bf16x3-abl1", "bf16x3-abl6", "bf16x3-abl7", "bf16x3-abl3", "bf16x3-abl1", "bf16x3-abl6", "bf16x3-abl7", "bf16x3-abl3", "bf16x3-abl2"):
+for arith in ARITHS + ("bf16x3-abl6", "bf16x3-abl8", "bf16x3-abl9", "bf16x3-abl6", "bf16x3-abl8", "bf16x3-abl9"):
     smpl.mesh_arith = arith.split("-")[0]
     if "stag" in arith:
         with _capi.dev_library() as lib:

@@ -556,7 +556,8 @@ def test_split_bf16_form_of_the_mesh_kernel(B, N, dev, smpl_gpu, smpl_assets):
     """SMPL.mesh_arith = "bf16x3" (hps_smpl_mesh_fused_shared_shape_bf16x3: the pose blend GEMM as six exact bf16 piece products per
     product, fp32 accumulation) on infer()'s mesh layout: within rounding of the fp32-MFMA form (4e-6 m), within the stated 2e-5 m of the
     oracle, and NO FURTHER from the float64 twin than the fp32-MFMA form is (fp32 accuracy, not fp32 bits); the joints follow from the
-    side output.  Calls the shared-shape form does not cover keep the fp32 kernel whatever the switch says."""
+    side output.  Without shared shapes the same kernel runs over all 217 rows (shape blend inside the GEMM); a call with a translation
+    keeps the fp32 kernel whatever the switch says."""
     model, extra, p = smpl_assets
     g = torch.Generator().manual_seed(7000 * B + N)
     loc = torch.randn(B, 10, generator=g)
@@ -569,24 +570,31 @@ def test_split_bf16_form_of_the_mesh_kernel(B, N, dev, smpl_gpu, smpl_assets):
     mesh_row, group_rows = smpl_gpu.shared_shape_tables(rows)
     args = dict(betas=betas.to(dev), body_pose=R[:, 1:].to(dev), global_orient=R[:, :1].to(dev), pose2rot=False)
     f32 = smpl_gpu(_shared_shapes=(loc.to(dev), mesh_row, group_rows), **args)
+    plain32 = smpl_gpu(**args)
+    tr = torch.randn(M, 3, generator=g).to(dev)
+    moved32 = smpl_gpu(transl=tr, **args)
     smpl_gpu.mesh_arith = "bf16x3"
     try:
         sp = smpl_gpu(_shared_shapes=(loc.to(dev), mesh_row, group_rows), **args)
         sp2 = smpl_gpu(_shared_shapes=(loc.to(dev), mesh_row, group_rows), **args)
-        plain = smpl_gpu(**args)                                  # no shared shapes: the fp32 K = 217 form
+        plain = smpl_gpu(**args)                                  # no shared shapes: the same kernel over all 217 rows
+        moved = smpl_gpu(transl=tr, **args)                       # a translation: the fp32 kernel
     finally:
         smpl_gpu.mesh_arith = "f32"
     assert torch.equal(sp.vertices, sp2.vertices) and torch.equal(sp.joints, sp2.joints)           # deterministic
     assert maxerr(sp.vertices, f32.vertices) <= 4e-6 and maxerr(sp.joints, f32.joints) <= 4e-6
-    assert maxerr(plain.vertices, f32.vertices) <= 4e-6
+    assert maxerr(plain.vertices, plain32.vertices) <= 4e-6 and maxerr(plain.joints, plain32.joints) <= 4e-6
+    assert not torch.equal(plain.vertices, plain32.vertices) and not torch.equal(sp.vertices, f32.vertices)     # (the other kernel did run)
+    assert torch.equal(moved.vertices, moved32.vertices) and torch.equal(moved.joints, moved32.joints)
     pick = torch.arange(M) if M <= 300 else torch.cat([torch.arange(0, 3), torch.arange(B, B + 3), torch.arange(2 * B, 2 * B + 70),
                                                          torch.arange(M - 40, M)])
     ref = O.smpl_forward(p, betas=betas[pick], body_pose=R[pick, 1:], global_orient=R[pick, :1], pose2rot=False)
     assert maxerr(sp.vertices[pick.to(dev)], ref["vertices"]) <= TOL and maxerr(sp.joints[pick.to(dev)], ref["joints"]) <= TOL
     v64, j64 = smpl_forward64(model, extra, configs.SMPLX_EXTRA_VERTEX_IDS, betas[pick].double().numpy(), R[pick].double().numpy())
-    e_sp = np.abs(sp.vertices[pick.to(dev)].cpu().numpy() - v64)
-    e_f32 = np.abs(f32.vertices[pick.to(dev)].cpu().numpy() - v64)
-    assert e_sp.max() <= max(1.25 * e_f32.max(), 1e-6) and e_sp.mean() <= 1.1 * e_f32.mean() + 1e-9, (e_sp.max(), e_f32.max(), e_sp.mean(), e_f32.mean())
+    for got, base in ((sp, f32), (plain, plain32)):
+        e_sp = np.abs(got.vertices[pick.to(dev)].cpu().numpy() - v64)
+        e_f32 = np.abs(base.vertices[pick.to(dev)].cpu().numpy() - v64)
+        assert e_sp.max() <= max(1.25 * e_f32.max(), 1e-6) and e_sp.mean() <= 1.1 * e_f32.mean() + 1e-9, (e_sp.max(), e_f32.max(), e_sp.mean(), e_f32.mean())
     with pytest.raises(ValueError):
         smpl_gpu.mesh_arith = "bf16"
         try:
