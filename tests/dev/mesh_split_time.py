@@ -1,5 +1,8 @@
 """Dev: the bf16x3 form of the shared-shape mesh kernel against the fp32-MFMA form -- accuracy vs the float64 twin and kernel time
-(B = 64, N = 100 = 6 528 meshes).  python tests/dev/mesh_split_time.py [--reps 30]"""
+(B = 64, N = 100 = 6 528 meshes).  python tests/dev/mesh_split_time.py [--reps 30] [--ablations]
+Ablations (dev library, timing only unless noted): abl1 K loop only, abl2 skinning only, abl3 operand stream without MFMAs, abl6 K loop
+without the operand stream, abl8 ... and without barriers, abl5 operands one chunk ahead (valid), abl4 DMA pieces in a burst (valid),
+stagN start delay of every CU's second workgroup."""
 import argparse
 import os
 import sys
@@ -17,6 +20,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--B", type=int, default=64)
 ap.add_argument("--N", type=int, default=100)
+ap.add_argument("--only", default=None, help="run one arithmetic only (f32 | bf16x3), no accuracy table: for rocprofv3 --pmc passes")
+ap.add_argument("--ablations", action="store_true", help="also time the dev library's ablations of the bf16x3 kernel")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 model = smpl_data.synthetic_smpl_model(0)
@@ -51,8 +56,13 @@ def run(arith):
     print("%-12s mesh kernel: median %.4f ms  min %.4f  max %.4f" % (arith, ts[len(ts) // 2], ts[0], ts[-1]), flush=True)
 
 
-ARITHS = ("f32", "bf16x3", "bf16x3-mg2")
-for arith in ARITHS + ("bf16x3-abl6", "bf16x3-abl8", "bf16x3-abl9", "bf16x3-abl6", "bf16x3-abl8", "bf16x3-abl9"):
+if a.only:
+    smpl.mesh_arith = a.only
+    run(a.only)
+    sys.exit(0)
+ARITHS = ("f32", "bf16x3", "f32", "bf16x3", "bf16x3-mg2")
+ABLATIONS = ("bf16x3-abl1", "bf16x3-abl2", "bf16x3-abl3", "bf16x3-abl6", "bf16x3-abl8", "bf16x3-abl5", "bf16x3-abl4", "bf16x3-stag0", "bf16x3-stag8") if a.ablations else ()
+for arith in ARITHS + ABLATIONS:
     smpl.mesh_arith = arith.split("-")[0]
     if "stag" in arith:
         with _capi.dev_library() as lib:

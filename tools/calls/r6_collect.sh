@@ -37,3 +37,15 @@ import json,sys; d=json.loads(sys.stdin.read()); print('unc mode $m: %6d images/
 } > $OUT/ab.txt 2>&1
 bash tools/calls/next_rows_stats.sh > $OUT/next_rows_stats.log 2>&1
 cat $OUT/ab.txt
+# the opt-in bf16x3 arithmetic of the mesh kernel: interleaved A/B of the headline, the kernel alone with its ablations, counters, the bf16 MFMA ceiling
+{
+echo "==== bench.py $Q --split-steps 0 [--mesh-arith bf16x3]: three interleaved pairs ===="
+for rep in 1 2 3; do one --split-steps 0; one --split-steps 0 --mesh-arith bf16x3; done
+echo "==== tests/dev/mesh_split_time.py --ablations (6 528 meshes, kernel alone) ===="
+python tests/dev/mesh_split_time.py --ablations 2>&1 | grep -v amdgpu.ids
+echo "==== tools/bin/mfma_bf16_peak ===="
+tools/bin/mfma_bf16_peak
+echo "==== tools/mesh_split_pmc.sh ===="
+bash tools/mesh_split_pmc.sh 2>&1
+} > $OUT/mesh_bf16x3.txt 2>&1
+cat $OUT/mesh_bf16x3.txt | tail -60

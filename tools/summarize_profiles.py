@@ -89,6 +89,8 @@ if os.path.exists(stats_p):
         ("stem_wino_kernel", "stem 7x7/2 in Winograd form + the 3x3/2 max pool in its epilogue (direct-convolution FLOPs; the MFMA pipe does 81/196 of them)", "mfma", stem_flop, "flop"),
         ("conv_", "the other 19 ResNet-18 convolutions, direct + Winograd F(2x2,3x3) (all launches of a step together; direct-convolution FLOPs)", "mfma", enc_flop - stem_flop, "flop/step"),
         ("mesh_fused_kernel", "blend GEMM + LBS, fused (FLOPs by SURVEY 8(d)'s K = 217 per mesh; the shared-shape form multiplies 207 rows per mesh)", "mfma", 2.0 * 217 * 3 * V * M, "flop"),
+        ("mesh_split_kernel", "the same kernel with the pose blend GEMM as six bf16 piece products per product (opt-in bf16x3 arithmetic; launched by bench.py's secondary.mesh_bf16x3 leg only; FLOPs: the fp32-equivalent 2 x 207 x 3 V per mesh)", "mfma", 2.0 * 207 * 3 * V * M, "flop"),
+        ("split_bf16x3_kernel", "the mesh operand of a call as bf16 piece planes (bf16x3 leg only)", "hbm", M * 208 * 10.0, "bytes"),
         ("uncertainty_joints_kernel", "per-vertex sample uncertainty + the joint regression of every mesh, one launch (bytes: sample vertices read once + uncertainties + the compact regressor vertices + joints)", "hbm",
          (B * N * V * 12.0 + B * V * 4.0) + M * (198 * 12.0 + 90 * 12.0 + 24 * 12.0), "bytes"),
         ("uncertainty_reg_kernel", "per-vertex sample uncertainty", "hbm", (B * N * V * 12.0 + B * V * 4.0), "bytes"),
@@ -146,5 +148,6 @@ for a, b in (("bench_driver_flags.json", "_bench_driver_flags.json"), ("latency_
              ("latency_b1_timeline.txt", "_latency_b1_timeline.txt"), ("next_rows.txt", "_next_rows.txt"),
              ("predict_time.txt", "_predict_time.txt"), ("mesh_pmc_lds.txt", "_mesh_pmc_lds.txt"), ("ab.txt", "_ab.txt"),
              ("step_launches.txt", "_step_launches.txt"), ("step_timeline.txt", "_step_timeline.txt"),
-             ("next_rows_stats.log", "_next_rows_kernels.txt"), ("bench_nographlat.json", "_bench_nographlat.json")):
+             ("next_rows_stats.log", "_next_rows_kernels.txt"), ("bench_nographlat.json", "_bench_nographlat.json"),
+             ("mesh_bf16x3.txt", "_mesh_bf16x3.txt")):
     copy(a, tag + b)
