@@ -410,6 +410,47 @@ def main():
     enc_ms = [e0.elapsed_time(e1) for (e0, e1) in enc_events_kept]
     smp_ms = [e0.elapsed_time(e1) for (e0, e1) in (sampling_utils.launch_events or [])]
     pipe.enc_events, sampling_utils.launch_events = None, None
+    # The opt-in arithmetic of the mesh kernel under the same clock: the same pipelined steps with SMPL.mesh_arith = "bf16x3" (the pose
+    # blend GEMM on the bf16 matrix pipe at fp32 accuracy: csrc/mesh_split.hip), a few steps RIGHT AFTER the timed region -- before the
+    # other legs create their own streams and pipelines (behind the configs[4] leg's CU-partition queues the same steps measured 0-30 %
+    # slower, run to run) --, wall clock + the kernel's own HIP events; and how far its vertices are from the fp32-MFMA kernel's on one
+    # batch (same seed, same samples).
+    mesh_bf16x3 = None
+    if args.split_steps > 0 and world == 1 and not args.no_pipeline and args.mesh_arith == "f32" and fused_path_ok(smpl):
+        ref = infer(net, smpl, x, num_samples=N, use_mean_shape=True, seed=31337, image_offset=lo)
+        smpl.mesh_arith = "bf16x3"
+        try:
+            alt = infer(net, smpl, x, num_samples=N, use_mean_shape=True, seed=31337, image_offset=lo)
+            dv = float((alt["verts_samples"] - ref["verts_samples"]).abs().max()) if "verts_samples" in alt else None
+            dm = float((alt["verts_mode"] - ref["verts_mode"]).abs().max())
+            du = float((alt["unc"] - ref["unc"]).abs().max())
+            del ref, alt
+            run_steps(0, 4)
+            torch.cuda.synchronize()
+            smpl.lbs_events = ev_lists["lbs"] = []
+            pipe.enc_events = ev_lists["enc"] = []
+            t_a = time.perf_counter()
+            run_steps(4, args.split_steps)
+            torch.cuda.synchronize()
+            dt_b = time.perf_counter() - t_a
+            b_mesh = [e0.elapsed_time(e1) for (m, e0, e1) in ev_lists["lbs"] if m == M]
+            b_enc = [e0.elapsed_time(e1) for (e0, e1) in ev_lists["enc"]]
+        finally:
+            smpl.mesh_arith = "f32"
+            smpl.lbs_events = pipe.enc_events = None
+            ev_lists["lbs"] = ev_lists["enc"] = None
+        bm = spread(b_mesh)
+        mesh_bf16x3 = {"images_per_s": B * args.split_steps / dt_b, "ms_per_step": dt_b / args.split_steps * 1e3, "steps": args.split_steps,
+                       "vs_headline": (B * args.split_steps / dt_b) / (B * world * args.steps / dt),
+                       "mesh_kernel": "hps::mesh_split_kernel<4,24,4,0>", "mesh_kernel_ms": bm, "encoder_avg_ms": sum(b_enc) / max(1, len(b_enc)),
+                       "max_abs_diff_vs_f32_m": {"verts_samples": dv, "verts_mode": dm, "vertex_uncertainty": du},
+                       "blend_tflops_fp32_equivalent": (2 * 207 * 3 * 6890 * M / (bm["median_ms"] * 1e-3) / 1e12) if bm else None,
+                       "issued_bf16_tflops": (6 * 2 * 208 * 3 * 6912 * M / (bm["median_ms"] * 1e-3) / 1e12) if bm else None,
+                       "note": "opt-in (SMPL.mesh_arith = 'bf16x3', bench.py --mesh-arith bf16x3 makes it the headline's kernel): every fp32 operand of "
+                               "the pose blend GEMM as three bf16 pieces (exact split), six exact piece products per product on "
+                               "v_mfma_f32_32x32x16_bf16, fp32 accumulation -- as close to the float64 twin as the fp32-MFMA kernel "
+                               "(tests/test_gpu_smpl.py::test_split_bf16_form_of_the_mesh_kernel), not the same bits.  The default keeps "
+                               "the reference's arithmetic type in every instruction."}
     # SURVEY 8(d)'s LBS kernel itself (BASELINE's "LBS HBM GB/s"): the product path skins inside the blend GEMM's epilogue,
     # so after the timed region the same workload is run a few more steps with the unfused pair hps_smpl_blend + hps_smpl_lbs
     # (bit-identical vertices) and the hps_smpl_lbs launches are timed with HIP events on their stream, like the product kernel.
@@ -644,45 +685,6 @@ def main():
                   "lbs_unfused": ({"median_ms": lbs_ms_s, "bound": "hbm", "achieved": LBS_BYTES_PER_MESH * Ms / (lbs_ms_s * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": LBS_BYTES_PER_MESH * Ms / (lbs_ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "note": "hps_smpl_lbs alone at %d meshes (not on the product path)" % Ms} if lbs_ms_s else None)}
-    # The opt-in arithmetic of the mesh kernel under the same clock: the same pipelined steps with SMPL.mesh_arith = "bf16x3" (the pose blend
-    # GEMM on the bf16 matrix pipe at fp32 accuracy: csrc/mesh_split.hip), a few steps after the timed region, wall clock + the kernel's
-    # own HIP events; and how far its vertices are from the fp32-MFMA kernel's on one batch (same seed, same samples).
-    mesh_bf16x3 = None
-    if args.split_steps > 0 and world == 1 and not args.no_pipeline and args.mesh_arith == "f32" and fused_path_ok(smpl):
-        ref = infer(net, smpl, x, num_samples=N, use_mean_shape=True, seed=31337, image_offset=lo)
-        smpl.mesh_arith = "bf16x3"
-        try:
-            alt = infer(net, smpl, x, num_samples=N, use_mean_shape=True, seed=31337, image_offset=lo)
-            dv = float((alt["verts_samples"] - ref["verts_samples"]).abs().max()) if "verts_samples" in alt else None
-            dm = float((alt["verts_mode"] - ref["verts_mode"]).abs().max())
-            du = float((alt["unc"] - ref["unc"]).abs().max())
-            del ref, alt
-            run_steps(0, 4)
-            torch.cuda.synchronize()
-            smpl.lbs_events = ev_lists["lbs"] = []
-            pipe.enc_events = ev_lists["enc"] = []
-            t_a = time.perf_counter()
-            run_steps(4, args.split_steps)
-            torch.cuda.synchronize()
-            dt_b = time.perf_counter() - t_a
-            b_mesh = [e0.elapsed_time(e1) for (m, e0, e1) in ev_lists["lbs"] if m == M]
-            b_enc = [e0.elapsed_time(e1) for (e0, e1) in ev_lists["enc"]]
-        finally:
-            smpl.mesh_arith = "f32"
-            smpl.lbs_events = pipe.enc_events = None
-            ev_lists["lbs"] = ev_lists["enc"] = None
-        bm = spread(b_mesh)
-        mesh_bf16x3 = {"images_per_s": B * args.split_steps / dt_b, "ms_per_step": dt_b / args.split_steps * 1e3, "steps": args.split_steps,
-                       "vs_headline": (B * args.split_steps / dt_b) / (B * world * args.steps / dt),
-                       "mesh_kernel": "hps::mesh_split_kernel<4,24,4,0>", "mesh_kernel_ms": bm, "encoder_avg_ms": sum(b_enc) / max(1, len(b_enc)),
-                       "max_abs_diff_vs_f32_m": {"verts_samples": dv, "verts_mode": dm, "vertex_uncertainty": du},
-                       "blend_tflops_fp32_equivalent": (2 * 207 * 3 * 6890 * M / (bm["median_ms"] * 1e-3) / 1e12) if bm else None,
-                       "issued_bf16_tflops": (6 * 2 * 208 * 3 * 6912 * M / (bm["median_ms"] * 1e-3) / 1e12) if bm else None,
-                       "note": "opt-in (SMPL.mesh_arith = 'bf16x3', bench.py --mesh-arith bf16x3 makes it the headline's kernel): every fp32 operand of "
-                               "the pose blend GEMM as three bf16 pieces (exact split), six exact piece products per product on "
-                               "v_mfma_f32_32x32x16_bf16, fp32 accumulation -- as close to the float64 twin as the fp32-MFMA kernel "
-                               "(tests/test_gpu_smpl.py::test_split_bf16_form_of_the_mesh_kernel), not the same bits.  The default keeps "
-                               "the reference's arithmetic type in every instruction."}
     secondary = {}
     if mesh_bf16x3:
         secondary["mesh_bf16x3"] = mesh_bf16x3

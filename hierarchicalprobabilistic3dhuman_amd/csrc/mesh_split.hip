@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 
 // ABL (dev library only): 1 = K loop only (no skinning), 2 = skinning only (no K loop), 3 = K loop without its MFMAs (operand stream only),
 // 4 = DMA pieces in a burst, 5 = operands one chunk ahead (the fp32 kernel's scheme); 4 and 5 give valid results; 6 = K loop only WITHOUT the operand stream after the first two chunks
-// (MFMAs, fragment reads, one barrier per chunk), 7 = 6 with the second barrier
+// (MFMAs, fragment reads, one barrier per chunk), 7 = 6 with the second barrier, 8 = 6 without barriers, 9 = 8 on one stage;
+// skinning only (like 2): 10 = without the DMA of the transforms, 11 = without the stores, 12 = without the skinning arithmetic (v_posed stored)
 template <int K, int JC, int MG, int ABL = 0>
 __global__ __launch_bounds__(SplitCfg<MG>::THREADS, SplitCfg<MG>::WAVES_PER_SIMD) void mesh_split_kernel(
     const char* __restrict__ xsplit, const char* __restrict__ bsplit, const float* __restrict__ v_shaped, const float* __restrict__ a,
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(SplitCfg<MG>::THREADS, SplitCfg<MG>::WAVES_PER_SIMD
             }
         }
     };
-    if (ABL == 2) {
+    if (ABL == 2 || ABL >= 10) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if (AHEAD2) {
         if (nchunks > 1) {
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(SplitCfg<MG>::THREADS, SplitCfg<MG>::WAVES_PER_SIMD
                 const float* a_src = a + (size_t)mh * a_stride;
                 for (int piece = wave; piece * 1024 < half_bytes; piece += SW) {
                     const int off = piece * 1024 + lane * 16;
-                    if (off < valid) lds_dma16((unsigned)off, a_src, lds0 + (unsigned)(h * half_bytes + piece * 1024));
+                    if (off < valid && ABL != 10) lds_dma16((unsigned)off, a_src, lds0 + (unsigned)(h * half_bytes + piece * 1024));
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -283,8 +284,12 @@ __global__ __launch_bounds__(SplitCfg<MG>::THREADS, SplitCfg<MG>::WAVES_PER_SIMD
                 int ao[K];
 #pragma unroll
                 for (int k = 0; k < K; ++k) ao[k] = aoff[k] + ds * a_stride;
-                const f3 o = skin_vertex<K>(smem, ao, w, pv, 0.f, 0.f, 0.f);
+                const f3 o = ABL == 12 ? pv : skin_vertex<K>(smem, ao, w, pv, 0.f, 0.f, 0.f);
                 asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z));      // (see mesh_fused_kernel: keeps the skinning out of the guarded block)
+                if (ABL == 11) {                           // dev: no stores (a never-true guard keeps the skinning alive)
+                    if (o.x == 12345.678f) *reinterpret_cast<f3*>(vbase + (size_t)dr * V * 12 + voff) = o;
+                    continue;
+                }
                 if (live_v && m < M) *reinterpret_cast<f3*>(vbase + (size_t)dr * V * 12 + voff) = o;
                 if (pick >= 0 && m < M) *reinterpret_cast<f3*>(pbase + (size_t)dr * n_picked * 12 + poff) = o;
             }
@@ -390,6 +395,9 @@ extern "C" int hps_smpl_mesh_fused_shared_shape_bf16x3(const void* xsplit, const
     if (mg == 4 && g_split_abl == 7) return launch_split<4, 7>(HPS_SPLIT_ARGS);
     if (mg == 4 && g_split_abl == 8) return launch_split<4, 8>(HPS_SPLIT_ARGS);
     if (mg == 4 && g_split_abl == 9) return launch_split<4, 9>(HPS_SPLIT_ARGS);
+    if (mg == 4 && g_split_abl == 10) return launch_split<4, 10>(HPS_SPLIT_ARGS);
+    if (mg == 4 && g_split_abl == 11) return launch_split<4, 11>(HPS_SPLIT_ARGS);
+    if (mg == 4 && g_split_abl == 12) return launch_split<4, 12>(HPS_SPLIT_ARGS);
 #undef HPS_SPLIT_ARGS
     if (mg == 2) return launch_split<2>(xsplit, bsplit, v_shaped, mesh_row, group_rows, a, w_idx, w_val, verts, M, V, rows, pick_slot, picked, n_picked, (hipStream_t)stream);
 #endif

@@ -21,6 +21,7 @@ ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--B", type=int, default=64)
 ap.add_argument("--N", type=int, default=100)
 ap.add_argument("--only", default=None, help="run one arithmetic only (f32 | bf16x3), no accuracy table: for rocprofv3 --pmc passes")
+ap.add_argument("--epilogue", action="store_true", help="the epilogue-only ablations")
 ap.add_argument("--ablations", action="store_true", help="also time the dev library's ablations of the bf16x3 kernel")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -62,6 +63,8 @@ if a.only:
     sys.exit(0)
 ARITHS = ("f32", "bf16x3", "f32", "bf16x3", "bf16x3-mg2")
 ABLATIONS = ("bf16x3-abl1", "bf16x3-abl2", "bf16x3-abl3", "bf16x3-abl6", "bf16x3-abl8", "bf16x3-abl5", "bf16x3-abl4", "bf16x3-stag0", "bf16x3-stag8") if a.ablations else ()
+if a.epilogue:
+    ARITHS, ABLATIONS = ("bf16x3",), ("bf16x3-abl2", "bf16x3-abl10", "bf16x3-abl11", "bf16x3-abl12") * 2
 for arith in ARITHS + ABLATIONS:
     smpl.mesh_arith = arith.split("-")[0]
     if "stag" in arith:
@@ -71,7 +74,7 @@ for arith in ARITHS + ABLATIONS:
             lib.hps_dev_mesh_split_stagger(-1)
     elif "abl" in arith:
         with _capi.dev_library() as lib:
-            lib.hps_dev_mesh_split_ablate(int(arith[-1]))
+            lib.hps_dev_mesh_split_ablate(int(arith.split("abl")[1]))
             run(arith)
             lib.hps_dev_mesh_split_ablate(0)
     elif arith.endswith("mg2"):
