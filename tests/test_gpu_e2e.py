@@ -617,3 +617,27 @@ def test_bf16x3_mesh_arithmetic_end_to_end(dev, net_gpu, net_cpu, smpl_gpu, smpl
         smpl_gpu.mesh_arith = "f32"
     for k in KEYS:
         assert maxerr(out[k], ref[k]) <= 1e-4, k
+
+
+@pytest.mark.parametrize("B,N", [(64, 100), (16, 1000)])
+def test_bf16x3_mesh_arithmetic_at_full_size(B, N, dev, net_gpu, smpl_gpu):
+    """BASELINE configs[1] and configs[4] with SMPL.mesh_arith = "bf16x3": finite, within rounding (4e-6 m) of the default arithmetic on
+    every vertex of every sample mesh, and a per-image output does not depend on the batch it was computed in -- an image alone, or a
+    half batch at another image offset, reproduces its slice BIT FOR BIT (a mesh's tile, neighbours and template group change, its sums do
+    not: the sharding invariance the multi-GPU path rests on)."""
+    x = torch.stack([torch.rand(18, 256, 256, generator=torch.Generator().manual_seed(3000 + i)) for i in range(B)]).to(dev)
+    ref = infer(net_gpu, smpl_gpu, x, num_samples=N, seed=21)
+    smpl_gpu.mesh_arith = "bf16x3"
+    try:
+        out = infer(net_gpu, smpl_gpu, x, num_samples=N, seed=21)
+        solo = infer(net_gpu, smpl_gpu, x[5:6], num_samples=N, seed=21, image_offset=5)
+        half = infer(net_gpu, smpl_gpu, x[B // 2:], num_samples=N, seed=21, image_offset=B // 2)
+    finally:
+        smpl_gpu.mesh_arith = "f32"
+    assert torch.equal(out["R_samples"], ref["R_samples"])
+    for k in ("verts_samples", "verts_mode", "verts_tpose", "joints_samples", "unc"):
+        assert torch.isfinite(out[k]).all(), k
+        assert maxerr(out[k], ref[k]) <= 4e-6, k
+    for k in ("verts_samples", "verts_mode", "verts_tpose", "joints_samples", "joints_mode", "unc"):
+        assert torch.equal(solo[k][0], out[k][5]), k
+        assert torch.equal(half[k], out[k][B // 2:]), k
