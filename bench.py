@@ -639,21 +639,6 @@ def main():
             finite = bool(torch.isfinite(r_last["unc"]).all())
             # ... and the same steps with the opt-in bf16x3 arithmetic of the mesh kernel (this configuration is the one the mesh kernel dominates)
             s_split = None
-            if args.split_steps > 0 and args.mesh_arith == "f32" and fused_path_ok(smpl):
-                smpl.mesh_arith = "bf16x3"
-                try:
-                    stress_steps(0, 3)
-                    torch.cuda.synchronize()
-                    smpl.lbs_events = []
-                    t_b = time.perf_counter()
-                    stress_steps(3, args.stress_steps)
-                    torch.cuda.synchronize()
-                    dt_sb = time.perf_counter() - t_b
-                    sb_mesh = [e0.elapsed_time(e1) for (m, e0, e1) in smpl.lbs_events if m == Ms]
-                finally:
-                    smpl.mesh_arith, smpl.lbs_events = "f32", None
-                s_split = {"images_per_s": Bs * args.stress_steps / dt_sb, "ms_per_step": dt_sb / args.stress_steps * 1e3,
-                           "mesh_kernel_median_ms": spread(sb_mesh)["median_ms"] if sb_mesh else None}
             # the unfused LBS kernel at this size (SURVEY 8(d)'s definition), a few sequential calls on the same stream
             smpl.fused_mesh, smpl.lbs_events = False, []
             for i in range(5):
@@ -661,6 +646,36 @@ def main():
             torch.cuda.synchronize()
             s_lbs = [e0.elapsed_time(e1) for (m, e0, e1) in smpl.lbs_events if m == Ms][2:]
             smpl.fused_mesh, smpl.lbs_events = True, None
+        # ... and the same steps with the opt-in bf16x3 arithmetic of the mesh kernel, on a pipeline of its own (the CU partition follows the
+        # arithmetic: 12 of every XCD's 32 CUs for the encoder instead of 8, InferencePipeline.encoder_cus)
+        if args.split_steps > 0 and args.mesh_arith == "f32" and fused_path_ok(smpl):
+            smpl.mesh_arith = "bf16x3"
+            try:
+                bpipe = InferencePipeline(net, smpl, num_samples=Ns, use_mean_shape=True)
+                b_stream = bpipe.caller_stream(Bs)
+                torch.cuda.synchronize()
+                with torch.cuda.stream(b_stream):
+                    def bsteps(first, count):
+                        ticket = bpipe.submit(sx[first % 2], input_ready=False)
+                        for i in range(count):
+                            nxt = bpipe.submit(sx[(first + i + 1) % 2], input_ready=False) if i + 1 < count else None
+                            bpipe.finish(ticket, seed=555 + first + i, image_offset=lo, after=nxt)
+                            ticket = nxt
+                    bsteps(0, 3)
+                    torch.cuda.synchronize()
+                    smpl.lbs_events = []
+                    t_b = time.perf_counter()
+                    bsteps(3, args.stress_steps)
+                    torch.cuda.synchronize()
+                    dt_sb = time.perf_counter() - t_b
+                    sb_mesh = [e0.elapsed_time(e1) for (m, e0, e1) in smpl.lbs_events if m == Ms]
+                s_split = {"images_per_s": Bs * args.stress_steps / dt_sb, "ms_per_step": dt_sb / args.stress_steps * 1e3,
+                           "mesh_kernel_median_ms": spread(sb_mesh)["median_ms"] if sb_mesh else None,
+                           "schedule": ("encoder on %d of the 32 CUs of every XCD, mesh kernels on the other %d" % (32 - _capi_mesh_cus(bpipe), _capi_mesh_cus(bpipe))
+                                        if bpipe.mesh_stream is not None else "shared CUs")}
+                del bpipe
+            finally:
+                smpl.mesh_arith, smpl.lbs_events = "f32", None
         torch.cuda.set_stream(loop_stream)
         med = lambda v: spread(v)["median_ms"] if v else None
         mesh_ms, unc_ms, smp_s_ms, lbs_ms_s = med(s_mesh), med(s_unc), med(s_smp), med(s_lbs)

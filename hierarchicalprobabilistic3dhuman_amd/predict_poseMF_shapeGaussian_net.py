@@ -199,7 +199,9 @@ class InferencePipeline:
         # shared CUs 5 570-5 580 images/s, 8 CUs per XCD 5 750-5 790, 10 -> 5 200-5 240, 4 or 6 -> 3 200-3 270 (the persistent
         # Winograd workgroups of 16 images need 64 CUs); with the slower round-2 encoder sharing won (4 925 against 4 860).  At
         # B = 16, N = 100 the mesh kernel is a tenth of that and a partition would only slow the encoder down.  None = decide from
-        # the work: 8 CUs per XCD when the batch is small enough to overlap at all AND carries at least 12 000 meshes, else 0.
+        # the work: 8 CUs per XCD when the batch is small enough to overlap at all AND carries at least 12 000 meshes, else 0 -- 12 when
+        # the SMPL object's mesh_arith is "bf16x3" at that moment (the faster mesh kernel shifts the balance: B = 16, N = 1000,
+        # images/s by encoder CUs 0 / 8 / 12 / 16 / 20: fp32 5 770 / 6 090 / 5 480 / 4 730 / 3 770, bf16x3 6 880 / 5 980 / 6 950 / 6 270 / 5 280).
         self.encoder_cus = None
         # head_cus > 0 (exclusive schedule only; an experiment, default off): the head's chain of small dependent kernels runs on
         # head_cus CUs of every XCD that the mesh kernel's stream does not use (the caller's stream becomes the partition of the other
@@ -241,7 +243,9 @@ class InferencePipeline:
         self._exclusive = self.exclusive_mesh if self.exclusive_mesh is not None else batch >= 32
         k = self.encoder_cus
         if k is None:
-            k = 8 if (not self._exclusive and batch * (self.num_samples + 2) >= 12000) else 0
+            k = 0
+            if not self._exclusive and batch * (self.num_samples + 2) >= 12000:
+                k = 12 if getattr(self.smpl, "mesh_arith", "f32") == "bf16x3" else 8
         self.enc_stream = None
         if not self._exclusive and k:
             # CUs per XCD from the device (MI355X: 256 / 8 = 32); a device or partition mode the mask scheme does not fit (a CU
