@@ -31,6 +31,11 @@ echo "configs[4] bench exit $?"
 grep -h '^{' $OUT/bench_n1000.log | tail -1 > $OUT/bench_n1000.json
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o n1000 -- python $R/bench.py --live-traffic off --batch 16 --num-samples 1000 --steps 6 --warmup 2 --cpu-images 0 --from-rgb-steps 0 --latency-reps 0 --stress-steps 0 > $OUT/n1000_stats.log 2>&1
 echo "configs[4] kernel stats exit $?"
+# the opt-in bf16x3 arithmetic of the mesh kernel as the headline's kernel (B = 64, N = 100, live PMC traffic of mesh_split_kernel) and at configs[4]
+timeout 600 python $R/bench.py --steps 40 --warmup 8 --cpu-images 0 --from-rgb-steps 0 --latency-reps 0 --stress-steps 0 --lbs-unfused-reps 0 --mesh-arith bf16x3 > $OUT/bench_bf16x3.log 2>&1
+grep -h '^{' $OUT/bench_bf16x3.log | tail -1 > $OUT/bench_bf16x3.json
+timeout 300 python $R/bench.py --live-traffic off --batch 16 --num-samples 1000 --steps 10 --warmup 3 --cpu-images 0 --from-rgb-steps 0 --latency-reps 0 --stress-steps 0 --lbs-unfused-reps 0 --mesh-arith bf16x3 > $OUT/bench_n1000_bf16x3.log 2>&1
+grep -h '^{' $OUT/bench_n1000_bf16x3.log | tail -1 > $OUT/bench_n1000_bf16x3.json
 # the unfused definition (blend GEMM + LBS as two kernels) for comparison, and the non-pipelined loop
 timeout 300 python $R/bench.py --live-traffic off --steps 20 --warmup 5 --cpu-images 0 --from-rgb-steps 0 --latency-reps 0 --stress-steps 0 --unfused-mesh > $OUT/bench_unfused.log 2>&1
 grep -h '^{' $OUT/bench_unfused.log | tail -1 > $OUT/bench_unfused.json

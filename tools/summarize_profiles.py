@@ -40,7 +40,8 @@ def load_json(name):
 copy("bench_kernel_stats.csv", tag + "_bench_kernel_stats.csv")
 copy("n1000_kernel_stats.csv", tag + "_n1000_kernel_stats.csv")
 for a, b in (("bench_line.json", "_bench_line.json"), ("bench_n1000.json", "_bench_n1000.json"),
-             ("bench_unfused.json", "_bench_unfused.json"), ("bench_nopipe.json", "_bench_nopipe.json")):
+             ("bench_unfused.json", "_bench_unfused.json"), ("bench_nopipe.json", "_bench_nopipe.json"),
+             ("bench_bf16x3.json", "_bench_bf16x3.json"), ("bench_n1000_bf16x3.json", "_bench_n1000_bf16x3.json")):
     copy(a, tag + b)
 
 
