@@ -314,7 +314,8 @@ static int launch_split(const void* xsplit, const void* bsplit, const float* v_s
     const int tiles_m = ceil_div(M, C::SM), n_panels = ceil_div(V, SV);
     const int tiles_m_per_xcd = tiles_m >= 8 ? ceil_div(tiles_m, 8) : 0;
     const dim3 grid(tiles_m_per_xcd ? tiles_m_per_xcd * 8 * n_panels : tiles_m * n_panels);
-    int stagger = SPLIT_STAGGER;
+    // (only launches of several resident rounds: a few hundred workgroups have no second round to keep apart, and the delay would be latency)
+    int stagger = grid.x >= 2048 ? SPLIT_STAGGER : 0;
 #ifdef HPS_DEV_BUILD
     if (g_split_stagger >= 0) stagger = g_split_stagger;
 #endif
