@@ -1,6 +1,7 @@
 // Fused mesh kernel, shared-shape form, with the pose blend GEMM on the bf16 matrix pipe at fp32 accuracy ("bf16x3"):
 // every fp32 operand x is carried as THREE bf16 pieces x = x1 + x2 + x3 (x1 = RN_bf16(x), x2 = RN_bf16(x - x1), x3 = RN_bf16(x - x1 - x2):
-// 3 x 8 significand bits = the 24 of an fp32 number, so the sum is exact for every normal x), and a product a b is formed as the six
+// 3 x 8 significand bits = the 24 of an fp32 number, so the sum is exact for every x with 2^-110 <= |x| < 3.39e38 -- the pieces stay normal
+// and finite --, tests/test_host_logic.py), and a product a b is formed as the six
 // piece products of weight >= 2^-16 -- a1 b3, a3 b1, a2 b2, a1 b2, a2 b1, a1 b1 -- each of them EXACT in the fp32 accumulator's input
 // (8 x 8 bits); what is dropped (a2 b3 + a3 b2 + a3 b3) is below 2^-23 |a b|, the size of the rounding of ONE fp32 multiply-add, and the
 // accumulator is rounded six times per 16 k instead of sixteen times (v_mfma_f32_32x32x2_f32 = a chain of fmaf).  Measured against the

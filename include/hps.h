@@ -196,7 +196,7 @@ int hps_smpl_v_shaped(const float* betas, int num_betas, const float* shape_rows
                       float* v_shaped, int R, int V, hps_stream_t stream);
 /* The shared-shape mesh kernel with its pose blend GEMM on the bf16 matrix pipe AT FP32 ACCURACY ("bf16x3", round 6, opt-in:
  * SMPL.mesh_arith).  Every fp32 operand x is carried as three bf16 pieces x = x1 + x2 + x3 (x1 = RN(x), x2 = RN(x - x1), x3 = RN(x - x1 -
- * x2): 3 x 8 significand bits = fp32's 24, the sum is exact) and a product is formed as the six piece products of weight >= 2^-16 of
+ * x2): 3 x 8 significand bits = fp32's 24, the sum is exact for 2^-110 <= |x| < 3.39e38, where all pieces are normal and finite) and a product is formed as the six piece products of weight >= 2^-16 of
  * the leading one, each exact in the fp32 accumulator; the dropped part is < 2^-23 |a b| -- one fp32 rounding.  Same tile, mapping,
  * skinning arithmetic, side output and HBM traffic as hps_smpl_mesh_fused_shared_shape; the vertices agree with it to rounding (<= 4e-6
  * m asserted; both within 2e-5 m of the oracle and equally close to the float64 twin).  Why it exists: v_mfma_f32_32x32x2_f32 runs at

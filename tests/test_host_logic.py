@@ -280,3 +280,38 @@ def test_kernel_selection_modes_survive_invalidation():
     enc.set_latency_mode(True)
     enc.set_latency_mode(False)
     assert all(not c.use_winograd and not c.latency for c in convs()), "set_latency_mode(False) must not force Winograd back on"
+
+
+def test_bf16x3_split_is_exact_and_the_dropped_products_are_below_one_fp32_rounding():
+    """The arithmetic behind SMPL.mesh_arith = "bf16x3" (csrc/mesh_split.hip), stated on the host with torch's own conversions: an fp32
+    number is EXACTLY the sum of three round-to-nearest bf16 pieces; the six piece products the kernel issues reproduce the fp32 product to
+    within 2^-23 |a b| (the three dropped ones are a2 b3, a3 b2, a3 b3), i.e. to one fp32 rounding; the product of two pieces is exact in fp32.  (Range: |x| below bf16's largest finite
+    value, 3.39e38 -- beyond it the first piece rounds to infinity -- and at least 2^-110, so that the third piece, 2^-16 of the first, is still
+    a normal number; the operands here are pose features and blend shapes: |x| < 10, and a pose-blend entry below 2^-110 m moves nothing.)"""
+    g = torch.Generator().manual_seed(0)
+    mags = torch.logspace(-30, 30, 4096, base=2.0)
+    x = torch.cat([torch.randn(4096, generator=g) * mags, torch.tensor([1.0, -1.0, 3.0, 1 / 3, 2.0 ** -100, 1.9999999, 16777215.0, 3.3e38,
+                                                                       -2.0 ** -126, 0.0])])
+    y = torch.cat([torch.randn(4096, generator=g), torch.tensor([0.1, 7.0, -1 / 3, 3.0, 2.0 ** 90, 1.0000001, 1e-3, 1.2345678 * 2.0 ** -100, 5.0, 1.0])])
+
+    def split(v):
+        v1 = v.bfloat16()
+        r1 = v - v1.float()
+        v2 = r1.bfloat16()
+        v3 = (r1 - v2.float()).bfloat16()
+        return v1.float(), v2.float(), v3.float()
+
+    xs, ys = split(x), split(y)
+    for v, vs in ((x, xs), (y, ys)):
+        assert torch.equal(vs[0].double() + vs[1].double() + vs[2].double(), v.double())             # exact, piece by piece
+        assert torch.equal((vs[0] + vs[1]) + vs[2], v)
+    kept = [(0, 2), (2, 0), (1, 1), (0, 1), (1, 0), (0, 0)]
+    total = torch.zeros_like(x, dtype=torch.float64)
+    for i, j in kept:
+        p32 = xs[i] * ys[j]                                                                          # fp32 product of two bf16 pieces
+        assert torch.equal(p32.double(), xs[i].double() * ys[j].double())                            # ... is exact (8 x 8 significand bits)
+        total += p32.double()
+    exact = x.double() * y.double()
+    finite = torch.isfinite(exact) & (exact.abs() > 2.0 ** -100) & (exact.abs() < 2.0 ** 100)
+    rel = ((total - exact).abs() / exact.abs())[finite]
+    assert float(rel.max()) <= 2.0 ** -23, float(rel.max())
