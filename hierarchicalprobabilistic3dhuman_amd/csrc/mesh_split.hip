@@ -48,7 +48,7 @@ template <int MG> struct SplitCfg {
     static constexpr int A_BYTES = 16 * MG * 24 * 12 * 4;      // skinning transforms of 16 meshes per mesh group (one epilogue pass)
     static constexpr int LDS = 2 * STAGE > A_BYTES ? 2 * STAGE : A_BYTES;
     static constexpr int WAVES_PER_SIMD = MG == 2 ? 3 : 4;     // MG 2: 48 KiB -> three workgroups per CU; MG 4: 72 KiB -> two (16 waves)
-    static_assert(STAGE % 1024 == 0 && PER_WAVE <= 6, "whole pieces; at most one per product group of three MFMAs");
+    static_assert(STAGE % 1024 == 0 && PER_WAVE <= 6 /* (ABL 13: <= 4) */, "whole pieces; at most one per product group of three MFMAs");
 };
 
 // RN-even fp32 -> bf16 (the bits torch's .bfloat16() produces); no NaN handling: operands are finite
@@ -189,7 +189,8 @@ __global__ __launch_bounds__(SplitCfg<MG>::THREADS, SplitCfg<MG>::WAVES_PER_SIMD
 #pragma unroll
             for (int s = 0; s < 3; ++s)
                 bf[t][s] = *reinterpret_cast<const bf16x8*>(stage + b_frag + s * (2 * SN * 16) + t * (SV * 16));
-        if (AHEAD2 && (issue || ABL == 7)) {               // every wave holds its fragments: the stage may be refilled
+        constexpr bool LATE = ABL == 13;                   // dev: the stage-free barrier behind the first two product groups instead of in front
+        if (AHEAD2 && (issue || ABL == 7) && !LATE) {      // every wave holds its fragments: the stage may be refilled
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -208,14 +209,20 @@ __global__ __launch_bounds__(SplitCfg<MG>::THREADS, SplitCfg<MG>::WAVES_PER_SIMD
                 if (ABL == 3) { acc[t][p] += (float)af[PA[p]][0] * (float)bf[t][PB[p]][0]; continue; }
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[p]], bf[t][PB[p]], acc[t], 0, 0, 0);
             }
-            if (issue && p < C::PER_WAVE && ABL != 4) {    // the pieces go out between the MFMAs, not in a burst
+            if (LATE && AHEAD2 && issue && p == 1) {
                 __builtin_amdgcn_sched_barrier(0);
-                dma_piece(p, nbuf, nx, nb);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (issue && ABL != 4 && (LATE ? (p >= 2 && p - 2 < C::PER_WAVE) : p < C::PER_WAVE)) {    // the pieces go out between the MFMAs, not in a burst
+                __builtin_amdgcn_sched_barrier(0);
+                dma_piece(LATE ? p - 2 : p, nbuf, nx, nb);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
-    if (ABL == 2 || ABL >= 10) {
+    if (ABL == 2 || (ABL >= 10 && ABL <= 12)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if (AHEAD2) {
         if (nchunks > 1) {
@@ -400,6 +407,7 @@ extern "C" int hps_smpl_mesh_fused_shared_shape_bf16x3(const void* xsplit, const
     if (mg == 4 && g_split_abl == 10) return launch_split<4, 10>(HPS_SPLIT_ARGS);
     if (mg == 4 && g_split_abl == 11) return launch_split<4, 11>(HPS_SPLIT_ARGS);
     if (mg == 4 && g_split_abl == 12) return launch_split<4, 12>(HPS_SPLIT_ARGS);
+    if (mg == 4 && g_split_abl == 13) return launch_split<4, 13>(HPS_SPLIT_ARGS);
 #undef HPS_SPLIT_ARGS
     if (mg == 2) return launch_split<2>(xsplit, bsplit, v_shaped, mesh_row, group_rows, a, w_idx, w_val, verts, M, V, rows, pick_slot, picked, n_picked, (hipStream_t)stream);
 #endif

@@ -107,7 +107,8 @@ int hps_dev_mesh_split_groups(int mg);
 /* timing ablations of the bf16x3 mesh kernel (results garbage): 1 = K loop only, 2 = skinning only, 3 = operand stream without MFMAs */
 int hps_dev_mesh_split_ablate(int ablate);   /* ... 4 = DMA pieces in one burst, 5 = operands one chunk ahead (both: results valid); 6-9 = K loop
                                               * without its operand stream / its barriers; 10-12 = skinning only without the transforms' DMA / the
-                                              * stores / the arithmetic (csrc/mesh_split.hip, tests/dev/mesh_split_time.py) */
+                                              * stores / the arithmetic; 13 = the stage-free barrier behind the first two product groups (results valid)
+                                              * (csrc/mesh_split.hip, tests/dev/mesh_split_time.py) */
 /* start delay of the second resident workgroup of every CU, in units of ~1.5 us (< 0: the product's value) */
 int hps_dev_mesh_split_stagger(int units);
 

@@ -21,6 +21,7 @@ ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--B", type=int, default=64)
 ap.add_argument("--N", type=int, default=100)
 ap.add_argument("--only", default=None, help="run one arithmetic only (f32 | bf16x3), no accuracy table: for rocprofv3 --pmc passes")
+ap.add_argument("--late", action="store_true", help="A/B: the stage-free barrier behind the first two product groups (ablate 13, valid results)")
 ap.add_argument("--epilogue", action="store_true", help="the epilogue-only ablations")
 ap.add_argument("--ablations", action="store_true", help="also time the dev library's ablations of the bf16x3 kernel")
 a = ap.parse_args()
@@ -63,6 +64,8 @@ if a.only:
     sys.exit(0)
 ARITHS = ("f32", "bf16x3", "f32", "bf16x3", "bf16x3-mg2")
 ABLATIONS = ("bf16x3-abl1", "bf16x3-abl2", "bf16x3-abl3", "bf16x3-abl6", "bf16x3-abl8", "bf16x3-abl5", "bf16x3-abl4", "bf16x3-stag0", "bf16x3-stag8") if a.ablations else ()
+if a.late:
+    ARITHS, ABLATIONS = ("bf16x3",), ("bf16x3-abl13", "bf16x3-abl0", "bf16x3-abl5") * 3
 if a.epilogue:
     ARITHS, ABLATIONS = ("bf16x3",), ("bf16x3-abl2", "bf16x3-abl10", "bf16x3-abl11", "bf16x3-abl12") * 2
 for arith in ARITHS + ABLATIONS:
@@ -87,8 +90,12 @@ for arith in ARITHS + ABLATIONS:
 pick = torch.cat([torch.arange(0, 3), torch.arange(B, B + 3), torch.arange(2 * B, 2 * B + 100), torch.arange(M - 60, M)])
 pick = pick[pick < M].unique()
 v64, j64 = smpl_forward64(model, extra, configs.SMPLX_EXTRA_VERTEX_IDS, betas[pick].double().numpy(), R[pick].double().numpy())
-for arith in ARITHS:
+for arith in [a_ for a_ in dict.fromkeys(ARITHS) if a_ in out]:
     e = np.abs(out[arith].vertices[pick.to(dev)].cpu().numpy() - v64)
     print("%-10s |verts - float64 twin|: max %.3e  mean %.3e  rms %.3e" % (arith, e.max(), e.mean(), np.sqrt((e ** 2).mean())))
-d = (out["f32"].vertices - out["bf16x3"].vertices).abs()
-print("bf16x3 vs f32: max %.3e mean %.3e; joints max %.3e" % (d.max().item(), d.mean().item(), (out["f32"].joints - out["bf16x3"].joints).abs().max().item()))
+if "f32" in out and "bf16x3" in out:
+    d = (out["f32"].vertices - out["bf16x3"].vertices).abs()
+    print("bf16x3 vs f32: max %.3e mean %.3e; joints max %.3e" % (d.max().item(), d.mean().item(), (out["f32"].joints - out["bf16x3"].joints).abs().max().item()))
+for name in ("bf16x3-abl13", "bf16x3-abl5", "bf16x3-abl4", "bf16x3-abl0", "bf16x3-mg2"):          # forms whose results are valid: the product's bits
+    if name in out and "bf16x3" in out:
+        print("%s == bf16x3 bit for bit: %s" % (name, torch.equal(out[name].vertices, out["bf16x3"].vertices)))
