@@ -258,10 +258,28 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                dst[(i * 4 + 0) * 512] = t1[i * 4 + 0] - t1[i * 4 + 2];
-                dst[(i * 4 + 1) * 512] = t1[i * 4 + 1] + t1[i * 4 + 2];
-                dst[(i * 4 + 2) * 512] = t1[i * 4 + 2] - t1[i * 4 + 1];
-                dst[(i * 4 + 3) * 512] = t1[i * 4 + 1] - t1[i * 4 + 3];
+                float o0 = t1[i * 4 + 0] - t1[i * 4 + 2], o1 = t1[i * 4 + 1] + t1[i * 4 + 2];
+                float o2 = t1[i * 4 + 2] - t1[i * 4 + 1], o3 = t1[i * 4 + 1] - t1[i * 4 + 3];
+                if (ab == 14) {                               // timing only: the VALU work of splitting every transformed value
+                    auto split_pair = [](float& p, float& q) {   // into three bf16 pieces, two values per v_cvt_pk_bf16_f32 (results garbage)
+                        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+                        typedef float f2 __attribute__((ext_vector_type(2)));
+                        f2 v = {p, q};
+                        const bf2 h1 = __builtin_convertvector(v, bf2);
+                        const f2 r1 = v - __builtin_convertvector(h1, f2);
+                        const bf2 h2 = __builtin_convertvector(r1, bf2);
+                        const f2 r2 = r1 - __builtin_convertvector(h2, f2);
+                        const bf2 h3 = __builtin_convertvector(r2, bf2);
+                        p = __uint_as_float(__builtin_bit_cast(unsigned, h1) ^ __builtin_bit_cast(unsigned, h3));
+                        q = __uint_as_float(__builtin_bit_cast(unsigned, h2));
+                    };
+                    split_pair(o0, o1);
+                    split_pair(o2, o3);
+                }
+                dst[(i * 4 + 0) * 512] = o0;
+                dst[(i * 4 + 1) * 512] = o1;
+                dst[(i * 4 + 2) * 512] = o2;
+                dst[(i * 4 + 3) * 512] = o3;
             }
             return;
         }
@@ -358,16 +376,27 @@ __global__ __launch_bounds__(W8 ? 512 : 256, 1) void conv_wino_kernel(const floa
                     __builtin_amdgcn_sched_barrier(0);
                     const float4 a = a4[pp & 1], b = b4[pp & 1];
                     if (ab == 12) __builtin_amdgcn_s_setprio(3);
+                    if (ab == 13 || ab == 14) {               // timing only: the K = 8 of this position as bf16x3 piece products = 3 x v_mfma_f32_32x32x16_bf16
+                        typedef __bf16 bf8 __attribute__((ext_vector_type(8)));          // (six per 16 k) on whatever bits the fp32 fragments hold
+                        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), acc[pp], 0, 0, 0);
+                        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, b), __builtin_bit_cast(bf8, a), acc[pp], 0, 0, 0);
+                    } else {
                     acc[pp] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc[pp], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[pp], 0, 0, 0);
                     acc[pp] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc[pp], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[pp], 0, 0, 0);
+                    }
                     if (ab == 12) __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (pp < 4 && more) { t_read2(c + 1, 2 * pp); t_read2(c + 1, 2 * pp + 1); }
                     if (pp == 5 && more) t_write(c + 1);
                     __builtin_amdgcn_sched_barrier(0);
                     if (ab == 12) __builtin_amdgcn_s_setprio(3);
+                    if (ab == 13 || ab == 14) {
+                        typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+                        acc[pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, a), acc[pp], 0, 0, 0);
+                    } else {
                     acc[pp] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc[pp], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[pp], 0, 0, 0);
                     acc[pp] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc[pp], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[pp], 0, 0, 0);
+                    }
                     if (ab == 12) __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -996,6 +1025,8 @@ static int wino_launch(const float* x, const float* u, const float* scale, const
         case 36: launch8(F(), F(), std::integral_constant<int, 6>()); break;    // ... transform but no window DMA
         case 40: launch8(F(), F(), std::integral_constant<int, 10>()); break;   // ... no barrier per chunk (races)
         case 42: launch8(F(), F(), std::integral_constant<int, 12>()); break;   // experiment: raised wave priority around the MFMAs
+        case 43: launch8(F(), F(), std::integral_constant<int, 13>()); break;   // timing only: the MFMAs as bf16x3 piece products (3 bf16 MFMAs per position and 8 k)
+        case 44: launch8(F(), F(), std::integral_constant<int, 14>()); break;   // ... + the VALU work of splitting the transformed input into three bf16 pieces
         case 11: launch8(F(), F(), std::integral_constant<int, 11>()); break;   // profiling: lane = channel form with clock stamps (hps_dev_wino_stamps)
         case 21: launch(std::integral_constant<int, 0>(), F()); break;          // the four-wave form (identical bits; the ablations below are its)
         case 1: launch(std::integral_constant<int, 1>(), F()); break;

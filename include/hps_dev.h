@@ -147,7 +147,9 @@ int hps_dev_mesh_fused(const float* xt, const float* bmat_p, const float* v_temp
 /* Profiling ablations of hps_conv3x3_winograd: 1 = no patch loads / input transform, 2 = no MFMA, 3 = no filter DMA,
  * 4 = no epilogue, 5 = raw DMA but no transform, 6 = transform but no raw DMA, 7 = raw DMA from one line, 8 = every item
  * reads the first window, 9 = DMAs issued in one burst per chunk, 10 = no barrier per chunk (races; results are garbage except for 9); 0 = the product
- * kernel.  16 x 16-block geometry only. */
+ * kernel.  16 x 16-block geometry only.  The eight-wave product form has its own set (21-44, csrc/conv_wino.hip), among them the two that
+ * price a bf16x3 arithmetic for these layers, timing only: 43 = every position's four fp32 MFMAs per 8 k as three v_mfma_f32_32x32x16_bf16,
+ * 44 = 43 + the VALU work of splitting the transformed input into three bf16 pieces (tests/dev/wino_bf16x3_price.py). */
 int hps_dev_conv3x3_winograd(const float* x, const float* u, const float* scale, const float* shift,
                              const float* residual, float* y, int B, int H, int W, int ipad, int Cin, int Cout,
                              int opad, int relu, float* splitk_ws, int ablate, hps_stream_t stream);
